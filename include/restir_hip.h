@@ -1,0 +1,226 @@
+/*
+ * restir_hip.h -- C ABI of librestir_hip.so: the MI355X (gfx950) implementation of the ReSTIR-DI
+ * per-pixel pipeline and MTBVH traversal of HummaWhite/ReSTIR, behind the reference's own render-pass
+ * entry points.  Plain pointers and sizes only; every image / G-buffer pointer is DEVICE memory
+ * (hipMalloc), row-major y*W+x, tightly packed float[3] exactly as the reference's glm::vec3 arrays.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository).  The C++ header restir_amd/host/restir_compat.h re-declares the reference's names
+ * (GBuffer::render, ReSTIRDirect, copyImageToPBO, ...) on top of this ABI; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Return convention: 0 = success, otherwise a hipError_t value (or RS_ERR_*); rs_last_error() gives
+ * the message.  (The reference prints and exit()s from checkCUDAError, src/cudaUtil.h:13-31; the
+ * compat header reproduces that on top of these codes.)
+ *
+ * Implicit inputs of the reference launchers (State::looper, Settings::reservoirReuse, the
+ * file-static ReSTIRFirstFrame; src/restir.cu:418-446) are explicit parameters / object state here.
+ */
+#ifndef RESTIR_HIP_H
+#define RESTIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_ERR_INVALID_ARGUMENT 10001
+#define RS_ERR_UNSUPPORTED      10002   /* textures / environment map: out of scope */
+
+/* src/material.h:258-267 -- identical 44-byte layout */
+typedef struct rs_material {
+    int   type;            /* Material::Type: 0 Lambertian 1 MetallicWorkflow 2 Dielectric 3 Disney 4 Light */
+    float baseColor[3];
+    float metallic;
+    float roughness;
+    float ior;
+    int   baseColorMapId;  /* must be -1 (NullTextureId) */
+    int   metallicMapId;
+    int   roughnessMapId;
+    int   normalMapId;
+} rs_material;
+
+/* src/sceneStructs.h:104-117 -- identical 196-byte layout (glm mat3/mat4 are column-major) */
+typedef struct rs_camera {
+    int   resolution[2];
+    float position[3];
+    float rotation[3];
+    float view[3];
+    float up[3];
+    float right[3];
+    float fov[2];
+    float pixelLength[2];
+    float rotationMatInv[9];
+    float viewProjection[16];   /* not read by any kernel on this path */
+    float lensRadius;
+    float focalDist;
+    float tanFovY;
+} rs_camera;
+
+/* src/restir.h:7-11,114-116 -- Reservoir<DirectLiSample>, identical 36-byte layout */
+typedef struct rs_reservoir {
+    float Li[3];
+    float wi[3];
+    float dist;
+    int   numSamples;
+    float weight;
+} rs_reservoir;
+
+/* Host arrays that define a device scene = the inputs of DevScene::create (src/scene.cpp:435-509),
+ * in the layouts Scene::buildDevData leaves them (src/scene.cpp:159-215). */
+typedef struct rs_scene_desc {
+    int                numPrims;
+    const float*       vertices;          /* 9 floats / triangle  (meshData.vertices)  */
+    const float*       normals;           /* 9 floats / triangle  (meshData.normals)   */
+    const float*       texcoords;         /* 6 floats / triangle  (meshData.texcoords), may be NULL */
+    const int*         materialIds;       /* 1 / triangle */
+    int                numMaterials;
+    const rs_material* materials;
+    int                bvhSize;           /* 2*numPrims-1 */
+    const float*       boundingBoxes;     /* 6 floats / node: AABB pMin,pMax (src/bvh.h:159-160) */
+    const int*         bvhNodes[6];       /* 3 ints / node: MTBVHNode (src/bvh.h:163-171), 6 orders */
+    int                numLights;
+    const int*         lightPrimIds;
+    const float*       lightUnitRadiance; /* 3 / light */
+    const float*       lightProb;         /* DiscreteSampler1D::binomDistribs[i].prob   */
+    const int*         lightFailId;       /* DiscreteSampler1D::binomDistribs[i].failId */
+    float              sumLightPower;     /* lightSampler.sumAll */
+} rs_scene_desc;
+
+typedef struct rs_scene   rs_scene;    /* = Scene::devScene / DevScene      (src/scene.h:64-481)  */
+typedef struct rs_gbuffer rs_gbuffer;  /* = GBuffer                          (src/gbuffer.h:15-59) */
+typedef struct rs_restir  rs_restir;   /* = module statics of restir.cu      (src/restir.cu:8-18)  */
+typedef struct rs_eaw     rs_eaw;      /* = LeveledEAWFilter                 (src/denoiser.h:33-43) */
+
+/* Device pointers of a GBuffer's planes (src/gbuffer.h:41-58). */
+typedef struct rs_gbuffer_view {
+    float* devAlbedo;        /* float[3] / px */
+    int*   devMotion;
+    float* devNormal[2];     /* float[3] / px */
+    int*   devPrimId[2];     /* holds the MATERIAL id (lights -2, miss -1), src/gbuffer.cu:29-42 */
+    float* devDepth[2];
+    int    frameIdx;
+    int    width, height;
+} rs_gbuffer_view;
+
+/* ---- library ------------------------------------------------------------------------- */
+const char* rs_last_error(void);
+/* Selects the HIP device for this process (hipSetDevice). */
+int  rs_init(int device);
+/* All work is enqueued on this hipStream_t (NULL = default stream). */
+int  rs_set_stream(void* hipStream);
+/* 1 (default): every entry point synchronises and checks errors before returning, like
+ * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
+int  rs_set_sync(int sync);
+int  rs_synchronize(void);
+
+/* ---- host scene build: replaces Scene::buildDevData (src/scene.cpp:159-215) ----------- */
+/* BVHBuilder::build + buildMTBVH (src/bvh.cpp:10-202).  boundingBoxes: 6*(2n-1) floats;
+ * bvhNodes[k]: 3*(2n-1) ints each.  Returns BVHSize via *bvhSize. */
+int  rs_build_bvh(int numPrims, const float* vertices, float* boundingBoxes, int* const bvhNodes[6], int* bvhSize);
+/* light table of buildDevData (src/scene.cpp:161-190); arrays sized numPrims. */
+int  rs_build_light_table(int numPrims, const float* vertices, const int* materialIds,
+                          int numMaterials, const rs_material* materials, int* numLights,
+                          int* lightPrimIds, float* lightUnitRadiance, float* lightPower);
+/* DiscreteSampler1D<float> constructor (src/sampler.h:79-121). */
+int  rs_build_alias_table(int n, const float* values, float* prob, int* failId, float* sumAll);
+/* The whole of buildDevData on a baked triangle soup: light table, alias table, BVH, upload. */
+int  rs_scene_build(int numPrims, const float* vertices, const float* normals, const float* texcoords,
+                    const int* materialIds, int numMaterials, const rs_material* materials,
+                    rs_scene** scene);
+/* DevScene::create (src/scene.cpp:435-509) from prebuilt host arrays. */
+int  rs_scene_create(const rs_scene_desc* desc, rs_scene** scene);
+/* Host copies of the arrays the scene was created from (valid until rs_scene_destroy). */
+int  rs_scene_host_desc(const rs_scene* scene, rs_scene_desc* desc);
+/* Scene::clear / DevScene::destroy (src/scene.cpp:217-220,511-532). */
+int  rs_scene_destroy(rs_scene* scene);
+
+/* Camera::update (src/sceneStructs.h:88-102): view/right/up/rotationMatInv from rotation. */
+int  rs_camera_update(rs_camera* cam);
+
+/* ---- scene services, batched (for parity tests of DevScene::intersect / testOcclusion) */
+/* DevScene::intersect (src/scene.h:245-284): n rays of 6 floats (origin, direction), device ptrs.
+ * Outputs (device): primId[n], matId[n], pos[3n], norm[3n]. */
+int  rs_trace_closest(const rs_scene* scene, int n, const float* devRays,
+                      int* devPrimId, int* devMatId, float* devPos, float* devNorm);
+/* DevScene::testOcclusion (src/scene.h:286-316): n segments of 6 floats (x, y). */
+int  rs_trace_occlusion(const rs_scene* scene, int n, const float* devSegments, int* devOccluded);
+
+/* ---- GBuffer (src/gbuffer.h:24-27; create/destroy are defined in src/denoiser.cu:373-403) */
+int  rs_gbuffer_create(int width, int height, rs_gbuffer** g);
+int  rs_gbuffer_destroy(rs_gbuffer* g);
+/* GBuffer::render (src/gbuffer.cu:80-86) */
+int  rs_gbuffer_render(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam);
+/* row-strip variant for framebuffer tiling: only rows [y0,y1) are rendered */
+int  rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, int y0, int y1);
+/* GBuffer::update (src/gbuffer.cu:75-78): lastCamera = cam; frameIdx ^= 1 */
+int  rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam);
+int  rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* view);
+
+/* ---- ReSTIR (src/restir.h:128-133) ------------------------------------------------------ */
+/* ReSTIRInit (src/restir.cu:478-504): reservoir buffers for width*height pixels, zero-filled. */
+int  rs_restir_init(int width, int height, rs_restir** r);
+/* ReSTIRFree (src/restir.cu:506-514) */
+int  rs_restir_free(rs_restir* r);
+/* ReSTIRReset (src/restir.cu:516-518): re-arms the first-frame flag */
+int  rs_restir_reset(rs_restir* r);
+/* ReSTIRDirect (src/restir.cu:418-446).  looper = State::looper (the caller increments it, as the
+ * reference launcher does at :441-445); reuse = Settings::reservoirReuse (bit0 temporal, bit1 spatial).
+ * Semantics: the two-phase contract (phase A for every pixel, then phase B), DESIGN.md "Q1". */
+int  rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                      float* devDirectIllum, int iter, int looper, int reuse);
+/* Row-strip variants for framebuffer tiling across GPUs: phase A (primary hit, RIS, shadow ray,
+ * temporal merge, publish) and phase B (spatial reuse, shade, accumulate) on rows [y0,y1).
+ * Between them the caller exchanges `halo` rows of published reservoirs with its neighbours
+ * (rs_restir_halo_pack / _unpack).  rs_restir_end_frame swaps the ping-pong buffers and clears the
+ * first-frame flag (src/restir.cu:434-438). */
+int  rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                       int looper, int reuse, int y0, int y1);
+int  rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                       float* devDirectIllum, int iter, int reuse, int y0, int y1);
+int  rs_restir_end_frame(rs_restir* r);
+#define RS_SPATIAL_HALO_ROWS 5           /* taps reach y-4..y+5 (src/restir.cu:49-56) */
+/* bytes needed for `rows` rows of published reservoirs */
+size_t rs_restir_halo_bytes(const rs_restir* r, int rows);
+int  rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer);
+int  rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer);
+/* Debug / parity: copy a reservoir buffer to host as the reference's AoS records.
+ * which: 0 = devDirectReservoir (next frame's output slot), 1 = devLastDirectReservoir (last
+ * written), 2 = devDirectTemp. */
+int  rs_restir_download(const rs_restir* r, int which, rs_reservoir* host);
+int  rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host);
+/* BVH walks (intersect + testOcclusion calls) performed by the last rs_restir_direct / phase_a,
+ * for the Mrays/s metric. Synchronises. */
+int  rs_restir_ray_count(rs_restir* r, unsigned long long* rays);
+/* Per-pass GPU time (ms) of the last frame, measured with hipEvents on the library's stream:
+ * ms[0] primary hit, ms[1] RIS, ms[2] shadow+temporal, ms[3] spatial+shade.  Synchronises. */
+int  rs_restir_pass_times(rs_restir* r, float ms[4]);
+/* Enables the hipEvent bracketing above (off by default: it adds 8 event records per frame). */
+int  rs_restir_enable_timing(rs_restir* r, int enable);
+
+/* ---- path-trace baseline (src/pathtrace.h:12-16) ---------------------------------------- */
+int  rs_path_trace_init(void);            /* pathTraceInit (src/pathtrace.cu:23-25) */
+int  rs_path_trace_free(void);            /* pathTraceFree (:27-28) */
+/* pathTraceDirect (src/pathtrace.cu:457-476) -> PTDirectKernel (:279-328) */
+int  rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum,
+                          int iter, int looper, unsigned long long* rays);
+
+/* ---- display conversion (src/pathtrace.h:8) ---------------------------------------------- */
+/* copyImageToPBO(uchar4*, glm::vec3*, w, h, toneMapping, scale) (src/pathtrace.cu:108-113) */
+int  rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int height, int toneMapping, float scale);
+
+/* ---- EAW denoiser (src/denoiser.h:33-43,72-74) -------------------------------------------- */
+int  rs_eaw_create(int width, int height, int level, rs_eaw** f);   /* LeveledEAWFilter::create */
+int  rs_eaw_destroy(rs_eaw* f);
+/* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
+ * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
+int  rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);
+int  rs_modulate_albedo(float* devImage, const rs_gbuffer* g);                        /* src/denoiser.cu:405-411 */
+int  rs_add_image(float* devImage, const float* devIn, int width, int height);       /* :413-418 */
+int  rs_add_image3(float* devOut, const float* devIn1, const float* devIn2, int width, int height); /* :420-425 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,346 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) and, when present, of the
+reference-derived checkers under oracle/_ref/.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by restir_amd/ (the product).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from restir_amd.ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_SUBSET_PATH = os.path.join(_HERE, "_ref", "libref_subset.so")
+THRUST_PROBE_PATH = os.path.join(_HERE, "_ref", "libthrust_probe.so")
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the C restatement (and oracle/_ref when /root/reference is mounted)."""
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+        os.path.join(_HERE, "restir_oracle.c")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class OrcScene(C.Structure):
+    _fields_ = [
+        ("numPrims", C.c_int),
+        ("vertices", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("texcoords", C.c_void_p),
+        ("materialIds", C.c_void_p),
+        ("numMaterials", C.c_int),
+        ("materials", C.c_void_p),
+        ("bvhSize", C.c_int),
+        ("boundingBoxes", C.c_void_p),
+        ("bvhNodes", C.c_void_p * 6),
+        ("numLights", C.c_int),
+        ("lightPrimIds", C.c_void_p),
+        ("lightUnitRadiance", C.c_void_p),
+        ("lightProb", C.c_void_p),
+        ("lightFailId", C.c_void_p),
+        ("sumLightPowerInv", C.c_float),
+    ]
+
+
+class OrcGBuffer(C.Structure):
+    _fields_ = [
+        ("albedo", C.c_void_p),
+        ("motion", C.c_void_p),
+        ("normal", C.c_void_p * 2),
+        ("primId", C.c_void_p * 2),
+        ("depth", C.c_void_p * 2),
+        ("frameIdx", C.c_int),
+        ("lastCamera", Camera),
+        ("width", C.c_int),
+        ("height", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    L.orc_intersect_triangle.argtypes = [C.c_int, f32p, f32p, i32p, f32p, f32p]
+    L.orc_aabb_intersect.argtypes = [C.c_int, f32p, f32p, i32p, f32p]
+    L.orc_utilhash.argtypes = [C.c_int, u32p, u32p]
+    L.orc_rng_stream.argtypes = [C.c_int, i32p, i32p, i32p, C.c_int, f32p]
+    L.orc_rng_stream_raw.argtypes = [C.c_int, i32p, C.c_int, f32p]
+    L.orc_bsdf.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
+    L.orc_camera_sample.argtypes = [C.POINTER(Camera), C.c_int, i32p, f32p, f32p]
+    L.orc_camera_raster_coord.argtypes = [C.POINTER(Camera), C.c_int, f32p, i32p]
+    L.orc_camera_position.argtypes = [C.POINTER(Camera), C.c_int, i32p, f32p, f32p]
+    L.orc_camera_update.argtypes = [C.POINTER(Camera)]
+    L.orc_sample_triangle_uniform.argtypes = [C.c_int, f32p, f32p, f32p]
+    L.orc_to_concentric_disk.argtypes = [C.c_int, f32p, f32p]
+    L.orc_triangle_misc.argtypes = [C.c_int, f32p, f32p, f32p, f32p, f32p]
+    L.orc_tonemap.argtypes = [C.c_int, f32p, C.c_int, f32p]
+    L.orc_bvh_build.argtypes = [C.c_int, f32p, f32p, C.POINTER(C.c_void_p * 6)]
+    L.orc_bvh_build.restype = C.c_int
+    L.orc_alias_build.argtypes = [C.c_int, f32p, f32p, i32p, C.POINTER(C.c_float)]
+    L.orc_light_table.argtypes = [C.c_int, f32p, i32p, C.c_void_p, i32p, f32p, f32p]
+    L.orc_light_table.restype = C.c_int
+    L.orc_intersect.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, i32p, i32p, f32p, f32p, f32p]
+    L.orc_test_occlusion.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, i32p]
+    L.orc_sample_direct_light_nv.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, f32p, f32p, f32p, f32p, f32p]
+    L.orc_gbuffer_render.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), C.c_int, C.c_int]
+    L.orc_gbuffer_update.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera)]
+    L.orc_pt_direct.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), f32p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    L.orc_restir_direct.argtypes = [
+        C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), f32p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong),
+    ]
+    L.orc_send_image_to_pbo.argtypes = [C.c_int, C.c_int, f32p, C.c_int, C.c_float, u8p]
+    L.orc_eaw_level.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.orc_eaw_filter.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, f32p]
+    L.orc_eaw_filter.restype = C.c_void_p
+    L.orc_modulate.argtypes = [C.c_int, C.c_int, f32p, f32p]
+    L.orc_add.argtypes = [C.c_int, C.c_int, f32p, f32p]
+    L.orc_add3.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------------------------------------
+# host scene build
+# ---------------------------------------------------------------------------------------------
+def bvh_build(vertices, fn=None):
+    """vertices: (numPrims, 3, 3) float32 -> (boxes (S,6) f32, nodes (6,S,3) i32).
+    fn: builder entry point (default orc_bvh_build; tests pass ref_subset().ref_bvh_build)."""
+    fn = fn or lib().orc_bvh_build
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1)
+    n = v.size // 9
+    size = 2 * n - 1
+    boxes = np.zeros((size, 6), np.float32)
+    nodes = np.zeros((6, size, 3), np.int32)
+    arr = (C.c_void_p * 6)(*[nodes[i].ctypes.data for i in range(6)])
+    got = fn(n, v, boxes.reshape(-1), C.byref(arr))
+    assert got == size
+    return boxes, nodes
+
+
+def alias_build(values):
+    values = np.ascontiguousarray(values, np.float32)
+    n = values.size
+    prob = np.zeros(n, np.float32)
+    fail = np.zeros(n, np.int32)
+    s = C.c_float(0)
+    lib().orc_alias_build(n, values, prob, fail, C.byref(s))
+    return prob, fail, np.float32(s.value)
+
+
+def light_table(vertices, material_ids, materials):
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1)
+    n = v.size // 9
+    ids = np.zeros(n, np.int32)
+    rad = np.zeros((n, 3), np.float32)
+    power = np.zeros(n, np.float32)
+    mats = np.ascontiguousarray(materials)
+    k = lib().orc_light_table(n, v, np.ascontiguousarray(material_ids, np.int32), _ptr(mats), ids, rad.reshape(-1), power)
+    return ids[:k].copy(), rad[:k].copy(), power[:k].copy()
+
+
+class Scene:
+    """Host image of DevScene, built the way Scene::buildDevData does (scene.cpp:159-215)."""
+
+    def __init__(self, vertices, normals, texcoords, material_ids, materials, prebuilt=None):
+        self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3, 3)
+        self.normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3, 3)
+        self.texcoords = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 3, 2)
+        self.material_ids = np.ascontiguousarray(material_ids, np.int32)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        n = self.vertices.shape[0]
+        if prebuilt is None:
+            self.light_prim_ids, self.light_radiance, self.light_power = light_table(
+                self.vertices, self.material_ids, self.materials)
+            if len(self.light_power):
+                self.light_prob, self.light_fail, self.sum_power = alias_build(self.light_power)
+            else:
+                self.light_prob = np.zeros(0, np.float32)
+                self.light_fail = np.zeros(0, np.int32)
+                self.sum_power = np.float32(0)
+            self.boxes, self.nodes = bvh_build(self.vertices)
+        else:
+            (self.light_prim_ids, self.light_radiance, self.light_power, self.light_prob,
+             self.light_fail, self.sum_power, self.boxes, self.nodes) = prebuilt
+        self.bvh_size = 2 * n - 1
+        s = OrcScene()
+        s.numPrims = n
+        s.vertices = self.vertices.ctypes.data
+        s.normals = self.normals.ctypes.data
+        s.texcoords = self.texcoords.ctypes.data
+        s.materialIds = self.material_ids.ctypes.data
+        s.numMaterials = len(self.materials)
+        s.materials = self.materials.ctypes.data
+        s.bvhSize = self.bvh_size
+        s.boundingBoxes = self.boxes.ctypes.data
+        for i in range(6):
+            s.bvhNodes[i] = self.nodes[i].ctypes.data
+        s.numLights = len(self.light_prim_ids)
+        s.lightPrimIds = self.light_prim_ids.ctypes.data
+        s.lightUnitRadiance = self.light_radiance.ctypes.data
+        s.lightProb = self.light_prob.ctypes.data
+        s.lightFailId = self.light_fail.ctypes.data
+        with np.errstate(divide="ignore"):
+            s.sumLightPowerInv = np.float32(1.0) / np.float32(self.sum_power)
+        self.c = s
+
+    # scene services ---------------------------------------------------------------
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        prim = np.zeros(n, np.int32); mat = np.zeros(n, np.int32)
+        pos = np.zeros((n, 3), np.float32); nrm = np.zeros((n, 3), np.float32); uv = np.zeros((n, 2), np.float32)
+        lib().orc_intersect(C.byref(self.c), n, rays.reshape(-1), prim, mat, pos.reshape(-1), nrm.reshape(-1), uv.reshape(-1))
+        return prim, mat, pos, nrm, uv
+
+    def test_occlusion(self, seg):
+        seg = np.ascontiguousarray(seg, np.float32).reshape(-1, 6)
+        occ = np.zeros(seg.shape[0], np.int32)
+        lib().orc_test_occlusion(C.byref(self.c), seg.shape[0], seg.reshape(-1), occ)
+        return occ
+
+    def sample_direct_light_nv(self, pos, r):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(r, np.float32).reshape(-1, 4)
+        n = pos.shape[0]
+        pdf = np.zeros(n, np.float32); Li = np.zeros((n, 3), np.float32)
+        wi = np.zeros((n, 3), np.float32); dist = np.zeros(n, np.float32)
+        lib().orc_sample_direct_light_nv(C.byref(self.c), n, pos.reshape(-1), r.reshape(-1), pdf, Li.reshape(-1), wi.reshape(-1), dist)
+        return pdf, Li, wi, dist
+
+
+class GBuffer:
+    """Host image of GBuffer (gbuffer.h:15-59; allocation as denoiser.cu:373-388)."""
+
+    def __init__(self, width, height):
+        n = width * height
+        self.width, self.height = width, height
+        self.albedo = np.zeros((n, 3), np.float32)
+        self.motion = np.zeros(n, np.int32)
+        self.normal = [np.zeros((n, 3), np.float32) for _ in range(2)]
+        self.prim_id = [np.zeros(n, np.int32) for _ in range(2)]
+        self.depth = [np.zeros(n, np.float32) for _ in range(2)]
+        g = OrcGBuffer()
+        g.albedo = self.albedo.ctypes.data
+        g.motion = self.motion.ctypes.data
+        for i in range(2):
+            g.normal[i] = self.normal[i].ctypes.data
+            g.primId[i] = self.prim_id[i].ctypes.data
+            g.depth[i] = self.depth[i].ctypes.data
+        g.frameIdx = 0
+        g.width, g.height = width, height
+        self.c = g
+
+    @property
+    def frame_idx(self):
+        return self.c.frameIdx
+
+    def render(self, scene, cam, y0=0, y1=None):
+        lib().orc_gbuffer_render(C.byref(scene.c), C.byref(cam), C.byref(self.c), y0, self.height if y1 is None else y1)
+
+    def update(self, cam):
+        lib().orc_gbuffer_update(C.byref(self.c), C.byref(cam))
+
+
+class ReSTIR:
+    """Module state of restir.cu:8-18,478-518 + launcher :418-446 on host memory."""
+
+    def __init__(self, width, height):
+        n = width * height
+        self.n = n
+        self.reservoir = np.zeros(n, RESERVOIR_DTYPE)       # devDirectReservoir
+        self.last = np.zeros(n, RESERVOIR_DTYPE)            # devLastDirectReservoir
+        self.temp = np.zeros(n, RESERVOIR_DTYPE)            # devDirectTemp
+        self.first = True
+        self.rays = 0
+
+    def reset(self):
+        self.first = True
+
+    def direct(self, scene, cam, gbuf, direct_illum, iter_, looper, reuse):
+        rays = C.c_ulonglong(0)
+        lib().orc_restir_direct(C.byref(scene.c), C.byref(cam), C.byref(gbuf.c), direct_illum.reshape(-1),
+                                _ptr(self.reservoir), _ptr(self.last), _ptr(self.temp),
+                                looper, iter_, int(self.first), reuse, C.byref(rays))
+        self.reservoir, self.last = self.last, self.reservoir
+        self.first = False
+        self.rays = rays.value
+        return rays.value
+
+
+def pt_direct(scene, cam, direct_illum, iter_, looper):
+    rays = C.c_ulonglong(0)
+    lib().orc_pt_direct(C.byref(scene.c), C.byref(cam), direct_illum.reshape(-1), looper, iter_, C.byref(rays))
+    return rays.value
+
+
+def send_image_to_pbo(image, w, h, tone_mapping, scale=1.0):
+    out = np.zeros((h * w, 4), np.uint8)
+    lib().orc_send_image_to_pbo(w, h, np.ascontiguousarray(image, np.float32).reshape(-1), tone_mapping, scale, out.reshape(-1))
+    return out
+
+
+def eaw_filter(gbuf, cam, color_in):
+    n = gbuf.width * gbuf.height
+    out = np.zeros((n, 3), np.float32); tmp = np.zeros((n, 3), np.float32)
+    p = lib().orc_eaw_filter(C.byref(gbuf.c), C.byref(cam), np.ascontiguousarray(color_in, np.float32).reshape(-1), out.reshape(-1), tmp.reshape(-1))
+    return out if p == out.ctypes.data else tmp
+
+
+def camera_update(cam):
+    lib().orc_camera_update(C.byref(cam))
+    return cam
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-derived checkers (this container only)
+# ---------------------------------------------------------------------------------------------
+def ref_subset():
+    if not os.path.exists(REF_SUBSET_PATH):
+        return None
+    R = C.CDLL(REF_SUBSET_PATH)
+    R.ref_intersect_triangle.argtypes = [C.c_int, f32p, f32p, i32p, f32p, f32p]
+    R.ref_aabb_intersect.argtypes = [C.c_int, f32p, f32p, i32p, f32p]
+    R.ref_utilhash.argtypes = [C.c_int, u32p, u32p]
+    R.ref_bsdf.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
+    R.ref_camera_sample.argtypes = [C.POINTER(Camera), C.c_int, i32p, f32p, f32p]
+    R.ref_camera_raster_coord.argtypes = [C.POINTER(Camera), C.c_int, f32p, i32p]
+    R.ref_camera_position.argtypes = [C.POINTER(Camera), C.c_int, i32p, f32p, f32p]
+    R.ref_camera_update.argtypes = [C.POINTER(Camera)]
+    R.ref_sample_triangle_uniform.argtypes = [C.c_int, f32p, f32p, f32p]
+    R.ref_to_concentric_disk.argtypes = [C.c_int, f32p, f32p]
+    R.ref_triangle_misc.argtypes = [C.c_int, f32p, f32p, f32p, f32p, f32p]
+    R.ref_tonemap.argtypes = [C.c_int, f32p, C.c_int, f32p]
+    R.ref_bvh_build.argtypes = [C.c_int, f32p, f32p, C.POINTER(C.c_void_p * 6)]
+    R.ref_bvh_build.restype = C.c_int
+    return R
+
+
+def thrust_probe():
+    if not os.path.exists(THRUST_PROBE_PATH):
+        return None
+    T = C.CDLL(THRUST_PROBE_PATH)
+    T.thr_rng_stream_raw.argtypes = [C.c_int, i32p, C.c_int, f32p]
+    T.thr_version.restype = C.c_int
+    return T

@@ -1,0 +1,140 @@
+/*
+ * ref_subset.cpp -- extern "C" wrappers over the REFERENCE'S OWN functions, compiled from the
+ * sources where they lie under /root/reference (nothing is copied into this repo).
+ *
+ * TEST INFRASTRUCTURE ONLY (builds oracle/_ref/libref_subset.so, see oracle/Makefile).
+ * Used in this container to pin oracle/restir_oracle.c bit-for-bit and to generate the golden
+ * vectors under tests/golden/ (tests/golden/make_golden.py).  /root/reference does not exist on
+ * the GPU box; nothing at run time there needs this file's output except as a prebuilt checker.
+ *
+ * What compiles: the thrust-free subset of the reference -- intersections.h, bvh.h, bvh.cpp,
+ * sceneStructs.h, material.h, mathUtil.h -- with plain g++, the reference's vendored GLM 0.9.6.3
+ * and the genuine CUDA runtime headers that ship inside this image's Triton wheel (only for the
+ * `#include <cuda_runtime.h>` lines and the __host__/__device__ annotations, which g++ ignores).
+ * What does not: scene.h / sampler.h / restir.h / gbuffer.h / *.cu need CUDA Thrust and nvcc
+ * (the image's rocThrust cannot coexist with CUDA headers); see DESIGN.md "Oracle".
+ */
+#include <cstring>
+#include <cstdint>
+#include <vector>
+
+#include "intersections.h"   // /root/reference/src (via -I)
+#include "bvh.h"
+#include "material.h"
+#include "sceneStructs.h"
+#include "mathUtil.h"
+
+static inline glm::vec3 ld3(const float* p) { return glm::vec3(p[0], p[1], p[2]); }
+static inline void st3(float* p, glm::vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+static inline Ray ldRay(const float* p) { Ray r; r.origin = ld3(p); r.direction = ld3(p + 3); return r; }
+
+static_assert(sizeof(Material) == 44, "Material layout");
+static_assert(sizeof(Camera) == 196, "Camera layout");
+static_assert(sizeof(AABB) == 24, "AABB layout");
+static_assert(sizeof(MTBVHNode) == 12, "MTBVHNode layout");
+
+extern "C" {
+
+void ref_intersect_triangle(int n, const float* rays, const float* tris, int* hit, float* bary, float* dist) {
+    for (int i = 0; i < n; i++) {
+        glm::vec2 b(0.f); float d = 0.f;
+        hit[i] = intersectTriangle(ldRay(rays + 6 * i), ld3(tris + 9 * i), ld3(tris + 9 * i + 3), ld3(tris + 9 * i + 6), b, d);
+        bary[2 * i] = b.x; bary[2 * i + 1] = b.y; dist[i] = d;
+    }
+}
+
+void ref_aabb_intersect(int n, const float* rays, const float* boxes, int* hit, float* tMin) {
+    for (int i = 0; i < n; i++) {
+        AABB box(ld3(boxes + 6 * i), ld3(boxes + 6 * i + 3));
+        float t = 0.f;
+        hit[i] = box.intersect(ldRay(rays + 6 * i), t);
+        tMin[i] = t;
+    }
+}
+
+void ref_utilhash(int n, const uint32_t* in, uint32_t* out) {
+    for (int i = 0; i < n; i++) out[i] = Math::utilhash(in[i]);
+}
+
+void ref_bsdf(int n, const void* mats, const float* nrm, const float* wo, const float* wi, float* out) {
+    for (int i = 0; i < n; i++) {
+        Material m;
+        std::memcpy(&m, (const char*)mats + (size_t)i * sizeof(Material), sizeof(Material));
+        st3(out + 3 * i, m.BSDF(ld3(nrm + 3 * i), ld3(wo + 3 * i), ld3(wi + 3 * i)));
+    }
+}
+
+void ref_camera_sample(const void* cam, int n, const int* xy, const float* r, float* rays) {
+    Camera c; std::memcpy(&c, cam, sizeof(Camera));
+    for (int i = 0; i < n; i++) {
+        Ray ray = c.sample(xy[2 * i], xy[2 * i + 1], glm::vec4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]));
+        st3(rays + 6 * i, ray.origin); st3(rays + 6 * i + 3, ray.direction);
+    }
+}
+
+void ref_camera_raster_coord(const void* cam, int n, const float* pos, int* xy) {
+    Camera c; std::memcpy(&c, cam, sizeof(Camera));
+    for (int i = 0; i < n; i++) {
+        glm::ivec2 p = c.getRasterCoord(ld3(pos + 3 * i));
+        xy[2 * i] = p.x; xy[2 * i + 1] = p.y;
+    }
+}
+
+void ref_camera_position(const void* cam, int n, const int* xy, const float* dist, float* pos) {
+    Camera c; std::memcpy(&c, cam, sizeof(Camera));
+    for (int i = 0; i < n; i++) st3(pos + 3 * i, c.getPosition(xy[2 * i], xy[2 * i + 1], dist[i]));
+}
+
+void ref_camera_update(void* cam) {
+    Camera c; std::memcpy(&c, cam, sizeof(Camera));
+    c.update();
+    std::memcpy(cam, &c, sizeof(Camera));
+}
+
+void ref_sample_triangle_uniform(int n, const float* tris, const float* ruv, float* out) {
+    for (int i = 0; i < n; i++)
+        st3(out + 3 * i, Math::sampleTriangleUniform(ld3(tris + 9 * i), ld3(tris + 9 * i + 3), ld3(tris + 9 * i + 6), ruv[2 * i], ruv[2 * i + 1]));
+}
+
+void ref_to_concentric_disk(int n, const float* xy, float* out) {
+    for (int i = 0; i < n; i++) {
+        glm::vec2 p = Math::toConcentricDisk(xy[2 * i], xy[2 * i + 1]);
+        out[2 * i] = p.x; out[2 * i + 1] = p.y;
+    }
+}
+
+/* triangleArea, triangleNormal, luminance, pdfAreaToSolidAngle: out = area, normal[3], lum(normal), pdf */
+void ref_triangle_misc(int n, const float* tris, const float* x, float* area, float* normal, float* pdf) {
+    for (int i = 0; i < n; i++) {
+        glm::vec3 v0 = ld3(tris + 9 * i), v1 = ld3(tris + 9 * i + 3), v2 = ld3(tris + 9 * i + 6);
+        area[i] = Math::triangleArea(v0, v1, v2);
+        glm::vec3 nrm = Math::triangleNormal(v0, v1, v2);
+        st3(normal + 3 * i, nrm);
+        pdf[i] = Math::pdfAreaToSolidAngle(Math::luminance(v1) , ld3(x + 3 * i), v0, nrm);
+    }
+}
+
+void ref_tonemap(int n, const float* in, int mode, float* out) {
+    for (int i = 0; i < n; i++) {
+        glm::vec3 color = ld3(in + 3 * i);
+        switch (mode) {
+        case ToneMapping::Filmic: color = Math::filmic(color); break;
+        case ToneMapping::ACES:   color = Math::ACES(color); break;
+        case ToneMapping::None:   break;
+        }
+        st3(out + 3 * i, Math::correctGamma(color));
+    }
+}
+
+int ref_bvh_build(int numPrims, const float* vertices, float* boxesOut, int* nodesOut[6]) {
+    std::vector<glm::vec3> verts((size_t)numPrims * 3);
+    std::memcpy(verts.data(), vertices, sizeof(float) * 9 * (size_t)numPrims);
+    std::vector<AABB> boxes;
+    std::vector<std::vector<MTBVHNode>> nodes;
+    int size = BVHBuilder::build(verts, boxes, nodes);
+    std::memcpy(boxesOut, boxes.data(), sizeof(AABB) * boxes.size());
+    for (int i = 0; i < 6; i++) std::memcpy(nodesOut[i], nodes[i].data(), sizeof(MTBVHNode) * nodes[i].size());
+    return size;
+}
+
+} // extern "C"

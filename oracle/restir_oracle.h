@@ -1,0 +1,196 @@
+/*
+ * restir_oracle.h -- CPU restatement of the ReSTIR-DI hot path of HummaWhite/ReSTIR.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (restir_amd/, include/) may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * use it, and only as the checker / the reported CPU baseline.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - pinned bit-for-bit against the reference's own code compiled here (oracle/_ref, built by
+ *     oracle/Makefile from /root/reference/src with g++): intersectTriangle, AABB::intersect,
+ *     BVHBuilder::build/buildMTBVH, Camera::{update,sample,getRasterCoord,getPosition},
+ *     Material::BSDF, Math::* helpers, tone-map operators;
+ *   - pinned against the third-party dependency itself (rocThrust 2.8.5 minstd_rand +
+ *     uniform_real_distribution compiled by hipcc host-only): the RNG stream;
+ *   - PARITY UNPINNED (restated from source text only; the reference's scene.h / sampler.h /
+ *     restir.h / *.cu cannot be compiled in this image without CUDA Thrust + nvcc):
+ *     DevScene::intersect / testOcclusion loops, sampleDirectLight*, DiscreteSampler1D,
+ *     Reservoir<>, and the kernel glue of restir.cu / gbuffer.cu / pathtrace.cu / denoiser.cu.
+ *
+ * All arithmetic is FP32, compiled with -ffp-contract=off; operation order follows GLM 0.9.6.3.
+ * Layout-compatible with include/restir_hip.h (rs_material / rs_camera / rs_reservoir).
+ */
+#ifndef RESTIR_ORACLE_H
+#define RESTIR_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: src/material.h:258-267 (44 bytes) */
+typedef struct orc_material {
+    int   type;              /* 0 Lambertian, 1 MetallicWorkflow, 2 Dielectric, 3 Disney, 4 Light */
+    float baseColor[3];
+    float metallic;
+    float roughness;
+    float ior;
+    int   baseColorMapId;    /* -1 = none; textures are out of scope and must be -1 */
+    int   metallicMapId;
+    int   roughnessMapId;
+    int   normalMapId;
+} orc_material;
+
+/* reference: src/sceneStructs.h:104-117 (196 bytes); mat3/mat4 column-major */
+typedef struct orc_camera {
+    int   resolution[2];
+    float position[3];
+    float rotation[3];
+    float view[3];
+    float up[3];
+    float right[3];
+    float fov[2];
+    float pixelLength[2];
+    float rotationMatInv[9];
+    float viewProjection[16];
+    float lensRadius;
+    float focalDist;
+    float tanFovY;
+} orc_camera;
+
+/* reference: src/restir.h:7-11,29-117 -- Reservoir<DirectLiSample> (36 bytes) */
+typedef struct orc_reservoir {
+    float Li[3];
+    float wi[3];
+    float dist;
+    int   numSamples;
+    float weight;
+} orc_reservoir;
+
+/* Host-memory image of DevScene (src/scene.h:461-480). */
+typedef struct orc_scene {
+    int           numPrims;
+    const float*  vertices;        /* 9 floats / prim */
+    const float*  normals;         /* 9 floats / prim */
+    const float*  texcoords;       /* 6 floats / prim */
+    const int*    materialIds;     /* 1 / prim */
+    int           numMaterials;
+    const orc_material* materials;
+    int           bvhSize;
+    const float*  boundingBoxes;   /* 6 floats / node: pMin, pMax */
+    const int*    bvhNodes[6];     /* 3 ints / node: primitiveId, boundingBoxId, nextNodeIfMiss */
+    int           numLights;
+    const int*    lightPrimIds;
+    const float*  lightUnitRadiance; /* 3 / light */
+    const float*  lightProb;       /* alias table: BinomialDistrib.prob   */
+    const int*    lightFailId;     /* alias table: BinomialDistrib.failId */
+    float         sumLightPowerInv;
+} orc_scene;
+
+/* Host-memory image of GBuffer (src/gbuffer.h:41-58). */
+typedef struct orc_gbuffer {
+    float* albedo;       /* 3 / px */
+    int*   motion;
+    float* normal[2];    /* 3 / px */
+    int*   primId[2];
+    float* depth[2];
+    int    frameIdx;
+    orc_camera lastCamera;
+    int    width, height;
+} orc_gbuffer;
+
+/* ---- function-level entry points (vectorised over n) ------------------------------ */
+
+/* src/intersections.h:17-54.  rays: 6 floats (origin, direction); tris: 9 floats. */
+void orc_intersect_triangle(int n, const float* rays, const float* tris,
+                            int* hit, float* bary, float* dist);
+/* src/bvh.h:85-157.  boxes: 6 floats (pMin, pMax). */
+void orc_aabb_intersect(int n, const float* rays, const float* boxes, int* hit, float* tMin);
+/* src/mathUtil.h:190-198 */
+void orc_utilhash(int n, const uint32_t* in, uint32_t* out);
+/* src/sampler.h:41-48 + thrust minstd_rand: m draws of sample1D for each (looper,index,dim) */
+void orc_rng_stream(int n, const int* looper, const int* index, const int* dim, int m, float* out);
+/* src/material.h:218-228 */
+void orc_bsdf(int n, const orc_material* mats, const float* nrm, const float* wo, const float* wi,
+              float* out);
+/* src/sceneStructs.h:69-86.  r: 4 floats / ray; out rays 6 floats */
+void orc_camera_sample(const orc_camera* cam, int n, const int* xy, const float* r, float* rays);
+/* src/sceneStructs.h:23-46 */
+void orc_camera_raster_coord(const orc_camera* cam, int n, const float* pos, int* xy);
+/* src/sceneStructs.h:48-64 */
+void orc_camera_position(const orc_camera* cam, int n, const int* xy, const float* dist, float* pos);
+/* src/sceneStructs.h:88-102 (host).  viewProjection is left untouched (not on the path). */
+void orc_camera_update(orc_camera* cam);
+/* src/mathUtil.h:94-100,86-92,182-185,128-132 */
+void orc_sample_triangle_uniform(int n, const float* tris, const float* ruv, float* out);
+void orc_to_concentric_disk(int n, const float* xy, float* out);
+/* mathUtil.h:86-92,119-123,182-185: area, normal, pdfAreaToSolidAngle(lum(v1), x, v0, normal) */
+void orc_triangle_misc(int n, const float* tris, const float* x, float* area, float* normal, float* pdf);
+/* raw-seed RNG stream: thrust::default_random_engine(seed) then m draws of uniform_real<float>(0,1) */
+void orc_rng_stream_raw(int n, const int* seeds, int m, float* out);
+/* src/mathUtil.h:102-117: mode 0 none, 1 filmic, 2 ACES; then correctGamma; float output */
+void orc_tonemap(int n, const float* in, int mode, float* out);
+
+/* ---- host scene build -------------------------------------------------------------- */
+
+/* src/bvh.cpp:10-202.  boxes: 6*(2n-1) floats; nodes: 6 arrays of 3*(2n-1) ints. Returns BVHSize. */
+int  orc_bvh_build(int numPrims, const float* vertices, float* boxes, int* nodes[6]);
+/* src/sampler.h:79-121 */
+void orc_alias_build(int n, const float* values, float* prob, int* failId, float* sumAll);
+/* src/scene.cpp:159-190 light table part.  Returns number of lights. */
+int  orc_light_table(int numPrims, const float* vertices, const int* materialIds,
+                     const orc_material* mats, int* lightPrimIds, float* lightUnitRadiance,
+                     float* lightPower);
+
+/* ---- scene services ---------------------------------------------------------------- */
+
+/* src/scene.h:245-284.  out: primId, matId, pos[3], norm[3], uv[2] (only valid when primId>=0) */
+void orc_intersect(const orc_scene* s, int n, const float* rays, int* primId, int* matId,
+                   float* pos, float* norm, float* uv);
+/* src/scene.h:286-316.  seg: 6 floats (x, y) */
+void orc_test_occlusion(const orc_scene* s, int n, const float* seg, int* occluded);
+/* src/scene.h:394-425.  r: 4 floats.  out pdf, Li[3], wi[3], dist */
+void orc_sample_direct_light_nv(const orc_scene* s, int n, const float* pos, const float* r,
+                                float* pdf, float* Li, float* wi, float* dist);
+
+/* ---- frame-level passes ------------------------------------------------------------ */
+
+/* src/gbuffer.cu:3-73 (writes the frameIdx planes + albedo + motion). rows [y0,y1). */
+void orc_gbuffer_render(const orc_scene* s, const orc_camera* cam, orc_gbuffer* g, int y0, int y1);
+/* src/gbuffer.cu:75-78 */
+void orc_gbuffer_update(orc_gbuffer* g, const orc_camera* cam);
+
+/* src/pathtrace.cu:279-328 */
+void orc_pt_direct(const orc_scene* s, const orc_camera* cam, float* directIllum,
+                   int looper, int iter, unsigned long long* rays);
+
+/* src/restir.cu:111-231 with the two-phase contract of SURVEY.md Q1:
+ * phase A (primary, RIS, shadow, temporal, publish) for all pixels, grid barrier,
+ * phase B (spatial, shade, accumulate).  reuse: bit0 temporal, bit1 spatial.
+ * rays (optional): number of BVH walks performed (intersect + testOcclusion). */
+void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
+                       float* directIllum, orc_reservoir* reservoirOut,
+                       const orc_reservoir* reservoirIn, orc_reservoir* reservoirTemp,
+                       int looper, int iter, int first, int reuse, unsigned long long* rays);
+
+/* src/pathtrace.cu:30-56: rgba8 out (4 bytes / px, a = 0) */
+void orc_send_image_to_pbo(int w, int h, const float* image, int toneMapping, float scale,
+                           unsigned char* rgba);
+
+/* src/denoiser.cu:64-134: one EAW level */
+void orc_eaw_level(const orc_gbuffer* g, const orc_camera* cam, const float* colorIn,
+                   float* colorOut, float sigDepth, float sigNormal, float sigLumin, int level);
+/* src/denoiser.cu:463-477: 5 levels, sigma 64 / .2 / 1; result in out, tmp is scratch. Returns
+ * pointer (out or tmp) that holds the final image, mirroring the pointer swap of the reference. */
+float* orc_eaw_filter(const orc_gbuffer* g, const orc_camera* cam, const float* colorIn,
+                      float* out, float* tmp);
+/* src/denoiser.cu:218-248 */
+void orc_modulate(int w, int h, float* image, const float* albedo);
+void orc_add(int w, int h, float* image, const float* in);
+void orc_add3(int w, int h, float* out, const float* in1, const float* in2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,414 @@
+"""ctypes binding of librestir_hip.so (include/restir_hip.h) plus thin Python mirrors of the
+reference's host objects (Scene / GBuffer / ReSTIR module state / LeveledEAWFilter).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is NO fallback:
+if the library is missing or no MI355X is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE, copy_camera
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librestir_hip.so")
+
+
+class RestirHipError(RuntimeError):
+    pass
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("numPrims", C.c_int),
+        ("vertices", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("texcoords", C.c_void_p),
+        ("materialIds", C.c_void_p),
+        ("numMaterials", C.c_int),
+        ("materials", C.c_void_p),
+        ("bvhSize", C.c_int),
+        ("boundingBoxes", C.c_void_p),
+        ("bvhNodes", C.c_void_p * 6),
+        ("numLights", C.c_int),
+        ("lightPrimIds", C.c_void_p),
+        ("lightUnitRadiance", C.c_void_p),
+        ("lightProb", C.c_void_p),
+        ("lightFailId", C.c_void_p),
+        ("sumLightPower", C.c_float),
+    ]
+
+
+class GBufferView(C.Structure):
+    _fields_ = [
+        ("devAlbedo", C.c_void_p),
+        ("devMotion", C.c_void_p),
+        ("devNormal", C.c_void_p * 2),
+        ("devPrimId", C.c_void_p * 2),
+        ("devDepth", C.c_void_p * 2),
+        ("frameIdx", C.c_int),
+        ("width", C.c_int),
+        ("height", C.c_int),
+    ]
+
+
+# every symbol include/restir_hip.h declares; tests check that the library exports all of them
+EXPORTS = [
+    "rs_last_error", "rs_init", "rs_set_stream", "rs_set_sync", "rs_synchronize",
+    "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_scene_build", "rs_scene_create",
+    "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
+    "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
+    "rs_gbuffer_get_view", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
+    "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
+    "rs_restir_halo_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_pass_times",
+    "rs_restir_enable_timing", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_copy_image_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
+    "rs_add_image", "rs_add_image3",
+]
+
+_lib = None
+
+
+def lib():
+    """Load librestir_hip.so.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RestirHipError(
+            f"{LIB_PATH} is missing: build it with `make -C restir_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the MI355X path.")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.rs_last_error.restype = C.c_char_p
+    L.rs_init.argtypes = [ci]
+    L.rs_set_stream.argtypes = [vp]
+    L.rs_set_sync.argtypes = [ci]
+    L.rs_build_bvh.argtypes = [ci, vp, vp, C.POINTER(vp * 6), C.POINTER(ci)]
+    L.rs_build_light_table.argtypes = [ci, vp, vp, ci, vp, C.POINTER(ci), vp, vp, vp]
+    L.rs_build_alias_table.argtypes = [ci, vp, vp, vp, C.POINTER(cf)]
+    L.rs_scene_build.argtypes = [ci, vp, vp, vp, vp, ci, vp, C.POINTER(vp)]
+    L.rs_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.rs_scene_host_desc.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.rs_scene_destroy.argtypes = [vp]
+    L.rs_camera_update.argtypes = [C.POINTER(Camera)]
+    L.rs_trace_closest.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    L.rs_trace_occlusion.argtypes = [vp, ci, vp, vp]
+    L.rs_gbuffer_create.argtypes = [ci, ci, C.POINTER(vp)]
+    L.rs_gbuffer_destroy.argtypes = [vp]
+    L.rs_gbuffer_render.argtypes = [vp, vp, C.POINTER(Camera)]
+    L.rs_gbuffer_render_rows.argtypes = [vp, vp, C.POINTER(Camera), ci, ci]
+    L.rs_gbuffer_update.argtypes = [vp, C.POINTER(Camera)]
+    L.rs_gbuffer_get_view.argtypes = [vp, C.POINTER(GBufferView)]
+    L.rs_restir_init.argtypes = [ci, ci, C.POINTER(vp)]
+    L.rs_restir_free.argtypes = [vp]
+    L.rs_restir_reset.argtypes = [vp]
+    L.rs_restir_direct.argtypes = [vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci]
+    L.rs_restir_phase_a.argtypes = [vp, vp, C.POINTER(Camera), vp, ci, ci, ci, ci]
+    L.rs_restir_phase_b.argtypes = [vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci, ci]
+    L.rs_restir_end_frame.argtypes = [vp]
+    L.rs_restir_halo_bytes.argtypes = [vp, ci]
+    L.rs_restir_halo_bytes.restype = C.c_size_t
+    L.rs_restir_halo_pack.argtypes = [vp, ci, ci, vp]
+    L.rs_restir_halo_unpack.argtypes = [vp, ci, ci, vp]
+    L.rs_restir_download.argtypes = [vp, ci, vp]
+    L.rs_restir_upload.argtypes = [vp, ci, vp]
+    L.rs_restir_ray_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.rs_restir_pass_times.argtypes = [vp, C.POINTER(cf * 4)]
+    L.rs_restir_enable_timing.argtypes = [vp, ci]
+    L.rs_path_trace_direct.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, C.POINTER(C.c_ulonglong)]
+    L.rs_copy_image_to_pbo.argtypes = [vp, vp, ci, ci, ci, cf]
+    L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
+    L.rs_eaw_destroy.argtypes = [vp]
+    L.rs_eaw_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
+    L.rs_modulate_albedo.argtypes = [vp, vp]
+    L.rs_add_image.argtypes = [vp, vp, ci, ci]
+    L.rs_add_image3.argtypes = [vp, vp, vp, ci, ci]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise RestirHipError(f"librestir_hip error {code}: {lib().rs_last_error().decode()}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def init(device=0):
+    check(lib().rs_init(device))
+
+
+def set_sync(sync):
+    check(lib().rs_set_sync(1 if sync else 0))
+
+
+def synchronize():
+    check(lib().rs_synchronize())
+
+
+def camera_update(cam):
+    check(lib().rs_camera_update(C.byref(cam)))
+    return cam
+
+
+# ---- host builders (no GPU needed) ----------------------------------------------------------------
+def build_bvh(vertices):
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1)
+    n = v.size // 9
+    size = 2 * n - 1
+    boxes = np.zeros((size, 6), np.float32)
+    nodes = np.zeros((6, size, 3), np.int32)
+    arr = (C.c_void_p * 6)(*[nodes[i].ctypes.data for i in range(6)])
+    got = C.c_int(0)
+    check(lib().rs_build_bvh(n, _p(v), _p(boxes), C.byref(arr), C.byref(got)))
+    assert got.value == size
+    return boxes, nodes
+
+
+def build_alias_table(values):
+    values = np.ascontiguousarray(values, np.float32)
+    n = values.size
+    prob = np.zeros(n, np.float32); fail = np.zeros(n, np.int32); s = C.c_float(0)
+    check(lib().rs_build_alias_table(n, _p(values), _p(prob), _p(fail), C.byref(s)))
+    return prob, fail, np.float32(s.value)
+
+
+def build_light_table(vertices, material_ids, materials):
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1)
+    n = v.size // 9
+    mats = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+    ids = np.zeros(n, np.int32); rad = np.zeros((n, 3), np.float32); power = np.zeros(n, np.float32)
+    k = C.c_int(0)
+    check(lib().rs_build_light_table(n, _p(v), _p(np.ascontiguousarray(material_ids, np.int32)), len(mats), _p(mats),
+                                     C.byref(k), _p(ids), _p(rad), _p(power)))
+    return ids[:k.value].copy(), rad[:k.value].copy(), power[:k.value].copy()
+
+
+# ---- device objects ---------------------------------------------------------------------------------
+class Scene:
+    """Scene::buildDevData + DevScene (src/scene.cpp:159-215): builds light table, alias table and the
+    MTBVH on the host (C++ in the library) and uploads the CDNA4 layout."""
+
+    def __init__(self, vertices, normals, texcoords, material_ids, materials):
+        self._keep = (np.ascontiguousarray(vertices, np.float32), np.ascontiguousarray(normals, np.float32),
+                      np.ascontiguousarray(texcoords, np.float32), np.ascontiguousarray(material_ids, np.int32),
+                      np.ascontiguousarray(materials, MATERIAL_DTYPE))
+        v, n, t, m, mats = self._keep
+        self.num_prims = v.size // 9
+        self.handle = C.c_void_p()
+        check(lib().rs_scene_build(self.num_prims, _p(v), _p(n), _p(t), _p(m), len(mats), _p(mats), C.byref(self.handle)))
+
+    def host_desc(self):
+        """numpy views of the arrays the scene was built from (for parity checks of the host build)."""
+        d = SceneDesc()
+        check(lib().rs_scene_host_desc(self.handle, C.byref(d)))
+        n, s, l = d.numPrims, d.bvhSize, d.numLights
+
+        def arr(ptr, ctype, count, shape):
+            if count == 0:
+                return np.zeros(shape, ctype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(ctype))), (count,)).reshape(shape).copy()
+
+        return dict(
+            boxes=arr(d.boundingBoxes, np.float32, s * 6, (s, 6)),
+            nodes=np.stack([arr(d.bvhNodes[k], np.int32, s * 3, (s, 3)) for k in range(6)]),
+            light_prim_ids=arr(d.lightPrimIds, np.int32, l, (l,)),
+            light_radiance=arr(d.lightUnitRadiance, np.float32, l * 3, (l, 3)),
+            light_prob=arr(d.lightProb, np.float32, l, (l,)),
+            light_fail=arr(d.lightFailId, np.int32, l, (l,)),
+            sum_power=np.float32(d.sumLightPower), num_lights=l, bvh_size=s, num_prims=n,
+        )
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class GBuffer:
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+        self.handle = C.c_void_p()
+        check(lib().rs_gbuffer_create(width, height, C.byref(self.handle)))
+
+    def render(self, scene, cam, y0=None, y1=None):
+        if y0 is None:
+            check(lib().rs_gbuffer_render(self.handle, scene.handle, C.byref(cam)))
+        else:
+            check(lib().rs_gbuffer_render_rows(self.handle, scene.handle, C.byref(cam), y0, y1))
+
+    def update(self, cam):
+        check(lib().rs_gbuffer_update(self.handle, C.byref(cam)))
+
+    def view(self):
+        v = GBufferView()
+        check(lib().rs_gbuffer_get_view(self.handle, C.byref(v)))
+        return v
+
+    def download(self):
+        """Copies every plane to host numpy arrays (torch is only used for the D2H copy)."""
+        import torch
+        v = self.view()
+        n = self.width * self.height
+
+        def grab(ptr, count, dtype):
+            t = torch.empty(count, dtype=dtype, device="cuda")
+            hip_memcpy_d2d(t.data_ptr(), ptr, count * t.element_size())
+            return t.cpu().numpy()
+
+        return dict(
+            albedo=grab(v.devAlbedo, n * 3, torch.float32).reshape(n, 3),
+            motion=grab(v.devMotion, n, torch.int32),
+            normal=[grab(v.devNormal[i], n * 3, torch.float32).reshape(n, 3) for i in range(2)],
+            prim_id=[grab(v.devPrimId[i], n, torch.int32) for i in range(2)],
+            depth=[grab(v.devDepth[i], n, torch.float32) for i in range(2)],
+            frame_idx=v.frameIdx,
+        )
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_gbuffer_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+_hip = None
+
+
+def hip_memcpy_d2d(dst, src, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    synchronize()
+    e = _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
+    if e != 0:
+        raise RestirHipError(f"hipMemcpy failed: {e}")
+
+
+class ReSTIR:
+    """restir.cu module state + ReSTIRInit/Free/Reset/Direct."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+        self.handle = C.c_void_p()
+        check(lib().rs_restir_init(width, height, C.byref(self.handle)))
+
+    def reset(self):
+        check(lib().rs_restir_reset(self.handle))
+
+    def direct(self, scene, cam, gbuf, dev_direct_illum_ptr, iter_, looper, reuse):
+        check(lib().rs_restir_direct(self.handle, scene.handle, C.byref(cam), gbuf.handle, dev_direct_illum_ptr, iter_, looper, reuse))
+
+    def phase_a(self, scene, cam, gbuf, looper, reuse, y0, y1):
+        check(lib().rs_restir_phase_a(self.handle, scene.handle, C.byref(cam), gbuf.handle, looper, reuse, y0, y1))
+
+    def phase_b(self, scene, cam, gbuf, dev_direct_illum_ptr, iter_, reuse, y0, y1):
+        check(lib().rs_restir_phase_b(self.handle, scene.handle, C.byref(cam), gbuf.handle, dev_direct_illum_ptr, iter_, reuse, y0, y1))
+
+    def end_frame(self):
+        check(lib().rs_restir_end_frame(self.handle))
+
+    def halo_bytes(self, rows):
+        return int(lib().rs_restir_halo_bytes(self.handle, rows))
+
+    def halo_pack(self, y0, rows, dev_ptr):
+        check(lib().rs_restir_halo_pack(self.handle, y0, rows, dev_ptr))
+
+    def halo_unpack(self, y0, rows, dev_ptr):
+        check(lib().rs_restir_halo_unpack(self.handle, y0, rows, dev_ptr))
+
+    def download(self, which):
+        out = np.zeros(self.width * self.height, RESERVOIR_DTYPE)
+        check(lib().rs_restir_download(self.handle, which, _p(out)))
+        return out
+
+    def upload(self, which, arr):
+        arr = np.ascontiguousarray(arr, RESERVOIR_DTYPE)
+        check(lib().rs_restir_upload(self.handle, which, _p(arr)))
+
+    def ray_count(self):
+        n = C.c_ulonglong(0)
+        check(lib().rs_restir_ray_count(self.handle, C.byref(n)))
+        return n.value
+
+    def enable_timing(self, on=True):
+        check(lib().rs_restir_enable_timing(self.handle, 1 if on else 0))
+
+    def pass_times(self):
+        ms = (C.c_float * 4)()
+        check(lib().rs_restir_pass_times(self.handle, C.byref(ms)))
+        return [float(x) for x in ms]
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_restir_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class EAWFilter:
+    """LeveledEAWFilter (src/denoiser.h:33-43)."""
+
+    def __init__(self, width, height, level=5):
+        self.handle = C.c_void_p()
+        check(lib().rs_eaw_create(width, height, level, C.byref(self.handle)))
+
+    def filter(self, out_ptr, in_ptr, gbuf, cam):
+        """Returns the device pointer that holds the result (the reference swaps the caller's pointer)."""
+        p = C.c_void_p(out_ptr)
+        check(lib().rs_eaw_filter(self.handle, C.byref(p), in_ptr, gbuf.handle, C.byref(cam)))
+        return p.value
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_eaw_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def path_trace_direct(scene, cam, dev_direct_illum_ptr, iter_, looper):
+    n = C.c_ulonglong(0)
+    check(lib().rs_path_trace_direct(scene.handle, C.byref(cam), dev_direct_illum_ptr, iter_, looper, C.byref(n)))
+    return n.value
+
+
+def copy_image_to_pbo(dev_pbo_ptr, dev_image_ptr, width, height, tone_mapping, scale=1.0):
+    check(lib().rs_copy_image_to_pbo(dev_pbo_ptr, dev_image_ptr, width, height, tone_mapping, scale))
+
+
+def trace_closest(scene, rays_t):
+    """rays_t: torch float32 cuda tensor (n,6). Returns (primId, matId, pos, norm) torch tensors."""
+    import torch
+    n = rays_t.shape[0]
+    prim = torch.empty(n, dtype=torch.int32, device="cuda"); mat = torch.empty(n, dtype=torch.int32, device="cuda")
+    pos = torch.empty((n, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    check(lib().rs_trace_closest(scene.handle, n, rays_t.data_ptr(), prim.data_ptr(), mat.data_ptr(), pos.data_ptr(), nrm.data_ptr()))
+    return prim, mat, pos, nrm
+
+
+def trace_occlusion(scene, seg_t):
+    import torch
+    n = seg_t.shape[0]
+    occ = torch.empty(n, dtype=torch.int32, device="cuda")
+    check(lib().rs_trace_occlusion(scene.handle, n, seg_t.data_ptr(), occ.data_ptr()))
+    return occ

@@ -1,0 +1,79 @@
+// api_common.hip -- library state (device, stream, sync mode, last error) of librestir_hip.
+#include <cmath>
+#include <cstdio>
+#include <mutex>
+
+#include "rs_internal.h"
+
+namespace {
+std::mutex g_errMutex;
+std::string g_lastError;
+hipStream_t g_stream = nullptr;
+bool g_sync = true;
+}  // namespace
+
+int rs_fail(int code, const char* msg) {
+    std::lock_guard<std::mutex> lock(g_errMutex);
+    g_lastError = msg ? msg : "";
+    return code;
+}
+
+int rs_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    std::string m = std::string(what ? what : "hip") + ": " + hipGetErrorString(e);
+    return rs_fail((int)e, m.c_str());
+}
+
+hipStream_t rs_stream() { return g_stream; }
+bool rs_sync_enabled() { return g_sync; }
+
+int rs_after_launch(const char* what) {
+    RS_TRY(rs_check_hip(hipGetLastError(), what));
+    if (g_sync) RS_TRY(rs_check_hip(hipStreamSynchronize(g_stream), what));
+    return 0;
+}
+
+rs::CamParams rs_make_cam_params(const rs_camera* cam) {
+    using namespace rs;
+    CamParams c;
+    c.position = ld3(cam->position);
+    c.right = ld3(cam->right);
+    c.up = ld3(cam->up);
+    c.view = ld3(cam->view);
+    c.inv0 = ld3(cam->rotationMatInv);
+    c.inv1 = ld3(cam->rotationMatInv + 3);
+    c.inv2 = ld3(cam->rotationMatInv + 6);
+    c.width = cam->resolution[0];
+    c.height = cam->resolution[1];
+    c.aspect = (float)cam->resolution[0] / (float)cam->resolution[1];
+    c.tanFovY = tanf(radians(cam->fov[1]));            // glm::tan(glm::radians(fov.y)), sceneStructs.h:72
+    c.focalDist = cam->focalDist;
+    c.lensRadius = cam->lensRadius;
+    c.pixelSizeX = 1.f / (float)cam->resolution[0];
+    c.pixelSizeY = 1.f / (float)cam->resolution[1];
+    return c;
+}
+
+extern "C" {
+
+const char* rs_last_error(void) {
+    std::lock_guard<std::mutex> lock(g_errMutex);
+    static thread_local std::string copy;
+    copy = g_lastError;
+    return copy.c_str();
+}
+
+int rs_init(int device) {
+    int n = 0;
+    RS_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_init: no HIP device visible (the MI355X path has no CPU fallback)");
+    if (device < 0 || device >= n) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_init: device index out of range");
+    RS_HIP(hipSetDevice(device));
+    return 0;
+}
+
+int rs_set_stream(void* hipStream) { g_stream = (hipStream_t)hipStream; return 0; }
+int rs_set_sync(int sync) { g_sync = sync != 0; return 0; }
+int rs_synchronize(void) { return rs_check_hip(hipStreamSynchronize(g_stream), "rs_synchronize"); }
+
+}  // extern "C"

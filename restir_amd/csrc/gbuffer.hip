@@ -1,0 +1,121 @@
+// gbuffer.hip -- GBuffer::create/destroy (src/denoiser.cu:373-403), GBuffer::render / update and the
+// renderGBuffer kernel (src/gbuffer.cu:3-86).
+//
+// Kernel: one lane per pixel, each 64-lane wave owns an 8x8 pixel tile so that the rays of a wave
+// stay coherent during the closest-hit walk (the walk is the cost; the 36 B/px of plane writes are
+// coalesced in 8-pixel row segments).  HBM per pixel: write albedo 12 + normal 12 + id 4 + depth 4
+// + motion 4 = 36 B; BVH node/triangle reads are data dependent and mostly served by L2 / MALL.
+#include "rs_internal.h"
+
+using namespace rs;
+
+struct GBufWrite {
+    float* albedo; int* motion; float* normal; int* primId; float* depth;
+};
+
+__global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
+                                                        int y0, int y1, int tilesX) {
+    // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const int x = bx * 32 + wave * 8 + (lane & 7);
+    const int y = y0 + by * 8 + (lane >> 3);
+    if (x >= cam.width || y >= y1) return;
+    const int idx = y * cam.width + x;
+
+    Ray ray = camera_center_ray(cam, x, y);
+    Hit h = trace_closest(s, ray);
+
+    if (h.primId != kNullPrim) {
+        int matId = h.matId;
+        const rs_material m = s.materials[h.matId];
+        if (m.type == 4) matId = kNullPrim - 1;          // lights -> -2 (gbuffer.cu:30-31)
+        st3(g.albedo + (size_t)idx * 3, ld3(m.baseColor));
+        st3(g.normal + (size_t)idx * 3, h.norm);
+        g.primId[idx] = matId;
+        g.depth[idx] = length(ray.o - h.pos);            // glm::distance(pos, origin) = length(origin - pos)
+        int lx, ly;
+        camera_raster_coord(lastCam, h.pos, lx, ly);
+        g.motion[idx] = (lx >= 0 && lx < cam.width && ly >= 0 && ly < cam.height) ? ly * cam.width + lx : -1;
+    }
+    else {
+        st3(g.albedo + (size_t)idx * 3, splat(0.f));
+        st3(g.normal + (size_t)idx * 3, splat(0.f));
+        g.primId[idx] = kNullPrim;
+        g.depth[idx] = 1.f;
+        g.motion[idx] = 0;
+    }
+}
+
+extern "C" {
+
+int rs_gbuffer_destroy(rs_gbuffer* g) {
+    if (!g) return 0;
+    rs_dev_free(g->devAlbedo); rs_dev_free(g->devMotion);
+    for (int i = 0; i < 2; i++) { rs_dev_free(g->devNormal[i]); rs_dev_free(g->devPrimId[i]); rs_dev_free(g->devDepth[i]); }
+    delete g;
+    return 0;
+}
+
+int rs_gbuffer_create(int width, int height, rs_gbuffer** out) {
+    if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_create: bad size");
+    *out = nullptr;
+    rs_gbuffer* g = new rs_gbuffer();
+    g->width = width; g->height = height;
+    const size_t n = (size_t)width * height;
+    int e = 0;
+    if (!e) e = rs_dev_alloc(&g->devAlbedo, n * 3);
+    if (!e) e = rs_dev_alloc(&g->devMotion, n);
+    for (int i = 0; i < 2 && !e; i++) {
+        if (!e) e = rs_dev_alloc(&g->devNormal[i], n * 3);
+        if (!e) e = rs_dev_alloc(&g->devPrimId[i], n);
+        if (!e) e = rs_dev_alloc(&g->devDepth[i], n);
+    }
+    // The reference leaves the planes uninitialised (cudaMalloc only).  They are zeroed here so that
+    // first-frame reads of the "last" planes are deterministic; no reference-visible value changes.
+    if (!e) e = rs_check_hip(hipMemset(g->devAlbedo, 0, n * 12), "memset");
+    if (!e) e = rs_check_hip(hipMemset(g->devMotion, 0, n * 4), "memset");
+    for (int i = 0; i < 2 && !e; i++) {
+        if (!e) e = rs_check_hip(hipMemset(g->devNormal[i], 0, n * 12), "memset");
+        if (!e) e = rs_check_hip(hipMemset(g->devPrimId[i], 0, n * 4), "memset");
+        if (!e) e = rs_check_hip(hipMemset(g->devDepth[i], 0, n * 4), "memset");
+    }
+    if (e) { rs_gbuffer_destroy(g); return e; }
+    *out = g;
+    return 0;
+}
+
+int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, int y0, int y1) {
+    if (!g || !scene || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_render: null argument");
+    if (cam->resolution[0] != g->width || cam->resolution[1] != g->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_render: camera resolution differs from the G-buffer size");
+    if (y0 < 0) y0 = 0;
+    if (y1 > g->height) y1 = g->height;
+    if (y1 <= y0) return 0;
+    GBufWrite w{ g->devAlbedo, g->devMotion, g->devNormal[g->frameIdx], g->devPrimId[g->frameIdx], g->devDepth[g->frameIdx] };
+    const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
+    hipLaunchKernelGGL(k_render_gbuffer, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(),
+                       scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
+    return rs_after_launch("renderGBuffer");
+}
+
+int rs_gbuffer_render(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam) {
+    return rs_gbuffer_render_rows(g, scene, cam, 0, g ? g->height : 0);
+}
+
+int rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam) {
+    if (!g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_update: null argument");
+    g->lastCamera = *cam;
+    g->frameIdx ^= 1;
+    return 0;
+}
+
+int rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* v) {
+    if (!g || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_get_view: null argument");
+    v->devAlbedo = g->devAlbedo; v->devMotion = g->devMotion;
+    for (int i = 0; i < 2; i++) { v->devNormal[i] = g->devNormal[i]; v->devPrimId[i] = g->devPrimId[i]; v->devDepth[i] = g->devDepth[i]; }
+    v->frameIdx = g->frameIdx; v->width = g->width; v->height = g->height;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// pathtrace.hip -- the non-ReSTIR baseline pass and the display conversion of src/pathtrace.cu:
+//   PTDirectKernel / pathTraceDirect   (src/pathtrace.cu:279-328,457-476)
+//   sendImageToPBO / copyImageToPBO    (src/pathtrace.cu:30-56,108-113; tone-map ops mathUtil.h:102-117)
+#include "rs_internal.h"
+
+using namespace rs;
+
+namespace {
+
+// sampleDirectLight (src/scene.h:427-459): like the NoVisibility form, but with an occlusion test to
+// the sampled point before the single-sided test.
+__device__ inline float sample_light_visible(const DevScene& s, f3 pos, f4 r, f3& Li, f3& wi, int& walks) {
+    LightSample c = sample_light_nv<const AliasRec*, const LightRec*>(s.alias, s.lights, s.numLights, pos, r);
+    if (s.numLights == 0) return kInvalidPdf;
+    walks++;
+    if (trace_occluded(s, pos, c.point)) return kInvalidPdf;
+    Li = c.Li; wi = c.wi;
+    return c.pdf;
+}
+
+__global__ void __launch_bounds__(256) k_pt_direct(DevScene s, CamParams cam, float* __restrict__ directIllum,
+                                                   int looper, int iter, int tilesX, unsigned long long* rayCount) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const int x = bx * 32 + wave * 8 + (lane & 7);
+    const int y = by * 8 + (lane >> 3);
+    int walks = 0;
+    if (x < cam.width && y < cam.height) {
+        const int index = y * cam.width + x;
+        f3 direct = splat(0.f);
+        Rng rng = seeded_rng(looper, index, 0);
+        f4 r = rng.uniform4();
+        Ray ray = camera_sample(cam, x, y, r.x, r.y);
+        Hit h = trace_closest(s, ray);
+        walks = 1;
+        if (h.primId != kNullPrim) {
+            const rs_material m = s.materials[h.matId];
+            if (m.type == 4) {
+                direct = ld3(m.baseColor);
+            }
+            else {
+                f3 wo = -ray.d;
+                f3 norm = h.norm;
+                const bool delta = m.type == 2;
+                if (!delta && dot(norm, wo) < 0.f) norm = -norm;
+                if (!delta) {
+                    f3 Li = splat(0.f), wi = splat(0.f);
+                    f4 rl = rng.uniform4();
+                    float pdf = sample_light_visible(s, h.pos, rl, Li, wi, walks);
+                    if (pdf > 0.f)
+                        direct = ((Li * eval_bsdf(m.type, ld3(m.baseColor), m.metallic, m.roughness, norm, wo, wi)) * sat_dot(norm, wi)) / pdf;
+                }
+            }
+        }
+        float* o = directIllum + (size_t)index * 3;
+        st3(o, (ld3(o) * (float)iter + direct) / (float)(iter + 1));
+    }
+    // wave-level sum of walks, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) walks += __shfl_down(walks, off);
+    if (lane == 0 && walks) atomicAdd(rayCount, (unsigned long long)walks);
+}
+
+__device__ __forceinline__ float filmic_curve(float c) {
+    return (c * (c * 0.22f + 0.03f) + 0.002f) / (c * (c * 0.22f + 0.3f) + 0.06f) - 1.f / 30.f;
+}
+// correctGamma: glm::pow(c, 1/2.2f).  Evaluated in double and rounded once so that the 8-bit
+// quantisation below sees the correctly rounded float power.
+__device__ __forceinline__ float gamma_pow(float c) { return (float)pow((double)c, (double)(1.f / 2.2f)); }
+
+__global__ void __launch_bounds__(256) k_send_image_to_pbo(uchar4* __restrict__ pbo, const float* __restrict__ image,
+                                                           int n, int toneMapping, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 c = ld3(image + (size_t)i * 3) * scale;
+    if (toneMapping == 1) {                                            // Math::filmic
+        f3 t = c * 1.6f;
+        const float d = filmic_curve(11.2f);
+        c = mk3(filmic_curve(t.x) / d, filmic_curve(t.y) / d, filmic_curve(t.z) / d);
+    }
+    else if (toneMapping == 2) {                                       // Math::ACES
+        c = (c * (c * 2.51f + 0.03f)) / (c * (c * 2.43f + 0.59f) + 0.14f);
+    }
+    c = mk3(gamma_pow(c.x), gamma_pow(c.y), gamma_pow(c.z));
+    pbo[i] = make_uchar4((unsigned char)iclamp(f2i(c.x * 255.f), 0, 255), (unsigned char)iclamp(f2i(c.y * 255.f), 0, 255),
+                         (unsigned char)iclamp(f2i(c.z * 255.f), 0, 255), 0);
+}
+
+unsigned long long* g_ptRayCount = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+int rs_path_trace_init(void) {
+    if (!g_ptRayCount) RS_TRY(rs_dev_alloc(&g_ptRayCount, 1));
+    return 0;
+}
+int rs_path_trace_free(void) { rs_dev_free(g_ptRayCount); return 0; }
+
+int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, int iter, int looper, unsigned long long* rays) {
+    if (!scene || !cam || !devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceDirect: null argument");
+    RS_TRY(rs_path_trace_init());
+    RS_HIP(hipMemsetAsync(g_ptRayCount, 0, 8, rs_stream()));
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
+    hipLaunchKernelGGL(k_pt_direct, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
+                       devDirectIllum, looper, iter, tilesX, g_ptRayCount);
+    RS_TRY(rs_after_launch("pathTrace"));
+    if (rays) {
+        RS_HIP(hipStreamSynchronize(rs_stream()));
+        RS_HIP(hipMemcpy(rays, g_ptRayCount, 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int height, int toneMapping, float scale) {
+    if (!devPBO || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "copyImageToPBO: bad argument");
+    const int n = width * height;
+    hipLaunchKernelGGL(k_send_image_to_pbo, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
+    return rs_after_launch("copyImageToPBO");
+}
+
+}  // extern "C"

@@ -1,0 +1,566 @@
+// restir.hip -- ReSTIRDirect (src/restir.cu:20-231,418-518) for CDNA4.
+//
+// The reference is one fused kernel per frame with a block-level __syncthreads() standing in for a
+// grid-wide dependency.  Here the frame is four launches on one stream, which gives
+// the two-phase contract by construction (stream order is the grid barrier):
+//
+//   phase A  k_primary          jittered primary ray, closest-hit MTBVH walk          restir.cu:127-153
+//            k_ris              32-candidate RIS over the light table (no rays)       restir.cu:155-170
+//            k_shadow_temporal  shadow ray on the RIS winner, temporal merge,
+//                               publish reservoirs                                    restir.cu:172-194,211-212
+//   phase B  k_spatial_shade    5-tap spatial reuse from an LDS-staged tile+halo,
+//                               shade, accumulate                                     restir.cu:196-230
+//
+// Splitting the walk-bound passes from the ALU-bound RIS loop keeps the traversal kernels at low
+// register counts (many waves per SIMD to hide the dependent node fetches) and lets the RIS kernel
+// run without divergence.  The price is ~100 B/px of per-pixel state between passes (surf*/cand*
+// planes below), which is small next to the walks.
+//
+// Reservoir storage is four planes (rs_internal.h ResvPlanes).  The spatial pass stages only the
+// planes its neighbour tests need -- weight, M, G-buffer id / normal / depth -- for a 32x8 tile
+// plus a 5-pixel halo into LDS (21 KB), tracks the SOURCE PIXEL of the surviving sample through the
+// merges, and gathers that one sample (32 B) at the end instead of staging Li/wi for 756 pixels.
+#include "rs_internal.h"
+
+using namespace rs;
+
+namespace {
+
+constexpr int kReservoirSize = 32;   // restir.cu:3
+constexpr int kTileW = 32, kTileH = 8, kHalo = RS_SPATIAL_HALO_ROWS;
+constexpr int kStageW = kTileW + 2 * kHalo, kStageH = kTileH + 2 * kHalo, kStageN = kStageW * kStageH;
+
+// kind of a pixel after the primary hit
+constexpr int kKindMiss = 0, kKindLight = 1, kKindShaded = 2;
+
+struct SurfPlanes {
+    float4* posMat;     // pos.xyz, bits(matId | kind << 24)
+    float4* normRng;    // shading normal xyz, bits(rng state)
+    float4* wo;         // wo.xyz, 0
+    int*    matKind;    // matId | kind << 24 (dense copy for the spatial pass)
+    float4* candLi;     // RIS winner Li.xyz, dist
+    float4* candWi;     // RIS winner wi.xyz, reservoir weight
+};
+
+__device__ __forceinline__ void pixel_of_lane(int tilesX, int y0, int& x, int& y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    x = bx * 32 + wave * 8 + (lane & 7);
+    y = y0 + by * 8 + (lane >> 3);
+}
+
+// ---- phase A.1: primary hit ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+                                                 int y0, int y1, int tilesX, unsigned long long* rayCount) {
+    int x, y;
+    pixel_of_lane(tilesX, y0, x, y);
+    const bool inside = x < cam.width && y < y1;
+    int shaded = 0;
+    if (inside) {
+        const int index = y * cam.width + x;
+        Rng rng = seeded_rng(looper, index, 0);
+        f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
+        Ray ray = camera_sample(cam, x, y, r.x, r.y);
+        Hit h = trace_closest(s, ray);
+
+        int kind = kKindMiss, matId = 0;
+        f3 norm = splat(0.f), wo = splat(0.f);
+        if (h.primId != kNullPrim) {
+            matId = h.matId;
+            const int type = s.materials[matId].type;
+            if (type == 4) {
+                kind = kKindLight;
+            }
+            else {
+                kind = kKindShaded;
+                wo = -ray.d;
+                norm = h.norm;
+                if (type != 2 && dot(norm, wo) < 0.f) norm = -norm;     // restir.cu:150-153
+                shaded = 1;
+            }
+        }
+        const int mk = matId | (kind << 24);
+        sp.posMat[index] = make_float4(h.pos.x, h.pos.y, h.pos.z, __int_as_float(mk));
+        sp.normRng[index] = make_float4(norm.x, norm.y, norm.z, __uint_as_float(rng.x));
+        sp.wo[index] = make_float4(wo.x, wo.y, wo.z, 0.f);
+        sp.matKind[index] = mk;
+    }
+    // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
+    const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
+        if (c) atomicAdd(rayCount, c);
+    }
+}
+
+// ---- phase A.2: RIS over the light table ----------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
+    const int n0 = y0 * width, n1 = y1 * width;
+    const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= n1) return;
+    const float4 pm = sp.posMat[index];
+    const int mk = __float_as_int(pm.w);
+    if ((mk >> 24) != kKindShaded) return;
+    const float4 nr = sp.normRng[index];
+    const f3 pos = mk3(pm.x, pm.y, pm.z), norm = mk3(nr.x, nr.y, nr.z);
+    const rs_material m = s.materials[mk & 0xffffff];
+    const f3 baseColor = splat(1.f);                       // material.baseColor = 1 (restir.cu:141)
+    f3 wo = splat(0.f);
+    if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); }
+
+    Rng rng; rng.x = __float_as_uint(nr.w);
+    f3 selLi = splat(0.f), selWi = splat(0.f);
+    float selDist = 0.f, wsum = 0.f;
+    for (int i = 0; i < kReservoirSize; i++) {
+        f4 r = rng.uniform4();
+        LightSample c = sample_light_nv<const AliasRec*, const LightRec*>(s.alias, s.lights, s.numLights, pos, r);
+        f3 g = c.Li * eval_bsdf(m.type, baseColor, m.metallic, m.roughness, norm, wo, c.wi) * sat_dot(norm, c.wi);
+        float weight = luminance(g / c.pdf);
+        if (is_nan_or_inf(weight) || c.pdf <= 0.f) weight = 0.f;
+        float u = rng.uniform();
+        wsum += weight;                                    // Reservoir::update (restir.h:38-44)
+        if (u * wsum < weight) { selLi = c.Li; selWi = c.wi; selDist = c.dist; }
+    }
+    sp.candLi[index] = make_float4(selLi.x, selLi.y, selLi.z, selDist);
+    sp.candWi[index] = make_float4(selWi.x, selWi.y, selWi.z, wsum);
+    sp.normRng[index] = make_float4(nr.x, nr.y, nr.z, __uint_as_float(rng.x));
+}
+
+// ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------
+struct Resv { f3 Li, wi; float dist; int M; float W; };
+
+__device__ __forceinline__ bool resv_invalid(float W) { return is_nan_or_inf(W) || W < 0.f; }   // restir.h:51-53
+
+__device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Resv& r) {
+    p.li[i] = make_float4(r.Li.x, r.Li.y, r.Li.z, r.dist);
+    p.wi[i] = make_float4(r.wi.x, r.wi.y, r.wi.z, 0.f);
+    p.w[i] = r.W;
+    p.m[i] = r.M;
+}
+
+__global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last,
+                                                         ResvPlanes cur, ResvPlanes temp, int first, int reuse,
+                                                         int y0, int y1, int tilesX) {
+    int x, y;
+    pixel_of_lane(tilesX, y0, x, y);
+    if (x >= g.width || y >= y1) return;
+    const int index = y * g.width + x;
+    const float4 pm = sp.posMat[index];
+    if ((__float_as_int(pm.w) >> 24) != kKindShaded) return;     // early-exit pixels publish nothing (Q1)
+    const float4 cl = sp.candLi[index], cw = sp.candWi[index];
+    const f3 pos = mk3(pm.x, pm.y, pm.z);
+
+    Resv r;
+    r.Li = mk3(cl.x, cl.y, cl.z); r.wi = mk3(cw.x, cw.y, cw.z); r.dist = cl.w;
+    r.M = kReservoirSize; r.W = cw.w;
+
+    if (trace_occluded(s, pos, pos + r.wi * r.dist)) r.W = 0.f;   // restir.cu:172-176
+
+    if (!first && (reuse & 1)) {                                  // findTemporalNeighbor, restir.cu:20-45
+        const int primId = g.primId[index];
+        const int lastIdx = g.motion[index];
+        bool diff = false;
+        if (lastIdx < 0) diff = true;
+        else if (primId <= kNullPrim) diff = true;
+        else if (g.lastPrimId[lastIdx] != primId) diff = true;
+        else {
+            f3 n = ld3(g.normal + (size_t)index * 3), ln = ld3(g.lastNormal + (size_t)lastIdx * 3);
+            float depth = g.depth[index], pdepth = g.lastDepth[lastIdx];
+            if (abs_dot(n, ln) < .9f || gabs(pdepth - depth) > depth * .1f) diff = true;
+        }
+        Resv t;
+        t.Li = splat(0.f); t.wi = splat(0.f); t.dist = 0.f; t.M = 0; t.W = 0.f;
+        if (!diff) {
+            const float4 a = last.li[lastIdx], b = last.wi[lastIdx];
+            t.Li = mk3(a.x, a.y, a.z); t.dist = a.w; t.wi = mk3(b.x, b.y, b.z);
+            t.W = last.w[lastIdx]; t.M = last.m[lastIdx];
+        }
+        if (!resv_invalid(t.W)) {
+            const float4 nr = sp.normRng[index];
+            Rng rng; rng.x = __float_as_uint(nr.w);
+            const float u = rng.uniform();
+            sp.normRng[index] = make_float4(nr.x, nr.y, nr.z, __uint_as_float(rng.x));
+            // preClampedMerge<20> (restir.h:95-102)
+            if (r.M > 0) {
+                const int cap = (20 - 1) * r.M;
+                if (t.M > cap) { t.W *= (float)cap / (float)t.M; t.M = cap; }
+            }
+            r.W += t.W;
+            r.M += t.M;
+            if (u * r.W < t.W) { r.Li = t.Li; r.wi = t.wi; r.dist = t.dist; }
+        }
+    }
+    // checkValidity (restir.h:55-59); the temp copy and the stored copy are the same value
+    if (resv_invalid(r.W)) { r.W = 0.f; r.M = 0; }
+    if (reuse & 2) resv_store(temp, index, r);
+    resv_store(cur, index, r);
+}
+
+// ---- phase B: spatial reuse + shade --------------------------------------------------------------
+__device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& px, int& py) {
+    // Math::toConcentricDisk (mathUtil.h:128-132) * Radius, then int(x + .5f + p.x) (restir.cu:53-55)
+    const float Radius = 5.f;
+    const float rr = sqrtf(rx);
+    const float theta = ry * kPi * 2.0f;
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    float fx = (float)x + .5f + (cs * rr) * Radius;
+    float fy = (float)y + .5f + (sn * rr) * Radius;
+    // The truncation below is the only place where a 1-ulp difference between this libm and the host
+    // libm could change a result.  When a coordinate lands within 2 ulp of an integer the
+    // trigonometry is redone in double precision and rounded once (matches a correctly rounded cosf).
+    const float nx = rintf(fx), ny = rintf(fy);
+    if (gabs(fx - nx) <= 4.f * 1.1920929e-7f * gabs(nx) + 1e-30f || gabs(fy - ny) <= 4.f * 1.1920929e-7f * gabs(ny) + 1e-30f) {
+        double sd, cd;
+        sincos((double)theta, &sd, &cd);
+        fx = (float)x + .5f + ((float)cd * rr) * Radius;
+        fy = (float)y + .5f + ((float)sd * rr) * Radius;
+    }
+    px = f2i(fx);
+    py = f2i(fy);
+}
+
+__global__ void __launch_bounds__(256) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes rp,
+                                                       float* __restrict__ directIllum, int iter, int reuse,
+                                                       int y0, int y1, int tilesX, int numTiles) {
+    __shared__ float sW[kStageN];
+    __shared__ int   sM[kStageN];
+    __shared__ int   sId[kStageN];
+    __shared__ float sDepth[kStageN];
+    __shared__ float sNx[kStageN], sNy[kStageN], sNz[kStageN];
+
+    // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
+    // contiguous run of tiles so neighbouring tiles' halos are served by the same L2.
+    int tile = blockIdx.x;
+    {
+        const int q = numTiles / 8, rem = numTiles % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int ox = (tile % tilesX) * kTileW, oy = y0 + (tile / tilesX) * kTileH;
+    const int W = g.width, H = g.height;
+    const bool spatial = (reuse & 2) != 0;
+
+    if (spatial) {
+        for (int e = threadIdx.x; e < kStageN; e += 256) {
+            const int sx = ox - kHalo + (e % kStageW), sy = oy - kHalo + (e / kStageW);
+            float w = 0.f, d = 0.f, nx = 0.f, ny = 0.f, nz = 0.f; int m = 0, id = -3;
+            if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
+                const int gi = sy * W + sx;
+                w = rp.w[gi]; m = rp.m[gi]; id = g.primId[gi]; d = g.depth[gi];
+                nx = g.normal[(size_t)gi * 3]; ny = g.normal[(size_t)gi * 3 + 1]; nz = g.normal[(size_t)gi * 3 + 2];
+            }
+            sW[e] = w; sM[e] = m; sId[e] = id; sDepth[e] = d; sNx[e] = nx; sNy[e] = ny; sNz[e] = nz;
+        }
+        __syncthreads();
+    }
+
+    const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
+    const int x = ox + tx, y = oy + ty;
+    if (x >= W || y >= y1) return;
+    const int index = y * W + x;
+    const int mk = sp.matKind[index];
+    const int kind = mk >> 24;
+
+    f3 direct = splat(0.f);
+    if (kind == kKindLight) direct = splat(1.f);               // restir.cu:143-146 (baseColor forced to 1)
+    if (kind == kKindShaded) {
+        const float4 nr = sp.normRng[index];
+        const f3 norm = mk3(nr.x, nr.y, nr.z);
+        Rng rng; rng.x = __float_as_uint(nr.w);
+
+        // own reservoir = what phase A published (post-temporal, validity-checked)
+        float W0; int M0; int src = index;
+        if (spatial) {
+            const int c = (ty + kHalo) * kStageW + (tx + kHalo);
+            W0 = sW[c]; M0 = sM[c];
+
+            // mergeSpatialNeighborDirect (restir.cu:87-100)
+            const int idC = sId[c];
+            const f3 nC = mk3(sNx[c], sNy[c], sNz[c]);
+            const float dC = sDepth[c];
+            float aW = 0.f; int aM = 0; int aSrc = -1;
+            for (int i = 0; i < 5; i++) {
+                const f2 r2 = rng.uniform2();
+                int px, py;
+                disk_tap(r2.x, r2.y, x, y, px, py);
+                float tW = 0.f; int tM = 0; int tSrc = -1;           // T(): zero sample, W = 0 (valid)
+                if (!(px < 0 || px >= W || py < 0 || py >= H || (px == x && py == y))) {
+                    const int lx = px - (ox - kHalo), ly = py - (oy - kHalo);
+                    int idP; f3 nP; float dP, wP; int mP;
+                    if (lx >= 0 && lx < kStageW && ly >= 0 && ly < kStageH) {
+                        const int e = ly * kStageW + lx;
+                        idP = sId[e]; nP = mk3(sNx[e], sNy[e], sNz[e]); dP = sDepth[e]; wP = sW[e]; mP = sM[e];
+                    }
+                    else {                                            // outside the staged halo: cannot happen for radius 5, kept for safety
+                        const int gi = py * W + px;
+                        idP = g.primId[gi]; nP = ld3(g.normal + (size_t)gi * 3); dP = g.depth[gi]; wP = rp.w[gi]; mP = rp.m[gi];
+                    }
+                    bool diff = false;
+                    if (idP != idC) diff = true;
+                    else {
+                        if (dot(nC, nP) < .9f) diff = true;
+                        if (gabs(dC - dP) > dC * .1f) diff = true;
+                    }
+                    if (!diff) { tW = wP; tM = mP; tSrc = py * W + px; }
+                }
+                if (!resv_invalid(tW)) {
+                    const float u = rng.uniform();
+                    aW += tW; aM += tM;                                // Reservoir::merge (restir.h:61-68)
+                    if (u * aW < tW) aSrc = tSrc;
+                }
+            }
+            if (!resv_invalid(aW) && !resv_invalid(W0)) {
+                const float u = rng.uniform();
+                W0 += aW; M0 += aM;
+                if (u * W0 < aW) src = aSrc;
+            }
+        }
+        else {
+            // No spatial pass: rp is the buffer phase A published this frame (validity-checked copy of
+            // the post-temporal reservoir).  The reference shades the unchecked one; they differ only
+            // when it was invalid, and then both give direct = 0 (0/0 -> NaN -> cleared below).
+            W0 = rp.w[index]; M0 = rp.m[index];
+        }
+
+        if (!resv_invalid(W0)) {
+            f3 Li = splat(0.f), wi = splat(0.f);
+            if (src >= 0) {
+                const float4 a = rp.li[src], b = rp.wi[src];
+                Li = mk3(a.x, a.y, a.z); wi = mk3(b.x, b.y, b.z);
+            }
+            const rs_material m = s.materials[mk & 0xffffff];
+            f3 wo = splat(0.f);
+            if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); }
+            const f3 LiBSDF = Li * eval_bsdf(m.type, splat(1.f), m.metallic, m.roughness, norm, wo, wi);
+            direct = ((LiBSDF / luminance(LiBSDF)) * W0) / (float)M0;       // restir.cu:220-221
+        }
+        if (any_nan_or_inf(direct)) direct = splat(0.f);
+    }
+    direct = direct * ld3(g.albedo + (size_t)index * 3);
+    float* o = directIllum + (size_t)index * 3;
+    st3(o, (ld3(o) * (float)iter + direct) / (float)(iter + 1));
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side: ReSTIRInit / Free / Reset / Direct (src/restir.cu:418-446,478-518)
+// ================================================================================================
+namespace {
+
+int alloc_planes(ResvPlanes& p, size_t n) {
+    RS_TRY(rs_dev_alloc(&p.li, n)); RS_TRY(rs_dev_alloc(&p.wi, n));
+    RS_TRY(rs_dev_alloc(&p.w, n));  RS_TRY(rs_dev_alloc(&p.m, n));
+    RS_HIP(hipMemset(p.li, 0, n * 16)); RS_HIP(hipMemset(p.wi, 0, n * 16));      // cudaMemset(.., 0, ..) restir.cu:483-489
+    RS_HIP(hipMemset(p.w, 0, n * 4));   RS_HIP(hipMemset(p.m, 0, n * 4));
+    return 0;
+}
+void free_planes(ResvPlanes& p) { rs_dev_free(p.li); rs_dev_free(p.wi); rs_dev_free(p.w); rs_dev_free(p.m); }
+
+ResvPlanes* pick(rs_restir* r, int which) { return which == 0 ? &r->cur : (which == 1 ? &r->last : (which == 2 ? &r->temp : nullptr)); }
+
+SurfPlanes surf_of(rs_restir* r) {
+    SurfPlanes sp;
+    sp.posMat = r->surfPosKind; sp.normRng = r->surfNormRng; sp.wo = r->surfWo; sp.matKind = r->matKind;
+    sp.candLi = r->candLi; sp.candWi = r->candWi;
+    return sp;
+}
+
+int check_frame_args(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g) {
+    if (!r || !scene || !cam || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: null argument");
+    if (cam->resolution[0] != r->width || cam->resolution[1] != r->height || g->width != r->width || g->height != r->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: camera / G-buffer size differs from the size given to rs_restir_init");
+    return 0;
+}
+
+void mark(rs_restir* r, int i) { if (r->timing) (void)hipEventRecord(r->ev[i], rs_stream()); }
+
+}  // namespace
+
+extern "C" {
+
+int rs_restir_free(rs_restir* r) {
+    if (!r) return 0;
+    free_planes(r->cur); free_planes(r->last); free_planes(r->temp);
+    rs_dev_free(r->surfPosKind); rs_dev_free(r->surfNormRng); rs_dev_free(r->surfWo); rs_dev_free(r->matKind);
+    rs_dev_free(r->candLi); rs_dev_free(r->candWi); rs_dev_free(r->dRayCount);
+    for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
+    delete r;
+    return 0;
+}
+
+int rs_restir_init(int width, int height, rs_restir** out) {
+    if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_init: bad size");
+    *out = nullptr;
+    rs_restir* r = new rs_restir();
+    r->width = width; r->height = height;
+    const size_t n = (size_t)width * height;
+    int e = 0;
+    if (!e) e = alloc_planes(r->cur, n);
+    if (!e) e = alloc_planes(r->last, n);
+    if (!e) e = alloc_planes(r->temp, n);
+    if (!e) e = rs_dev_alloc(&r->surfPosKind, n);
+    if (!e) e = rs_dev_alloc(&r->surfNormRng, n);
+    if (!e) e = rs_dev_alloc(&r->surfWo, n);
+    if (!e) e = rs_dev_alloc(&r->matKind, n);
+    if (!e) e = rs_dev_alloc(&r->candLi, n);
+    if (!e) e = rs_dev_alloc(&r->candWi, n);
+    if (!e) e = rs_dev_alloc(&r->dRayCount, 1);
+    if (!e) e = rs_check_hip(hipMemset(r->matKind, 0, n * 4), "memset");
+    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8), "memset");
+    for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
+    if (e) { rs_restir_free(r); return e; }
+    *out = r;
+    return 0;
+}
+
+int rs_restir_reset(rs_restir* r) {
+    if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_reset: null");
+    r->firstFrame = true;
+    return 0;
+}
+
+int rs_restir_enable_timing(rs_restir* r, int enable) {
+    if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_enable_timing: null");
+    r->timing = enable != 0;
+    return 0;
+}
+
+int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                      int looper, int reuse, int y0, int y1) {
+    RS_TRY(check_frame_args(r, scene, cam, g));
+    if (y0 < 0) y0 = 0;
+    if (y1 > r->height) y1 = r->height;
+    RS_HIP(hipMemsetAsync(r->dRayCount, 0, 8, rs_stream()));
+    if (y1 <= y0) return 0;
+    const int W = r->width;
+    const int tilesX = (W + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
+    const SurfPlanes sp = surf_of(r);
+    const CamParams cp = rs_make_cam_params(cam);
+    mark(r, 0);
+    hipLaunchKernelGGL(k_primary, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, r->dRayCount);
+    mark(r, 1);
+    const int npx = (y1 - y0) * W;
+    hipLaunchKernelGGL(k_ris, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+    mark(r, 2);
+    hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
+                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
+    mark(r, 3);
+    return rs_after_launch("ReSTIR Direct (phase A)");
+}
+
+int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                      float* devDirectIllum, int iter, int reuse, int y0, int y1) {
+    RS_TRY(check_frame_args(r, scene, cam, g));
+    if (!devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: null radiance buffer");
+    if (y0 < 0) y0 = 0;
+    if (y1 > r->height) y1 = r->height;
+    if (y1 <= y0) return 0;
+    const int tilesX = (r->width + kTileW - 1) / kTileW, tilesY = (y1 - y0 + kTileH - 1) / kTileH;
+    const int numTiles = tilesX * tilesY;
+    hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(256), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
+                       (reuse & 2) ? r->temp : r->cur, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
+    mark(r, 4);
+    return rs_after_launch("ReSTIR Direct (phase B)");
+}
+
+int rs_restir_end_frame(rs_restir* r) {
+    if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_end_frame: null");
+    ResvPlanes t = r->cur; r->cur = r->last; r->last = t;       // std::swap(devDirectReservoir, devLastDirectReservoir)
+    r->firstFrame = false;
+    return 0;
+}
+
+int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                     float* devDirectIllum, int iter, int looper, int reuse) {
+    RS_TRY(check_frame_args(r, scene, cam, g));
+    const bool sync = rs_sync_enabled();
+    rs_set_sync(0);                                               // one synchronisation for the whole call
+    int e = rs_restir_phase_a(r, scene, cam, g, looper, reuse, 0, r->height);
+    if (!e) e = rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, 0, r->height);
+    rs_set_sync(sync ? 1 : 0);
+    if (e) return e;
+    RS_TRY(rs_restir_end_frame(r));
+    return rs_after_launch("ReSTIR Direct");
+}
+
+size_t rs_restir_halo_bytes(const rs_restir* r, int rows) {
+    return r ? (size_t)r->width * (size_t)(rows > 0 ? rows : 0) * 40u : 0;
+}
+
+// packed layout: [li rows][wi rows][w rows][m rows]
+int rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer) {
+    if (!r || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_halo_pack: bad rows");
+    const size_t n = (size_t)r->width * rows, off = (size_t)y0 * r->width;
+    char* b = (char*)devBuffer;
+    RS_HIP(hipMemcpyAsync(b, r->temp.li + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 16, r->temp.wi + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 32, r->temp.w + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 36, r->temp.m + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    return rs_after_launch("rs_restir_halo_pack");
+}
+
+int rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer) {
+    if (!r || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_halo_unpack: bad rows");
+    const size_t n = (size_t)r->width * rows, off = (size_t)y0 * r->width;
+    const char* b = (const char*)devBuffer;
+    RS_HIP(hipMemcpyAsync(r->temp.li + off, b, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(r->temp.wi + off, b + n * 16, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(r->temp.w + off, b + n * 32, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(r->temp.m + off, b + n * 36, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    return rs_after_launch("rs_restir_halo_unpack");
+}
+
+int rs_restir_download(const rs_restir* rc, int which, rs_reservoir* host) {
+    rs_restir* r = const_cast<rs_restir*>(rc);
+    ResvPlanes* p = r ? pick(r, which) : nullptr;
+    if (!p || !host) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_download: bad argument");
+    const size_t n = (size_t)r->width * r->height;
+    std::vector<float4> li(n), wi(n); std::vector<float> w(n); std::vector<int> m(n);
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(li.data(), p->li, n * 16, hipMemcpyDeviceToHost));
+    RS_HIP(hipMemcpy(wi.data(), p->wi, n * 16, hipMemcpyDeviceToHost));
+    RS_HIP(hipMemcpy(w.data(), p->w, n * 4, hipMemcpyDeviceToHost));
+    RS_HIP(hipMemcpy(m.data(), p->m, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        host[i].Li[0] = li[i].x; host[i].Li[1] = li[i].y; host[i].Li[2] = li[i].z;
+        host[i].wi[0] = wi[i].x; host[i].wi[1] = wi[i].y; host[i].wi[2] = wi[i].z;
+        host[i].dist = li[i].w; host[i].numSamples = m[i]; host[i].weight = w[i];
+    }
+    return 0;
+}
+
+int rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host) {
+    ResvPlanes* p = r ? pick(r, which) : nullptr;
+    if (!p || !host) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_upload: bad argument");
+    const size_t n = (size_t)r->width * r->height;
+    std::vector<float4> li(n), wi(n); std::vector<float> w(n); std::vector<int> m(n);
+    for (size_t i = 0; i < n; i++) {
+        li[i] = make_float4(host[i].Li[0], host[i].Li[1], host[i].Li[2], host[i].dist);
+        wi[i] = make_float4(host[i].wi[0], host[i].wi[1], host[i].wi[2], 0.f);
+        w[i] = host[i].weight; m[i] = host[i].numSamples;
+    }
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(p->li, li.data(), n * 16, hipMemcpyHostToDevice));
+    RS_HIP(hipMemcpy(p->wi, wi.data(), n * 16, hipMemcpyHostToDevice));
+    RS_HIP(hipMemcpy(p->w, w.data(), n * 4, hipMemcpyHostToDevice));
+    RS_HIP(hipMemcpy(p->m, m.data(), n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int rs_restir_ray_count(rs_restir* r, unsigned long long* rays) {
+    if (!r || !rays) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_count: null");
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(rays, r->dRayCount, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rs_restir_pass_times(rs_restir* r, float ms[4]) {
+    if (!r || !ms) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_pass_times: null");
+    if (!r->timing) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_pass_times: timing is not enabled");
+    RS_HIP(hipEventSynchronize(r->ev[4]));
+    for (int i = 0; i < 4; i++) RS_HIP(hipEventElapsedTime(&ms[i], r->ev[i], r->ev[i + 1]));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// rs_internal.h -- host-side objects behind the opaque handles of include/restir_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "rs_scene.h"
+
+// ---- error plumbing --------------------------------------------------------------------------
+int rs_fail(int code, const char* msg);                 // records msg, returns code
+int rs_check_hip(hipError_t e, const char* what);       // 0 on success
+hipStream_t rs_stream();
+bool rs_sync_enabled();
+// after a launch: hipGetLastError (+ stream sync when sync mode is on), like checkCUDAError
+int rs_after_launch(const char* what);
+
+#define RS_TRY(expr)                                       \
+    do {                                                   \
+        int _rs_e = (expr);                                \
+        if (_rs_e != 0) return _rs_e;                      \
+    } while (0)
+#define RS_HIP(expr) RS_TRY(rs_check_hip((expr), #expr))
+
+template <typename T>
+static inline int rs_dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    return rs_check_hip(hipMalloc((void**)p, sizeof(T) * count), "hipMalloc");
+}
+template <typename T>
+static inline void rs_dev_free(T*& p) {
+    if (p) { (void)hipFree((void*)p); p = nullptr; }
+}
+
+// ---- scene -------------------------------------------------------------------------------------
+struct rs_scene {
+    rs::DevScene dev{};              // passed to kernels by value (pointers into the arrays below)
+    // owned device arrays
+    rs::BvhNode* dNodes[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    rs::TriRec* dTris = nullptr;
+    float* dVertices = nullptr;
+    float* dNormals = nullptr;
+    int* dMaterialIds = nullptr;
+    rs_material* dMaterials = nullptr;
+    rs::LightRec* dLights = nullptr;
+    rs::AliasRec* dAlias = nullptr;
+    // host copies of the source arrays (rs_scene_host_desc)
+    std::vector<float> hVertices, hNormals, hTexcoords, hBoxes, hLightRadiance, hLightProb;
+    std::vector<int> hMaterialIds, hNodes[6], hLightPrimIds, hLightFailId;
+    std::vector<rs_material> hMaterials;
+    float sumLightPower = 0.f;
+    int numPrims = 0, bvhSize = 0, numLights = 0;
+};
+
+// ---- G-buffer (src/gbuffer.h:41-58) ------------------------------------------------------------
+struct rs_gbuffer {
+    float* devAlbedo = nullptr;
+    int* devMotion = nullptr;
+    float* devNormal[2] = { nullptr, nullptr };
+    int* devPrimId[2] = { nullptr, nullptr };
+    float* devDepth[2] = { nullptr, nullptr };
+    int frameIdx = 0;
+    rs_camera lastCamera{};      // uninitialised in the reference until the first update (Q14); zero here
+    int width = 0, height = 0;
+};
+
+// device view of the planes the kernels read
+struct GBufView {
+    const float* albedo;
+    const int* motion;
+    const float* normal; const float* lastNormal;
+    const int* primId;   const int* lastPrimId;
+    const float* depth;  const float* lastDepth;
+    int width, height;
+};
+static inline GBufView gbuf_view(const rs_gbuffer* g) {
+    GBufView v;
+    v.albedo = g->devAlbedo; v.motion = g->devMotion;
+    v.normal = g->devNormal[g->frameIdx]; v.lastNormal = g->devNormal[g->frameIdx ^ 1];
+    v.primId = g->devPrimId[g->frameIdx]; v.lastPrimId = g->devPrimId[g->frameIdx ^ 1];
+    v.depth = g->devDepth[g->frameIdx]; v.lastDepth = g->devDepth[g->frameIdx ^ 1];
+    v.width = g->width; v.height = g->height;
+    return v;
+}
+
+// ---- reservoirs ----------------------------------------------------------------------------------
+// One Reservoir<DirectLiSample> (36 B AoS in the reference, src/restir.h:114-116) is stored as four
+// planes so that streaming passes read 16 B / lane and the spatial pass can stage only what its
+// neighbour tests need:
+//   li  float4[N]  { Li.x, Li.y, Li.z, dist }
+//   wi  float4[N]  { wi.x, wi.y, wi.z, 0    }
+//   w   float [N]  weight
+//   m   int   [N]  numSamples
+struct ResvPlanes {
+    float4* li = nullptr;
+    float4* wi = nullptr;
+    float*  w = nullptr;
+    int*    m = nullptr;
+};
+
+struct rs_restir {
+    int width = 0, height = 0;
+    ResvPlanes cur;      // devDirectReservoir      (written this frame)
+    ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
+    ResvPlanes temp;     // devDirectTemp           (published for the spatial pass)
+    bool firstFrame = true;
+    // per-pixel state carried between the passes of one frame (implementation bytes, not in the
+    // reference: its single fused kernel keeps these in registers)
+    float4* surfPosKind = nullptr;   // hit position xyz, w = bit pattern of (matId | kind<<24)
+    float4* surfNormRng = nullptr;   // shading normal xyz (flipped to wo side), w = RNG state bits
+    float4* surfWo = nullptr;        // wo xyz (read only for non-Lambertian materials)
+    int*    matKind = nullptr;       // matId | kind<<24, dense copy for the spatial pass
+    float4* candLi = nullptr;        // RIS winner: Li xyz, w = dist
+    float4* candWi = nullptr;        // RIS winner: wi xyz, w = weight (sum of candidate weights)
+    unsigned long long* dRayCount = nullptr;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+};
+
+struct rs_eaw {
+    int width = 0, height = 0, level = 0;
+    float sigLumin = 64.f, sigNormal = .2f, sigDepth = 1.f;     // src/denoiser.cu:455
+    float* devTempImg = nullptr;
+    float* devPos = nullptr;        // per-pixel cam.getPosition(x,y,depth), computed once per filter call
+};
+
+rs::CamParams rs_make_cam_params(const rs_camera* cam);

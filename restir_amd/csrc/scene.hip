@@ -1,0 +1,228 @@
+// scene.hip -- DevScene::create / destroy (src/scene.cpp:435-532) re-laid-out for CDNA4 (see
+// rs_scene.h), Scene::buildDevData as one call, and batched ray entry points for parity tests.
+#include <cmath>
+#include <cstring>
+
+#include "rs_internal.h"
+
+using namespace rs;
+
+namespace {
+
+int check_materials(int n, const rs_material* m) {
+    for (int i = 0; i < n; i++) {
+        if (m[i].baseColorMapId != -1 || m[i].metallicMapId != -1 || m[i].roughnessMapId != -1 || m[i].normalMapId != -1)
+            return rs_fail(RS_ERR_UNSUPPORTED, "material textures are outside the scope of this path (DESIGN.md); map ids must be -1");
+    }
+    return 0;
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+    RS_TRY(rs_dev_alloc(dst, src.size()));
+    if (!src.empty()) RS_HIP(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int rs_scene_destroy(rs_scene* s) {
+    if (!s) return 0;
+    for (int k = 0; k < 6; k++) rs_dev_free(s->dNodes[k]);
+    rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
+    rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
+    delete s;
+    return 0;
+}
+
+extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
+    if (!d || !out) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: null argument");
+    *out = nullptr;
+    if (d->numPrims <= 0 || d->bvhSize != 2 * d->numPrims - 1 || !d->vertices || !d->normals || !d->materialIds ||
+        !d->materials || d->numMaterials <= 0 || !d->boundingBoxes)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: inconsistent scene description");
+    for (int k = 0; k < 6; k++)
+        if (!d->bvhNodes[k]) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: missing BVH order");
+    RS_TRY(check_materials(d->numMaterials, d->materials));
+
+    const size_t np = (size_t)d->numPrims, nn = (size_t)d->bvhSize, nl = (size_t)(d->numLights > 0 ? d->numLights : 0);
+    rs_scene* s = new rs_scene();
+    s->numPrims = d->numPrims; s->bvhSize = d->bvhSize; s->numLights = (int)nl;
+    s->sumLightPower = d->sumLightPower;
+    s->hVertices.assign(d->vertices, d->vertices + np * 9);
+    s->hNormals.assign(d->normals, d->normals + np * 9);
+    if (d->texcoords) s->hTexcoords.assign(d->texcoords, d->texcoords + np * 6); else s->hTexcoords.assign(np * 6, 0.f);
+    s->hMaterialIds.assign(d->materialIds, d->materialIds + np);
+    s->hMaterials.assign(d->materials, d->materials + d->numMaterials);
+    s->hBoxes.assign(d->boundingBoxes, d->boundingBoxes + nn * 6);
+    for (int k = 0; k < 6; k++) s->hNodes[k].assign(d->bvhNodes[k], d->bvhNodes[k] + nn * 3);
+    if (nl) {
+        s->hLightPrimIds.assign(d->lightPrimIds, d->lightPrimIds + nl);
+        s->hLightRadiance.assign(d->lightUnitRadiance, d->lightUnitRadiance + nl * 3);
+        s->hLightProb.assign(d->lightProb, d->lightProb + nl);
+        s->hLightFailId.assign(d->lightFailId, d->lightFailId + nl);
+    }
+
+    // validate indices the kernels will chase (a bad link would walk off the arrays on the GPU)
+    for (size_t i = 0; i < np; i++)
+        if (s->hMaterialIds[i] < 0 || s->hMaterialIds[i] >= d->numMaterials) { delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: material id out of range"); }
+    for (int k = 0; k < 6; k++)
+        for (size_t i = 0; i < nn; i++) {
+            const int* n = &s->hNodes[k][i * 3];
+            if (n[0] < -1 || n[0] >= d->numPrims || n[1] < 0 || n[1] >= d->bvhSize || n[2] <= (int)i || n[2] > d->bvhSize) {
+                delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: malformed MTBVH node (links must point forward)");
+            }
+        }
+    for (size_t i = 0; i < nl; i++)
+        if (s->hLightPrimIds[i] < 0 || s->hLightPrimIds[i] >= d->numPrims || s->hLightFailId[i] < 0 || s->hLightFailId[i] >= (int)nl) {
+            delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: light table index out of range");
+        }
+
+    // fused node records, one array per threaded order
+    {
+        std::vector<BvhNode> rec(nn);
+        for (int k = 0; k < 6; k++) {
+            for (size_t i = 0; i < nn; i++) {
+                const int* n = &s->hNodes[k][i * 3];
+                const float* b = &s->hBoxes[(size_t)n[1] * 6];
+                rec[i].bminx = b[0]; rec[i].bminy = b[1]; rec[i].bminz = b[2]; rec[i].primId = n[0];
+                rec[i].bmaxx = b[3]; rec[i].bmaxy = b[4]; rec[i].bmaxz = b[5]; rec[i].next = n[2];
+            }
+            if (int e = upload(&s->dNodes[k], rec)) { rs_scene_destroy(s); return e; }
+        }
+    }
+    // pre-differenced triangles
+    {
+        std::vector<TriRec> rec(np);
+        for (size_t i = 0; i < np; i++) {
+            const float* t = &s->hVertices[i * 9];
+            f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+            f3 e1 = v1 - v0, e2 = v2 - v0;
+            rec[i] = TriRec{ v0.x, v0.y, v0.z, 0.f, e1.x, e1.y, e1.z, 0.f, e2.x, e2.y, e2.z, 0.f };
+        }
+        if (int e = upload(&s->dTris, rec)) { rs_scene_destroy(s); return e; }
+    }
+    // light records with the per-light constants of sampleDirectLightNoVisibility (scene.h:411-424)
+    {
+        std::vector<LightRec> rec(nl);
+        std::vector<AliasRec> al(nl);
+        const float sumInv = 1.f / d->sumLightPower;                       // scene.cpp:489
+        for (size_t i = 0; i < nl; i++) {
+            const float* t = &s->hVertices[(size_t)s->hLightPrimIds[i] * 9];
+            f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+            f3 c = cross(v1 - v0, v2 - v0);
+            f3 nrm = normalize(c);                                          // Math::triangleNormal
+            float area = length(c) * .5f;                                   // Math::triangleArea
+            f3 Le = ld3(&s->hLightRadiance[i * 3]);
+            float power = luminance(Le) / (area * 2.f * kGlmPi);
+            rec[i] = LightRec{ v0.x, v0.y, v0.z, nrm.x, v1.x, v1.y, v1.z, nrm.y, v2.x, v2.y, v2.z, nrm.z,
+                               Le.x, Le.y, Le.z, power * sumInv };
+            al[i].prob = s->hLightProb[i];
+            al[i].failId = s->hLightFailId[i];
+        }
+        if (int e = upload(&s->dLights, rec)) { rs_scene_destroy(s); return e; }
+        if (int e = upload(&s->dAlias, al)) { rs_scene_destroy(s); return e; }
+    }
+    if (int e = upload(&s->dVertices, s->hVertices)) { rs_scene_destroy(s); return e; }
+    if (int e = upload(&s->dNormals, s->hNormals)) { rs_scene_destroy(s); return e; }
+    if (int e = upload(&s->dMaterialIds, s->hMaterialIds)) { rs_scene_destroy(s); return e; }
+    if (int e = upload(&s->dMaterials, s->hMaterials)) { rs_scene_destroy(s); return e; }
+
+    for (int k = 0; k < 6; k++) s->dev.nodes[k] = s->dNodes[k];
+    s->dev.tris = s->dTris;
+    s->dev.vertices = s->dVertices;
+    s->dev.normals = s->dNormals;
+    s->dev.materialIds = s->dMaterialIds;
+    s->dev.materials = s->dMaterials;
+    s->dev.lights = s->dLights;
+    s->dev.alias = s->dAlias;
+    s->dev.bvhSize = s->bvhSize;
+    s->dev.numPrims = s->numPrims;
+    s->dev.numLights = s->numLights;
+    s->dev.numMaterials = d->numMaterials;
+    *out = s;
+    return 0;
+}
+
+extern "C" int rs_scene_build(int numPrims, const float* vertices, const float* normals, const float* texcoords,
+                              const int* materialIds, int numMaterials, const rs_material* materials, rs_scene** out) {
+    if (!out) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_build: null output");
+    *out = nullptr;
+    if (numPrims <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_build: no mesh data");   // scene.cpp:192-195
+    const size_t np = (size_t)numPrims, nn = 2 * np - 1;
+
+    int numLights = 0;
+    std::vector<int> lightPrim(np);
+    std::vector<float> lightRad(np * 3), lightPower(np);
+    RS_TRY(rs_build_light_table(numPrims, vertices, materialIds, numMaterials, materials, &numLights,
+                                lightPrim.data(), lightRad.data(), lightPower.data()));
+    std::vector<float> prob((size_t)numLights);
+    std::vector<int> fail((size_t)numLights);
+    float sumAll = 0.f;
+    RS_TRY(rs_build_alias_table(numLights, lightPower.data(), prob.data(), fail.data(), &sumAll));
+
+    std::vector<float> boxes(nn * 6);
+    std::vector<int> nodes[6];
+    int* nodePtr[6];
+    for (int k = 0; k < 6; k++) { nodes[k].resize(nn * 3); nodePtr[k] = nodes[k].data(); }
+    int bvhSize = 0;
+    RS_TRY(rs_build_bvh(numPrims, vertices, boxes.data(), nodePtr, &bvhSize));
+
+    rs_scene_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.numPrims = numPrims; d.vertices = vertices; d.normals = normals; d.texcoords = texcoords;
+    d.materialIds = materialIds; d.numMaterials = numMaterials; d.materials = materials;
+    d.bvhSize = bvhSize; d.boundingBoxes = boxes.data();
+    for (int k = 0; k < 6; k++) d.bvhNodes[k] = nodes[k].data();
+    d.numLights = numLights; d.lightPrimIds = lightPrim.data(); d.lightUnitRadiance = lightRad.data();
+    d.lightProb = prob.data(); d.lightFailId = fail.data(); d.sumLightPower = sumAll;
+    return rs_scene_create(&d, out);
+}
+
+extern "C" int rs_scene_host_desc(const rs_scene* s, rs_scene_desc* d) {
+    if (!s || !d) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_host_desc: null argument");
+    std::memset(d, 0, sizeof *d);
+    d->numPrims = s->numPrims; d->vertices = s->hVertices.data(); d->normals = s->hNormals.data();
+    d->texcoords = s->hTexcoords.data(); d->materialIds = s->hMaterialIds.data();
+    d->numMaterials = (int)s->hMaterials.size(); d->materials = s->hMaterials.data();
+    d->bvhSize = s->bvhSize; d->boundingBoxes = s->hBoxes.data();
+    for (int k = 0; k < 6; k++) d->bvhNodes[k] = s->hNodes[k].data();
+    d->numLights = s->numLights; d->lightPrimIds = s->hLightPrimIds.data();
+    d->lightUnitRadiance = s->hLightRadiance.data(); d->lightProb = s->hLightProb.data();
+    d->lightFailId = s->hLightFailId.data(); d->sumLightPower = s->sumLightPower;
+    return 0;
+}
+
+// ---- batched scene services (parity tests of DevScene::intersect / testOcclusion) -------------
+__global__ void __launch_bounds__(256) k_trace_closest(DevScene s, int n, const float* __restrict__ rays,
+                                                       int* __restrict__ primId, int* __restrict__ matId,
+                                                       float* __restrict__ pos, float* __restrict__ norm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = ld3(rays + (size_t)i * 6); r.d = ld3(rays + (size_t)i * 6 + 3);
+    Hit h = trace_closest(s, r);
+    primId[i] = h.primId;
+    matId[i] = h.primId != kNullPrim ? h.matId : -1;
+    st3(pos + (size_t)i * 3, h.pos);
+    st3(norm + (size_t)i * 3, h.norm);
+}
+
+__global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    occ[i] = trace_occluded(s, ld3(seg + (size_t)i * 6), ld3(seg + (size_t)i * 6 + 3)) ? 1 : 0;
+}
+
+extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {
+    if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_closest: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_trace_closest, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devRays, devPrimId, devMatId, devPos, devNorm);
+    return rs_after_launch("rs_trace_closest");
+}
+
+extern "C" int rs_trace_occlusion(const rs_scene* s, int n, const float* devSegments, int* devOccluded) {
+    if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_occlusion: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_trace_occlusion, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devSegments, devOccluded);
+    return rs_after_launch("rs_trace_occlusion");
+}
