@@ -193,6 +193,8 @@ int  rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host);
 /* BVH walks (intersect + testOcclusion calls) performed by the last rs_restir_direct / phase_a,
  * for the Mrays/s metric. Synchronises. */
 int  rs_restir_ray_count(rs_restir* r, unsigned long long* rays);
+/* Sum of the walk counters of the last `frames` (<= 1024) frames. Synchronises. */
+int  rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays);
 /* Per-pass GPU time (ms) of the last frame, measured with hipEvents on the library's stream:
  * ms[0] primary hit, ms[1] RIS, ms[2] shadow+temporal, ms[3] spatial+shade.  Synchronises. */
 int  rs_restir_pass_times(rs_restir* r, float ms[4]);

@@ -61,7 +61,7 @@ EXPORTS = [
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
-    "rs_restir_halo_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_pass_times",
+    "rs_restir_halo_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
     "rs_restir_enable_timing", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_copy_image_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
@@ -115,6 +115,7 @@ def lib():
     L.rs_restir_download.argtypes = [vp, ci, vp]
     L.rs_restir_upload.argtypes = [vp, ci, vp]
     L.rs_restir_ray_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.rs_restir_ray_total.argtypes = [vp, ci, C.POINTER(C.c_ulonglong)]
     L.rs_restir_pass_times.argtypes = [vp, C.POINTER(cf * 4)]
     L.rs_restir_enable_timing.argtypes = [vp, ci]
     L.rs_path_trace_direct.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, C.POINTER(C.c_ulonglong)]
@@ -345,6 +346,11 @@ class ReSTIR:
     def ray_count(self):
         n = C.c_ulonglong(0)
         check(lib().rs_restir_ray_count(self.handle, C.byref(n)))
+        return n.value
+
+    def ray_total(self, frames):
+        n = C.c_ulonglong(0)
+        check(lib().rs_restir_ray_total(self.handle, frames, C.byref(n)))
         return n.value
 
     def enable_timing(self, on=True):

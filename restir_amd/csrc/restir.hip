@@ -32,6 +32,7 @@ constexpr int kStageW = kTileW + 2 * kHalo, kStageH = kTileH + 2 * kHalo, kStage
 
 // kind of a pixel after the primary hit
 constexpr int kKindMiss = 0, kKindLight = 1, kKindShaded = 2;
+constexpr int kRaySlots = 1024;   // ring of per-frame BVH-walk counters
 
 struct SurfPlanes {
     float4* posMat;     // pos.xyz, bits(matId | kind << 24)
@@ -405,9 +406,9 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     if (!e) e = rs_dev_alloc(&r->matKind, n);
     if (!e) e = rs_dev_alloc(&r->candLi, n);
     if (!e) e = rs_dev_alloc(&r->candWi, n);
-    if (!e) e = rs_dev_alloc(&r->dRayCount, 1);
+    if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots);
     if (!e) e = rs_check_hip(hipMemset(r->matKind, 0, n * 4), "memset");
-    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8), "memset");
+    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * kRaySlots), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (e) { rs_restir_free(r); return e; }
     *out = r;
@@ -431,14 +432,16 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     RS_TRY(check_frame_args(r, scene, cam, g));
     if (y0 < 0) y0 = 0;
     if (y1 > r->height) y1 = r->height;
-    RS_HIP(hipMemsetAsync(r->dRayCount, 0, 8, rs_stream()));
+    r->raySlot = (r->raySlot + 1) % kRaySlots;                  // one counter slot per frame (ring)
+    unsigned long long* rayCounter = r->dRayCount + r->raySlot;
+    RS_HIP(hipMemsetAsync(rayCounter, 0, 8, rs_stream()));
     if (y1 <= y0) return 0;
     const int W = r->width;
     const int tilesX = (W + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
     const SurfPlanes sp = surf_of(r);
     const CamParams cp = rs_make_cam_params(cam);
     mark(r, 0);
-    hipLaunchKernelGGL(k_primary, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, r->dRayCount);
+    hipLaunchKernelGGL(k_primary, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     mark(r, 1);
     const int npx = (y1 - y0) * W;
     hipLaunchKernelGGL(k_ris, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
@@ -551,7 +554,18 @@ int rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host) {
 int rs_restir_ray_count(rs_restir* r, unsigned long long* rays) {
     if (!r || !rays) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_count: null");
     RS_HIP(hipStreamSynchronize(rs_stream()));
-    RS_HIP(hipMemcpy(rays, r->dRayCount, 8, hipMemcpyDeviceToHost));
+    RS_HIP(hipMemcpy(rays, r->dRayCount + r->raySlot, 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays) {
+    if (!r || !rays || frames < 0 || frames > kRaySlots) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_total: frames must be in [0, 1024]");
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    std::vector<unsigned long long> h((size_t)kRaySlots);
+    RS_HIP(hipMemcpy(h.data(), r->dRayCount, 8 * kRaySlots, hipMemcpyDeviceToHost));
+    unsigned long long t = 0;
+    for (int i = 0; i < frames; i++) t += h[(size_t)((r->raySlot - i) % kRaySlots + kRaySlots) % kRaySlots];
+    *rays = t;
     return 0;
 }
 

@@ -114,7 +114,8 @@ struct rs_restir {
     int*    matKind = nullptr;       // matId | kind<<24, dense copy for the spatial pass
     float4* candLi = nullptr;        // RIS winner: Li xyz, w = dist
     float4* candWi = nullptr;        // RIS winner: wi xyz, w = weight (sum of candidate weights)
-    unsigned long long* dRayCount = nullptr;
+    unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
+    int raySlot = 0;
     // timing
     bool timing = false;
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };

@@ -160,6 +160,15 @@ RS_HD bool slab_min_max(float t1, float t2, float& tMin) {                      
     return tMax >= 0.f && tMax >= tMin;
 }
 
+// true only when the ray's coordinate on the ignored axis stays outside [lo-tol, hi+tol] for every
+// t in [max(t0,0), t1]; NaN / infinite inputs never skip.
+RS_HD bool skip_far_on_axis(float o, float d, float lo, float hi, float t0, float t1) {
+    const float a = o + d * fmaxf(t0, 0.f), b = o + d * t1;
+    const float tol = 1e-3f * (1.f + fmaxf(gabs(lo), gabs(hi)));
+    const float mn = fminf(a, b), mx = fmaxf(a, b);
+    return (mx < lo - tol) || (mn > hi + tol);
+}
+
 RS_HD bool box_hit(const RayBoxCtx& c, f3 bmin, f3 bmax, float& tMin) {
     if (c.mode != 0) {                         // axis-aligned rays (bvh.h:91-123), rare
         if (c.mode == 1) {
@@ -185,9 +194,17 @@ RS_HD bool box_hit(const RayBoxCtx& c, f3 bmin, f3 bmax, float& tMin) {
     float zx = tf.x - tn.z;
     float xy = tf.y - tn.x;
     bool oyz = td.y + td.z > yz, ozx = td.z + td.x > zx, oxy = td.x + td.y > xy;
-    if (c.zx && oyz) return slab_max_min(tn.y, tn.z, tf.y, tf.z, tMin);
-    if (c.zy && ozx) return slab_max_min(tn.z, tn.x, tf.z, tf.x, tMin);
-    if (c.zz && oxy) return slab_max_min(tn.x, tn.y, tf.x, tf.y, tMin);
+    // Near-zero direction component: the reference tests only the other two slabs (bvh.h:136-146), so
+    // such a ray "enters" every box its projection crosses and walks thousands of nodes (measured:
+    // 2.5k-10k steps against a mean of 130; a handful of such rays per 1080p frame set the kernel's
+    // tail).  skip_far_on_axis() adds a conservative cull on the ignored axis: a box is skipped only
+    // if the ray stays farther than a generous tolerance from it over the interval it crosses the
+    // other two slabs.  A skipped subtree cannot contain a triangle the ray hits (a Moeller-Trumbore
+    // hit point lies inside its triangle's box up to rounding << tol), the visiting order of the
+    // remaining nodes is unchanged, so closest hit, ties and occlusion results are identical.
+    if (c.zx && oyz) return slab_max_min(tn.y, tn.z, tf.y, tf.z, tMin) && !skip_far_on_axis(c.o.x, c.d.x, bmin.x, bmax.x, tMin, fminf(tf.y, tf.z));
+    if (c.zy && ozx) return slab_max_min(tn.z, tn.x, tf.z, tf.x, tMin) && !skip_far_on_axis(c.o.y, c.d.y, bmin.y, bmax.y, tMin, fminf(tf.z, tf.x));
+    if (c.zz && oxy) return slab_max_min(tn.x, tn.y, tf.x, tf.y, tMin) && !skip_far_on_axis(c.o.z, c.d.z, bmin.z, bmax.z, tMin, fminf(tf.x, tf.y));
     if (oyz && ozx && oxy)
         return slab_max_min(fmaxf(tn.x, tn.y), tn.z, fminf(tf.x, tf.y), tf.z, tMin);
     return false;

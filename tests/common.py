@@ -1,0 +1,109 @@
+"""Shared helpers for the parity tests: build the same scene for the oracle and for the HIP
+library, drive both through the reference's per-frame call sequence (runCuda, src/main.cpp:146-185)
+and compare."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import binding as ob
+from restir_amd import scenes
+from restir_amd.ctypes_structs import RESERVOIR_DTYPE, copy_camera
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype == np.float32:
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    return np.array_equal(a, b)
+
+
+def mismatch_fraction(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype == np.float32:
+        ne = a.view(np.uint32) != b.view(np.uint32)
+    else:
+        ne = a != b
+    return float(np.count_nonzero(ne)) / max(1, ne.size)
+
+
+def oracle_scene(sd):
+    return ob.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+
+
+def get_scene(name):
+    if name == "cornell":
+        return scenes.cornell_box()
+    if name.startswith("sponza"):
+        return scenes.sponza_class(1, float(name.split(":")[1]))
+    if name.startswith("bistro"):
+        return scenes.bistro_class(2, float(name.split(":")[1]))
+    raise KeyError(name)
+
+
+class OracleRenderer:
+    """runCuda on the CPU oracle."""
+
+    def __init__(self, sd, width, height, scene=None):
+        self.sd = sd
+        self.scene = scene or oracle_scene(sd)
+        self.W, self.H = width, height
+        self.cam = ob.camera_update(sd.camera(width, height))
+        self.gbuf = ob.GBuffer(width, height)
+        self.restir = ob.ReSTIR(width, height)
+        self.image = np.zeros((width * height, 3), np.float32)
+        self.looper = 0
+        self.rays = 0
+
+    def set_camera_position(self, pos):
+        for i in range(3):
+            self.cam.position[i] = float(pos[i])
+        ob.camera_update(self.cam)
+
+    def frame(self, reuse, use_reservoir=True, iteration=0):
+        self.gbuf.render(self.scene, self.cam)
+        if use_reservoir:
+            self.rays = self.restir.direct(self.scene, self.cam, self.gbuf, self.image, iteration, self.looper, reuse)
+        else:
+            self.rays = ob.pt_direct(self.scene, self.cam, self.image, iteration, self.looper)
+        self.looper += 1
+        self.gbuf.update(self.cam)
+        return self.image
+
+
+class HipRenderer:
+    """runCuda on librestir_hip through the C ABI."""
+
+    def __init__(self, capi, sd, width, height, scene=None):
+        import torch
+        self.torch = torch
+        self.capi = capi
+        self.sd = sd
+        self.scene = scene or capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+        self.W, self.H = width, height
+        self.cam = capi.camera_update(sd.camera(width, height))
+        self.gbuf = capi.GBuffer(width, height)
+        self.restir = capi.ReSTIR(width, height)
+        self.image = torch.zeros((width * height, 3), dtype=torch.float32, device="cuda")
+        self.looper = 0
+
+    def set_camera_position(self, pos):
+        for i in range(3):
+            self.cam.position[i] = float(pos[i])
+        self.capi.camera_update(self.cam)
+
+    def frame(self, reuse, use_reservoir=True, iteration=0):
+        self.gbuf.render(self.scene, self.cam)
+        if use_reservoir:
+            self.restir.direct(self.scene, self.cam, self.gbuf, self.image.data_ptr(), iteration, self.looper, reuse)
+            self.rays = self.restir.ray_count()
+        else:
+            self.rays = self.capi.path_trace_direct(self.scene, self.cam, self.image.data_ptr(), iteration, self.looper)
+        self.looper += 1
+        self.gbuf.update(self.cam)
+        return self.image.cpu().numpy()
+
+
+def radiance_stats(a, b):
+    """a, b: (N,3) float32.  mean per-pixel L1, fraction of pixels with L1 > 1e-3, bit mismatch fraction."""
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)).sum(axis=1)
+    return dict(mean_l1=float(d.mean()), flip_frac=float(np.mean(d > 1e-3)), bit_mismatch=mismatch_fraction(a, b), max_l1=float(d.max()))

@@ -1,0 +1,287 @@
+"""GPU parity tests: librestir_hip (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tolerances (BASELINE.json north_star: per-pixel L1 radiance error < 1e-4):
+
+  * integer planes (G-buffer ids, motion, reservoir M, hit primitive ids): exact;
+  * FP32 planes produced only by + - * / sqrt (rays, hits, G-buffer, RIS / temporal reservoirs,
+    radiance without spatial reuse): BIT-EXACT -- device code is built with -ffp-contract=off and
+    IEEE divide/sqrt, the oracle with the same op order;
+  * spatial reuse (uses sinf/cosf for the tap position) : mean per-pixel L1 < 1e-4 and
+    fraction of pixels with L1 > 1e-3 below 1e-3 (expected: 0 mismatches);
+  * tone-mapped RGBA8 (powf): at most 1 LSB on at most 1e-4 of the bytes;
+  * EAW (expf): relative 1e-5.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from restir_amd.ctypes_structs import RESERVOIR_DTYPE
+from tests.common import (HipRenderer, OracleRenderer, bits_equal, get_scene, mismatch_fraction, oracle_scene,
+                          radiance_stats)
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {"cornell": (128, 128), "sponza:0.03": (160, 96)}
+
+
+def _random_rays(sd, n, seed):
+    rng = np.random.default_rng(seed)
+    v = sd.vertices.reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    o = rng.uniform(lo + 0.05 * (hi - lo), hi - 0.05 * (hi - lo), (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    k = n // 16                              # axis-aligned and near-zero-component directions (bvh.h:91-146)
+    d[:k] = 0; d[np.arange(k), rng.integers(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+    d[k:2 * k, 0] = rng.uniform(-1e-6, 1e-6, k)
+    d[2 * k:3 * k, 1] = 0.0
+    nn = np.linalg.norm(d, axis=1, keepdims=True)
+    d = (d / nn).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_trace_closest_and_occlusion(hip, name):
+    import torch
+    sd = get_scene(name)
+    osc = oracle_scene(sd)
+    hsc = hip.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+    rays = _random_rays(sd, 40000, 3)
+    prim, mat, pos, nrm, _ = osc.intersect(rays)
+    gp, gm, gpos, gn = hip.trace_closest(hsc, torch.from_numpy(rays).cuda())
+    assert np.array_equal(prim, gp.cpu().numpy())
+    hitmask = prim >= 0
+    assert hitmask.sum() > 1000
+    assert np.array_equal(mat[hitmask], gm.cpu().numpy()[hitmask])
+    assert bits_equal(pos[hitmask], gpos.cpu().numpy()[hitmask])
+    assert bits_equal(nrm[hitmask], gn.cpu().numpy()[hitmask])
+    # occlusion: segments between hit points and random points
+    rng = np.random.default_rng(4)
+    a = pos[hitmask][:15000]
+    b = a[rng.permutation(len(a))]
+    seg = np.ascontiguousarray(np.concatenate([a, b], 1), np.float32)
+    seg[:50, 3:] = seg[:50, :3]                       # degenerate x == y (Q9): NaN direction must terminate
+    occ = osc.test_occlusion(seg)
+    gocc = hip.trace_occlusion(hsc, torch.from_numpy(seg).cuda()).cpu().numpy()
+    assert np.array_equal(occ, gocc)
+    assert 0 < occ.sum() < len(occ)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_gbuffer(hip, name):
+    sd = get_scene(name)
+    W, H = SCENES[name]
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(2):                            # second frame exercises motion vectors vs lastCamera
+        if frame == 1:
+            p = (sd.camera_args["position"][0] + 0.15, sd.camera_args["position"][1], sd.camera_args["position"][2] - 0.1)
+            o.set_camera_position(p); h.set_camera_position(p)
+        o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+        g = h.gbuf.download()
+        f = g["frame_idx"]
+        assert f == o.gbuf.frame_idx
+        assert np.array_equal(o.gbuf.prim_id[f], g["prim_id"][f])
+        assert np.array_equal(o.gbuf.motion, g["motion"])
+        assert bits_equal(o.gbuf.albedo, g["albedo"])
+        assert bits_equal(o.gbuf.normal[f], g["normal"][f])
+        assert bits_equal(o.gbuf.depth[f], g["depth"][f])
+        o.gbuf.update(o.cam); h.gbuf.update(h.cam)
+
+
+def _compare_reservoirs(a, b):
+    for k in ("numSamples",):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("Li", "wi", "dist", "weight"):
+        assert bits_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+@pytest.mark.parametrize("reuse", [0, 1])
+def test_restir_no_spatial_bit_exact(hip, name, reuse):
+    """RIS-only (config 2 semantics) and temporal reuse: bit-exact radiance and reservoirs over 4 frames."""
+    sd = get_scene(name)
+    W, H = SCENES[name]
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(4):
+        a = o.frame(reuse); b = h.frame(reuse)
+        assert o.rays == h.rays, (frame, o.rays, h.rays)
+        assert bits_equal(a, b), (frame, radiance_stats(a, b))
+        _compare_reservoirs(o.restir.last, h.restir.download(1))      # the buffer written this frame
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+@pytest.mark.parametrize("reuse", [2, 3])
+def test_restir_spatial(hip, name, reuse):
+    sd = get_scene(name)
+    W, H = SCENES[name]
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(4):
+        a = o.frame(reuse); b = h.frame(reuse)
+        st = radiance_stats(a, b)
+        assert st["mean_l1"] < 1e-4 and st["flip_frac"] <= 1e-3, (frame, st)
+        _compare_reservoirs(o.restir.last, h.restir.download(1))
+        _compare_reservoirs(o.restir.temp, h.restir.download(2))
+    # expected in practice: no mismatch at all
+    assert st["bit_mismatch"] <= 1e-3, st
+
+
+def test_restir_moving_camera_temporal(hip):
+    """Orbiting camera (runCuda :149-153 with a fixed dt): reprojection through devMotion."""
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.03")
+    W, H = SCENES["sponza:0.03"]
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(5):
+        p = orbit_position(sd.camera_args["position"], frame, radius=0.3)
+        o.set_camera_position(p); h.set_camera_position(p)
+        a = o.frame(3); b = h.frame(3)
+        st = radiance_stats(a, b)
+        assert st["mean_l1"] < 1e-4 and st["flip_frac"] <= 1e-3, (frame, st)
+    _compare_reservoirs(o.restir.last, h.restir.download(1))
+
+
+def test_restir_reset_and_accumulate(hip):
+    """ReSTIRReset re-arms the first-frame flag; iter>0 takes the running mean (restir.cu:230)."""
+    sd = get_scene("cornell")
+    W, H = 96, 64
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(3):
+        a = o.frame(1, iteration=frame); b = h.frame(1, iteration=frame)
+        assert bits_equal(a, b)
+    o.restir.reset(); h.restir.reset()
+    a = o.frame(1, iteration=0); b = h.frame(1, iteration=0)
+    assert bits_equal(a, b)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_path_trace_direct(hip, name):
+    """Config 1 semantics (PTDirectKernel, 1 spp, looper = 0) plus an accumulated second sample."""
+    sd = get_scene(name)
+    W, H = SCENES[name]
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for it in range(2):
+        a = o.frame(0, use_reservoir=False, iteration=it); b = h.frame(0, use_reservoir=False, iteration=it)
+        assert o.rays == h.rays
+        assert bits_equal(a, b), radiance_stats(a, b)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_copy_image_to_pbo(hip, mode):
+    import torch
+    rng = np.random.default_rng(7)
+    W, H = 200, 100
+    img = rng.uniform(0, 4, (W * H, 3)).astype(np.float32)
+    img[:100] = 0; img[100:200] = 1e6; img[200:210] = np.nan; img[210:220] = -1.0
+    ref = ob.send_image_to_pbo(img, W, H, mode, 0.9)
+    t = torch.from_numpy(img).cuda()
+    out = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")
+    hip.copy_image_to_pbo(out.data_ptr(), t.data_ptr(), W, H, mode, 0.9)
+    got = out.cpu().numpy()
+    diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
+    assert diff.max() <= 1
+    assert np.mean(diff > 0) <= 1e-4
+
+
+def test_eaw_filter(hip):
+    import torch
+    sd = get_scene("sponza:0.03")
+    W, H = 160, 96
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    a = o.frame(3); h.frame(3)
+    # the G-buffer frame index was flipped by update(); filter against the planes just rendered
+    o.gbuf.c.frameIdx ^= 1
+    ref = ob.eaw_filter(o.gbuf, o.cam, a)
+    o.gbuf.c.frameIdx ^= 1
+    hip.check(hip.lib().rs_gbuffer_update(h.gbuf.handle, C.byref(h.cam)))      # flip back
+    f = hip.EAWFilter(W, H, 5)
+    out = torch.zeros_like(h.image)
+    p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+    hip.synchronize()
+    res = torch.empty_like(h.image)
+    hip.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+    got = res.cpu().numpy()
+    f.destroy()
+    assert np.allclose(ref, got, rtol=1e-5, atol=1e-6), float(np.abs(ref - got).max())
+    assert np.abs(ref - a).max() > 1e-3               # the filter did something
+
+
+def test_modulate_and_add(hip):
+    import torch
+    sd = get_scene("cornell")
+    W, H = 64, 64
+    o = OracleRenderer(sd, W, H); h = HipRenderer(hip, sd, W, H)
+    o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 0.95, (W * H, 3)).astype(np.float32)
+    other = rng.uniform(0, 1, (W * H, 3)).astype(np.float32)
+    ref = img.copy(); ob.lib().orc_modulate(W, H, ref.reshape(-1), o.gbuf.albedo.reshape(-1))
+    t = torch.from_numpy(img).cuda()
+    hip.check(hip.lib().rs_modulate_albedo(t.data_ptr(), h.gbuf.handle))
+    assert bits_equal(ref, t.cpu().numpy())
+    t2 = torch.from_numpy(other).cuda()
+    hip.check(hip.lib().rs_add_image(t.data_ptr(), t2.data_ptr(), W, H))
+    assert bits_equal(ref + other, t.cpu().numpy())
+    t3 = torch.empty_like(t)
+    hip.check(hip.lib().rs_add_image3(t3.data_ptr(), t.data_ptr(), t2.data_ptr(), W, H))
+    assert bits_equal((ref + other) + other, t3.cpu().numpy())
+
+
+def test_strip_tiling_equals_full_frame(hip):
+    """Framebuffer row strips with a 5-row reservoir halo (the multi-GPU decomposition) reproduce the
+    full-frame result bit for bit.  Two 'ranks' are emulated on one GPU, each with its own buffers."""
+    import torch
+    sd = get_scene("sponza:0.03")
+    W, H = 160, 96
+    full = HipRenderer(hip, sd, W, H)
+    ranks = [HipRenderer(hip, sd, W, H, scene=full.scene) for _ in range(2)]
+    bounds = [(0, 40), (40, H)]
+    halo = 5
+    for frame in range(3):
+        ref = full.frame(3)
+        # phase A on each strip
+        for r, (y0, y1) in zip(ranks, bounds):
+            r.gbuf.render(r.scene, r.cam, max(0, y0 - halo), min(H, y1 + halo))    # G-buffer halo is recomputed locally
+            r.restir.phase_a(r.scene, r.cam, r.gbuf, r.looper, 3, y0, y1)
+        # halo exchange of published reservoirs (what RCCL send/recv carries between neighbours)
+        nbytes = ranks[0].restir.halo_bytes(halo)
+        up = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); down = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        ranks[0].restir.halo_pack(bounds[0][1] - halo, halo, down.data_ptr())       # rank0's last rows -> rank1
+        ranks[1].restir.halo_pack(bounds[1][0], halo, up.data_ptr())                # rank1's first rows -> rank0
+        ranks[1].restir.halo_unpack(bounds[0][1] - halo, halo, down.data_ptr())
+        ranks[0].restir.halo_unpack(bounds[1][0], halo, up.data_ptr())
+        for r, (y0, y1) in zip(ranks, bounds):
+            r.restir.phase_b(r.scene, r.cam, r.gbuf, r.image.data_ptr(), 0, 3, y0, y1)
+            r.restir.end_frame()
+            r.looper += 1
+            r.gbuf.update(r.cam)
+        hip.synchronize()
+        got = np.concatenate([ranks[0].image.cpu().numpy()[:bounds[0][1] * W], ranks[1].image.cpu().numpy()[bounds[1][0] * W:]])
+        assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
+
+
+def test_full_size_properties(hip):
+    """BASELINE config 3 size (1920x1080, spatiotemporal, Sponza-class 262 144 triangles): properties
+    that do not need the oracle -- run-to-run determinism (no races), ray accounting, finite output,
+    and agreement of a 64-row band with the oracle run on the same band's pixels is covered by the
+    small-scene tests above."""
+    sd = get_scene("sponza:1.0")
+    W, H = 1920, 1080
+    a = HipRenderer(hip, sd, W, H)
+    b = HipRenderer(hip, sd, W, H, scene=a.scene)
+    for frame in range(3):
+        ia = a.frame(3); ib = b.frame(3)
+        assert bits_equal(ia, ib)
+        assert np.isfinite(ia).all()
+        assert W * H <= a.rays <= 2 * W * H
+    assert ia.mean() > 1e-3
+    ga = a.gbuf.download()
+    ids = ga["prim_id"][ga["frame_idx"] ^ 1]
+    assert (ids >= -2).all() and (ids < len(sd.materials)).all()
