@@ -157,6 +157,13 @@ int  rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camer
 /* GBuffer::update (src/gbuffer.cu:75-78): lastCamera = cam; frameIdx ^= 1 */
 int  rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam);
 int  rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* view);
+/* Rows [y0,y0+rows) of the id / normal / depth planes as one packed device buffer (20 B/px); sel 0 =
+ * planes of the current frame index, 1 = the "last" planes.  Used by the multi-GPU tiling to share
+ * G-buffer history when the camera moves (findTemporalNeighbor reads lastPrimId/lastNormal/lastDepth
+ * at a reprojected pixel that may belong to another strip). */
+size_t rs_gbuffer_rows_bytes(const rs_gbuffer* g, int rows);
+int  rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* devBuffer);
+int  rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void* devBuffer);
 
 /* ---- ReSTIR (src/restir.h:128-133) ------------------------------------------------------ */
 /* ReSTIRInit (src/restir.cu:478-504): reservoir buffers for width*height pixels, zero-filled. */
@@ -185,6 +192,10 @@ int  rs_restir_end_frame(rs_restir* r);
 size_t rs_restir_halo_bytes(const rs_restir* r, int rows);
 int  rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer);
 int  rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer);
+/* Same packing for any of the three reservoir buffers (which: as rs_restir_download); which = 1 after
+ * rs_restir_end_frame is the history the next frame's temporal merge reads. */
+int  rs_restir_rows_pack(const rs_restir* r, int which, int y0, int rows, void* devBuffer);
+int  rs_restir_rows_unpack(rs_restir* r, int which, int y0, int rows, const void* devBuffer);
 /* Debug / parity: copy a reservoir buffer to host as the reference's AoS records.
  * which: 0 = devDirectReservoir (next frame's output slot), 1 = devLastDirectReservoir (last
  * written), 2 = devDirectTemp. */

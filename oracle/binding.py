@@ -106,6 +106,17 @@ def lib():
         C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), f32p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong),
     ]
+    L.orc_restir_state_create.argtypes = [C.c_int, C.c_int]
+    L.orc_restir_state_create.restype = C.c_void_p
+    L.orc_restir_state_destroy.argtypes = [C.c_void_p]
+    L.orc_restir_phase_a.argtypes = [
+        C.c_void_p, C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong),
+    ]
+    L.orc_restir_phase_b.argtypes = [
+        C.c_void_p, C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), f32p, C.c_void_p,
+        C.c_int, C.c_int, C.c_int, C.c_int,
+    ]
     L.orc_send_image_to_pbo.argtypes = [C.c_int, C.c_int, f32p, C.c_int, C.c_float, u8p]
     L.orc_eaw_level.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_int]
     L.orc_eaw_filter.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, f32p]
@@ -277,6 +288,23 @@ class ReSTIR:
 
     def reset(self):
         self.first = True
+
+    # row-range phases (the decomposition the strip tiling uses)
+    def phase_a(self, scene, cam, gbuf, looper, reuse, y0, y1):
+        if getattr(self, "_state", None) is None:
+            self._state = lib().orc_restir_state_create(gbuf.width, gbuf.height)
+        rays = C.c_ulonglong(0)
+        lib().orc_restir_phase_a(self._state, C.byref(scene.c), C.byref(cam), C.byref(gbuf.c), _ptr(self.reservoir),
+                                 _ptr(self.last), _ptr(self.temp), looper, int(self.first), reuse, y0, y1, C.byref(rays))
+        self.rays = rays.value
+
+    def phase_b(self, scene, cam, gbuf, direct_illum, iter_, reuse, y0, y1):
+        lib().orc_restir_phase_b(self._state, C.byref(scene.c), C.byref(cam), C.byref(gbuf.c), direct_illum.reshape(-1),
+                                 _ptr(self.temp), iter_, reuse, y0, y1)
+
+    def end_frame(self):
+        self.reservoir, self.last = self.last, self.reservoir
+        self.first = False
 
     def direct(self, scene, cam, gbuf, direct_illum, iter_, looper, reuse):
         rays = C.c_ulonglong(0)

@@ -863,17 +863,23 @@ typedef struct {
 
 #define RESERVOIR_SIZE 32   /* restir.cu:3 */
 
-void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
-                       float* directIllum, orc_reservoir* reservoirOut,
-                       const orc_reservoir* reservoirIn, orc_reservoir* reservoirTemp,
-                       int looper, int iter, int first, int reuse, unsigned long long* rays) {
-    const int W = cam->resolution[0], H = cam->resolution[1];
-    pixel_state_t* st = (pixel_state_t*)malloc(sizeof(pixel_state_t) * (size_t)W * H);
-    unsigned long long total = 0;
+void* orc_restir_state_create(int width, int height) {
+    return calloc((size_t)width * height, sizeof(pixel_state_t));
+}
+void orc_restir_state_destroy(void* st) { free(st); }
 
-    /* ---- phase A: restir.cu:119-194 (everything before the barrier) + :211-212 ---- */
+/* ---- phase A: restir.cu:119-194 (everything before the barrier) + :211-212, rows [y0,y1) ---- */
+void orc_restir_phase_a(void* state, const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
+                        orc_reservoir* reservoirOut, const orc_reservoir* reservoirIn,
+                        orc_reservoir* reservoirTemp, int looper, int first, int reuse,
+                        int y0, int y1, unsigned long long* rays) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    pixel_state_t* st = (pixel_state_t*)state;
+    unsigned long long total = 0;
+    if (y0 < 0) y0 = 0;
+    if (y1 > H) y1 = H;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
-    for (int y = 0; y < H; y++) {
+    for (int y = y0; y < y1; y++) {
         for (int x = 0; x < W; x++) {
             int index = y * W + x;
             pixel_state_t* ps = &st[index];
@@ -948,10 +954,19 @@ void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuf
             ps->matId = it.matId;
         }
     }
+    if (rays) *rays = total;
+}
 
-    /* ---- phase B: restir.cu:196-230 ---- */
+/* ---- phase B: restir.cu:196-230, rows [y0,y1) ---- */
+void orc_restir_phase_b(void* state, const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
+                        float* directIllum, const orc_reservoir* reservoirTemp, int iter, int reuse,
+                        int y0, int y1) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    pixel_state_t* st = (pixel_state_t*)state;
+    if (y0 < 0) y0 = 0;
+    if (y1 > H) y1 = H;
 #pragma omp parallel for schedule(dynamic, 4)
-    for (int y = 0; y < H; y++) {
+    for (int y = y0; y < y1; y++) {
         for (int x = 0; x < W; x++) {
             int index = y * W + x;
             pixel_state_t* ps = &st[index];
@@ -994,8 +1009,17 @@ void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuf
             st3(o, dvs(add(scl(ld3(o), (float)iter), direct), (float)(iter + 1)));
         }
     }
-    free(st);
-    if (rays) *rays = total;
+}
+
+void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
+                       float* directIllum, orc_reservoir* reservoirOut,
+                       const orc_reservoir* reservoirIn, orc_reservoir* reservoirTemp,
+                       int looper, int iter, int first, int reuse, unsigned long long* rays) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    void* st = orc_restir_state_create(W, H);
+    orc_restir_phase_a(st, s, cam, g, reservoirOut, reservoirIn, reservoirTemp, looper, first, reuse, 0, H, rays);
+    orc_restir_phase_b(st, s, cam, g, directIllum, reservoirTemp, iter, reuse, 0, H);
+    orc_restir_state_destroy(st);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -174,6 +174,19 @@ void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuf
                        const orc_reservoir* reservoirIn, orc_reservoir* reservoirTemp,
                        int looper, int iter, int first, int reuse, unsigned long long* rays);
 
+/* The same pass split at the barrier, on a row range, with the per-pixel carried state (RNG, surface,
+ * post-temporal reservoir) kept in an opaque buffer: the decomposition the multi-GPU row-strip tiling
+ * uses (phase A on own rows, exchange of reservoirTemp halo rows, phase B on own rows). */
+void* orc_restir_state_create(int width, int height);
+void  orc_restir_state_destroy(void* state);
+void  orc_restir_phase_a(void* state, const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
+                         orc_reservoir* reservoirOut, const orc_reservoir* reservoirIn,
+                         orc_reservoir* reservoirTemp, int looper, int first, int reuse,
+                         int y0, int y1, unsigned long long* rays);
+void  orc_restir_phase_b(void* state, const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g,
+                         float* directIllum, const orc_reservoir* reservoirTemp, int iter, int reuse,
+                         int y0, int y1);
+
 /* src/pathtrace.cu:30-56: rgba8 out (4 bytes / px, a = 0) */
 void orc_send_image_to_pbo(int w, int h, const float* image, int toneMapping, float scale,
                            unsigned char* rgba);

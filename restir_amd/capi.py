@@ -59,9 +59,9 @@ EXPORTS = [
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_scene_build", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
-    "rs_gbuffer_get_view", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
+    "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
-    "rs_restir_halo_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
+    "rs_restir_halo_unpack", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
     "rs_restir_enable_timing", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_copy_image_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
@@ -112,6 +112,12 @@ def lib():
     L.rs_restir_halo_bytes.restype = C.c_size_t
     L.rs_restir_halo_pack.argtypes = [vp, ci, ci, vp]
     L.rs_restir_halo_unpack.argtypes = [vp, ci, ci, vp]
+    L.rs_restir_rows_pack.argtypes = [vp, ci, ci, ci, vp]
+    L.rs_restir_rows_unpack.argtypes = [vp, ci, ci, ci, vp]
+    L.rs_gbuffer_rows_bytes.argtypes = [vp, ci]
+    L.rs_gbuffer_rows_bytes.restype = C.c_size_t
+    L.rs_gbuffer_rows_pack.argtypes = [vp, ci, ci, ci, vp]
+    L.rs_gbuffer_rows_unpack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_restir_download.argtypes = [vp, ci, vp]
     L.rs_restir_upload.argtypes = [vp, ci, vp]
     L.rs_restir_ray_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
@@ -251,6 +257,15 @@ class GBuffer:
     def update(self, cam):
         check(lib().rs_gbuffer_update(self.handle, C.byref(cam)))
 
+    def rows_bytes(self, rows):
+        return int(lib().rs_gbuffer_rows_bytes(self.handle, rows))
+
+    def rows_pack(self, sel, y0, rows, dev_ptr):
+        check(lib().rs_gbuffer_rows_pack(self.handle, sel, y0, rows, dev_ptr))
+
+    def rows_unpack(self, sel, y0, rows, dev_ptr):
+        check(lib().rs_gbuffer_rows_unpack(self.handle, sel, y0, rows, dev_ptr))
+
     def view(self):
         v = GBufferView()
         check(lib().rs_gbuffer_get_view(self.handle, C.byref(v)))
@@ -333,6 +348,12 @@ class ReSTIR:
 
     def halo_unpack(self, y0, rows, dev_ptr):
         check(lib().rs_restir_halo_unpack(self.handle, y0, rows, dev_ptr))
+
+    def rows_pack(self, which, y0, rows, dev_ptr):
+        check(lib().rs_restir_rows_pack(self.handle, which, y0, rows, dev_ptr))
+
+    def rows_unpack(self, which, y0, rows, dev_ptr):
+        check(lib().rs_restir_rows_unpack(self.handle, which, y0, rows, dev_ptr))
 
     def download(self, which):
         out = np.zeros(self.width * self.height, RESERVOIR_DTYPE)

@@ -110,6 +110,32 @@ int rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam) {
     return 0;
 }
 
+// rows of the id / normal / depth planes, packed [id rows][normal rows][depth rows] (20 B / px);
+// sel 0 = the planes of the current frameIdx, 1 = the "last" planes (what findTemporalNeighbor reads)
+size_t rs_gbuffer_rows_bytes(const rs_gbuffer* g, int rows) { return g ? (size_t)g->width * (size_t)(rows > 0 ? rows : 0) * 20u : 0; }
+
+int rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* devBuffer) {
+    if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_pack: bad argument");
+    const int f = g->frameIdx ^ sel;
+    const size_t n = (size_t)g->width * rows, off = (size_t)y0 * g->width;
+    char* b = (char*)devBuffer;
+    RS_HIP(hipMemcpyAsync(b, g->devPrimId[f] + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 4, g->devNormal[f] + off * 3, n * 12, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 16, g->devDepth[f] + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    return rs_after_launch("rs_gbuffer_rows_pack");
+}
+
+int rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void* devBuffer) {
+    if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_unpack: bad argument");
+    const int f = g->frameIdx ^ sel;
+    const size_t n = (size_t)g->width * rows, off = (size_t)y0 * g->width;
+    const char* b = (const char*)devBuffer;
+    RS_HIP(hipMemcpyAsync(g->devPrimId[f] + off, b, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(g->devNormal[f] + off * 3, b + n * 4, n * 12, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(g->devDepth[f] + off, b + n * 16, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    return rs_after_launch("rs_gbuffer_rows_unpack");
+}
+
 int rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* v) {
     if (!g || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_get_view: null argument");
     v->devAlbedo = g->devAlbedo; v->devMotion = g->devMotion;

@@ -491,28 +491,34 @@ size_t rs_restir_halo_bytes(const rs_restir* r, int rows) {
     return r ? (size_t)r->width * (size_t)(rows > 0 ? rows : 0) * 40u : 0;
 }
 
-// packed layout: [li rows][wi rows][w rows][m rows]
-int rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer) {
-    if (!r || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_halo_pack: bad rows");
+// packed layout of `rows` rows: [li rows][wi rows][w rows][m rows]
+int rs_restir_rows_pack(const rs_restir* rc, int which, int y0, int rows, void* devBuffer) {
+    rs_restir* r = const_cast<rs_restir*>(rc);
+    const ResvPlanes* p = r ? pick(r, which) : nullptr;
+    if (!p || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_rows_pack: bad rows");
     const size_t n = (size_t)r->width * rows, off = (size_t)y0 * r->width;
     char* b = (char*)devBuffer;
-    RS_HIP(hipMemcpyAsync(b, r->temp.li + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 16, r->temp.wi + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 32, r->temp.w + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 36, r->temp.m + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    return rs_after_launch("rs_restir_halo_pack");
+    RS_HIP(hipMemcpyAsync(b, p->li + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 16, p->wi + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 32, p->w + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 36, p->m + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    return rs_after_launch("rs_restir_rows_pack");
 }
 
-int rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer) {
-    if (!r || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_halo_unpack: bad rows");
+int rs_restir_rows_unpack(rs_restir* r, int which, int y0, int rows, const void* devBuffer) {
+    ResvPlanes* p = r ? pick(r, which) : nullptr;
+    if (!p || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_rows_unpack: bad rows");
     const size_t n = (size_t)r->width * rows, off = (size_t)y0 * r->width;
     const char* b = (const char*)devBuffer;
-    RS_HIP(hipMemcpyAsync(r->temp.li + off, b, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(r->temp.wi + off, b + n * 16, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(r->temp.w + off, b + n * 32, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(r->temp.m + off, b + n * 36, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    return rs_after_launch("rs_restir_halo_unpack");
+    RS_HIP(hipMemcpyAsync(p->li + off, b, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(p->wi + off, b + n * 16, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(p->w + off, b + n * 32, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(p->m + off, b + n * 36, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    return rs_after_launch("rs_restir_rows_unpack");
 }
+
+int rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer) { return rs_restir_rows_pack(r, 2, y0, rows, devBuffer); }
+int rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer) { return rs_restir_rows_unpack(r, 2, y0, rows, devBuffer); }
 
 int rs_restir_download(const rs_restir* rc, int which, rs_reservoir* host) {
     rs_restir* r = const_cast<rs_restir*>(rc);

@@ -1,0 +1,160 @@
+"""Framebuffer row-strip tiling across the GPUs of one node (BASELINE config 4).
+
+The scene is replicated; the WxH framebuffer is cut into `world` contiguous row strips.  Per frame a
+rank (one process per GPU, torch.distributed over RCCL/xGMI) does
+
+    G-buffer for its rows +- HALO          (recomputed locally: cheaper than exchanging 20 B/px)
+    phase A on its rows                    (primary hit, RIS, shadow ray, temporal merge, publish)
+    exchange HALO rows of published reservoirs with the strip above and below   <- point-to-point
+                                            send/recv, 40 B/px: 384 KB per edge at 1080p
+    phase B on its rows                    (spatial reuse, shade, accumulate)
+
+The spatial taps reach y-4..y+5 (src/restir.cu:49-56), so HALO = 5 rows is exact.
+
+Temporal reuse reads last frame's reservoirs and G-buffer history at devMotion[idx] (restir.cu:20-45).
+With the reference's default static camera that is the pixel itself, i.e. strip-local.  When the
+camera moves the reprojected pixel may belong to another strip, so `share_history=True` all-gathers,
+after each frame, the rows every rank just produced of (a) the reservoirs the next temporal merge
+reads and (b) the G-buffer id/normal/depth planes that become "last" -- 60 B/px, exact for any motion.
+
+The driver is backend-agnostic: `HipBackend` runs librestir_hip; tests/ provide an oracle-backed
+double so the decomposition and the exchanges are exercised with gloo on CPU.
+"""
+
+HALO = 5
+
+
+def strip_bounds(height, world, rank):
+    """Contiguous row strips whose heights differ by at most one row."""
+    base, rem = divmod(height, world)
+    y0 = rank * base + min(rank, rem)
+    return y0, y0 + base + (1 if rank < rem else 0)
+
+
+class StripRenderer:
+    """runCuda (src/main.cpp:146-185) for one rank of a row-strip decomposition.
+
+    backend must provide: gbuffer_render(y0,y1), phase_a(looper,reuse,y0,y1), phase_b(iter,reuse,y0,y1),
+    end_frame(), halo_pack(y0,rows)->tensor, halo_unpack(y0,rows,tensor), empty(nbytes)->tensor,
+    history_bytes(rows), history_pack(y0,rows)->tensor, history_unpack(y0,rows,tensor).
+    """
+
+    def __init__(self, backend, world, rank, height, dist=None, share_history=False):
+        self.b = backend
+        self.world, self.rank, self.height = world, rank, height
+        self.dist = dist
+        self.share_history = share_history and world > 1
+        self.bounds = [strip_bounds(height, world, r) for r in range(world)]
+        self.y0, self.y1 = self.bounds[rank]
+        if world > 1 and min(b[1] - b[0] for b in self.bounds) < HALO:
+            raise ValueError("strips must be at least HALO rows tall")
+        self.gy0, self.gy1 = max(0, self.y0 - HALO), min(height, self.y1 + HALO)
+        self.up = rank - 1 if rank > 0 else None
+        self.down = rank + 1 if rank + 1 < world else None
+        self.max_rows = max(b[1] - b[0] for b in self.bounds)
+        self.looper = 0
+
+    def exchange_halo(self):
+        d = self.dist
+        ops, recvs = [], []
+        if self.up is not None:
+            send = self.b.halo_pack(self.y0, HALO)
+            recv = self.b.empty(send.numel())
+            ops += [d.P2POp(d.isend, send, self.up), d.P2POp(d.irecv, recv, self.up)]
+            recvs.append((self.y0 - HALO, recv))
+        if self.down is not None:
+            send = self.b.halo_pack(self.y1 - HALO, HALO)
+            recv = self.b.empty(send.numel())
+            ops += [d.P2POp(d.isend, send, self.down), d.P2POp(d.irecv, recv, self.down)]
+            recvs.append((self.y1, recv))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        for y, buf in recvs:
+            self.b.halo_unpack(y, HALO, buf)
+
+    def exchange_history(self):
+        """All-gather of the rows this frame produced that the next frame's temporal merge may read."""
+        d = self.dist
+        rows = self.y1 - self.y0
+        mine = self.b.history_pack(self.y0, rows)
+        nmax = self.b.history_bytes(self.max_rows)
+        send = self.b.empty(nmax)
+        send[: mine.numel()] = mine
+        out = [self.b.empty(nmax) for _ in range(self.world)]
+        d.all_gather(out, send)
+        for r, (a, bnd) in enumerate(self.bounds):
+            if r != self.rank:
+                self.b.history_unpack(a, bnd - a, out[r][: self.b.history_bytes(bnd - a)])
+
+    def frame(self, reuse, iteration=0):
+        b = self.b
+        if self.world == 1:
+            b.gbuffer_render(0, self.height)
+            b.phase_a(self.looper, reuse, 0, self.height)
+            b.phase_b(iteration, reuse, 0, self.height)
+        else:
+            b.gbuffer_render(self.gy0, self.gy1)
+            b.phase_a(self.looper, reuse, self.y0, self.y1)
+            if reuse & 2:
+                self.exchange_halo()
+            b.phase_b(iteration, reuse, self.y0, self.y1)
+        b.end_frame()
+        if self.share_history and (reuse & 1):
+            self.exchange_history()
+        self.looper += 1
+
+
+class HipBackend:
+    """librestir_hip objects of one rank."""
+
+    def __init__(self, capi, scene, cam, width, height):
+        import torch
+        self.torch = torch
+        self.capi = capi
+        self.scene, self.cam = scene, cam
+        self.W, self.H = width, height
+        self.gbuf = capi.GBuffer(width, height)
+        self.restir = capi.ReSTIR(width, height)
+        self.image = torch.zeros((width * height, 3), dtype=torch.float32, device="cuda")
+
+    def empty(self, nbytes):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8, device="cuda")
+
+    def gbuffer_render(self, y0, y1):
+        self.gbuf.render(self.scene, self.cam, y0, y1)
+
+    def phase_a(self, looper, reuse, y0, y1):
+        self.restir.phase_a(self.scene, self.cam, self.gbuf, looper, reuse, y0, y1)
+
+    def phase_b(self, iteration, reuse, y0, y1):
+        self.restir.phase_b(self.scene, self.cam, self.gbuf, self.image.data_ptr(), iteration, reuse, y0, y1)
+
+    def end_frame(self):
+        self.restir.end_frame()
+        self.gbuf.update(self.cam)
+
+    def halo_pack(self, y0, rows):
+        buf = self.empty(self.restir.halo_bytes(rows))
+        self.restir.halo_pack(y0, rows, buf.data_ptr())
+        return buf
+
+    def halo_unpack(self, y0, rows, buf):
+        self.restir.halo_unpack(y0, rows, buf.data_ptr())
+
+    # history = reservoirs the next temporal merge reads (buffer 1 after end_frame) + "last" G-buffer planes
+    def history_bytes(self, rows):
+        return self.restir.halo_bytes(rows) + self.gbuf.rows_bytes(rows)
+
+    def history_pack(self, y0, rows):
+        nr = self.restir.halo_bytes(rows)
+        buf = self.empty(self.history_bytes(rows))
+        self.restir.rows_pack(1, y0, rows, buf.data_ptr())
+        self.gbuf.rows_pack(1, y0, rows, buf.data_ptr() + nr)
+        return buf
+
+    def history_unpack(self, y0, rows, buf):
+        nr = self.restir.halo_bytes(rows)
+        buf = buf.contiguous()
+        self.restir.rows_unpack(1, y0, rows, buf.data_ptr())
+        self.gbuf.rows_unpack(1, y0, rows, buf.data_ptr() + nr)

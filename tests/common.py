@@ -107,3 +107,63 @@ def radiance_stats(a, b):
     """a, b: (N,3) float32.  mean per-pixel L1, fraction of pixels with L1 > 1e-3, bit mismatch fraction."""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64)).sum(axis=1)
     return dict(mean_l1=float(d.mean()), flip_frac=float(np.mean(d > 1e-3)), bit_mismatch=mismatch_fraction(a, b), max_l1=float(d.max()))
+
+
+class OracleBackend:
+    """Test double with the HipBackend interface (restir_amd/tiling.py), computing with the CPU oracle
+    and exchanging torch CPU tensors, so the strip decomposition runs under gloo without a GPU."""
+
+    def __init__(self, scene, cam, width, height):
+        import torch
+        self.torch = torch
+        self.scene, self.cam = scene, cam
+        self.W, self.H = width, height
+        self.gbuf = ob.GBuffer(width, height)
+        self.restir = ob.ReSTIR(width, height)
+        self.image = np.zeros((width * height, 3), np.float32)
+
+    def empty(self, nbytes):
+        return self.torch.zeros(nbytes, dtype=self.torch.uint8)
+
+    def gbuffer_render(self, y0, y1):
+        self.gbuf.render(self.scene, self.cam, y0, y1)
+
+    def phase_a(self, looper, reuse, y0, y1):
+        self.restir.phase_a(self.scene, self.cam, self.gbuf, looper, reuse, y0, y1)
+
+    def phase_b(self, iteration, reuse, y0, y1):
+        self.restir.phase_b(self.scene, self.cam, self.gbuf, self.image, iteration, reuse, y0, y1)
+
+    def end_frame(self):
+        self.restir.end_frame()
+        self.gbuf.update(self.cam)
+
+    def _rows(self, arr, y0, rows):
+        return arr[y0 * self.W:(y0 + rows) * self.W]
+
+    def halo_pack(self, y0, rows):
+        return self.torch.from_numpy(self._rows(self.restir.temp, y0, rows).copy().view(np.uint8).reshape(-1))
+
+    def halo_unpack(self, y0, rows, buf):
+        self._rows(self.restir.temp, y0, rows)[:] = buf.numpy().view(RESERVOIR_DTYPE)
+
+    def history_bytes(self, rows):
+        return rows * self.W * (36 + 20)
+
+    def history_pack(self, y0, rows):
+        last = self.gbuf.frame_idx ^ 1
+        parts = [self._rows(self.restir.last, y0, rows).view(np.uint8).reshape(-1),
+                 self._rows(self.gbuf.prim_id[last], y0, rows).view(np.uint8).reshape(-1),
+                 self._rows(self.gbuf.normal[last], y0, rows).reshape(-1).view(np.uint8),
+                 self._rows(self.gbuf.depth[last], y0, rows).view(np.uint8).reshape(-1)]
+        return self.torch.from_numpy(np.concatenate(parts))
+
+    def history_unpack(self, y0, rows, buf):
+        last = self.gbuf.frame_idx ^ 1
+        n = rows * self.W
+        b = buf.numpy()
+        o = 0
+        self._rows(self.restir.last, y0, rows)[:] = b[o:o + n * 36].view(RESERVOIR_DTYPE); o += n * 36
+        self._rows(self.gbuf.prim_id[last], y0, rows)[:] = b[o:o + n * 4].view(np.int32); o += n * 4
+        self._rows(self.gbuf.normal[last], y0, rows)[:] = b[o:o + n * 12].view(np.float32).reshape(n, 3); o += n * 12
+        self._rows(self.gbuf.depth[last], y0, rows)[:] = b[o:o + n * 4].view(np.float32)

@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library loads and exports every symbol include/restir_hip.h declares, and its
+host-side builders (BVH, alias table, light table, camera) agree bit-for-bit with the oracle.
+No compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from restir_amd import capi, scenes
+from restir_amd.ctypes_structs import LIGHT, copy_camera, make_camera, make_materials
+from tests.common import bits_equal, get_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "restir_hip.h")).read()
+    declared = set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 45
+    lib = capi.lib()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+
+
+def test_struct_layouts_match_reference_sizes():
+    from restir_amd.ctypes_structs import Camera, Material, Reservoir
+    assert C.sizeof(Material) == 44 and C.sizeof(Camera) == 196 and C.sizeof(Reservoir) == 36
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza:0.02", "sponza:0.1"])
+def test_scene_build_matches_oracle(name):
+    sd = get_scene(name)
+    ba, na = capi.build_bvh(sd.vertices)
+    bb, nb = ob.bvh_build(sd.vertices)
+    assert bits_equal(ba, bb) and np.array_equal(na, nb)
+    la = capi.build_light_table(sd.vertices, sd.material_ids, sd.materials)
+    lb = ob.light_table(sd.vertices, sd.material_ids, sd.materials)
+    assert np.array_equal(la[0], lb[0]) and bits_equal(la[1], lb[1]) and bits_equal(la[2], lb[2])
+    aa = capi.build_alias_table(la[2]); ab = ob.alias_build(lb[2])
+    assert bits_equal(aa[0], ab[0]) and np.array_equal(aa[1], ab[1]) and aa[2] == ab[2]
+
+
+def test_bvh_degenerate_inputs():
+    rng = np.random.default_rng(3)
+    one = rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32)
+    b, n = capi.build_bvh(one)
+    assert n.shape == (6, 1, 3) and (n[:, 0, 0] == 0).all() and (n[:, 0, 2] == 1).all()
+    # identical triangles: every split has dimMax == dimMin (bvh.cpp:83 int(NaN) -> bucket 0)
+    same = np.repeat(one, 9, axis=0)
+    ba, na = capi.build_bvh(same); bb, nb = ob.bvh_build(same)
+    assert bits_equal(ba, bb) and np.array_equal(na, nb)
+    # threaded links always point forward and end at BVHSize
+    size = na.shape[1]
+    assert (na[:, :, 2] > np.arange(size)[None, :]).all() and (na[:, :, 2] <= size).all()
+    for k in range(6):
+        assert sorted(na[k, :, 1].tolist()) == list(range(size))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1024])
+def test_alias_table_properties(n):
+    rng = np.random.default_rng(n)
+    v = np.exp(rng.uniform(-4, 4, n)).astype(np.float32)
+    prob, fail, total = capi.build_alias_table(v)
+    pr, fr, tr = ob.alias_build(v)
+    assert bits_equal(prob, pr) and np.array_equal(fail, fr) and total == tr
+    # the table reproduces the distribution: p_i = (prob_i + sum_{j: fail_j = i} (1 - prob_j)) / n
+    p = np.minimum(prob, 1.0).astype(np.float64)
+    mass = p.copy()
+    for j in range(n):
+        if fail[j] != j:
+            mass[fail[j]] += 1.0 - p[j]
+    assert np.allclose(mass / n, v.astype(np.float64) / v.astype(np.float64).sum(), atol=2e-5)
+
+
+def test_light_table_empty_and_errors():
+    sd = scenes.cornell_box()
+    mats = sd.materials.copy(); mats["type"] = 0
+    ids, rad, power = capi.build_light_table(sd.vertices, sd.material_ids, mats)
+    assert len(ids) == 0
+    with pytest.raises(capi.RestirHipError):
+        capi.build_light_table(sd.vertices, sd.material_ids + 100, sd.materials)
+    assert b"out of range" in capi.lib().rs_last_error()
+
+
+def test_camera_update_matches_oracle():
+    for args in [(256, 256, (0, 1, 3.5), (-90, 0, 0), 19.5), (1920, 1080, (3, 2, -7), (37, -12, 0), 30.0), (640, 360, (0, 0, 0), (0, 89.5, 0), 45.0)]:
+        a = make_camera(*args); b = copy_camera(a)
+        capi.camera_update(a); ob.camera_update(b)
+        assert bytes(a) == bytes(b)
+
+
+def test_no_gpu_means_loud_failure():
+    """On a machine without an MI355X the device entry points raise; nothing silently falls back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.RestirHipError):
+        capi.init(0)
+
+
+def test_procedural_scene_budgets():
+    sd = scenes.sponza_class(1, 1.0)
+    assert sd.num_prims == 262144
+    assert int((sd.materials["type"][sd.material_ids] == LIGHT).sum()) == 1024
+    b = scenes.bistro_class(2, 0.01)
+    assert b.num_prims > 10000 and int((b.materials["type"][b.material_ids] == LIGHT).sum()) == 2 * max(8, round(5120 * 0.01))
