@@ -9,14 +9,15 @@ scene (262 144 triangles, 1 024 emissive; BASELINE config 3).
 A step = one frame.  A ray = one BVH walk (intersect or testOcclusion call): 1 G-buffer ray + 1
 shading ray per pixel + 1 shadow ray per shaded pixel; counted by the kernels.
 
-N > 1: the 1920x1080 framebuffer is cut into N row strips (strong scaling, fixed total work).  Every
-rank renders its strip (+5 G-buffer halo rows), exchanges 5 rows of published reservoirs with its
-strip neighbours over RCCL point-to-point between phase A and phase B, tone-maps its strip and the
-RGBA8 strips are gathered on rank 0 -- all inside the timed region.
+N > 1: the 1920x1080 framebuffer is cut into N row strips (strong scaling: the total work is fixed).
+Every rank renders its strip (+5 G-buffer halo rows), exchanges 5 rows of published reservoirs with
+its strip neighbours over RCCL point-to-point between phase A and phase B (restir_amd/tiling.py),
+tone-maps its strip, and the RGBA8 strips are gathered on rank 0 -- all inside the timed region.
 
 One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its
-                HIP-event duration, against the 8 TB/s HBM3E peak
+                HIP-event duration (events recorded on the stream the kernel is launched on),
+                against the 8 TB/s HBM3E peak; `traffic` is filled from profiles/ PMC runs when known
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a
                 bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -26,8 +27,6 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -35,24 +34,29 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT = 1920, 1080
 REUSE = 3                      # ReservoirReuse::Spatiotemporal
 TONEMAP = 2                    # ToneMapping::ACES (Settings default, src/common.cpp:4)
-HALO = 5
 ALGO_BYTES_PER_PIXEL = 92      # spatial-reuse pass
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def strip_bounds(height, n, rank):
-    """Contiguous row strips; strip heights differ by at most one row."""
-    base, rem = divmod(height, n)
-    y0 = rank * base + min(rank, rem)
-    return y0, y0 + base + (1 if rank < rem else 0)
+def host_threads():
+    """CPU share of this process: min(affinity, cgroup quota), capped at 64."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
 
 
 def cpu_baseline(sd, frames):
     """The oracle on the host cores: `frames` full 1920x1080 spatiotemporal frames (bounded sample)."""
+    threads = host_threads()
+    os.environ["OMP_NUM_THREADS"] = str(threads)          # read by libgomp when liboracle.so is loaded
     from tests.common import OracleRenderer
-    threads = len(os.sched_getaffinity(0))
     o = OracleRenderer(sd, WIDTH, HEIGHT)
-    o.frame(REUSE)                                   # untimed: thread-pool start-up, page faults
+    o.frame(REUSE)                                        # untimed: thread-pool start-up, page faults
     rays = 0
     t0 = time.perf_counter()
     for _ in range(frames):
@@ -67,20 +71,21 @@ def cpu_baseline(sd, frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--orbit", action="store_true", help="orbit the camera (runCuda animateCamera) instead of the static default")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank per GPU")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no fallback"
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -88,66 +93,33 @@ def main():
 
     from restir_amd import capi, scenes
     from restir_amd.scenes import orbit_position
+    from restir_amd.tiling import HipBackend, StripRenderer
     capi.init(local_rank)
 
     sd = scenes.sponza_class(seed=1, scale=1.0)
     scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
     cam = capi.camera_update(sd.camera(WIDTH, HEIGHT))
-    gbuf = capi.GBuffer(WIDTH, HEIGHT)
-    restir = capi.ReSTIR(WIDTH, HEIGHT)
-    restir.enable_timing(True)
-    image = torch.zeros((WIDTH * HEIGHT, 3), dtype=torch.float32, device="cuda")
-    pbo = torch.zeros((WIDTH * HEIGHT, 4), dtype=torch.uint8, device="cuda")
-
-    y0, y1 = strip_bounds(HEIGHT, world, rank)
-    gy0, gy1 = max(0, y0 - HALO), min(HEIGHT, y1 + HALO)
-    up, down = rank - 1, rank + 1
-    if world > 1:
-        nb = restir.halo_bytes(HALO)
-        send_up = torch.empty(nb, dtype=torch.uint8, device="cuda"); recv_up = torch.empty_like(send_up)
-        send_dn = torch.empty(nb, dtype=torch.uint8, device="cuda"); recv_dn = torch.empty_like(send_dn)
-        # ragged strips: gather buffers sized to the largest strip
-        max_rows = max(strip_bounds(HEIGHT, world, r)[1] - strip_bounds(HEIGHT, world, r)[0] for r in range(world))
-        gather_out = [torch.empty((max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
-        strip_rgba = torch.zeros((max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda")
+    backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
+    backend.restir.enable_timing(True)
+    strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit)
+    y0, y1 = strips.y0, strips.y1
+    rows = y1 - y0
+    pbo = torch.zeros((strips.max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda")
+    gather_out = [torch.empty_like(pbo) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     base_pos = sd.camera_args["position"]
-    state = {"looper": 0}
-    capi.set_sync(False)                   # launches are enqueued; the timed region is bracketed by synchronize()
+    capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
 
     def frame():
         if args.orbit:
-            p = orbit_position(base_pos, state["looper"], radius=1.0)
+            p = orbit_position(base_pos, strips.looper, radius=1.0)
             for i in range(3):
                 cam.position[i] = float(p[i])
             capi.camera_update(cam)
-        if world == 1:
-            gbuf.render(scene, cam)
-            restir.direct(scene, cam, gbuf, image.data_ptr(), 0, state["looper"], REUSE)
-            capi.copy_image_to_pbo(pbo.data_ptr(), image.data_ptr(), WIDTH, HEIGHT, TONEMAP, 1.0)
-        else:
-            gbuf.render(scene, cam, gy0, gy1)
-            restir.phase_a(scene, cam, gbuf, state["looper"], REUSE, y0, y1)
-            ops = []
-            if up >= 0:
-                restir.halo_pack(y0, HALO, send_up.data_ptr())
-                ops += [dist.P2POp(dist.isend, send_up, up), dist.P2POp(dist.irecv, recv_up, up)]
-            if down < world:
-                restir.halo_pack(y1 - HALO, HALO, send_dn.data_ptr())
-                ops += [dist.P2POp(dist.isend, send_dn, down), dist.P2POp(dist.irecv, recv_dn, down)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            if up >= 0:
-                restir.halo_unpack(y0 - HALO, HALO, recv_up.data_ptr())
-            if down < world:
-                restir.halo_unpack(y1, HALO, recv_dn.data_ptr())
-            restir.phase_b(scene, cam, gbuf, image.data_ptr(), 0, REUSE, y0, y1)
-            restir.end_frame()
-            rows = y1 - y0
-            capi.copy_image_to_pbo(strip_rgba.data_ptr(), image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
-            dist.gather(strip_rgba, gather_out, dst=0)
-        state["looper"] += 1
-        gbuf.update(cam)
+        strips.frame(REUSE, 0)             # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), GBuffer::update
+        capi.copy_image_to_pbo(pbo.data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+        if world > 1:
+            dist.gather(pbo, gather_out, dst=0)
 
     def barrier():
         if world > 1:
@@ -157,25 +129,23 @@ def main():
     for _ in range(args.warmup):
         frame()
     barrier()
-    spatial_ms = []
-    pass_ms = np.zeros(4)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
     barrier()
     elapsed = time.perf_counter() - t0
+    counted = min(args.steps, 1024)
+    local_rays = backend.restir.ray_total(counted) / counted * args.steps + (strips.gy1 - strips.gy0 if world > 1 else HEIGHT) * WIDTH * args.steps
 
-    # per-pass times of a few extra (untimed) frames, measured with HIP events on the library's stream
-    for _ in range(min(20, max(3, args.steps))):
+    # per-pass times of a few extra (untimed) frames, HIP events on the library's stream
+    spatial_ms, pass_ms = [], np.zeros(4)
+    for _ in range(20):
         frame()
         torch.cuda.synchronize()
-        ms = restir.pass_times()
+        ms = backend.restir.pass_times()
         spatial_ms.append(ms[3]); pass_ms += np.array(ms)
     pass_ms /= len(spatial_ms)
-    torch.cuda.synchronize()
 
-    rows = y1 - y0
-    local_rays = restir.ray_total(min(args.steps, 1024)) / min(args.steps, 1024) * args.steps + (gy1 - gy0) * WIDTH * args.steps
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -185,7 +155,6 @@ def main():
         total_rays = float(local_rays)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
         spatial_us = float(np.median(spatial_ms)) * 1e3
         algo_bytes = ALGO_BYTES_PER_PIXEL * WIDTH * rows
         achieved = algo_bytes / (spatial_us * 1e-6) / 1e9
@@ -196,15 +165,16 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE config 3: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 1920x1080, "
-                                   "32 RIS candidates, spatiotemporal ReSTIR-DI, frame = GBuffer::render + ReSTIRDirect + copyImageToPBO",
-                       "camera": "orbit" if args.orbit else "static", "tiling": f"{world} row strips, 5-row reservoir halo over RCCL p2p" if world > 1 else "none",
+                                   "32 RIS candidates, spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update",
+                       "camera": "orbit" if args.orbit else "static",
+                       "tiling": f"{world} row strips, 5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0" if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

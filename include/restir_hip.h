@@ -194,6 +194,7 @@ int  rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer);
 int  rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer);
 /* Same packing for any of the three reservoir buffers (which: as rs_restir_download); which = 1 after
  * rs_restir_end_frame is the history the next frame's temporal merge reads. */
+size_t rs_restir_rows_bytes(const rs_restir* r, int which, int rows);
 int  rs_restir_rows_pack(const rs_restir* r, int which, int y0, int rows, void* devBuffer);
 int  rs_restir_rows_unpack(rs_restir* r, int which, int y0, int rows, const void* devBuffer);
 /* Debug / parity: copy a reservoir buffer to host as the reference's AoS records.
@@ -209,8 +210,12 @@ int  rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays);
 /* Per-pass GPU time (ms) of the last frame, measured with hipEvents on the library's stream:
  * ms[0] primary hit, ms[1] RIS, ms[2] shadow+temporal, ms[3] spatial+shade.  Synchronises. */
 int  rs_restir_pass_times(rs_restir* r, float ms[4]);
-/* Enables the hipEvent bracketing above (off by default: it adds 8 event records per frame). */
+/* Enables the hipEvent bracketing above (off by default: it adds 5 event records per frame). */
 int  rs_restir_enable_timing(rs_restir* r, int enable);
+/* Test hook: the spatial pass estimates tap positions with the hardware sqrt/sin/cos and falls back
+ * to the exact evaluation inside an error band; this returns the largest estimate error over n
+ * pseudo-random samples so a test can assert the band really covers it. */
+int  rs_debug_tap_estimate_error(int n, float* maxErr);
 
 /* ---- path-trace baseline (src/pathtrace.h:12-16) ---------------------------------------- */
 int  rs_path_trace_init(void);            /* pathTraceInit (src/pathtrace.cu:23-25) */

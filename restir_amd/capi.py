@@ -12,7 +12,7 @@ import numpy as np
 from .ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE, copy_camera
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librestir_hip.so")
+LIB_PATH = os.environ.get("RESTIR_HIP_LIB") or os.path.join(_HERE, "librestir_hip.so")   # env override: A/B builds
 
 
 class RestirHipError(RuntimeError):
@@ -61,8 +61,8 @@ EXPORTS = [
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
-    "rs_restir_halo_unpack", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
-    "rs_restir_enable_timing", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
+    "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_copy_image_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
 ]
@@ -75,6 +75,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch bundles its own HIP/HSA runtime; it has to be the first one loaded in the process,
+        # otherwise two runtimes race for the device and hipGetDeviceCount reports none.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RestirHipError(
             f"{LIB_PATH} is missing: build it with `make -C restir_amd/csrc` (or __graft_entry__.build()). "
@@ -112,6 +118,9 @@ def lib():
     L.rs_restir_halo_bytes.restype = C.c_size_t
     L.rs_restir_halo_pack.argtypes = [vp, ci, ci, vp]
     L.rs_restir_halo_unpack.argtypes = [vp, ci, ci, vp]
+    L.rs_restir_rows_bytes.argtypes = [vp, ci, ci]
+    L.rs_restir_rows_bytes.restype = C.c_size_t
+    L.rs_debug_tap_estimate_error.argtypes = [ci, C.POINTER(cf)]
     L.rs_restir_rows_pack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_restir_rows_unpack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_gbuffer_rows_bytes.argtypes = [vp, ci]
@@ -348,6 +357,9 @@ class ReSTIR:
 
     def halo_unpack(self, y0, rows, dev_ptr):
         check(lib().rs_restir_halo_unpack(self.handle, y0, rows, dev_ptr))
+
+    def rows_bytes(self, which, rows):
+        return int(lib().rs_restir_rows_bytes(self.handle, which, rows))
 
     def rows_pack(self, which, y0, rows, dev_ptr):
         check(lib().rs_restir_rows_pack(self.handle, which, y0, rows, dev_ptr))

@@ -20,11 +20,12 @@ __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams ca
     const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
     const int x = bx * 32 + wave * 8 + (lane & 7);
     const int y = y0 + by * 8 + (lane >> 3);
-    if (x >= cam.width || y >= y1) return;
+    const bool inside = x < cam.width && y < y1;
     const int idx = y * cam.width + x;
 
     Ray ray = camera_center_ray(cam, x, y);
-    Hit h = trace_closest(s, ray);
+    Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
+    if (!inside) return;
 
     if (h.primId != kNullPrim) {
         int matId = h.matId;

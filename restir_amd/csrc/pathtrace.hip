@@ -25,13 +25,14 @@ __global__ void __launch_bounds__(256) k_pt_direct(DevScene s, CamParams cam, fl
     const int x = bx * 32 + wave * 8 + (lane & 7);
     const int y = by * 8 + (lane >> 3);
     int walks = 0;
-    if (x < cam.width && y < cam.height) {
-        const int index = y * cam.width + x;
+    const bool inside = x < cam.width && y < cam.height;
+    const int index = y * cam.width + x;
+    Rng rng = seeded_rng(looper, index, 0);
+    f4 r = rng.uniform4();
+    Ray ray = camera_sample(cam, x, y, r.x, r.y);
+    Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
+    if (inside) {
         f3 direct = splat(0.f);
-        Rng rng = seeded_rng(looper, index, 0);
-        f4 r = rng.uniform4();
-        Ray ray = camera_sample(cam, x, y, r.x, r.y);
-        Hit h = trace_closest(s, ray);
         walks = 1;
         if (h.primId != kNullPrim) {
             const rs_material m = s.materials[h.matId];

@@ -20,6 +20,8 @@
 // planes its neighbour tests need -- weight, M, G-buffer id / normal / depth -- for a 32x8 tile
 // plus a 5-pixel halo into LDS (21 KB), tracks the SOURCE PIXEL of the surviving sample through the
 // merges, and gathers that one sample (32 B) at the end instead of staging Li/wi for 756 pixels.
+#include <cstring>
+
 #include "rs_internal.h"
 
 using namespace rs;
@@ -27,8 +29,7 @@ using namespace rs;
 namespace {
 
 constexpr int kReservoirSize = 32;   // restir.cu:3
-constexpr int kTileW = 32, kTileH = 8, kHalo = RS_SPATIAL_HALO_ROWS;
-constexpr int kStageW = kTileW + 2 * kHalo, kStageH = kTileH + 2 * kHalo, kStageN = kStageW * kStageH;
+constexpr int kHalo = RS_SPATIAL_HALO_ROWS;
 
 // kind of a pixel after the primary hit
 constexpr int kKindMiss = 0, kKindLight = 1, kKindShaded = 2;
@@ -57,12 +58,12 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
     pixel_of_lane(tilesX, y0, x, y);
     const bool inside = x < cam.width && y < y1;
     int shaded = 0;
+    const int index = y * cam.width + x;
+    Rng rng = seeded_rng(looper, index, 0);
+    f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
+    Ray ray = camera_sample(cam, x, y, r.x, r.y);
+    Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
     if (inside) {
-        const int index = y * cam.width + x;
-        Rng rng = seeded_rng(looper, index, 0);
-        f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
-        Ray ray = camera_sample(cam, x, y, r.x, r.y);
-        Hit h = trace_closest(s, ray);
 
         int kind = kKindMiss, matId = 0;
         f3 norm = splat(0.f), wo = splat(0.f);
@@ -140,14 +141,21 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
 }
 
 __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last,
-                                                         ResvPlanes cur, ResvPlanes temp, int first, int reuse,
+                                                         ResvPlanes cur, TempPlanes temp, int first, int reuse,
                                                          int y0, int y1, int tilesX) {
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
     if (x >= g.width || y >= y1) return;
     const int index = y * g.width + x;
     const float4 pm = sp.posMat[index];
-    if ((__float_as_int(pm.w) >> 24) != kKindShaded) return;     // early-exit pixels publish nothing (Q1)
+    const int gid = g.primId[index];
+    const float gdepth = g.depth[index];
+    if ((__float_as_int(pm.w) >> 24) != kKindShaded) {
+        // early-exit pixels publish no reservoir (Q1: their slot keeps its stale value); only the
+        // G-buffer half of the tap record is refreshed
+        if (reuse & 2) reinterpret_cast<float2*>(temp.tap + index)[1] = make_float2(__int_as_float(gid), gdepth);
+        return;
+    }
     const float4 cl = sp.candLi[index], cw = sp.candWi[index];
     const f3 pos = mk3(pm.x, pm.y, pm.z);
 
@@ -158,7 +166,7 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
     if (trace_occluded(s, pos, pos + r.wi * r.dist)) r.W = 0.f;   // restir.cu:172-176
 
     if (!first && (reuse & 1)) {                                  // findTemporalNeighbor, restir.cu:20-45
-        const int primId = g.primId[index];
+        const int primId = gid;
         const int lastIdx = g.motion[index];
         bool diff = false;
         if (lastIdx < 0) diff = true;
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
         else if (g.lastPrimId[lastIdx] != primId) diff = true;
         else {
             f3 n = ld3(g.normal + (size_t)index * 3), ln = ld3(g.lastNormal + (size_t)lastIdx * 3);
-            float depth = g.depth[index], pdepth = g.lastDepth[lastIdx];
+            float depth = gdepth, pdepth = g.lastDepth[lastIdx];
             if (abs_dot(n, ln) < .9f || gabs(pdepth - depth) > depth * .1f) diff = true;
         }
         Resv t;
@@ -193,13 +201,26 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
     }
     // checkValidity (restir.h:55-59); the temp copy and the stored copy are the same value
     if (resv_invalid(r.W)) { r.W = 0.f; r.M = 0; }
-    if (reuse & 2) resv_store(temp, index, r);
+    if (reuse & 2) {
+        temp.li[index] = make_float4(r.Li.x, r.Li.y, r.Li.z, r.dist);
+        temp.wi[index] = make_float4(r.wi.x, r.wi.y, r.wi.z, 0.f);
+        temp.tap[index] = make_float4(r.W, __int_as_float(r.M), __int_as_float(gid), gdepth);
+    }
     resv_store(cur, index, r);
 }
 
 // ---- phase B: spatial reuse + shade --------------------------------------------------------------
-__device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& px, int& py) {
-    // Math::toConcentricDisk (mathUtil.h:128-132) * Radius, then int(x + .5f + p.x) (restir.cu:53-55)
+// Tap position: Math::toConcentricDisk (mathUtil.h:128-132) * Radius, then int(x + .5f + p.x)
+// (restir.cu:53-55).  Only the TRUNCATED pixel coordinate matters, so the position is first estimated
+// with the hardware sqrt / sin / cos (v_sqrt_f32, v_sin_f32, v_cos_f32: a handful of instructions
+// against ~90 for correctly rounded sqrtf + sincosf).  The estimate can differ from the exact value by
+// at most kTapErr (trig + sqrt error, measured by rs_debug_tap_estimate_error and asserted in the
+// tests) plus one rounding of the sum; if an integer lies within that band the exact path runs, and
+// the exact path itself re-does the trigonometry in double when its own 2-ulp band straddles an
+// integer.  Result: the same pixel as the host evaluation, at a fraction of the instruction count.
+constexpr float kTapErr = 4e-5f;
+
+__device__ __forceinline__ void disk_tap_exact(float rx, float ry, int x, int y, int& px, int& py) {
     const float Radius = 5.f;
     const float rr = sqrtf(rx);
     const float theta = ry * kPi * 2.0f;
@@ -207,9 +228,6 @@ __device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& 
     sincosf(theta, &sn, &cs);
     float fx = (float)x + .5f + (cs * rr) * Radius;
     float fy = (float)y + .5f + (sn * rr) * Radius;
-    // The truncation below is the only place where a 1-ulp difference between this libm and the host
-    // libm could change a result.  When a coordinate lands within 2 ulp of an integer the
-    // trigonometry is redone in double precision and rounded once (matches a correctly rounded cosf).
     const float nx = rintf(fx), ny = rintf(fy);
     if (gabs(fx - nx) <= 4.f * 1.1920929e-7f * gabs(nx) + 1e-30f || gabs(fy - ny) <= 4.f * 1.1920929e-7f * gabs(ny) + 1e-30f) {
         double sd, cd;
@@ -221,41 +239,81 @@ __device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& 
     py = f2i(fy);
 }
 
-__global__ void __launch_bounds__(256) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes rp,
-                                                       float* __restrict__ directIllum, int iter, int reuse,
-                                                       int y0, int y1, int tilesX, int numTiles) {
-    __shared__ float sW[kStageN];
-    __shared__ int   sM[kStageN];
-    __shared__ int   sId[kStageN];
-    __shared__ float sDepth[kStageN];
-    __shared__ float sNx[kStageN], sNy[kStageN], sNz[kStageN];
+__device__ __forceinline__ void disk_tap_estimate(float rx, float ry, int x, int y, float& fx, float& fy) {
+    const float rr5 = __builtin_amdgcn_sqrtf(rx) * 5.f;
+    // v_sin/v_cos take revolutions: theta / 2pi = ry (theta = ry * Pi * 2)
+    fx = (float)x + .5f + __builtin_amdgcn_cosf(ry) * rr5;
+    fy = (float)y + .5f + __builtin_amdgcn_sinf(ry) * rr5;
+}
+
+__device__ __forceinline__ bool tap_ambiguous(float f) {
+    return gabs(f - rintf(f)) <= kTapErr + 2.4e-7f * gabs(f);
+}
+
+__device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& px, int& py) {
+    float fx, fy;
+    disk_tap_estimate(rx, ry, x, y, fx, fy);
+    px = f2i(fx);
+    py = f2i(fy);
+    if (tap_ambiguous(fx) || tap_ambiguous(fy)) disk_tap_exact(rx, ry, x, y, px, py);
+}
+
+// debug / test hook: largest |estimate - exact(double)| of the tap offset over n samples
+__global__ void k_tap_estimate_error(int n, float* maxErr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float e = 0.f;
+    if (i < n) {
+        Rng rng = seeded_rng(i, 12345, 0);
+        const float rx = rng.uniform(), ry = rng.uniform();
+        float fx, fy;
+        disk_tap_estimate(rx, ry, 0, 0, fx, fy);
+        const double th = (double)(ry * kPi * 2.0f), rr = sqrt((double)rx) * 5.0;
+        e = fmaxf(gabs((float)((double)fx - (0.5 + cos(th) * rr))), gabs((float)((double)fy - (0.5 + sin(th) * rr))));
+    }
+    for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_down(e, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(maxErr), __float_as_uint(e));   // e >= 0
+}
+
+// one staged pixel: tap record {W, M, id, depth} + G-buffer normal, 32 B
+struct __attribute__((aligned(16))) Staged { float4 tap; float nx, ny, nz, pad; };
+
+constexpr int kBTileW = 32, kBTileH = 16, kBThreads = kBTileW * kBTileH;
+constexpr int kBStageW = kBTileW + 2 * kHalo, kBStageH = kBTileH + 2 * kHalo, kBStageN = kBStageW * kBStageH;
+
+__global__ void __launch_bounds__(kBThreads) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
+                                                             float* __restrict__ directIllum, int iter, int reuse,
+                                                             int y0, int y1, int tilesX, int numTiles) {
+    __shared__ Staged stage[kBStageN];
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
-    // contiguous run of tiles so neighbouring tiles' halos are served by the same L2.
+    // contiguous run of tiles so that neighbouring tiles' halos are served by the same L2.
     int tile = blockIdx.x;
     {
         const int q = numTiles / 8, rem = numTiles % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
     }
-    const int ox = (tile % tilesX) * kTileW, oy = y0 + (tile / tilesX) * kTileH;
+    const int ox = (tile % tilesX) * kBTileW, oy = y0 + (tile / tilesX) * kBTileH;
     const int W = g.width, H = g.height;
     const bool spatial = (reuse & 2) != 0;
 
     if (spatial) {
-        for (int e = threadIdx.x; e < kStageN; e += 256) {
-            const int sx = ox - kHalo + (e % kStageW), sy = oy - kHalo + (e / kStageW);
-            float w = 0.f, d = 0.f, nx = 0.f, ny = 0.f, nz = 0.f; int m = 0, id = -3;
+        for (int e = threadIdx.x; e < kBStageN; e += kBThreads) {
+            const int sx = ox - kHalo + (e % kBStageW), sy = oy - kHalo + (e / kBStageW);
+            Staged v;
+            v.tap = make_float4(0.f, 0.f, __int_as_float(-3), 0.f);     // id -3 matches nothing
+            v.nx = v.ny = v.nz = v.pad = 0.f;
             if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
                 const int gi = sy * W + sx;
-                w = rp.w[gi]; m = rp.m[gi]; id = g.primId[gi]; d = g.depth[gi];
-                nx = g.normal[(size_t)gi * 3]; ny = g.normal[(size_t)gi * 3 + 1]; nz = g.normal[(size_t)gi * 3 + 2];
+                v.tap = temp.tap[gi];
+                const f3 n = ld3(g.normal + (size_t)gi * 3);
+                v.nx = n.x; v.ny = n.y; v.nz = n.z;
             }
-            sW[e] = w; sM[e] = m; sId[e] = id; sDepth[e] = d; sNx[e] = nx; sNy[e] = ny; sNz[e] = nz;
+            stage[e] = v;
         }
         __syncthreads();
     }
 
-    const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
+    const int tx = threadIdx.x % kBTileW, ty = threadIdx.x / kBTileW;
     const int x = ox + tx, y = oy + ty;
     if (x >= W || y >= y1) return;
     const int index = y * W + x;
@@ -272,14 +330,15 @@ __global__ void __launch_bounds__(256) k_spatial_shade(DevScene s, SurfPlanes sp
         // own reservoir = what phase A published (post-temporal, validity-checked)
         float W0; int M0; int src = index;
         if (spatial) {
-            const int c = (ty + kHalo) * kStageW + (tx + kHalo);
-            W0 = sW[c]; M0 = sM[c];
+            const Staged c = stage[(ty + kHalo) * kBStageW + (tx + kHalo)];
+            W0 = c.tap.x; M0 = __float_as_int(c.tap.y);
+            const int idC = __float_as_int(c.tap.z);
+            const float dC = c.tap.w;
+            const f3 nC = mk3(c.nx, c.ny, c.nz);
 
             // mergeSpatialNeighborDirect (restir.cu:87-100)
-            const int idC = sId[c];
-            const f3 nC = mk3(sNx[c], sNy[c], sNz[c]);
-            const float dC = sDepth[c];
             float aW = 0.f; int aM = 0; int aSrc = -1;
+#pragma unroll 1
             for (int i = 0; i < 5; i++) {
                 const f2 r2 = rng.uniform2();
                 int px, py;
@@ -287,22 +346,22 @@ __global__ void __launch_bounds__(256) k_spatial_shade(DevScene s, SurfPlanes sp
                 float tW = 0.f; int tM = 0; int tSrc = -1;           // T(): zero sample, W = 0 (valid)
                 if (!(px < 0 || px >= W || py < 0 || py >= H || (px == x && py == y))) {
                     const int lx = px - (ox - kHalo), ly = py - (oy - kHalo);
-                    int idP; f3 nP; float dP, wP; int mP;
-                    if (lx >= 0 && lx < kStageW && ly >= 0 && ly < kStageH) {
-                        const int e = ly * kStageW + lx;
-                        idP = sId[e]; nP = mk3(sNx[e], sNy[e], sNz[e]); dP = sDepth[e]; wP = sW[e]; mP = sM[e];
+                    float4 tp; f3 nP;
+                    if (lx >= 0 && lx < kBStageW && ly >= 0 && ly < kBStageH) {
+                        const Staged q = stage[ly * kBStageW + lx];
+                        tp = q.tap; nP = mk3(q.nx, q.ny, q.nz);
                     }
                     else {                                            // outside the staged halo: cannot happen for radius 5, kept for safety
                         const int gi = py * W + px;
-                        idP = g.primId[gi]; nP = ld3(g.normal + (size_t)gi * 3); dP = g.depth[gi]; wP = rp.w[gi]; mP = rp.m[gi];
+                        tp = temp.tap[gi]; nP = ld3(g.normal + (size_t)gi * 3);
                     }
                     bool diff = false;
-                    if (idP != idC) diff = true;
+                    if (__float_as_int(tp.z) != idC) diff = true;
                     else {
                         if (dot(nC, nP) < .9f) diff = true;
-                        if (gabs(dC - dP) > dC * .1f) diff = true;
+                        if (gabs(dC - tp.w) > dC * .1f) diff = true;
                     }
-                    if (!diff) { tW = wP; tM = mP; tSrc = py * W + px; }
+                    if (!diff) { tW = tp.x; tM = __float_as_int(tp.y); tSrc = py * W + px; }
                 }
                 if (!resv_invalid(tW)) {
                     const float u = rng.uniform();
@@ -317,16 +376,16 @@ __global__ void __launch_bounds__(256) k_spatial_shade(DevScene s, SurfPlanes sp
             }
         }
         else {
-            // No spatial pass: rp is the buffer phase A published this frame (validity-checked copy of
+            // No spatial pass: `own` is the buffer phase A published this frame (validity-checked copy of
             // the post-temporal reservoir).  The reference shades the unchecked one; they differ only
             // when it was invalid, and then both give direct = 0 (0/0 -> NaN -> cleared below).
-            W0 = rp.w[index]; M0 = rp.m[index];
+            W0 = own.w[index]; M0 = own.m[index];
         }
 
         if (!resv_invalid(W0)) {
             f3 Li = splat(0.f), wi = splat(0.f);
             if (src >= 0) {
-                const float4 a = rp.li[src], b = rp.wi[src];
+                const float4 a = spatial ? temp.li[src] : own.li[src], b = spatial ? temp.wi[src] : own.wi[src];
                 Li = mk3(a.x, a.y, a.z); wi = mk3(b.x, b.y, b.z);
             }
             const rs_material m = s.materials[mk & 0xffffff];
@@ -358,7 +417,7 @@ int alloc_planes(ResvPlanes& p, size_t n) {
 }
 void free_planes(ResvPlanes& p) { rs_dev_free(p.li); rs_dev_free(p.wi); rs_dev_free(p.w); rs_dev_free(p.m); }
 
-ResvPlanes* pick(rs_restir* r, int which) { return which == 0 ? &r->cur : (which == 1 ? &r->last : (which == 2 ? &r->temp : nullptr)); }
+ResvPlanes* pick(rs_restir* r, int which) { return which == 0 ? &r->cur : (which == 1 ? &r->last : nullptr); }
 
 SurfPlanes surf_of(rs_restir* r) {
     SurfPlanes sp;
@@ -382,7 +441,8 @@ extern "C" {
 
 int rs_restir_free(rs_restir* r) {
     if (!r) return 0;
-    free_planes(r->cur); free_planes(r->last); free_planes(r->temp);
+    free_planes(r->cur); free_planes(r->last);
+    rs_dev_free(r->temp.li); rs_dev_free(r->temp.wi); rs_dev_free(r->temp.tap);
     rs_dev_free(r->surfPosKind); rs_dev_free(r->surfNormRng); rs_dev_free(r->surfWo); rs_dev_free(r->matKind);
     rs_dev_free(r->candLi); rs_dev_free(r->candWi); rs_dev_free(r->dRayCount);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
@@ -399,7 +459,12 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     int e = 0;
     if (!e) e = alloc_planes(r->cur, n);
     if (!e) e = alloc_planes(r->last, n);
-    if (!e) e = alloc_planes(r->temp, n);
+    if (!e) e = rs_dev_alloc(&r->temp.li, n);
+    if (!e) e = rs_dev_alloc(&r->temp.wi, n);
+    if (!e) e = rs_dev_alloc(&r->temp.tap, n);
+    if (!e) e = rs_check_hip(hipMemset(r->temp.li, 0, n * 16), "memset");
+    if (!e) e = rs_check_hip(hipMemset(r->temp.wi, 0, n * 16), "memset");
+    if (!e) e = rs_check_hip(hipMemset(r->temp.tap, 0, n * 16), "memset");
     if (!e) e = rs_dev_alloc(&r->surfPosKind, n);
     if (!e) e = rs_dev_alloc(&r->surfNormRng, n);
     if (!e) e = rs_dev_alloc(&r->surfWo, n);
@@ -459,10 +524,10 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     if (y0 < 0) y0 = 0;
     if (y1 > r->height) y1 = r->height;
     if (y1 <= y0) return 0;
-    const int tilesX = (r->width + kTileW - 1) / kTileW, tilesY = (y1 - y0 + kTileH - 1) / kTileH;
+    const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
-    hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(256), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
-                       (reuse & 2) ? r->temp : r->cur, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
+    hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(kBThreads), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
+                       r->cur, r->temp, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);
     return rs_after_launch("ReSTIR Direct (phase B)");
 }
@@ -488,72 +553,122 @@ int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, 
 }
 
 size_t rs_restir_halo_bytes(const rs_restir* r, int rows) {
-    return r ? (size_t)r->width * (size_t)(rows > 0 ? rows : 0) * 40u : 0;
+    return r ? (size_t)r->width * (size_t)(rows > 0 ? rows : 0) * 48u : 0;      // li 16 + wi 16 + tap 16
+}
+size_t rs_restir_rows_bytes(const rs_restir* r, int which, int rows) {
+    if (!r || rows < 0) return 0;
+    return (size_t)r->width * (size_t)rows * (which == 2 ? 48u : 40u);         // cur/last: li 16 + wi 16 + w 4 + m 4
 }
 
-// packed layout of `rows` rows: [li rows][wi rows][w rows][m rows]
-int rs_restir_rows_pack(const rs_restir* rc, int which, int y0, int rows, void* devBuffer) {
-    rs_restir* r = const_cast<rs_restir*>(rc);
-    const ResvPlanes* p = r ? pick(r, which) : nullptr;
-    if (!p || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_rows_pack: bad rows");
+namespace {
+struct Span { void* ptr; size_t bytesPerPixel; };
+int spans_of(rs_restir* r, int which, Span out[4]) {
+    if (which == 2) {
+        out[0] = { r->temp.li, 16 }; out[1] = { r->temp.wi, 16 }; out[2] = { r->temp.tap, 16 };
+        return 3;
+    }
+    ResvPlanes* p = pick(r, which);
+    if (!p) return 0;
+    out[0] = { p->li, 16 }; out[1] = { p->wi, 16 }; out[2] = { p->w, 4 }; out[3] = { p->m, 4 };
+    return 4;
+}
+int copy_rows(rs_restir* r, int which, int y0, int rows, char* buf, bool pack, const char* what) {
+    Span sp[4];
+    const int k = r ? spans_of(r, which, sp) : 0;
+    if (!k || !buf || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, what);
     const size_t n = (size_t)r->width * rows, off = (size_t)y0 * r->width;
-    char* b = (char*)devBuffer;
-    RS_HIP(hipMemcpyAsync(b, p->li + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 16, p->wi + off, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 32, p->w + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 36, p->m + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    return rs_after_launch("rs_restir_rows_pack");
+    size_t pos = 0;
+    for (int i = 0; i < k; i++) {
+        char* plane = (char*)sp[i].ptr + off * sp[i].bytesPerPixel;
+        const size_t bytes = n * sp[i].bytesPerPixel;
+        if (bytes) RS_HIP(hipMemcpyAsync(pack ? (void*)(buf + pos) : (void*)plane, pack ? (const void*)plane : (const void*)(buf + pos), bytes,
+                                         hipMemcpyDeviceToDevice, rs_stream()));
+        pos += bytes;
+    }
+    return rs_after_launch(what);
 }
+}  // namespace
 
+// packed layout of `rows` rows: the planes of the buffer one after the other (cur/last: li, wi, w, m;
+// temp: li, wi, tap)
+int rs_restir_rows_pack(const rs_restir* r, int which, int y0, int rows, void* devBuffer) {
+    return copy_rows(const_cast<rs_restir*>(r), which, y0, rows, (char*)devBuffer, true, "rs_restir_rows_pack: bad argument");
+}
 int rs_restir_rows_unpack(rs_restir* r, int which, int y0, int rows, const void* devBuffer) {
-    ResvPlanes* p = r ? pick(r, which) : nullptr;
-    if (!p || !devBuffer || y0 < 0 || rows < 0 || y0 + rows > r->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_rows_unpack: bad rows");
-    const size_t n = (size_t)r->width * rows, off = (size_t)y0 * r->width;
-    const char* b = (const char*)devBuffer;
-    RS_HIP(hipMemcpyAsync(p->li + off, b, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(p->wi + off, b + n * 16, n * 16, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(p->w + off, b + n * 32, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(p->m + off, b + n * 36, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    return rs_after_launch("rs_restir_rows_unpack");
+    return copy_rows(r, which, y0, rows, (char*)const_cast<void*>(devBuffer), false, "rs_restir_rows_unpack: bad argument");
 }
-
 int rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer) { return rs_restir_rows_pack(r, 2, y0, rows, devBuffer); }
 int rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer) { return rs_restir_rows_unpack(r, 2, y0, rows, devBuffer); }
 
 int rs_restir_download(const rs_restir* rc, int which, rs_reservoir* host) {
     rs_restir* r = const_cast<rs_restir*>(rc);
-    ResvPlanes* p = r ? pick(r, which) : nullptr;
-    if (!p || !host) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_download: bad argument");
+    if (!r || !host || which < 0 || which > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_download: bad argument");
     const size_t n = (size_t)r->width * r->height;
-    std::vector<float4> li(n), wi(n); std::vector<float> w(n); std::vector<int> m(n);
+    std::vector<float4> li(n), wi(n), tap; std::vector<float> w; std::vector<int> m;
     RS_HIP(hipStreamSynchronize(rs_stream()));
-    RS_HIP(hipMemcpy(li.data(), p->li, n * 16, hipMemcpyDeviceToHost));
-    RS_HIP(hipMemcpy(wi.data(), p->wi, n * 16, hipMemcpyDeviceToHost));
-    RS_HIP(hipMemcpy(w.data(), p->w, n * 4, hipMemcpyDeviceToHost));
-    RS_HIP(hipMemcpy(m.data(), p->m, n * 4, hipMemcpyDeviceToHost));
+    if (which == 2) {
+        tap.resize(n);
+        RS_HIP(hipMemcpy(li.data(), r->temp.li, n * 16, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(wi.data(), r->temp.wi, n * 16, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(tap.data(), r->temp.tap, n * 16, hipMemcpyDeviceToHost));
+    }
+    else {
+        ResvPlanes* p = pick(r, which);
+        w.resize(n); m.resize(n);
+        RS_HIP(hipMemcpy(li.data(), p->li, n * 16, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(wi.data(), p->wi, n * 16, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(w.data(), p->w, n * 4, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(m.data(), p->m, n * 4, hipMemcpyDeviceToHost));
+    }
     for (size_t i = 0; i < n; i++) {
         host[i].Li[0] = li[i].x; host[i].Li[1] = li[i].y; host[i].Li[2] = li[i].z;
         host[i].wi[0] = wi[i].x; host[i].wi[1] = wi[i].y; host[i].wi[2] = wi[i].z;
-        host[i].dist = li[i].w; host[i].numSamples = m[i]; host[i].weight = w[i];
+        host[i].dist = li[i].w;
+        if (which == 2) { host[i].weight = tap[i].x; std::memcpy(&host[i].numSamples, &tap[i].y, 4); }
+        else { host[i].weight = w[i]; host[i].numSamples = m[i]; }
     }
     return 0;
 }
 
 int rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host) {
-    ResvPlanes* p = r ? pick(r, which) : nullptr;
-    if (!p || !host) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_upload: bad argument");
+    if (!r || !host || which < 0 || which > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_upload: bad argument");
     const size_t n = (size_t)r->width * r->height;
-    std::vector<float4> li(n), wi(n); std::vector<float> w(n); std::vector<int> m(n);
+    std::vector<float4> li(n), wi(n);
     for (size_t i = 0; i < n; i++) {
         li[i] = make_float4(host[i].Li[0], host[i].Li[1], host[i].Li[2], host[i].dist);
         wi[i] = make_float4(host[i].wi[0], host[i].wi[1], host[i].wi[2], 0.f);
-        w[i] = host[i].weight; m[i] = host[i].numSamples;
     }
     RS_HIP(hipStreamSynchronize(rs_stream()));
-    RS_HIP(hipMemcpy(p->li, li.data(), n * 16, hipMemcpyHostToDevice));
-    RS_HIP(hipMemcpy(p->wi, wi.data(), n * 16, hipMemcpyHostToDevice));
-    RS_HIP(hipMemcpy(p->w, w.data(), n * 4, hipMemcpyHostToDevice));
-    RS_HIP(hipMemcpy(p->m, m.data(), n * 4, hipMemcpyHostToDevice));
+    if (which == 2) {
+        std::vector<float4> tap(n);
+        RS_HIP(hipMemcpy(tap.data(), r->temp.tap, n * 16, hipMemcpyDeviceToHost));      // keep the G-buffer half
+        for (size_t i = 0; i < n; i++) { tap[i].x = host[i].weight; std::memcpy(&tap[i].y, &host[i].numSamples, 4); }
+        RS_HIP(hipMemcpy(r->temp.li, li.data(), n * 16, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(r->temp.wi, wi.data(), n * 16, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(r->temp.tap, tap.data(), n * 16, hipMemcpyHostToDevice));
+    }
+    else {
+        ResvPlanes* p = pick(r, which);
+        std::vector<float> w(n); std::vector<int> m(n);
+        for (size_t i = 0; i < n; i++) { w[i] = host[i].weight; m[i] = host[i].numSamples; }
+        RS_HIP(hipMemcpy(p->li, li.data(), n * 16, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(p->wi, wi.data(), n * 16, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(p->w, w.data(), n * 4, hipMemcpyHostToDevice));
+        RS_HIP(hipMemcpy(p->m, m.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// test hook: largest error of the hardware-trig tap estimate against a double evaluation (see disk_tap)
+int rs_debug_tap_estimate_error(int n, float* maxErr) {
+    if (n <= 0 || !maxErr) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_tap_estimate_error: bad argument");
+    float* d = nullptr;
+    RS_TRY(rs_dev_alloc(&d, 1));
+    RS_HIP(hipMemsetAsync(d, 0, 4, rs_stream()));
+    hipLaunchKernelGGL(k_tap_estimate_error, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), n, d);
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(maxErr, d, 4, hipMemcpyDeviceToHost));
+    rs_dev_free(d);
     return 0;
 }
 

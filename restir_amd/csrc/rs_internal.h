@@ -38,7 +38,7 @@ static inline void rs_dev_free(T*& p) {
 struct rs_scene {
     rs::DevScene dev{};              // passed to kernels by value (pointers into the arrays below)
     // owned device arrays
-    rs::BvhNode* dNodes[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    rs::BvhNode* dNodesAll = nullptr;
     rs::TriRec* dTris = nullptr;
     float* dVertices = nullptr;
     float* dNormals = nullptr;
@@ -100,11 +100,23 @@ struct ResvPlanes {
     int*    m = nullptr;
 };
 
+// devDirectTemp (src/restir.cu:10), the buffer the spatial pass gathers from.  Weight and M travel
+// together with the two G-buffer values every tap test needs, so that the spatial pass stages ONE
+// 16-byte record (+ the 12-byte normal) per neighbour instead of four 4-byte planes:
+//   tap float4[N] { weight, bits(numSamples), bits(G-buffer id), depth }
+// The reservoir half of a record is only written for pixels that published this frame (stale
+// otherwise, Q1); the G-buffer half is refreshed for every pixel.
+struct TempPlanes {
+    float4* li = nullptr;
+    float4* wi = nullptr;
+    float4* tap = nullptr;
+};
+
 struct rs_restir {
     int width = 0, height = 0;
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
-    ResvPlanes temp;     // devDirectTemp           (published for the spatial pass)
+    TempPlanes temp;     // devDirectTemp           (published for the spatial pass)
     bool firstFrame = true;
     // per-pixel state carried between the passes of one frame (implementation bytes, not in the
     // reference: its single fused kernel keeps these in registers)

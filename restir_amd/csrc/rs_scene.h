@@ -2,7 +2,7 @@
 // and the per-ray / per-sample services the kernels call.
 //
 // HBM layout (all arrays hipMalloc'ed once by rs_scene_create, read-only afterwards):
-//   nodes[k]   BvhNode[bvhSize]   32 B: MTBVHNode (src/bvh.h:163-171) fused with the AABB it points to,
+//   nodesAll   BvhNode[6*bvhSize+1] 32 B: MTBVHNode (src/bvh.h:163-171) fused with the AABB it points to,
 //                                 so one traversal step is ONE 32-byte fetch (two dwordx4 from one
 //                                 sector) instead of the reference's two dependent loads
 //                                 (12-B node -> 24-B box, src/scene.h:254).  6 threaded orders.
@@ -40,7 +40,7 @@ struct __attribute__((aligned(16))) LightRec {
 struct AliasRec { float prob; int failId; };
 
 struct DevScene {
-    const BvhNode* nodes[6];
+    const BvhNode* nodesAll;      // 6 * bvhSize records (+1 padding record): order k starts at k * bvhSize
     const TriRec*  tris;
     const float*   vertices;
     const float*   normals;
@@ -241,59 +241,220 @@ RS_HD int mtbvh_order(f3 dir) {
 }
 
 #if defined(__HIPCC__)
-__device__ __forceinline__ void load_node(const BvhNode* nodes, int node, f3& bmin, f3& bmax, int& prim, int& next) {
-    const float4* p = reinterpret_cast<const float4*>(nodes + node);
-    float4 a = p[0], b = p[1];
-    bmin = mk3(a.x, a.y, a.z); prim = __float_as_int(a.w);
-    bmax = mk3(b.x, b.y, b.z); next = __float_as_int(b.w);
+// ---- traversal ---------------------------------------------------------------------------------
+// All six threaded orders live in ONE array (order k at records [k*bvhSize, (k+1)*bvhSize), one padding
+// record at the very end), so a lane addresses its node with a 32-bit byte offset from a wave-uniform
+// base: the loads compile to `global_load_dwordx4 v, v_off, s[base]` (no 64-bit address arithmetic),
+// and the two possible successors of a node can be prefetched before its box test has finished:
+//   * entered  -> the next record in memory (pre-order layout: first child / next sibling)
+//   * rejected -> nextNodeIfMiss, which is part of the record just loaded
+// Both are requested at the top of the step, so the ~40-instruction slab test of node n overlaps the
+// memory latency of node n+1 whichever way the test goes.  The walk itself is unchanged: same nodes,
+// same order, same arithmetic as DevScene::intersect / testOcclusion (src/scene.h:245-316).
+
+#ifndef RS_PREFETCH
+#define RS_PREFETCH 0
+#endif
+
+__device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
+    return *reinterpret_cast<const float4*>(base + off);
 }
+
+// General-case slab test (bvh.h:124-156 with none of the special cases): valid when every
+// |d.c| is in [1e-6, 1-1e-6].  Then all t are finite, so glm::min/max equal fminf/fmaxf up to the
+// sign of a zero, which no comparison below can see.
+__device__ __forceinline__ bool box_hit_general(f3 o, f3 dinv, float4 lo, float4 hi, float& tMin) {
+    const float t1x = (lo.x - o.x) * dinv.x, t1y = (lo.y - o.y) * dinv.y, t1z = (lo.z - o.z) * dinv.z;
+    const float t2x = (hi.x - o.x) * dinv.x, t2y = (hi.y - o.y) * dinv.y, t2z = (hi.z - o.z) * dinv.z;
+    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
+    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
+    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
+    tMin = fmaxf(fmaxf(nx, ny), nz);
+    const float tMax = fminf(fminf(fx, fy), fz);
+    return overlap & (tMax >= 0.f) & (tMax >= tMin);
+}
+
 __device__ __forceinline__ void load_tri(const TriRec* tris, int prim, f3& v0, f3& e1, f3& e2) {
     const float4* p = reinterpret_cast<const float4*>(tris + prim);
     float4 a = p[0], b = p[1], c = p[2];
     v0 = mk3(a.x, a.y, a.z); e1 = mk3(b.x, b.y, b.z); e2 = mk3(c.x, c.y, c.z);
 }
 
-// DevScene::intersect (src/scene.h:245-284): closest hit, stackless threaded walk
-__device__ inline Hit trace_closest(const DevScene& s, const Ray& ray) {
-    float closest = 3.402823466e+38f;   // FLT_MAX
-    int   cprim = kNullPrim;
-    float cbx = 0.f, cby = 0.f;
-    const BvhNode* nodes = s.nodes[mtbvh_order(-ray.d)];
-    const RayBoxCtx ctx = make_box_ctx(ray);
-    const int end = s.bvhSize;
-    int node = 0;
-    while (node != end) {
-        f3 bmin, bmax; int prim, next;
-        load_node(nodes, node, bmin, bmax, prim, next);
+struct WalkResult { float closest; int prim; float bx, by; bool any; };
+
+// One MTBVH walk.  ANYHIT: stop at the first triangle closer than `limit` (testOcclusion);
+// otherwise keep the closest (intersect).  GENERAL: every lane of the wave is a general-case ray.
+template <bool ANYHIT, bool GENERAL>
+__device__ __forceinline__ WalkResult walk(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit) {
+    WalkResult r;
+    r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f; r.any = false;
+    const char* base = reinterpret_cast<const char*>(s.nodesAll);
+    const unsigned first = (unsigned)mtbvh_order(-ray.d) * (unsigned)s.bvhSize * 32u;
+    const unsigned endOff = first + (unsigned)s.bvhSize * 32u;
+    unsigned cur = first;
+    float4 lo = ld16(base, cur), hi = ld16(base, cur + 16);
+    while (cur != endOff) {
+        const unsigned seq = cur + 32u;
+        const unsigned jmp = first + (unsigned)__float_as_int(hi.w) * 32u;
+#if RS_PREFETCH >= 1
+        const float4 sLo = ld16(base, seq), sHi = ld16(base, seq + 16);      // successor if entered
+#endif
+#if RS_PREFETCH >= 2
+        const float4 jLo = ld16(base, jmp), jHi = ld16(base, jmp + 16);      // successor if rejected
+#endif
         float tb;
-        bool bh = box_hit(ctx, bmin, bmax, tb);
-        if (bh && tb < closest) {
+        bool bh;
+        if (GENERAL) bh = box_hit_general(ctx.o, ctx.dinv, lo, hi, tb);
+        else bh = box_hit(ctx, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), tb);
+        if (bh && tb < r.closest) {
+            const int prim = __float_as_int(lo.w);
             if (prim != kNullPrim) {
                 f3 v0, e1, e2;
                 load_tri(s.tris, prim, v0, e1, e2);
                 float bx, by, dist;
-                if (tri_hit(ray.o, ray.d, v0, e1, e2, bx, by, dist) && dist < closest) {
-                    closest = dist; cbx = bx; cby = by; cprim = prim;
+                if (tri_hit(ray.o, ray.d, v0, e1, e2, bx, by, dist) && dist < r.closest) {
+                    if (ANYHIT) { r.any = true; return r; }
+                    r.closest = dist; r.bx = bx; r.by = by; r.prim = prim;
                 }
             }
-            node++;
+            cur = seq;
+#if RS_PREFETCH >= 1
+            lo = sLo; hi = sHi;
+#else
+            lo = ld16(base, cur); hi = ld16(base, cur + 16);
+#endif
         }
         else {
-            node = next;
+            cur = jmp;
+#if RS_PREFETCH >= 2
+            lo = jLo; hi = jHi;
+#else
+            lo = ld16(base, cur); hi = ld16(base, cur + 16);
+#endif
         }
     }
+    return r;
+}
+
+template <bool ANYHIT>
+__device__ __forceinline__ WalkResult walk_dispatch(const DevScene& s, const Ray& ray, float limit) {
+    const RayBoxCtx ctx = make_box_ctx(ray);
+    const bool special = ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x);
+    // the special cases are ~1e-6 of the rays: a wave that has none runs the branch-free test
+    if (__any(special)) return walk<ANYHIT, false>(s, ray, ctx, limit);
+    return walk<ANYHIT, true>(s, ray, ctx, limit);
+}
+
+// DevScene::intersect (src/scene.h:245-284): closest hit, stackless threaded walk
+__device__ inline Hit trace_closest(const DevScene& s, const Ray& ray) {
+    const WalkResult w = walk_dispatch<false>(s, ray, 3.402823466e+38f);   // FLT_MAX
     Hit h;
-    h.primId = cprim;
+    h.primId = w.prim;
     h.matId = 0;
     h.pos = splat(0.f);
     h.norm = splat(0.f);
-    if (cprim != kNullPrim) {             // getIntersecGeomInfo (scene.h:135-151)
-        const float* v = s.vertices + (size_t)cprim * 9;
-        const float* n = s.normals + (size_t)cprim * 9;
-        float w = 1.f - cbx - cby;
-        h.pos = ld3(v + 3) * cbx + ld3(v + 6) * cby + ld3(v) * w;
-        h.norm = normalize(ld3(n + 3) * cbx + ld3(n + 6) * cby + ld3(n) * w);
-        h.matId = s.materialIds[cprim];
+    if (w.prim != kNullPrim) {             // getIntersecGeomInfo (scene.h:135-151)
+        const float* v = s.vertices + (size_t)w.prim * 9;
+        const float* n = s.normals + (size_t)w.prim * 9;
+        float wgt = 1.f - w.bx - w.by;
+        h.pos = ld3(v + 3) * w.bx + ld3(v + 6) * w.by + ld3(v) * wgt;
+        h.norm = normalize(ld3(n + 3) * w.bx + ld3(n + 6) * w.by + ld3(n) * wgt);
+        h.matId = s.materialIds[w.prim];
+    }
+    return h;
+}
+
+// ---- wave-cooperative ("packet") closest-hit walk for coherent rays ------------------------------
+// Measured on the per-lane walk above (rocprofv3, profiles/): the G-buffer and primary-ray kernels
+// are bound by the vector-memory return path (TD busy 87-89 %): every lane fetches its own 32-byte
+// node, 2 KiB per wave-step, although the 64 rays of an 8x8 pixel tile visit almost the same nodes
+// (union of visited nodes 158 vs 142 for the slowest single ray, one threaded order per tile).
+//
+// Here the WAVE walks the union once.  All walks of one order move forward through the same array,
+// so the wave visits c = min over lanes of "the node I want next"; the node record is fetched ONCE
+// through the scalar cache (s_load_dwordx8: 32 B per wave-step instead of 2 KiB), every lane whose
+// own walk is at c runs its slab / triangle test against the SGPR-resident record, the others wait.
+// Each lane still visits exactly the nodes of DevScene::intersect (src/scene.h:245-284), in the same
+// order with the same arithmetic, so results are bit-identical to the per-lane walk.
+//
+// Must be called by all 64 lanes of the wave (`active` false for lanes without a ray).
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    // butterfly inside rows of 16 (quad_perm xor1, xor2, row_half_mirror, row_mirror), then the two
+    // row broadcasts of gfx9; lane 63 ends up with the minimum of all 64 lanes
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <bool GENERAL>
+__device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, bool mine, const Ray& ray,
+                                                  const RayBoxCtx& ctx, WalkResult& r) {
+    const BvhNode* __restrict__ nodes = s.nodesAll + (size_t)order * (size_t)s.bvhSize;
+    const unsigned end = (unsigned)s.bvhSize;
+    unsigned myNext = mine ? 0u : end;
+    unsigned c = 0;                                           // wave-uniform
+    while (c != end) {
+        // uniform address -> scalar loads
+        const float4* np = reinterpret_cast<const float4*>(nodes + c);
+        const float4 lo = np[0], hi = np[1];
+        const int prim = __float_as_int(lo.w);
+        const unsigned nxt = (unsigned)__float_as_int(hi.w);
+        const bool part = myNext == c;
+        float tb;
+        bool bh;
+        if (GENERAL) bh = box_hit_general(ctx.o, ctx.dinv, lo, hi, tb);
+        else bh = box_hit(ctx, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), tb);
+        const bool entered = part & bh & (tb < r.closest);
+        if (prim != kNullPrim) {                              // uniform branch
+            if (__any(entered)) {
+                const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);      // uniform -> scalar
+                const float4 a = tp[0], b = tp[1], e = tp[2];
+                float bx, by, dist;
+                const bool hit = tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist);
+                if (entered && hit && dist < r.closest) { r.closest = dist; r.bx = bx; r.by = by; r.prim = prim; }
+            }
+        }
+        myNext = part ? (entered ? c + 1u : nxt) : myNext;
+        // every pending target is > c; if some lane wants c+1 that is the minimum
+        c = __any(myNext == c + 1u) ? c + 1u : wave_min_u32(myNext);
+    }
+}
+
+// closest hit for a wave of coherent rays; lanes with active == false carry no ray
+__device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bool active) {
+    WalkResult w;
+    w.closest = 3.402823466e+38f; w.prim = kNullPrim; w.bx = 0.f; w.by = 0.f; w.any = false;
+    const RayBoxCtx ctx = make_box_ctx(ray);
+    const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
+    const bool anySpecial = __any(special);
+    const int order = mtbvh_order(-ray.d);
+    unsigned long long todo = __ballot(active);
+    while (todo) {                                            // one pass per threaded order present in the wave
+        const int lead = __ffsll((long long)todo) - 1;
+        const int k = __builtin_amdgcn_readlane(order, lead);
+        const bool mine = active && order == k;
+        todo &= ~__ballot(mine);
+        if (anySpecial) packet_walk_order<false>(s, k, mine, ray, ctx, w);
+        else packet_walk_order<true>(s, k, mine, ray, ctx, w);
+    }
+    Hit h;
+    h.primId = w.prim;
+    h.matId = 0;
+    h.pos = splat(0.f);
+    h.norm = splat(0.f);
+    if (w.prim != kNullPrim) {             // getIntersecGeomInfo (scene.h:135-151)
+        const float* v = s.vertices + (size_t)w.prim * 9;
+        const float* n = s.normals + (size_t)w.prim * 9;
+        float wgt = 1.f - w.bx - w.by;
+        h.pos = ld3(v + 3) * w.bx + ld3(v + 6) * w.by + ld3(v) * wgt;
+        h.norm = normalize(ld3(n + 3) * w.bx + ld3(n + 6) * w.by + ld3(n) * wgt);
+        h.matId = s.materialIds[w.prim];
     }
     return h;
 }
@@ -305,29 +466,7 @@ __device__ inline bool trace_occluded(const DevScene& s, f3 x, f3 y) {
     dir = dir / dist;
     Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
     dist -= 1e-4f * 2.f;
-    const BvhNode* nodes = s.nodes[mtbvh_order(-ray.d)];
-    const RayBoxCtx ctx = make_box_ctx(ray);
-    const int end = s.bvhSize;
-    int node = 0;
-    while (node != end) {
-        f3 bmin, bmax; int prim, next;
-        load_node(nodes, node, bmin, bmax, prim, next);
-        float tb;
-        bool bh = box_hit(ctx, bmin, bmax, tb);
-        if (bh && tb < dist) {
-            if (prim != kNullPrim) {
-                f3 v0, e1, e2;
-                load_tri(s.tris, prim, v0, e1, e2);
-                float bx, by, d;
-                if (tri_hit(ray.o, ray.d, v0, e1, e2, bx, by, d) && d < dist) return true;
-            }
-            node++;
-        }
-        else {
-            node = next;
-        }
-    }
-    return false;
+    return walk_dispatch<true>(s, ray, dist).any;
 }
 #endif  // __HIPCC__
 
@@ -362,7 +501,7 @@ RS_HD f3 eval_bsdf(int type, f3 baseColor, float metallic, float roughness, f3 n
 }
 
 // ---- light sampling (src/scene.h:394-459, src/sampler.h:203-207, src/mathUtil.h:94-100,182-185) --
-struct LightSample { float pdf; f3 Li, wi; float dist; f3 point; };
+struct LightSample { float pdf; f3 Li, wi; float dist; f3 point; int id; };
 
 #if defined(__HIPCC__)
 // sampleDirectLightNoVisibility; `lights`/`alias` may point to global memory or to an LDS copy.
@@ -371,11 +510,12 @@ struct LightSample { float pdf; f3 Li, wi; float dist; f3 point; };
 template <typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ LightSample sample_light_nv(AliasPtr alias, LightPtr lights, int numLights, f3 pos, f4 r) {
     LightSample o;
-    o.pdf = kInvalidPdf; o.Li = splat(0.f); o.wi = splat(0.f); o.dist = 0.f; o.point = splat(0.f);
+    o.pdf = kInvalidPdf; o.Li = splat(0.f); o.wi = splat(0.f); o.dist = 0.f; o.point = splat(0.f); o.id = 0;
     if (numLights == 0) return o;
     int pass = imin(f2i((float)numLights * r.x), numLights - 1);      // DevDiscreteSampler1D::sample
     AliasRec al = alias[pass];
     int id = r.y < al.prob ? pass : al.failId;
+    o.id = id;
     const float4* lp = reinterpret_cast<const float4*>(&lights[id]);
     float4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
     f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);

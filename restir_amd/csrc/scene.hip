@@ -28,7 +28,7 @@ int upload(T** dst, const std::vector<T>& src) {
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
-    for (int k = 0; k < 6; k++) rs_dev_free(s->dNodes[k]);
+    rs_dev_free(s->dNodesAll);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     delete s;
@@ -78,18 +78,23 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
             delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: light table index out of range");
         }
 
-    // fused node records, one array per threaded order
+    // fused node records: the six threaded orders back to back in one array, plus one padding record so
+    // that the speculative successor fetch of the very last node stays inside the allocation
     {
-        std::vector<BvhNode> rec(nn);
+        std::vector<BvhNode> rec(nn * 6 + 1);
         for (int k = 0; k < 6; k++) {
             for (size_t i = 0; i < nn; i++) {
                 const int* n = &s->hNodes[k][i * 3];
                 const float* b = &s->hBoxes[(size_t)n[1] * 6];
-                rec[i].bminx = b[0]; rec[i].bminy = b[1]; rec[i].bminz = b[2]; rec[i].primId = n[0];
-                rec[i].bmaxx = b[3]; rec[i].bmaxy = b[4]; rec[i].bmaxz = b[5]; rec[i].next = n[2];
+                BvhNode& r = rec[(size_t)k * nn + i];
+                r.bminx = b[0]; r.bminy = b[1]; r.bminz = b[2]; r.primId = n[0];
+                r.bmaxx = b[3]; r.bmaxy = b[4]; r.bmaxz = b[5]; r.next = n[2];
             }
-            if (int e = upload(&s->dNodes[k], rec)) { rs_scene_destroy(s); return e; }
         }
+        BvhNode& pad = rec[nn * 6];
+        pad.bminx = pad.bminy = pad.bminz = pad.bmaxx = pad.bmaxy = pad.bmaxz = 0.f; pad.primId = -1; pad.next = 0;
+        if ((nn * 6 + 1) * sizeof(BvhNode) >= 0xffffffffull) { delete s; return rs_fail(RS_ERR_UNSUPPORTED, "rs_scene_create: BVH larger than 4 GiB of node records"); }
+        if (int e = upload(&s->dNodesAll, rec)) { rs_scene_destroy(s); return e; }
     }
     // pre-differenced triangles
     {
@@ -128,7 +133,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     if (int e = upload(&s->dMaterialIds, s->hMaterialIds)) { rs_scene_destroy(s); return e; }
     if (int e = upload(&s->dMaterials, s->hMaterials)) { rs_scene_destroy(s); return e; }
 
-    for (int k = 0; k < 6; k++) s->dev.nodes[k] = s->dNodes[k];
+    s->dev.nodesAll = s->dNodesAll;
     s->dev.tris = s->dTris;
     s->dev.vertices = s->dVertices;
     s->dev.normals = s->dNormals;

@@ -1,0 +1,143 @@
+// restir_compat.h -- the reference's host-side names on top of the C ABI (include/restir_hip.h).
+//
+// A maintainer of HummaWhite/ReSTIR replaces src/restir.cu, src/pathtrace.cu, src/gbuffer.cu,
+// src/denoiser.cu (and the device side of scene.h / intersections.h) by this header + librestir_hip.so;
+// runCuda() (src/main.cpp:146-185) and main() (:78-100) then compile against the same calls:
+//
+//     gBuffer.render(scene->devScene, scene->camera);
+//     ReSTIRDirect(devDirectIllum, iteration, gBuffer);        // or pathTraceDirect(devDirectIllum, iteration)
+//     copyImageToPBO(devPBO, devImage, width, height, Settings::toneMapping);
+//     gBuffer.update(scene->camera);
+//
+// Differences that remain visible to the caller:
+//   * image pointers are hipMalloc memory; the CUDA-GL PBO interop of main.cpp:176-181 is replaced by
+//     a plain device buffer (display interop is outside this path);
+//   * Scene::buildDevData() hands the baked triangle soup to rs_scene_build (BVH, light table and alias
+//     table are built by the library with the reference's exact results).
+// Errors keep the reference's convention: print and exit (checkCUDAError, src/cudaUtil.h:13-31).
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+
+#include "../../include/restir_hip.h"
+
+#ifdef RESTIR_COMPAT_USE_GLM
+#include <glm/glm.hpp>
+namespace rsc { using vec3 = glm::vec3; }
+#else
+namespace rsc { struct vec3 { float x, y, z; }; }
+#endif
+static_assert(sizeof(rsc::vec3) == 12, "glm::vec3 must be 3 packed floats");
+
+namespace rsc {
+inline void check(int code, const char* msg) {          // checkCUDAError(msg)
+    if (code == 0) return;
+    std::fprintf(stderr, "HIP error: %s: %s\n", msg, rs_last_error());
+    std::exit(EXIT_FAILURE);
+}
+}  // namespace rsc
+
+// ---- src/common.h:18-67 -------------------------------------------------------------------------
+struct ToneMapping { enum { None = 0, Filmic = 1, ACES = 2 }; };
+struct ReservoirReuse { enum { None = 0, Temporal = 1, Spatial = 2, Spatiotemporal = 3 }; };
+
+struct Scene;
+struct Settings {
+    static inline int traceDepth = 0;
+    static inline int toneMapping = ToneMapping::ACES;
+    static inline bool useReservoir = true;
+    static inline int reservoirReuse = ReservoirReuse::Temporal;
+    static inline bool accumulate = false;
+};
+struct State {
+    static inline bool camChanged = true;
+    static inline int looper = 0;
+    static inline Scene* scene = nullptr;
+};
+
+// ---- src/sceneStructs.h:22-126 -------------------------------------------------------------------
+struct Camera : rs_camera {
+    void update() { rsc::check(rs_camera_update(this), "Camera::update"); }
+};
+static_assert(sizeof(Camera) == 196, "Camera layout (src/sceneStructs.h:104-117)");
+
+using Material = rs_material;                           // src/material.h:113-268 (data members)
+using DevScene = rs_scene;                              // src/scene.h:64-481
+
+// ---- src/scene.h:483-531 (only what the path needs) -----------------------------------------------
+struct Scene {
+    Camera camera{};
+    DevScene* devScene = nullptr;
+    // buildDevData (src/scene.cpp:159-215) on an already baked, de-indexed triangle soup
+    void buildDevData(int numPrims, const float* vertices, const float* normals, const float* texcoords,
+                      const int* materialIds, int numMaterials, const Material* materials) {
+        rsc::check(rs_scene_build(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials, &devScene), "Dev Scene");
+    }
+    void clear() { rs_scene_destroy(devScene); devScene = nullptr; }     // src/scene.cpp:217-220
+};
+
+// ---- src/gbuffer.h:15-59 ---------------------------------------------------------------------------
+struct GBuffer {
+    rs_gbuffer* impl = nullptr;
+    int width = 0, height = 0;
+    void create(int w, int h) { width = w; height = h; rsc::check(rs_gbuffer_create(w, h, &impl), "GBuffer::create"); }
+    void destroy() { rs_gbuffer_destroy(impl); impl = nullptr; }
+    void render(DevScene* scene, const Camera& cam) { rsc::check(rs_gbuffer_render(impl, scene, &cam), "renderGBuffer"); }
+    void update(const Camera& cam) { rsc::check(rs_gbuffer_update(impl, &cam), "GBuffer::update"); }
+    rs_gbuffer_view planes() const { rs_gbuffer_view v; rsc::check(rs_gbuffer_get_view(impl, &v), "GBuffer"); return v; }
+};
+
+// ---- src/restir.h:128-133 ---------------------------------------------------------------------------
+namespace rsc { inline rs_restir* g_restir = nullptr; }
+
+inline void ReSTIRInit() {                               // src/restir.cu:478-504
+    const Camera& cam = State::scene->camera;
+    rsc::check(rs_restir_init(cam.resolution[0], cam.resolution[1], &rsc::g_restir), "ReSTIRInit");
+}
+inline void ReSTIRFree() { rs_restir_free(rsc::g_restir); rsc::g_restir = nullptr; }
+inline void ReSTIRReset() { rsc::check(rs_restir_reset(rsc::g_restir), "ReSTIRReset"); }
+inline void ReSTIRDirect(rsc::vec3* devDirectIllum, int iter, const GBuffer& gBuffer) {   // src/restir.cu:418-446
+    rsc::check(rs_restir_direct(rsc::g_restir, State::scene->devScene, &State::scene->camera, gBuffer.impl,
+                                reinterpret_cast<float*>(devDirectIllum), iter, State::looper, Settings::reservoirReuse),
+               "ReSTIR Direct");
+    State::looper++;
+}
+
+// ---- src/pathtrace.h:8-16 ----------------------------------------------------------------------------
+inline void pathTraceInit() { rsc::check(rs_path_trace_init(), "pathTraceInit"); }
+inline void pathTraceFree() { rs_path_trace_free(); }
+inline void pathTraceDirect(rsc::vec3* devDirectIllum, int iter) {                        // src/pathtrace.cu:457-476
+    rsc::check(rs_path_trace_direct(State::scene->devScene, &State::scene->camera, reinterpret_cast<float*>(devDirectIllum),
+                                    iter, State::looper, nullptr), "pathTrace");
+    State::looper++;
+}
+struct uchar4_t { unsigned char x, y, z, w; };
+inline void copyImageToPBO(void* devPBO, rsc::vec3* devImage, int width, int height, int toneMapping, float scale = 1.f) {
+    rsc::check(rs_copy_image_to_pbo(devPBO, reinterpret_cast<const float*>(devImage), width, height, toneMapping, scale), "copyImageToPBO");
+}
+
+// ---- src/denoiser.h:33-43,72-74 -------------------------------------------------------------------------
+struct LeveledEAWFilter {
+    rs_eaw* impl = nullptr;
+    int level = 0;
+    void create(int width, int height, int lv) { level = lv; rsc::check(rs_eaw_create(width, height, lv, &impl), "EAW create"); }
+    void destroy() { rs_eaw_destroy(impl); impl = nullptr; }
+    void filter(rsc::vec3*& devColorOut, rsc::vec3* devColorIn, const GBuffer& gBuffer, const Camera& cam) {
+        float* out = reinterpret_cast<float*>(devColorOut);
+        rsc::check(rs_eaw_filter(impl, &out, reinterpret_cast<const float*>(devColorIn), gBuffer.impl, &cam), "EAW Filter");
+        devColorOut = reinterpret_cast<rsc::vec3*>(out);
+    }
+};
+inline void modulateAlbedo(rsc::vec3* devImage, const GBuffer& gBuffer) {
+    rsc::check(rs_modulate_albedo(reinterpret_cast<float*>(devImage), gBuffer.impl), "modulate");
+}
+inline void addImage(rsc::vec3* devImage, rsc::vec3* devIn, int width, int height) {
+    rsc::check(rs_add_image(reinterpret_cast<float*>(devImage), reinterpret_cast<const float*>(devIn), width, height), "addImage");
+}
+inline void addImage(rsc::vec3* devOut, rsc::vec3* devIn1, rsc::vec3* devIn2, int width, int height) {
+    rsc::check(rs_add_image3(reinterpret_cast<float*>(devOut), reinterpret_cast<const float*>(devIn1),
+                             reinterpret_cast<const float*>(devIn2), width, height), "addImage");
+}

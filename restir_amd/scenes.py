@@ -297,3 +297,15 @@ def orbit_position(base_position, frame, radius=1.0, dt=1.0 / 60.0, speed=2.7):
     return (np.float32(base_position[0]) + np.float32(np.cos(t)) * np.float32(radius),
             np.float32(base_position[1]),
             np.float32(base_position[2]) + np.float32(np.sin(t)) * np.float32(radius))
+
+
+def dump_scene(sd, path):
+    """Binary triangle soup read by restir_amd/host/headless_viewer.cpp: int32 numPrims, numMaterials;
+    float32 camera position[3], rotation[3], fovY, focalDist; vertices; normals; texcoords; int32
+    materialIds; 44-byte Material records."""
+    with open(path, "wb") as f:
+        np.array([sd.num_prims, len(sd.materials)], np.int32).tofile(f)
+        a = sd.camera_args
+        np.array([*a["position"], *a["rotation"], a["fov_y"], a.get("focal_dist", 1.0)], np.float32).tofile(f)
+        sd.vertices.tofile(f); sd.normals.tofile(f); sd.texcoords.tofile(f); sd.material_ids.tofile(f)
+        sd.materials.tofile(f)

@@ -144,17 +144,17 @@ class HipBackend:
 
     # history = reservoirs the next temporal merge reads (buffer 1 after end_frame) + "last" G-buffer planes
     def history_bytes(self, rows):
-        return self.restir.halo_bytes(rows) + self.gbuf.rows_bytes(rows)
+        return self.restir.rows_bytes(1, rows) + self.gbuf.rows_bytes(rows)
 
     def history_pack(self, y0, rows):
-        nr = self.restir.halo_bytes(rows)
+        nr = self.restir.rows_bytes(1, rows)
         buf = self.empty(self.history_bytes(rows))
         self.restir.rows_pack(1, y0, rows, buf.data_ptr())
         self.gbuf.rows_pack(1, y0, rows, buf.data_ptr() + nr)
         return buf
 
     def history_unpack(self, y0, rows, buf):
-        nr = self.restir.halo_bytes(rows)
+        nr = self.restir.rows_bytes(1, rows)
         buf = buf.contiguous()
         self.restir.rows_unpack(1, y0, rows, buf.data_ptr())
         self.gbuf.rows_unpack(1, y0, rows, buf.data_ptr() + nr)
