@@ -145,25 +145,30 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
                                                          int y0, int y1, int tilesX) {
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
-    if (x >= g.width || y >= y1) return;
-    const int index = y * g.width + x;
-    const float4 pm = sp.posMat[index];
-    const int gid = g.primId[index];
-    const float gdepth = g.depth[index];
-    if ((__float_as_int(pm.w) >> 24) != kKindShaded) {
-        // early-exit pixels publish no reservoir (Q1: their slot keeps its stale value); only the
-        // G-buffer half of the tap record is refreshed
-        if (reuse & 2) reinterpret_cast<float2*>(temp.tap + index)[1] = make_float2(__int_as_float(gid), gdepth);
-        return;
-    }
-    const float4 cl = sp.candLi[index], cw = sp.candWi[index];
+    const bool inside = x < g.width && y < y1;
+    const int index = inside ? y * g.width + x : 0;
+    const float4 pm = inside ? sp.posMat[index] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool shaded = inside && (__float_as_int(pm.w) >> 24) == kKindShaded;
+    float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
+    if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
     const f3 pos = mk3(pm.x, pm.y, pm.z);
 
     Resv r;
     r.Li = mk3(cl.x, cl.y, cl.z); r.wi = mk3(cw.x, cw.y, cw.z); r.dist = cl.w;
     r.M = kReservoirSize; r.W = cw.w;
 
-    if (trace_occluded(s, pos, pos + r.wi * r.dist)) r.W = 0.f;   // restir.cu:172-176
+    // every lane of the wave takes part in the cooperative any-hit walk (restir.cu:172-176)
+    const bool occluded = trace_occluded_wave(s, pos, pos + r.wi * r.dist, shaded);
+    if (!inside) return;
+    const int gid = g.primId[index];
+    const float gdepth = g.depth[index];
+    if (!shaded) {
+        // early-exit pixels publish no reservoir (Q1: their slot keeps its stale value); only the
+        // G-buffer half of the tap record is refreshed
+        if (reuse & 2) reinterpret_cast<float2*>(temp.tap + index)[1] = make_float2(__int_as_float(gid), gdepth);
+        return;
+    }
+    if (occluded) r.W = 0.f;
 
     if (!first && (reuse & 1)) {                                  // findTemporalNeighbor, restir.cu:20-45
         const int primId = gid;

@@ -252,10 +252,6 @@ RS_HD int mtbvh_order(f3 dir) {
 // memory latency of node n+1 whichever way the test goes.  The walk itself is unchanged: same nodes,
 // same order, same arithmetic as DevScene::intersect / testOcclusion (src/scene.h:245-316).
 
-#ifndef RS_PREFETCH
-#define RS_PREFETCH 0
-#endif
-
 __device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
     return *reinterpret_cast<const float4*>(base + off);
 }
@@ -283,7 +279,7 @@ __device__ __forceinline__ void load_tri(const TriRec* tris, int prim, f3& v0, f
 
 struct WalkResult { float closest; int prim; float bx, by; bool any; };
 
-// One MTBVH walk.  ANYHIT: stop at the first triangle closer than `limit` (testOcclusion);
+// One per-lane MTBVH walk.  ANYHIT: stop at the first triangle closer than `limit` (testOcclusion);
 // otherwise keep the closest (intersect).  GENERAL: every lane of the wave is a general-case ray.
 template <bool ANYHIT, bool GENERAL>
 __device__ __forceinline__ WalkResult walk(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit) {
@@ -293,16 +289,8 @@ __device__ __forceinline__ WalkResult walk(const DevScene& s, const Ray& ray, co
     const unsigned first = (unsigned)mtbvh_order(-ray.d) * (unsigned)s.bvhSize * 32u;
     const unsigned endOff = first + (unsigned)s.bvhSize * 32u;
     unsigned cur = first;
-    float4 lo = ld16(base, cur), hi = ld16(base, cur + 16);
     while (cur != endOff) {
-        const unsigned seq = cur + 32u;
-        const unsigned jmp = first + (unsigned)__float_as_int(hi.w) * 32u;
-#if RS_PREFETCH >= 1
-        const float4 sLo = ld16(base, seq), sHi = ld16(base, seq + 16);      // successor if entered
-#endif
-#if RS_PREFETCH >= 2
-        const float4 jLo = ld16(base, jmp), jHi = ld16(base, jmp + 16);      // successor if rejected
-#endif
+        const float4 lo = ld16(base, cur), hi = ld16(base, cur + 16);
         float tb;
         bool bh;
         if (GENERAL) bh = box_hit_general(ctx.o, ctx.dinv, lo, hi, tb);
@@ -318,20 +306,67 @@ __device__ __forceinline__ WalkResult walk(const DevScene& s, const Ray& ray, co
                     r.closest = dist; r.bx = bx; r.by = by; r.prim = prim;
                 }
             }
-            cur = seq;
-#if RS_PREFETCH >= 1
-            lo = sLo; hi = sHi;
-#else
-            lo = ld16(base, cur); hi = ld16(base, cur + 16);
-#endif
+            cur += 32u;
         }
         else {
-            cur = jmp;
-#if RS_PREFETCH >= 2
-            lo = jLo; hi = jHi;
-#else
-            lo = ld16(base, cur); hi = ld16(base, cur + 16);
-#endif
+            cur = first + (unsigned)__float_as_int(hi.w) * 32u;
+        }
+    }
+    return r;
+}
+
+// ---- pair-cooperative node fetch for incoherent rays ---------------------------------------------
+// Measured on the per-lane walk with shadow rays (profiles/): the L1 can look up one cache line per
+// clock, and a wave of incoherent rays touches ~64 different lines in EACH of the two 16-byte loads
+// of a step (TD/TA busy 92 %).  Here lanes 2k and 2k+1 fetch together: one load instruction reads
+// both halves of the even lane's node (one line), the next both halves of the odd lane's node, and a
+// DPP quad-permute hands each lane the half it is missing -- the same 32 bytes per lane, half the
+// line look-ups.  Every lane still walks exactly its own node sequence with the same arithmetic.
+// Must be called by all 64 lanes (`active` false for lanes without a ray): finished lanes keep
+// fetching for their partner.
+__device__ __forceinline__ int dpp_swap1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ float4 dpp_swap1(float4 v) {
+    return make_float4(__int_as_float(dpp_swap1(__float_as_int(v.x))), __int_as_float(dpp_swap1(__float_as_int(v.y))),
+                       __int_as_float(dpp_swap1(__float_as_int(v.z))), __int_as_float(dpp_swap1(__float_as_int(v.w))));
+}
+
+template <bool ANYHIT, bool GENERAL>
+__device__ __forceinline__ WalkResult walk_paired(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
+    WalkResult r;
+    r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f; r.any = false;
+    const char* base = reinterpret_cast<const char*>(s.nodesAll);
+    const unsigned first = (unsigned)mtbvh_order(-ray.d) * (unsigned)s.bvhSize * 32u;
+    const unsigned endOff = first + (unsigned)s.bvhSize * 32u;
+    const bool odd = (__lane_id() & 1u) != 0;
+    const unsigned halfOff = odd ? 16u : 0u;
+    unsigned cur = active ? first : endOff;            // endOff is a readable record (next order / padding)
+    while (__any(cur != endOff)) {
+        const unsigned partner = (unsigned)dpp_swap1((int)cur);
+        const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);      // even lane's node, split over the pair
+        const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);      // odd lane's node
+        const float4 s1 = dpp_swap1(r1), s2 = dpp_swap1(r2);
+        const float4 lo = odd ? s2 : r1, hi = odd ? r2 : s1;
+        if (cur != endOff) {
+            float tb;
+            bool bh;
+            if (GENERAL) bh = box_hit_general(ctx.o, ctx.dinv, lo, hi, tb);
+            else bh = box_hit(ctx, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), tb);
+            if (bh && tb < r.closest) {
+                const int prim = __float_as_int(lo.w);
+                cur += 32u;
+                if (prim != kNullPrim) {
+                    f3 v0, e1, e2;
+                    load_tri(s.tris, prim, v0, e1, e2);
+                    float bx, by, dist;
+                    if (tri_hit(ray.o, ray.d, v0, e1, e2, bx, by, dist) && dist < r.closest) {
+                        if (ANYHIT) { r.any = true; cur = endOff; }
+                        else { r.closest = dist; r.bx = bx; r.by = by; r.prim = prim; }
+                    }
+                }
+            }
+            else {
+                cur = first + (unsigned)__float_as_int(hi.w) * 32u;
+            }
         }
     }
     return r;
@@ -344,6 +379,85 @@ __device__ __forceinline__ WalkResult walk_dispatch(const DevScene& s, const Ray
     // the special cases are ~1e-6 of the rays: a wave that has none runs the branch-free test
     if (__any(special)) return walk<ANYHIT, false>(s, ray, ctx, limit);
     return walk<ANYHIT, true>(s, ray, ctx, limit);
+}
+
+// ---- any-hit walk with deferred, batched leaf tests ------------------------------------------------
+// Measured (profiles/): a vector-memory instruction occupies the return path for ~26 cycles however
+// few lanes are active, and in the any-hit walk more than half of all load instructions were the
+// three 16-byte triangle loads of a leaf visit, each issued for the one or two lanes that happened to
+// sit on a leaf in that step.  testOcclusion only asks whether ANY visited triangle is hit closer than
+// the limit, and the walk past a leaf does not depend on that leaf's outcome, so a lane may queue the
+// leaf and keep walking.  Queued leaves are tested in rounds in which every lane with a pending leaf
+// takes part; a lane that finds a hit is occluded and stops.  The set of triangles tested is the
+// reference's set (src/scene.h:286-316) up to its first hit plus possibly a few later ones, so the
+// boolean is identical.  Rounds run when a queue is full or when no lane can walk on (A/B: triggering
+// earlier, once 12/24/40 lanes wait, was 2-5 % slower).  Node fetches are pair-cooperative as in walk_paired.
+constexpr int kLeafQueue = 4;
+
+template <bool GENERAL>
+__device__ __forceinline__ bool walk_anyhit_deferred(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
+    const char* base = reinterpret_cast<const char*>(s.nodesAll);
+    const unsigned first = (unsigned)mtbvh_order(-ray.d) * (unsigned)s.bvhSize * 32u;
+    const unsigned endOff = first + (unsigned)s.bvhSize * 32u;
+    const bool odd = (__lane_id() & 1u) != 0;
+    const unsigned halfOff = odd ? 16u : 0u;
+    unsigned cur = active ? first : endOff;
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;        // LIFO of queued leaf primitives
+    bool occluded = false;
+    for (;;) {
+        const bool walking = cur != endOff;
+        const unsigned long long wmask = __ballot(walking);
+        const unsigned long long pmask = __ballot(qn > 0);
+        if (!(wmask | pmask)) break;
+        const bool round = __any(qn == kLeafQueue) || wmask == 0;
+        if (round) {
+            if (qn > 0) {
+                const int prim = q0;
+                q0 = q1; q1 = q2; q2 = q3; qn--;
+                f3 v0, e1, e2;
+                load_tri(s.tris, prim, v0, e1, e2);
+                float bx, by, dist;
+                if (tri_hit(ray.o, ray.d, v0, e1, e2, bx, by, dist) && dist < limit) { occluded = true; cur = endOff; qn = 0; }
+            }
+            continue;
+        }
+        const unsigned partner = (unsigned)dpp_swap1((int)cur);
+        const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);
+        const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);
+        const float4 s1 = dpp_swap1(r1), s2 = dpp_swap1(r2);
+        const float4 lo = odd ? s2 : r1, hi = odd ? r2 : s1;
+        if (walking) {
+            float tb;
+            bool bh;
+            if (GENERAL) bh = box_hit_general(ctx.o, ctx.dinv, lo, hi, tb);
+            else bh = box_hit(ctx, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), tb);
+            if (bh && tb < limit) {
+                const int prim = __float_as_int(lo.w);
+                cur += 32u;
+                if (prim != kNullPrim) { q3 = q2; q2 = q1; q1 = q0; q0 = prim; qn++; }
+            }
+            else {
+                cur = first + (unsigned)__float_as_int(hi.w) * 32u;
+            }
+        }
+    }
+    return occluded;
+}
+
+// all 64 lanes of the wave must call this
+template <bool ANYHIT>
+__device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active) {
+    const RayBoxCtx ctx = make_box_ctx(ray);
+    const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
+    if (ANYHIT) {
+        WalkResult r;
+        r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f;
+        r.any = __any(special) ? walk_anyhit_deferred<false>(s, ray, ctx, limit, active)
+                               : walk_anyhit_deferred<true>(s, ray, ctx, limit, active);
+        return r;
+    }
+    if (__any(special)) return walk_paired<ANYHIT, false>(s, ray, ctx, limit, active);
+    return walk_paired<ANYHIT, true>(s, ray, ctx, limit, active);
 }
 
 // DevScene::intersect (src/scene.h:245-284): closest hit, stackless threaded walk
@@ -457,6 +571,17 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
         h.matId = s.materialIds[w.prim];
     }
     return h;
+}
+
+// testOcclusion for a whole wave of (incoherent) segments with the pair-cooperative fetch; every lane of
+// the wave must call it, `active` false where there is no segment
+__device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool active) {
+    f3 dir = y - x;
+    float dist = length(dir);
+    dir = dir / dist;
+    Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
+    dist -= 1e-4f * 2.f;
+    return walk_dispatch_paired<true>(s, ray, dist, active).any;
 }
 
 // DevScene::testOcclusion (src/scene.h:286-316): any hit between x and y
