@@ -37,9 +37,9 @@ constexpr int kRaySlots = 1024;   // ring of per-frame BVH-walk counters
 
 struct SurfPlanes {
     float4* posMat;     // pos.xyz, bits(matId | kind << 24)
-    float4* normRng;    // shading normal xyz, bits(rng state)
+    float4* norm;       // shading normal xyz (flipped to the wo side), w unused
     float4* wo;         // wo.xyz, 0
-    int*    matKind;    // matId | kind << 24 (dense copy for the spatial pass)
+    uint2*  rngMat;     // { RNG state carried from pass to pass, matId | kind << 24 }: all the spatial pass needs for a Lambertian pixel
     float4* candLi;     // RIS winner Li.xyz, dist
     float4* candWi;     // RIS winner wi.xyz, reservoir weight
 };
@@ -83,9 +83,9 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
         }
         const int mk = matId | (kind << 24);
         sp.posMat[index] = make_float4(h.pos.x, h.pos.y, h.pos.z, __int_as_float(mk));
-        sp.normRng[index] = make_float4(norm.x, norm.y, norm.z, __uint_as_float(rng.x));
+        sp.norm[index] = make_float4(norm.x, norm.y, norm.z, 0.f);
         sp.wo[index] = make_float4(wo.x, wo.y, wo.z, 0.f);
-        sp.matKind[index] = mk;
+        sp.rngMat[index] = make_uint2(rng.x, (unsigned)mk);
     }
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
@@ -103,14 +103,14 @@ __global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int widt
     const float4 pm = sp.posMat[index];
     const int mk = __float_as_int(pm.w);
     if ((mk >> 24) != kKindShaded) return;
-    const float4 nr = sp.normRng[index];
+    const float4 nr = sp.norm[index];
     const f3 pos = mk3(pm.x, pm.y, pm.z), norm = mk3(nr.x, nr.y, nr.z);
     const rs_material m = s.materials[mk & 0xffffff];
     const f3 baseColor = splat(1.f);                       // material.baseColor = 1 (restir.cu:141)
     f3 wo = splat(0.f);
     if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); }
 
-    Rng rng; rng.x = __float_as_uint(nr.w);
+    Rng rng; rng.x = sp.rngMat[index].x;
     f3 selLi = splat(0.f), selWi = splat(0.f);
     float selDist = 0.f, wsum = 0.f;
     for (int i = 0; i < kReservoirSize; i++) {
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int widt
     }
     sp.candLi[index] = make_float4(selLi.x, selLi.y, selLi.z, selDist);
     sp.candWi[index] = make_float4(selWi.x, selWi.y, selWi.z, wsum);
-    sp.normRng[index] = make_float4(nr.x, nr.y, nr.z, __uint_as_float(rng.x));
+    reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;
 }
 
 // ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------
@@ -190,10 +190,10 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
             t.W = last.w[lastIdx]; t.M = last.m[lastIdx];
         }
         if (!resv_invalid(t.W)) {
-            const float4 nr = sp.normRng[index];
-            Rng rng; rng.x = __float_as_uint(nr.w);
+            unsigned* rs = reinterpret_cast<unsigned*>(sp.rngMat + index);
+            Rng rng; rng.x = rs[0];
             const float u = rng.uniform();
-            sp.normRng[index] = make_float4(nr.x, nr.y, nr.z, __uint_as_float(rng.x));
+            rs[0] = rng.x;
             // preClampedMerge<20> (restir.h:95-102)
             if (r.M > 0) {
                 const int cap = (20 - 1) * r.M;
@@ -223,25 +223,38 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
 // tests) plus one rounding of the sum; if an integer lies within that band the exact path runs, and
 // the exact path itself re-does the trigonometry in double when its own 2-ulp band straddles an
 // integer.  Result: the same pixel as the host evaluation, at a fraction of the instruction count.
-constexpr float kTapErr = 4e-5f;
+constexpr float kTapErr = 2e-5f;
 
+// sin and cos of theta in [0, 2*pi] in double precision: quadrant reduction with a two-term pi/2 and
+// the classic degree-13/14 kernels (fdlibm k_sin / k_cos coefficients), < 1 ulp(double).  Rounded to
+// float this is the correctly rounded sinf/cosf for all but ~1e-9 of the arguments.  A hand-rolled
+// routine instead of OCML's sincos(double) because the latter costs 26 VGPRs (6 instead of 8 waves per
+// SIMD for the whole spatial pass) for a path taken by ~0.03 % of the taps.
+__device__ __forceinline__ void sincos_2pi(double t, double& sn, double& cs) {
+    const double k = rint(t * 6.36619772367581382433e-01);                 // 2/pi
+    double r = fma(-k, 1.57079632673412561417e+00, t);                      // pi/2 high (33 bits)
+    r = fma(-k, 6.07710050650619224932e-11, r);                             // pi/2 low
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double s0 = r + r * z * ps;
+    const double c0 = 1.0 - 0.5 * z + z * z * pc;
+    const int q = (int)k & 3;
+    sn = (q == 0) ? s0 : (q == 1) ? c0 : (q == 2) ? -s0 : -c0;
+    cs = (q == 0) ? c0 : (q == 1) ? -s0 : (q == 2) ? -c0 : s0;
+}
+
+// exact evaluation of the tap: correctly rounded cos/sin, then the reference's float arithmetic
 __device__ __forceinline__ void disk_tap_exact(float rx, float ry, int x, int y, int& px, int& py) {
     const float Radius = 5.f;
     const float rr = sqrtf(rx);
     const float theta = ry * kPi * 2.0f;
-    float sn, cs;
-    sincosf(theta, &sn, &cs);
-    float fx = (float)x + .5f + (cs * rr) * Radius;
-    float fy = (float)y + .5f + (sn * rr) * Radius;
-    const float nx = rintf(fx), ny = rintf(fy);
-    if (gabs(fx - nx) <= 4.f * 1.1920929e-7f * gabs(nx) + 1e-30f || gabs(fy - ny) <= 4.f * 1.1920929e-7f * gabs(ny) + 1e-30f) {
-        double sd, cd;
-        sincos((double)theta, &sd, &cd);
-        fx = (float)x + .5f + ((float)cd * rr) * Radius;
-        fy = (float)y + .5f + ((float)sd * rr) * Radius;
-    }
-    px = f2i(fx);
-    py = f2i(fy);
+    double sd, cd;
+    sincos_2pi((double)theta, sd, cd);
+    px = f2i((float)x + .5f + ((float)cd * rr) * Radius);
+    py = f2i((float)y + .5f + ((float)sd * rr) * Radius);
 }
 
 __device__ __forceinline__ void disk_tap_estimate(float rx, float ry, int x, int y, float& fx, float& fy) {
@@ -251,8 +264,12 @@ __device__ __forceinline__ void disk_tap_estimate(float rx, float ry, int x, int
     fy = (float)y + .5f + __builtin_amdgcn_sinf(ry) * rr5;
 }
 
+// The estimate and the exact chain differ by at most kTapErr before the final addition, and that
+// addition rounds each to the float grid, so their truncations can differ only if an integer lies
+// within kTapErr + ulp(f) of the estimate.
 __device__ __forceinline__ bool tap_ambiguous(float f) {
-    return gabs(f - rintf(f)) <= kTapErr + 2.4e-7f * gabs(f);
+    const float ulp = __uint_as_float((__float_as_uint(f) & 0x7f800000u) - (23u << 23));   // f is >= 0.5 in magnitude here or tiny
+    return gabs(f - rintf(f)) <= kTapErr + ((gabs(f) >= 1.f) ? ulp : 1.2e-7f);
 }
 
 __device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& px, int& py) {
@@ -282,97 +299,73 @@ __global__ void k_tap_estimate_error(int n, float* maxErr) {
 // one staged pixel: tap record {W, M, id, depth} + G-buffer normal, 32 B
 struct __attribute__((aligned(16))) Staged { float4 tap; float nx, ny, nz, pad; };
 
+#ifndef RS_K4_WAVES
+#define RS_K4_WAVES 6
+#endif
 constexpr int kBTileW = 32, kBTileH = 16, kBThreads = kBTileW * kBTileH;
 constexpr int kBStageW = kBTileW + 2 * kHalo, kBStageH = kBTileH + 2 * kHalo, kBStageN = kBStageW * kBStageH;
 
-__global__ void __launch_bounds__(kBThreads) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
-                                                             float* __restrict__ directIllum, int iter, int reuse,
-                                                             int y0, int y1, int tilesX, int numTiles) {
-    __shared__ Staged stage[kBStageN];
+__device__ __forceinline__ Staged fetch_staged_global(const GBufView& g, const TempPlanes& temp, int gi) {
+    Staged v;
+    v.tap = temp.tap[gi];
+    const f3 n = ld3(g.normal + (size_t)gi * 3);
+    v.nx = n.x; v.ny = n.y; v.nz = n.z; v.pad = 0.f;
+    return v;
+}
 
-    // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
-    // contiguous run of tiles so that neighbouring tiles' halos are served by the same L2.
-    int tile = blockIdx.x;
-    {
-        const int q = numTiles / 8, rem = numTiles % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
-    }
-    const int ox = (tile % tilesX) * kBTileW, oy = y0 + (tile / tilesX) * kBTileH;
+// The per-pixel body of phase B (restir.cu:196-230).  STAGED: neighbour records come from the LDS tile
+// `stage` (origin sox, soy); otherwise from global memory.
+template <bool STAGED>
+__device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlanes& sp, const GBufView& g, const ResvPlanes& own,
+                                              const TempPlanes& temp, const Staged* stage, int sox, int soy,
+                                              float* __restrict__ directIllum, int iter, bool spatial,
+                                              int x, int y, int index, uint2 rm, f3 albedo, f3 prev) {
     const int W = g.width, H = g.height;
-    const bool spatial = (reuse & 2) != 0;
-
-    if (spatial) {
-        for (int e = threadIdx.x; e < kBStageN; e += kBThreads) {
-            const int sx = ox - kHalo + (e % kBStageW), sy = oy - kHalo + (e / kBStageW);
-            Staged v;
-            v.tap = make_float4(0.f, 0.f, __int_as_float(-3), 0.f);     // id -3 matches nothing
-            v.nx = v.ny = v.nz = v.pad = 0.f;
-            if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
-                const int gi = sy * W + sx;
-                v.tap = temp.tap[gi];
-                const f3 n = ld3(g.normal + (size_t)gi * 3);
-                v.nx = n.x; v.ny = n.y; v.nz = n.z;
-            }
-            stage[e] = v;
-        }
-        __syncthreads();
-    }
-
-    const int tx = threadIdx.x % kBTileW, ty = threadIdx.x / kBTileW;
-    const int x = ox + tx, y = oy + ty;
-    if (x >= W || y >= y1) return;
-    const int index = y * W + x;
-    const int mk = sp.matKind[index];
+    const int mk = (int)rm.y;
     const int kind = mk >> 24;
 
     f3 direct = splat(0.f);
     if (kind == kKindLight) direct = splat(1.f);               // restir.cu:143-146 (baseColor forced to 1)
     if (kind == kKindShaded) {
-        const float4 nr = sp.normRng[index];
-        const f3 norm = mk3(nr.x, nr.y, nr.z);
-        Rng rng; rng.x = __float_as_uint(nr.w);
+        Rng rng; rng.x = rm.x;
 
         // own reservoir = what phase A published (post-temporal, validity-checked)
         float W0; int M0; int src = index;
         if (spatial) {
-            const Staged c = stage[(ty + kHalo) * kBStageW + (tx + kHalo)];
+            const Staged c = STAGED ? stage[(y - soy) * kBStageW + (x - sox)] : fetch_staged_global(g, temp, index);
             W0 = c.tap.x; M0 = __float_as_int(c.tap.y);
             const int idC = __float_as_int(c.tap.z);
             const float dC = c.tap.w;
             const f3 nC = mk3(c.nx, c.ny, c.nz);
 
-            // mergeSpatialNeighborDirect (restir.cu:87-100)
+            // mergeSpatialNeighborDirect (restir.cu:87-100), written branch-free: a rejected tap merges the
+            // default reservoir (W = 0, M = 0), exactly what the reference's `diff ? T() : ...` does
             float aW = 0.f; int aM = 0; int aSrc = -1;
 #pragma unroll 1
             for (int i = 0; i < 5; i++) {
                 const f2 r2 = rng.uniform2();
                 int px, py;
                 disk_tap(r2.x, r2.y, x, y, px, py);
-                float tW = 0.f; int tM = 0; int tSrc = -1;           // T(): zero sample, W = 0 (valid)
-                if (!(px < 0 || px >= W || py < 0 || py >= H || (px == x && py == y))) {
-                    const int lx = px - (ox - kHalo), ly = py - (oy - kHalo);
-                    float4 tp; f3 nP;
-                    if (lx >= 0 && lx < kBStageW && ly >= 0 && ly < kBStageH) {
-                        const Staged q = stage[ly * kBStageW + lx];
-                        tp = q.tap; nP = mk3(q.nx, q.ny, q.nz);
-                    }
-                    else {                                            // outside the staged halo: cannot happen for radius 5, kept for safety
-                        const int gi = py * W + px;
-                        tp = temp.tap[gi]; nP = ld3(g.normal + (size_t)gi * 3);
-                    }
-                    bool diff = false;
-                    if (__float_as_int(tp.z) != idC) diff = true;
-                    else {
-                        if (dot(nC, nP) < .9f) diff = true;
-                        if (gabs(dC - tp.w) > dC * .1f) diff = true;
-                    }
-                    if (!diff) { tW = tp.x; tM = __float_as_int(tp.y); tSrc = py * W + px; }
+                const bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & !((px == x) & (py == y));
+                Staged q;
+                if (STAGED) {       // taps reach x-4..x+5, y-4..y+5: always inside the staged halo; the clamp keeps garbage in bounds
+                    const int lx = iclamp(px - sox, 0, kBStageW - 1), ly = iclamp(py - soy, 0, kBStageH - 1);
+                    q = stage[ly * kBStageW + lx];
                 }
-                if (!resv_invalid(tW)) {
-                    const float u = rng.uniform();
-                    aW += tW; aM += tM;                                // Reservoir::merge (restir.h:61-68)
-                    if (u * aW < tW) aSrc = tSrc;
-                }
+                else q = fetch_staged_global(g, temp, iclamp(py, 0, H - 1) * W + iclamp(px, 0, W - 1));
+                const bool same = inb & (__float_as_int(q.tap.z) == idC) & !(dot(nC, mk3(q.nx, q.ny, q.nz)) < .9f) &
+                                  !(gabs(dC - q.tap.w) > dC * .1f);
+                const float tW = same ? q.tap.x : 0.f;
+                const int tM = same ? __float_as_int(q.tap.y) : 0;
+                const int tSrc = same ? py * W + px : -1;
+                const bool valid = !resv_invalid(tW);                  // `if (!spatial.invalid())`: the draw happens only then
+                Rng adv = rng;
+                const float u = adv.uniform();
+                rng.x = valid ? adv.x : rng.x;
+                const float nW = aW + tW;                              // Reservoir::merge (restir.h:61-68)
+                aSrc = (valid & (u * nW < tW)) ? tSrc : aSrc;
+                aW = valid ? nW : aW;
+                aM = valid ? aM + tM : aM;
             }
             if (!resv_invalid(aW) && !resv_invalid(W0)) {
                 const float u = rng.uniform();
@@ -389,21 +382,69 @@ __global__ void __launch_bounds__(kBThreads) k_spatial_shade(DevScene s, SurfPla
 
         if (!resv_invalid(W0)) {
             f3 Li = splat(0.f), wi = splat(0.f);
-            if (src >= 0) {
+            if (src >= 0) {                                            // the surviving sample: one 32-byte gather
                 const float4 a = spatial ? temp.li[src] : own.li[src], b = spatial ? temp.wi[src] : own.wi[src];
                 Li = mk3(a.x, a.y, a.z); wi = mk3(b.x, b.y, b.z);
             }
             const rs_material m = s.materials[mk & 0xffffff];
-            f3 wo = splat(0.f);
-            if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); }
+            f3 wo = splat(0.f), norm = splat(0.f);
+            if (m.type == 1) {                                         // only the metallic BSDF looks at n and wo
+                const float4 w4 = sp.wo[index], n4 = sp.norm[index];
+                wo = mk3(w4.x, w4.y, w4.z); norm = mk3(n4.x, n4.y, n4.z);
+            }
             const f3 LiBSDF = Li * eval_bsdf(m.type, splat(1.f), m.metallic, m.roughness, norm, wo, wi);
             direct = ((LiBSDF / luminance(LiBSDF)) * W0) / (float)M0;       // restir.cu:220-221
         }
         if (any_nan_or_inf(direct)) direct = splat(0.f);
     }
-    direct = direct * ld3(g.albedo + (size_t)index * 3);
-    float* o = directIllum + (size_t)index * 3;
-    st3(o, (ld3(o) * (float)iter + direct) / (float)(iter + 1));
+    direct = direct * albedo;
+    // (prev * iter + direct) / (iter + 1), restir.cu:230; for iter == 0 the division by 1.f is the identity
+    const f3 acc = prev * (float)iter + direct;
+    st3(directIllum + (size_t)index * 3, iter == 0 ? acc : acc / (float)(iter + 1));
+}
+
+__global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
+                                                             float* __restrict__ directIllum, int iter, int reuse,
+                                                             int y0, int y1, int tilesX, int numTiles) {
+    __shared__ Staged stage[kBStageN];
+
+    // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
+    // contiguous run of tiles so that neighbouring tiles' halos are served by the same L2.
+    int tile = blockIdx.x;
+    {
+        const int q = numTiles / 8, rem = numTiles % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int ox = (tile % tilesX) * kBTileW, oy = y0 + (tile / tilesX) * kBTileH;
+    const int W = g.width, H = g.height;
+    const bool spatial = (reuse & 2) != 0;
+
+    // own-pixel loads are issued before the staging so that their latency overlaps it
+    const int tx = threadIdx.x % kBTileW, ty = threadIdx.x / kBTileW;
+    const int x = ox + tx, y = oy + ty;
+    const bool inside = x < W && y < y1;
+    const int index = inside ? y * W + x : 0;
+    uint2 rm = make_uint2(0u, 0u);
+    f3 albedo = splat(0.f), prev = splat(0.f);
+    if (inside) {
+        rm = sp.rngMat[index];
+        albedo = ld3(g.albedo + (size_t)index * 3);
+        prev = ld3(directIllum + (size_t)index * 3);
+    }
+
+    if (spatial) {
+        for (int e = threadIdx.x; e < kBStageN; e += kBThreads) {
+            const int sx = ox - kHalo + (e % kBStageW), sy = oy - kHalo + (e / kBStageW);
+            Staged v;
+            v.tap = make_float4(0.f, 0.f, __int_as_float(-3), 0.f);     // id -3 matches nothing
+            v.nx = v.ny = v.nz = v.pad = 0.f;
+            if (sx >= 0 && sx < W && sy >= 0 && sy < H) v = fetch_staged_global(g, temp, sy * W + sx);
+            stage[e] = v;
+        }
+        __syncthreads();
+    }
+    if (!inside) return;
+    spatial_pixel<true>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, spatial, x, y, index, rm, albedo, prev);
 }
 
 }  // namespace
@@ -426,7 +467,7 @@ ResvPlanes* pick(rs_restir* r, int which) { return which == 0 ? &r->cur : (which
 
 SurfPlanes surf_of(rs_restir* r) {
     SurfPlanes sp;
-    sp.posMat = r->surfPosKind; sp.normRng = r->surfNormRng; sp.wo = r->surfWo; sp.matKind = r->matKind;
+    sp.posMat = r->surfPosKind; sp.norm = r->surfNorm; sp.wo = r->surfWo; sp.rngMat = r->rngMat;
     sp.candLi = r->candLi; sp.candWi = r->candWi;
     return sp;
 }
@@ -448,7 +489,7 @@ int rs_restir_free(rs_restir* r) {
     if (!r) return 0;
     free_planes(r->cur); free_planes(r->last);
     rs_dev_free(r->temp.li); rs_dev_free(r->temp.wi); rs_dev_free(r->temp.tap);
-    rs_dev_free(r->surfPosKind); rs_dev_free(r->surfNormRng); rs_dev_free(r->surfWo); rs_dev_free(r->matKind);
+    rs_dev_free(r->surfPosKind); rs_dev_free(r->surfNorm); rs_dev_free(r->surfWo); rs_dev_free(r->rngMat);
     rs_dev_free(r->candLi); rs_dev_free(r->candWi); rs_dev_free(r->dRayCount);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     delete r;
@@ -471,13 +512,13 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     if (!e) e = rs_check_hip(hipMemset(r->temp.wi, 0, n * 16), "memset");
     if (!e) e = rs_check_hip(hipMemset(r->temp.tap, 0, n * 16), "memset");
     if (!e) e = rs_dev_alloc(&r->surfPosKind, n);
-    if (!e) e = rs_dev_alloc(&r->surfNormRng, n);
+    if (!e) e = rs_dev_alloc(&r->surfNorm, n);
     if (!e) e = rs_dev_alloc(&r->surfWo, n);
-    if (!e) e = rs_dev_alloc(&r->matKind, n);
+    if (!e) e = rs_dev_alloc(&r->rngMat, n);
     if (!e) e = rs_dev_alloc(&r->candLi, n);
     if (!e) e = rs_dev_alloc(&r->candWi, n);
     if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots);
-    if (!e) e = rs_check_hip(hipMemset(r->matKind, 0, n * 4), "memset");
+    if (!e) e = rs_check_hip(hipMemset(r->rngMat, 0, n * 8), "memset");
     if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * kRaySlots), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (e) { rs_restir_free(r); return e; }

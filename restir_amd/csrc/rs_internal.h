@@ -121,9 +121,9 @@ struct rs_restir {
     // per-pixel state carried between the passes of one frame (implementation bytes, not in the
     // reference: its single fused kernel keeps these in registers)
     float4* surfPosKind = nullptr;   // hit position xyz, w = bit pattern of (matId | kind<<24)
-    float4* surfNormRng = nullptr;   // shading normal xyz (flipped to wo side), w = RNG state bits
+    float4* surfNorm = nullptr;      // shading normal xyz (flipped to wo side)
     float4* surfWo = nullptr;        // wo xyz (read only for non-Lambertian materials)
-    int*    matKind = nullptr;       // matId | kind<<24, dense copy for the spatial pass
+    uint2*  rngMat = nullptr;        // { RNG state, matId | kind<<24 }
     float4* candLi = nullptr;        // RIS winner: Li xyz, w = dist
     float4* candWi = nullptr;        // RIS winner: wi xyz, w = weight (sum of candidate weights)
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
