@@ -1,0 +1,179 @@
+// occlusion_bvh.cpp -- host build of the second acceleration structure used ONLY by shadow rays.
+//
+// DevScene::testOcclusion (src/scene.h:286-316) answers "is there a triangle T such that (a) every
+// node on the path from the root of the reference's MTBVH to T's leaf passes the reference's box test
+// with tBox < range and (b) intersectTriangle(T) hits closer than range" -- the visiting order does
+// not matter.  The reference's tree is poor for this (its SAH sweep is not cumulative, src/bvh.cpp:92-100:
+// depth up to 52, 86 node visits per shadow ray on the Sponza-class scene), so shadow rays here look
+// for candidates T satisfying (b) in a compact, well-built tree with CONSERVATIVE (slightly inflated)
+// boxes and then check (a) for each candidate by walking T's ancestor chain in the reference's own
+// tree with the reference's exact box test.  A conservative tree finds every T with (b), therefore
+// OR over candidates of (a) is exactly the reference's answer (rs_scene.h trace_occluded_fast).
+//
+// "Conservative" needs no epsilon: the primitive bounds used here ARE the reference's leaf boxes and every
+// box of this tree is an exact (min/max) union of them, so it contains the leaf box L of each of its
+// triangles.  IEEE rounding is monotone, hence for a box B' containing L the slab distances computed
+// with the reference's own expression (b - o) * (1/d) satisfy tNear' <= tNear and tFar' >= tFar on every
+// axis, and  tMax >= 0 && tMax >= tMin && tMin < range  for L (part of the reference's test, bvh.h:124-156)
+// implies the same for B'.  The walk of this tree uses exactly that relaxed test, so it reaches every
+// triangle whose reference leaf box the ray passes; the rest of (a) -- the reference's extra overlap
+// conditions at the leaf and all of its ancestors -- is what the chain check evaluates.  Rays that take one
+// of the reference's special cases (axis-aligned / near-zero components / NaN) use the reference walk.
+//
+// Built here: binned-SAH BVH2, up to 4 triangles per leaf, pre-order with miss links (stackless,
+// one order: any-hit does not care), and the reference-chain tables (parent of every reference node,
+// leaf node of every primitive).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "rs_internal.h"
+
+using namespace rs;
+
+namespace {
+
+struct Bx {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; } }
+    void add(const Bx& o) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); } }
+    void add(const float* p) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int kBins = 16, kMaxLeaf = 4;
+constexpr float kCostTri = 1.5f, kCostBox = 1.f;     // a leaf test is three 16-byte loads + ~45 VALU ops, a box 32 B + ~25
+
+struct Builder {
+    std::vector<Bx> pb;            // per-primitive bounds
+    std::vector<float> pc;         // per-primitive centroids (3 each)
+    std::vector<int> ids;          // permutation
+    std::vector<BvhNode> nodes;    // output, pre-order
+    std::vector<int> leafPrims;    // primitive ids in leaf order
+
+    // returns index of the emitted node
+    int build(int first, int count) {
+        Bx box; box.reset();
+        Bx cb; cb.reset();
+        for (int i = first; i < first + count; i++) { box.add(pb[ids[i]]); cb.add(&pc[(size_t)ids[i] * 3]); }
+        const int me = (int)nodes.size();
+        nodes.emplace_back();
+        auto make_leaf = [&]() {
+            const int start = (int)leafPrims.size();
+            for (int i = first; i < first + count; i++) leafPrims.push_back(ids[i]);
+            set(me, box, start * 8 + count);
+        };
+        if (count <= 1) { make_leaf(); return me; }
+
+        // binned SAH, all three axes
+        int ax = 0;
+        for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;      // fallback axis
+        int mid = -1;
+        {
+            float best = FLT_MAX; int cut = -1, cutAx = -1;
+            for (int a = 0; a < 3; a++) {
+                const float ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0.f)) continue;
+                Bx bb[kBins]; int bn[kBins];
+                for (int b = 0; b < kBins; b++) { bb[b].reset(); bn[b] = 0; }
+                const float scale = (float)kBins / ext;
+                for (int i = first; i < first + count; i++) {
+                    const int b = std::min(kBins - 1, std::max(0, (int)((pc[(size_t)ids[i] * 3 + a] - cb.lo[a]) * scale)));
+                    bb[b].add(pb[ids[i]]); bn[b]++;
+                }
+                float rightArea[kBins]; int rightCnt[kBins];
+                Bx acc; acc.reset(); int c = 0;
+                for (int b = kBins - 1; b > 0; b--) { acc.add(bb[b]); c += bn[b]; rightArea[b] = c ? acc.half_area() : 0.f; rightCnt[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.add(bb[b]); c += bn[b];
+                    if (c == 0 || rightCnt[b + 1] == 0) continue;
+                    const float cost = acc.half_area() * (float)c + rightArea[b + 1] * (float)rightCnt[b + 1];
+                    if (cost < best) { best = cost; cut = b; cutAx = a; }
+                }
+            }
+            const float leafCost = box.half_area() * (float)count * kCostTri;
+            if (cut >= 0 && (count > kMaxLeaf || best * kCostTri + box.half_area() * 2.f * kCostBox < leafCost)) {
+                const float lo = cb.lo[cutAx], scale = (float)kBins / (cb.hi[cutAx] - cb.lo[cutAx]);
+                auto it = std::partition(ids.begin() + first, ids.begin() + first + count, [&](int prim) {
+                    return std::min(kBins - 1, std::max(0, (int)((pc[(size_t)prim * 3 + cutAx] - lo) * scale))) <= cut; });
+                mid = (int)(it - ids.begin());
+            }
+        }
+        if (mid < 0) {
+            if (count <= kMaxLeaf) { make_leaf(); return me; }
+            mid = first + count / 2;                                   // degenerate centroids: median split
+            std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count,
+                             [&](int a, int b) { return pc[(size_t)a * 3 + ax] < pc[(size_t)b * 3 + ax]; });
+        }
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        // the child with the larger box first: more likely to hold an occluder
+        Bx lb, rb; lb.reset(); rb.reset();
+        for (int i = first; i < mid; i++) lb.add(pb[ids[i]]);
+        for (int i = mid; i < first + count; i++) rb.add(pb[ids[i]]);
+        if (rb.half_area() > lb.half_area()) {
+            std::rotate(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count);
+            mid = first + (first + count - mid);
+        }
+        build(first, mid - first);
+        build(mid, first + count - mid);
+        set(me, box, -1);
+        return me;
+    }
+
+    void set(int node, const Bx& b, int leaf) {
+        BvhNode& n = nodes[(size_t)node];
+        n.bminx = b.lo[0]; n.bminy = b.lo[1]; n.bminz = b.lo[2];
+        n.bmaxx = b.hi[0]; n.bmaxy = b.hi[1]; n.bmaxz = b.hi[2];
+        n.primId = leaf;                     // -1 inner, else firstTriangle * 8 + count
+        n.next = (int)nodes.size();          // pre-order: everything emitted after `node` so far is its subtree
+    }
+};
+
+}  // namespace
+
+// primBoxes: 6 floats (min, max) per primitive = the reference's leaf boxes
+int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<BvhNode>& nodes, std::vector<int>& leafPrims) {
+    if (numPrims <= 0 || !primBoxes) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_build_occlusion_bvh: bad argument");
+    Builder b;
+    b.pb.resize((size_t)numPrims); b.pc.resize((size_t)numPrims * 3); b.ids.resize((size_t)numPrims);
+    for (int i = 0; i < numPrims; i++) {
+        const float* t = primBoxes + (size_t)i * 6;
+        b.pb[i].reset(); b.pb[i].add(t); b.pb[i].add(t + 3);
+        for (int k = 0; k < 3; k++) b.pc[(size_t)i * 3 + k] = 0.5f * (b.pb[i].lo[k] + b.pb[i].hi[k]);
+        b.ids[i] = i;
+    }
+    b.nodes.reserve((size_t)numPrims);
+    b.leafPrims.reserve((size_t)numPrims);
+    b.build(0, numPrims);
+    nodes.swap(b.nodes);
+    leafPrims.swap(b.leafPrims);
+    return 0;
+}
+
+// parent of every reference node (indexed by the ORIGINAL pre-order id = MTBVHNode::boundingBoxId) and
+// the leaf node of every primitive, derived from one threaded order (src/bvh.cpp:156-193: order 0).
+int rs_reference_chain_tables(int bvhSize, const int* order0 /* 3 ints per node */, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims) {
+    parent.assign((size_t)bvhSize, -1);
+    leafOfPrim.assign((size_t)numPrims, -1);
+    // order0[i] = {prim, origId, next}; subtree of i = [i, next); children of an inner node: i+1 and next(i+1)
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int i = stack.back(); stack.pop_back();
+        const int prim = order0[(size_t)i * 3], orig = order0[(size_t)i * 3 + 1];
+        if (prim >= 0) { if (prim < numPrims) leafOfPrim[(size_t)prim] = orig; continue; }
+        const int a = i + 1, b = order0[(size_t)a * 3 + 2];
+        if (b >= bvhSize) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: malformed tree");
+        parent[(size_t)order0[(size_t)a * 3 + 1]] = orig;
+        parent[(size_t)order0[(size_t)b * 3 + 1]] = orig;
+        stack.push_back(b); stack.push_back(a);
+    }
+    for (int p = 0; p < numPrims; p++) if (leafOfPrim[(size_t)p] < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: primitive without a leaf");
+    return 0;
+}

@@ -46,6 +46,8 @@ struct rs_scene {
     rs_material* dMaterials = nullptr;
     rs::LightRec* dLights = nullptr;
     rs::AliasRec* dAlias = nullptr;
+    rs::BvhNode* dOccAll = nullptr;  // shadow-ray tree + reference chain records (occlusion_bvh.cpp)
+    rs::TriRec* dOccTris = nullptr;
     // host copies of the source arrays (rs_scene_host_desc)
     std::vector<float> hVertices, hNormals, hTexcoords, hBoxes, hLightRadiance, hLightProb;
     std::vector<int> hMaterialIds, hNodes[6], hLightPrimIds, hLightFailId;
@@ -141,3 +143,7 @@ struct rs_eaw {
 };
 
 rs::CamParams rs_make_cam_params(const rs_camera* cam);
+
+// occlusion_bvh.cpp
+int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<rs::BvhNode>& nodes, std::vector<int>& leafPrims);
+int rs_reference_chain_tables(int bvhSize, const int* order0, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims);

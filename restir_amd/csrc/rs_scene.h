@@ -15,6 +15,12 @@
 //                                 per-light constant pdfArea = lum(Le)/(area*2*pi) * sumLightPowerInv
 //                                 (src/scene.h:411,419-424: per-candidate in the reference, per-light here)
 //   alias      AliasRec[numLights] 8 B: BinomialDistrib {prob, failId} (src/sampler.h:63-67)
+//   occAll     BvhNode[occCount + 1 + bvhSize + 1]: the shadow-ray tree (occlusion_bvh.cpp; primId = leaf code
+//                                 firstTriangle*8+count or -1), one padding record, then the reference's boxes indexed by
+//                                 ORIGINAL node id with primId = parent id (-1 at the root): the chain a
+//                                 candidate occluder is verified against.  Null when the fast path is off.
+//   occTris    TriRec[numPrims]   the same pre-differenced triangles in the shadow tree's leaf order,
+//                                 pad0 = bit pattern of the triangle's reference leaf node id
 #pragma once
 
 #include "rs_math.h"
@@ -48,6 +54,9 @@ struct DevScene {
     const rs_material* materials;
     const LightRec* lights;
     const AliasRec* alias;
+    const BvhNode* occAll;
+    const TriRec*  occTris;
+    int occCount;
     int bvhSize;
     int numPrims;
     int numLights;
@@ -444,6 +453,89 @@ __device__ __forceinline__ bool walk_anyhit_deferred(const DevScene& s, const Ra
     return occluded;
 }
 
+// ---- shadow rays through the second tree ------------------------------------------------------------
+// testOcclusion (src/scene.h:286-316) is true iff some triangle T has (a) every node on the reference
+// tree's path to T passing the reference's box test with tBox < range and (b) intersectTriangle(T) closer
+// than range; the visiting order is irrelevant.  The reference's tree costs 86 node visits per shadow
+// ray on the Sponza-class scene (its SAH sweep is not cumulative, src/bvh.cpp:92-100), so general-case
+// rays look for triangles with (b) in a well-built tree over the SAME leaf boxes (occlusion_bvh.cpp
+// shows why its relaxed slab test cannot miss a triangle whose reference leaf box the ray passes) and
+// then evaluate (a) for such a candidate literally: the reference's box test on T's leaf and on each
+// of its ancestors (parent links by original node id).  The first candidate that passes is what the
+// reference's walk would also have reached and hit -> occluded; if none passes the reference reports
+// no occlusion either.  A lane is in one of two modes, both "fetch a 32-byte record, slab test, move
+// on", so the pair-cooperative fetch and the deferred leaf rounds of walk_anyhit_deferred are shared:
+//   walk   : cur in the shadow tree; relaxed test; leaves are queued (code = firstTriangle*8+count)
+//   verify : cur in the reference chain records; full reference test; fail -> back to `resume`
+// Only for rays that take none of AABB::intersect's special cases (all |d.c| in [1e-6, 1-1e-6]).
+__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
+    const char* base = reinterpret_cast<const char*>(s.occAll);
+    const unsigned endOff = (unsigned)s.occCount * 32u;        // the padding record: readable for idle partners
+    const unsigned chain = endOff + 32u;                        // chain record of reference node 0
+    const unsigned kWalking = 0xffffffffu;
+    const bool odd = (__lane_id() & 1u) != 0;
+    const unsigned halfOff = odd ? 16u : 0u;
+    unsigned cur = active ? 0u : endOff;
+    unsigned resume = kWalking;                                 // walk position while a candidate is verified
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
+    bool occluded = false;
+    for (;;) {
+        const unsigned long long smask = __ballot(cur != endOff);
+        const unsigned long long pmask = __ballot(qn > 0);
+        if (!(smask | pmask)) break;
+        if (__any(qn == kLeafQueue && resume == kWalking) || smask == 0) {
+            // leaf round: every lane that is not verifying tests the triangles of its newest leaf
+            const bool take = qn > 0 && resume == kWalking;
+            int tri = 0, cnt = 0;
+            if (take) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
+            while (__any(cnt > 0)) {
+                if (cnt > 0) {
+                    const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
+                    const float4 a = p[0], b = p[1], c = p[2];
+                    float bx, by, dist;
+                    tri++; cnt--;
+                    if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit) {
+                        if (cnt > 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tri * 8 + cnt; qn++; cnt = 0; }   // rest of the leaf, should the candidate fail
+                        resume = cur;
+                        cur = chain + (unsigned)__float_as_int(a.w) * 32u;
+                    }
+                }
+            }
+            continue;
+        }
+        const unsigned partner = (unsigned)dpp_swap1((int)cur);
+        const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);
+        const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);
+        const float4 s1 = dpp_swap1(r1), s2 = dpp_swap1(r2);
+        const float4 lo = odd ? s2 : r1, hi = odd ? r2 : s1;
+        if (cur != endOff) {
+            const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
+            const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
+            const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
+            const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
+            const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
+            const bool relaxed = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
+            const int tag = __float_as_int(lo.w), link = __float_as_int(hi.w);
+            if (resume == kWalking) {
+                if (relaxed) {
+                    cur += 32u;
+                    if (tag >= 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tag; qn++; }
+                }
+                else cur = (unsigned)link * 32u;
+            }
+            else {
+                // the rest of the general case of AABB::intersect (box_hit_general)
+                const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+                const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
+                if (!(relaxed & overlap)) { cur = resume; resume = kWalking; }                  // the reference never reaches this triangle
+                else if (tag < 0) { occluded = true; cur = endOff; qn = 0; resume = kWalking; }   // root passed: the whole path is open
+                else cur = chain + (unsigned)tag * 32u;
+            }
+        }
+    }
+    return occluded;
+}
+
 // all 64 lanes of the wave must call this
 template <bool ANYHIT>
 __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active) {
@@ -452,8 +544,13 @@ __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, co
     if (ANYHIT) {
         WalkResult r;
         r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f;
-        r.any = __any(special) ? walk_anyhit_deferred<false>(s, ray, ctx, limit, active)
-                               : walk_anyhit_deferred<true>(s, ray, ctx, limit, active);
+        if (s.occAll) {
+            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !special);
+            if (__any(special)) r.any = walk_anyhit_deferred<false>(s, ray, ctx, limit, special) || r.any;
+        }
+        else
+            r.any = __any(special) ? walk_anyhit_deferred<false>(s, ray, ctx, limit, active)
+                                   : walk_anyhit_deferred<true>(s, ray, ctx, limit, active);
         return r;
     }
     if (__any(special)) return walk_paired<ANYHIT, false>(s, ray, ctx, limit, active);

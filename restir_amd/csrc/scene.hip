@@ -1,6 +1,7 @@
 // scene.hip -- DevScene::create / destroy (src/scene.cpp:435-532) re-laid-out for CDNA4 (see
 // rs_scene.h), Scene::buildDevData as one call, and batched ray entry points for parity tests.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "rs_internal.h"
@@ -24,11 +25,58 @@ int upload(T** dst, const std::vector<T>& src) {
     return 0;
 }
 
+// The shadow-ray tree and the reference chain records (rs_scene.h walk_occlusion_tree).  Needs every
+// reference box finite with min <= max (always true for boxes from rs_build_bvh; a caller-supplied table
+// that is not leaves the fast path off and shadow rays walk the reference's tree).
+int build_occlusion_side(rs_scene* s) {
+    const size_t np = (size_t)s->numPrims, nn = (size_t)s->bvhSize;
+    if (std::getenv("RS_NO_OCCLUSION_TREE")) return 0;          // A/B switch for measurements
+    for (size_t i = 0; i < nn * 6; i++) if (!std::isfinite(s->hBoxes[i])) return 0;
+    for (size_t i = 0; i < nn; i++)
+        for (int k = 0; k < 3; k++) if (s->hBoxes[i * 6 + k] > s->hBoxes[i * 6 + 3 + k]) return 0;
+    std::vector<int> parent, leafOf;
+    RS_TRY(rs_reference_chain_tables(s->bvhSize, s->hNodes[0].data(), parent, leafOf, s->numPrims));
+    std::vector<float> primBoxes(np * 6);
+    for (size_t p = 0; p < np; p++) std::memcpy(&primBoxes[p * 6], &s->hBoxes[(size_t)leafOf[p] * 6], 6 * sizeof(float));
+    std::vector<BvhNode> nodes;
+    std::vector<int> leafPrims;
+    RS_TRY(rs_build_occlusion_bvh(s->numPrims, primBoxes.data(), nodes, leafPrims));
+    const size_t no = nodes.size();
+    if ((no + nn + 2) * sizeof(BvhNode) >= 0xffffffffull || np >= (1u << 27)) return 0;
+    BvhNode pad;
+    pad.bminx = pad.bminy = pad.bminz = pad.bmaxx = pad.bmaxy = pad.bmaxz = 0.f; pad.primId = -1; pad.next = 0;
+    nodes.push_back(pad);
+    for (size_t i = 0; i < nn; i++) {
+        const float* b = &s->hBoxes[i * 6];
+        BvhNode r;
+        r.bminx = b[0]; r.bminy = b[1]; r.bminz = b[2]; r.primId = parent[i];
+        r.bmaxx = b[3]; r.bmaxy = b[4]; r.bmaxz = b[5]; r.next = 0;
+        nodes.push_back(r);
+    }
+    nodes.push_back(pad);
+    std::vector<TriRec> rec(np);
+    for (size_t i = 0; i < np; i++) {
+        const size_t p = (size_t)leafPrims[i];
+        const float* t = &s->hVertices[p * 9];
+        f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+        f3 e1 = v1 - v0, e2 = v2 - v0;
+        float leafBits;
+        std::memcpy(&leafBits, &leafOf[p], 4);
+        rec[i] = TriRec{ v0.x, v0.y, v0.z, leafBits, e1.x, e1.y, e1.z, 0.f, e2.x, e2.y, e2.z, 0.f };
+    }
+    RS_TRY(upload(&s->dOccAll, nodes));
+    RS_TRY(upload(&s->dOccTris, rec));
+    s->dev.occAll = s->dOccAll;
+    s->dev.occTris = s->dOccTris;
+    s->dev.occCount = (int)no;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
-    rs_dev_free(s->dNodesAll);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dOccAll); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     delete s;
@@ -145,6 +193,8 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.numPrims = s->numPrims;
     s->dev.numLights = s->numLights;
     s->dev.numMaterials = d->numMaterials;
+    s->dev.occAll = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
+    if (int e = build_occlusion_side(s)) { rs_scene_destroy(s); return e; }
     *out = s;
     return 0;
 }
@@ -213,9 +263,12 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevScene s, int n, const 
 }
 
 __global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    occ[i] = trace_occluded(s, ld3(seg + (size_t)i * 6), ld3(seg + (size_t)i * 6 + 3)) ? 1 : 0;
+    // same wave-level service the ReSTIR shadow pass uses: every lane of the wave takes part
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const size_t j = active ? (size_t)i : 0;
+    const bool o = trace_occluded_wave(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active);
+    if (active) occ[i] = o ? 1 : 0;
 }
 
 extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {
