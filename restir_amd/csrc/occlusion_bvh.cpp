@@ -156,6 +156,50 @@ int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<Bvh
     return 0;
 }
 
+// ---- 16-byte nodes -------------------------------------------------------------------------------
+// Any box that CONTAINS a node's exact box keeps the walk conservative, so the device tree stores boxes
+// on a 16-bit grid over the scene bounds: plane = base + q * scale.  The walk evaluates the slab distance
+// of such a plane as fma(q, scale/d, (base - o)/d), which is not the reference's expression, so here the
+// containment carries a margin instead of the exact monotonicity argument above: with D = the largest
+// |coordinate difference| involved (<= 4 extents, enforced per ray on the device), both this value and the
+// reference's fl(fl(p - o) * (1/d)) are within 2^-21 * D / |d| of the real-number distance of their
+// plane, i.e. within 2^-21 * D in space; the grid planes are moved outward until they clear the exact
+// box by 2^-17 * extent >= 4 * 2^-21 * D * 2 on every axis (checked here in double), a fraction of one
+// grid step (2^-16 * extent).
+int rs_quantize_occlusion_bvh(const std::vector<BvhNode>& nodes, float base[3], float scale[3], std::vector<unsigned>& out) {
+    if (nodes.empty()) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_quantize_occlusion_bvh: empty tree");
+    const BvhNode& root = nodes[0];
+    const float lo[3] = { root.bminx, root.bminy, root.bminz }, hi[3] = { root.bmaxx, root.bmaxy, root.bmaxz };
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) ext = std::max(ext, hi[k] - lo[k]);
+    if (!(ext > 0.f) || !std::isfinite(ext)) return rs_fail(RS_ERR_UNSUPPORTED, "rs_quantize_occlusion_bvh: degenerate scene bounds");
+    const double margin = std::ldexp((double)ext, -17);
+    for (int k = 0; k < 3; k++) {
+        scale[k] = ext / 65000.f;                       // one cubic grid: same resolution on every axis
+        base[k] = lo[k] - 200.f * scale[k];
+    }
+    out.resize(nodes.size() * 4);
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const BvhNode& n = nodes[i];
+        const float blo[3] = { n.bminx, n.bminy, n.bminz }, bhi[3] = { n.bmaxx, n.bmaxy, n.bmaxz };
+        unsigned ql[3], qh[3];
+        for (int k = 0; k < 3; k++) {
+            long a = (long)std::floor(((double)blo[k] - margin - (double)base[k]) / (double)scale[k]);
+            long b = (long)std::ceil(((double)bhi[k] + margin - (double)base[k]) / (double)scale[k]);
+            while ((double)base[k] + (double)a * (double)scale[k] > (double)blo[k] - margin) a--;
+            while ((double)base[k] + (double)b * (double)scale[k] < (double)bhi[k] + margin) b++;
+            if (a < 0 || b > 65535) return rs_fail(RS_ERR_UNSUPPORTED, "rs_quantize_occlusion_bvh: box outside the grid");
+            ql[k] = (unsigned)a; qh[k] = (unsigned)b;
+        }
+        unsigned* o = &out[i * 4];
+        o[0] = ql[0] | (ql[1] << 16);
+        o[1] = ql[2] | (qh[0] << 16);
+        o[2] = qh[1] | (qh[2] << 16);
+        o[3] = n.primId >= 0 ? ~(unsigned)n.primId : (unsigned)n.next;      // leaf: ~code (sign bit set), inner: miss link
+    }
+    return 0;
+}
+
 // parent of every reference node (indexed by the ORIGINAL pre-order id = MTBVHNode::boundingBoxId) and
 // the leaf node of every primitive, derived from one threaded order (src/bvh.cpp:156-193: order 0).
 int rs_reference_chain_tables(int bvhSize, const int* order0 /* 3 ints per node */, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims) {

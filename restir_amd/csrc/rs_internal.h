@@ -46,8 +46,10 @@ struct rs_scene {
     rs_material* dMaterials = nullptr;
     rs::LightRec* dLights = nullptr;
     rs::AliasRec* dAlias = nullptr;
-    rs::BvhNode* dOccAll = nullptr;  // shadow-ray tree + reference chain records (occlusion_bvh.cpp)
+    uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
+    rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
+    unsigned long long* dWalkStats = nullptr;   // -DRS_WALK_STATS builds only
     // host copies of the source arrays (rs_scene_host_desc)
     std::vector<float> hVertices, hNormals, hTexcoords, hBoxes, hLightRadiance, hLightProb;
     std::vector<int> hMaterialIds, hNodes[6], hLightPrimIds, hLightFailId;
@@ -146,4 +148,5 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam);
 
 // occlusion_bvh.cpp
 int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<rs::BvhNode>& nodes, std::vector<int>& leafPrims);
+int rs_quantize_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, float base[3], float scale[3], std::vector<unsigned>& out);
 int rs_reference_chain_tables(int bvhSize, const int* order0, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims);

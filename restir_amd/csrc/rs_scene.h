@@ -15,10 +15,11 @@
 //                                 per-light constant pdfArea = lum(Le)/(area*2*pi) * sumLightPowerInv
 //                                 (src/scene.h:411,419-424: per-candidate in the reference, per-light here)
 //   alias      AliasRec[numLights] 8 B: BinomialDistrib {prob, failId} (src/sampler.h:63-67)
-//   occAll     BvhNode[occCount + 1 + bvhSize + 1]: the shadow-ray tree (occlusion_bvh.cpp; primId = leaf code
-//                                 firstTriangle*8+count or -1), one padding record, then the reference's boxes indexed by
-//                                 ORIGINAL node id with primId = parent id (-1 at the root): the chain a
-//                                 candidate occluder is verified against.  Null when the fast path is off.
+//   occNodes   uint4[occCount]    16 B: the shadow-ray tree (occlusion_bvh.cpp): box on a 16-bit grid over the
+//                                 scene bounds {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16}, w = miss link of an
+//                                 inner node or ~(firstTriangle*8+count) of a leaf.  Null when the fast path is off.
+//   occChain   BvhNode[bvhSize]   32 B: the reference's boxes by ORIGINAL node id with primId = next = parent id
+//                                 (-1 at the root): the path a candidate occluder is verified against
 //   occTris    TriRec[numPrims]   the same pre-differenced triangles in the shadow tree's leaf order,
 //                                 pad0 = bit pattern of the triangle's reference leaf node id
 #pragma once
@@ -54,9 +55,14 @@ struct DevScene {
     const rs_material* materials;
     const LightRec* lights;
     const AliasRec* alias;
-    const BvhNode* occAll;
+    const uint4*   occNodes;
+    const BvhNode* occChain;
     const TriRec*  occTris;
+    f3 occBase, occScale;         // grid plane q on axis c = occBase.c + q * occScale.c
+    f3 occRootLo, occRootHi;      // the reference's root box
+    bool occNested;               // every reference box lies inside its parent's (enables the leaf shortcut)
     int occCount;
+    unsigned long long* walkStats;   // null unless built with -DRS_WALK_STATS (tools/walk_stats.py)
     int bvhSize;
     int numPrims;
     int numLights;
@@ -457,38 +463,57 @@ __device__ __forceinline__ bool walk_anyhit_deferred(const DevScene& s, const Ra
 // testOcclusion (src/scene.h:286-316) is true iff some triangle T has (a) every node on the reference
 // tree's path to T passing the reference's box test with tBox < range and (b) intersectTriangle(T) closer
 // than range; the visiting order is irrelevant.  The reference's tree costs 86 node visits per shadow
-// ray on the Sponza-class scene (its SAH sweep is not cumulative, src/bvh.cpp:92-100), so general-case
-// rays look for triangles with (b) in a well-built tree over the SAME leaf boxes (occlusion_bvh.cpp
-// shows why its relaxed slab test cannot miss a triangle whose reference leaf box the ray passes) and
-// then evaluate (a) for such a candidate literally: the reference's box test on T's leaf and on each
-// of its ancestors (parent links by original node id).  The first candidate that passes is what the
-// reference's walk would also have reached and hit -> occluded; if none passes the reference reports
-// no occlusion either.  A lane is in one of two modes, both "fetch a 32-byte record, slab test, move
-// on", so the pair-cooperative fetch and the deferred leaf rounds of walk_anyhit_deferred are shared:
-//   walk   : cur in the shadow tree; relaxed test; leaves are queued (code = firstTriangle*8+count)
-//   verify : cur in the reference chain records; full reference test; fail -> back to `resume`
-// Only for rays that take none of AABB::intersect's special cases (all |d.c| in [1e-6, 1-1e-6]).
+// ray on the Sponza-class scene (its SAH sweep is not cumulative, src/bvh.cpp:92-100) at 32 bytes each,
+// so general-case rays look for triangles with (b) in a well-built tree of 16-byte nodes over the SAME
+// leaf boxes (occlusion_bvh.cpp shows why its relaxed slab test cannot miss a triangle whose reference
+// leaf box the ray passes) and then evaluate (a) for such a candidate literally: the reference's box test
+// on T's leaf and on each of its ancestors (parent links by original node id).  The first candidate that
+// passes is what the reference's walk would also have reached and hit -> occluded; if none passes the
+// reference reports no occlusion either.  A lane is in one of two modes:
+//   walk   : cur = byte offset in occNodes; relaxed test on the grid box; leaves are queued and tested
+//            in rounds (as in walk_anyhit_deferred); branch-free step
+//   verify : cur = reference node id in occChain; the reference's full test; fail -> back to the walk
+// Only for rays that take none of AABB::intersect's special cases (all |d.c| in [1e-6, 1-1e-6]) and start
+// within 4 grid extents of the scene (the error bound of the grid test, occlusion_bvh.cpp).
+__device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
+    const float reach = 4.f * 65535.f;
+    return gabs(o.x - s.occBase.x) <= reach * s.occScale.x && gabs(o.y - s.occBase.y) <= reach * s.occScale.y &&
+           gabs(o.z - s.occBase.z) <= reach * s.occScale.z;
+}
+
 __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
-    const char* base = reinterpret_cast<const char*>(s.occAll);
-    const unsigned endOff = (unsigned)s.occCount * 32u;        // the padding record: readable for idle partners
-    const unsigned chain = endOff + 32u;                        // chain record of reference node 0
-    const unsigned kWalking = 0xffffffffu;
-    const bool odd = (__lane_id() & 1u) != 0;
-    const unsigned halfOff = odd ? 16u : 0u;
+    const char* nodes = reinterpret_cast<const char*>(s.occNodes);
+    const unsigned endOff = (unsigned)s.occCount * 16u;
+    // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
+    const f3 A = mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z);
+    const f3 B = mk3((s.occBase.x - ctx.o.x) * ctx.dinv.x, (s.occBase.y - ctx.o.y) * ctx.dinv.y, (s.occBase.z - ctx.o.z) * ctx.dinv.z);
+    // largest |slab distance| of the reference's root box
+    const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
+                                    fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
+                              fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
     unsigned cur = active ? 0u : endOff;
-    unsigned resume = kWalking;                                 // walk position while a candidate is verified
+    int verify = -1;                                            // reference node being checked, -1 = walking
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
     bool occluded = false;
+#ifdef RS_WALK_STATS
+    unsigned long long st[10] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define RS_STAT(i, v) st[i] += (v)
+#else
+#define RS_STAT(i, v)
+#endif
     for (;;) {
-        const unsigned long long smask = __ballot(cur != endOff);
-        const unsigned long long pmask = __ballot(qn > 0);
-        if (!(smask | pmask)) break;
-        if (__any(qn == kLeafQueue && resume == kWalking) || smask == 0) {
+        const bool walking = (verify < 0) & (cur != endOff);
+        const unsigned long long smask = __ballot(walking | (verify >= 0));
+        if (!(smask | __ballot(qn > 0))) break;
+        RS_STAT(1, 1);
+        if (__any((qn == kLeafQueue) & (verify < 0)) || smask == 0) {
+            RS_STAT(2, 1);
             // leaf round: every lane that is not verifying tests the triangles of its newest leaf
-            const bool take = qn > 0 && resume == kWalking;
+            const bool take = (qn > 0) & (verify < 0);
             int tri = 0, cnt = 0;
             if (take) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
             while (__any(cnt > 0)) {
+                RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot(cnt > 0)));
                 if (cnt > 0) {
                     const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
                     const float4 a = p[0], b = p[1], c = p[2];
@@ -496,43 +521,62 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                     tri++; cnt--;
                     if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit) {
                         if (cnt > 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tri * 8 + cnt; qn++; cnt = 0; }   // rest of the leaf, should the candidate fail
-                        resume = cur;
-                        cur = chain + (unsigned)__float_as_int(a.w) * 32u;
+                        verify = __float_as_int(a.w) | 0x40000000;
                     }
                 }
             }
             continue;
         }
-        const unsigned partner = (unsigned)dpp_swap1((int)cur);
-        const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);
-        const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);
-        const float4 s1 = dpp_swap1(r1), s2 = dpp_swap1(r2);
-        const float4 lo = odd ? s2 : r1, hi = odd ? r2 : s1;
-        if (cur != endOff) {
-            const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
-            const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
-            const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
-            const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
-            const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
-            const bool relaxed = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
-            const int tag = __float_as_int(lo.w), link = __float_as_int(hi.w);
-            if (resume == kWalking) {
-                if (relaxed) {
-                    cur += 32u;
-                    if (tag >= 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tag; qn++; }
-                }
-                else cur = (unsigned)link * 32u;
-            }
-            else {
-                // the rest of the general case of AABB::intersect (box_hit_general)
+        RS_STAT(5, __any(walking) ? 1 : 0); RS_STAT(6, __popcll(__ballot(walking)));
+        RS_STAT(7, __popcll(__ballot(verify >= 0))); RS_STAT(8, __any(walking) ? 0 : 1);
+        if (__any(verify >= 0)) {
+            RS_STAT(4, 1);
+            if (verify >= 0) {
+                const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
+                const float4 lo = rec[0], hi = rec[1];
+                // the general case of AABB::intersect (box_hit_general), spelled out for the margins below
+                const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
+                const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
+                const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
+                const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
                 const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
                 const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
-                if (!(relaxed & overlap)) { cur = resume; resume = kWalking; }                  // the reference never reaches this triangle
-                else if (tag < 0) { occluded = true; cur = endOff; qn = 0; resume = kWalking; }   // root passed: the whole path is open
-                else cur = chain + (unsigned)tag * 32u;
+                const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
+                const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
+                // Shortcut at the leaf (first record of a chain, flagged in bit 30).  Every ancestor box contains
+                // the leaf box (checked at scene build), so by monotone rounding its near distances are <= and
+                // its far distances >= the leaf's: tMax >= 0, tMax >= tMin and tMin < range carry over exactly.
+                // The three overlap conditions are, in real arithmetic, fy > nz, fz > nx, fx > ny, and those
+                // differences can only grow towards the root; evaluated in float they are off by less than
+                // 2^-20 * tRoot (four roundings of values below 4 * tRoot, tRoot = largest |slab distance| of the
+                // root box, which bounds every ancestor's).  A leaf that clears them by 2^-18 * tRoot therefore
+                // settles the whole path; otherwise the ancestors are tested one by one.
+                const bool first = (verify & 0x40000000) != 0;
+                const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
+                const int parent = __float_as_int(lo.w);
+                const bool done = open & ((parent < 0) | (first & clear & s.occNested));
+                if (done) { occluded = true; cur = endOff; qn = 0; }
+                verify = (open & !done) ? parent : -1;              // closed: the reference never reaches the triangle
             }
         }
+        if (walking) {
+            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+            const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
+            const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
+            const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+            const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+            const bool pass = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
+            const int meta = (int)n.w;
+            const bool leaf = meta < 0;
+            const bool push = pass & leaf;
+            q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn += push ? 1 : 0;
+            cur = (pass | leaf) ? cur + 16u : (unsigned)meta * 16u;
+        }
     }
+#ifdef RS_WALK_STATS
+    if (s.walkStats && __lane_id() == 0) for (int i = 0; i < 10; i++) atomicAdd(&s.walkStats[i], st[i]);
+#endif
+#undef RS_STAT
     return occluded;
 }
 
@@ -544,9 +588,10 @@ __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, co
     if (ANYHIT) {
         WalkResult r;
         r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f;
-        if (s.occAll) {
-            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !special);
-            if (__any(special)) r.any = walk_anyhit_deferred<false>(s, ray, ctx, limit, special) || r.any;
+        if (s.occNodes) {
+            const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
+            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !slow);
+            if (__any(slow)) r.any = walk_anyhit_deferred<false>(s, ray, ctx, limit, slow) || r.any;
         }
         else
             r.any = __any(special) ? walk_anyhit_deferred<false>(s, ray, ctx, limit, active)

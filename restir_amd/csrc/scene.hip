@@ -42,18 +42,17 @@ int build_occlusion_side(rs_scene* s) {
     std::vector<int> leafPrims;
     RS_TRY(rs_build_occlusion_bvh(s->numPrims, primBoxes.data(), nodes, leafPrims));
     const size_t no = nodes.size();
-    if ((no + nn + 2) * sizeof(BvhNode) >= 0xffffffffull || np >= (1u << 27)) return 0;
-    BvhNode pad;
-    pad.bminx = pad.bminy = pad.bminz = pad.bmaxx = pad.bmaxy = pad.bmaxz = 0.f; pad.primId = -1; pad.next = 0;
-    nodes.push_back(pad);
+    if (no * 16 >= 0xffffffffull || nn * sizeof(BvhNode) >= 0xffffffffull || np >= (1u << 27)) return 0;
+    float base[3], scale[3];
+    std::vector<unsigned> packed;
+    RS_TRY(rs_quantize_occlusion_bvh(nodes, base, scale, packed));
+    std::vector<BvhNode> chain(nn);
     for (size_t i = 0; i < nn; i++) {
         const float* b = &s->hBoxes[i * 6];
-        BvhNode r;
+        BvhNode& r = chain[i];
         r.bminx = b[0]; r.bminy = b[1]; r.bminz = b[2]; r.primId = parent[i];
-        r.bmaxx = b[3]; r.bmaxy = b[4]; r.bmaxz = b[5]; r.next = 0;
-        nodes.push_back(r);
+        r.bmaxx = b[3]; r.bmaxy = b[4]; r.bmaxz = b[5]; r.next = parent[i];
     }
-    nodes.push_back(pad);
     std::vector<TriRec> rec(np);
     for (size_t i = 0; i < np; i++) {
         const size_t p = (size_t)leafPrims[i];
@@ -64,11 +63,27 @@ int build_occlusion_side(rs_scene* s) {
         std::memcpy(&leafBits, &leafOf[p], 4);
         rec[i] = TriRec{ v0.x, v0.y, v0.z, leafBits, e1.x, e1.y, e1.z, 0.f, e2.x, e2.y, e2.z, 0.f };
     }
-    RS_TRY(upload(&s->dOccAll, nodes));
+    bool nested = true;
+    int root = 0;
+    for (size_t i = 0; i < nn; i++) {
+        if (parent[i] < 0) { root = (int)i; continue; }
+        const float* c = &s->hBoxes[i * 6];
+        const float* q = &s->hBoxes[(size_t)parent[i] * 6];
+        for (int k = 0; k < 3; k++) nested = nested && q[k] <= c[k] && q[3 + k] >= c[3 + k];
+    }
+    s->dev.occNested = nested;
+    s->dev.occRootLo = ld3(&s->hBoxes[(size_t)root * 6]);
+    s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
+    RS_TRY(rs_dev_alloc(&s->dOccNodes, no));
+    RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), no * 16, hipMemcpyHostToDevice));
+    RS_TRY(upload(&s->dOccChain, chain));
     RS_TRY(upload(&s->dOccTris, rec));
-    s->dev.occAll = s->dOccAll;
+    s->dev.occNodes = s->dOccNodes;
+    s->dev.occChain = s->dOccChain;
     s->dev.occTris = s->dOccTris;
     s->dev.occCount = (int)no;
+    s->dev.occBase = mk3(base[0], base[1], base[2]);
+    s->dev.occScale = mk3(scale[0], scale[1], scale[2]);
     return 0;
 }
 
@@ -76,7 +91,7 @@ int build_occlusion_side(rs_scene* s) {
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
-    rs_dev_free(s->dNodesAll); rs_dev_free(s->dOccAll); rs_dev_free(s->dOccTris);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     delete s;
@@ -193,11 +208,29 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.numPrims = s->numPrims;
     s->dev.numLights = s->numLights;
     s->dev.numMaterials = d->numMaterials;
-    s->dev.occAll = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
+    s->dev.occNodes = nullptr; s->dev.occChain = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
+    s->dev.occBase = splat(0.f); s->dev.occScale = splat(0.f);
+    s->dev.walkStats = nullptr;
+    s->dev.occNested = false; s->dev.occRootLo = splat(0.f); s->dev.occRootHi = splat(0.f);
+#ifdef RS_WALK_STATS
+    if (int e = rs_dev_alloc(&s->dWalkStats, 16)) { rs_scene_destroy(s); return e; }
+    (void)hipMemset(s->dWalkStats, 0, 16 * sizeof(unsigned long long));
+    s->dev.walkStats = s->dWalkStats;
+#endif
     if (int e = build_occlusion_side(s)) { rs_scene_destroy(s); return e; }
     *out = s;
     return 0;
 }
+
+#ifdef RS_WALK_STATS
+// measurement builds only (tools/walk_stats.py): wave-level counters of walk_occlusion_tree
+extern "C" int rs_debug_walk_stats(rs_scene* s, unsigned long long* out16, int reset) {
+    RS_HIP(hipDeviceSynchronize());
+    RS_HIP(hipMemcpy(out16, s->dWalkStats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) RS_HIP(hipMemset(s->dWalkStats, 0, 16 * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
 
 extern "C" int rs_scene_build(int numPrims, const float* vertices, const float* normals, const float* texcoords,
                               const int* materialIds, int numMaterials, const rs_material* materials, rs_scene** out) {

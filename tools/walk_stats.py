@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""tools/walk_stats.py -- wave-level counters of the shadow-ray walk on the bench workload.
+Needs a measurement build:  make -C restir_amd/csrc EXTRA=-DRS_WALK_STATS OUT=../librestir_stats.so VIEWER=
+and RESTIR_HIP_LIB=restir_amd/librestir_stats.so."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from restir_amd import capi, scenes
+from restir_amd.tiling import HipBackend, StripRenderer
+
+W, H = 1920, 1080
+capi.init(0)
+sd = scenes.sponza_class(seed=1, scale=1.0)
+scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+cam = capi.camera_update(sd.camera(W, H))
+backend = HipBackend(capi, scene, cam, W, H)
+strips = StripRenderer(backend, 1, 0, H)
+for _ in range(6):
+    strips.frame(3, 0)
+out = (C.c_ulonglong * 16)()
+L = capi.lib()
+L.rs_debug_walk_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+assert L.rs_debug_walk_stats(scene.handle, out, 1) == 0
+frames = 4
+for _ in range(frames):
+    strips.frame(3, 0)
+assert L.rs_debug_walk_stats(scene.handle, out, 1) == 0
+names = ["waves", "iterations", "leaf rounds", "triangle iterations", "verify iterations", "walk iterations",
+         "walking lanes (sum)", "verifying lanes (sum)", "iterations without a walker", "triangle lane-tests"]
+w = out[0]
+print("per wave, mean over %d frames (%d waves/frame):" % (frames, w // frames))
+for i, n in enumerate(names):
+    print("  %-28s %10.2f" % (n, out[i] / w))
+print("  walking lanes per walk iteration %.1f, verifying lanes per verify iteration %.1f, lanes per triangle iteration %.1f" %
+      (out[6] / max(out[5], 1), out[7] / max(out[4], 1), out[9] / max(out[3], 1)))
