@@ -470,9 +470,12 @@ __device__ __forceinline__ bool walk_anyhit_deferred(const DevScene& s, const Ra
 // on T's leaf and on each of its ancestors (parent links by original node id).  The first candidate that
 // passes is what the reference's walk would also have reached and hit -> occluded; if none passes the
 // reference reports no occlusion either.  A lane is in one of two modes:
-//   walk   : cur = byte offset in occNodes; relaxed test on the grid box; leaves are queued and tested
-//            in rounds (as in walk_anyhit_deferred); branch-free step
-//   verify : cur = reference node id in occChain; the reference's full test; fail -> back to the walk
+// Three phases alternate until no lane has work left:
+//   walk   : cur = byte offset in occNodes; relaxed test on the grid box, branch-free step; leaves are
+//            queued (as in walk_anyhit_deferred); ends when a queue is full or all walks have ended
+//   leaves : every lane tests the triangles of its newest queued leaf
+//   verify : lanes with a candidate run the reference's test along occChain; pass -> occluded,
+//            fail -> the lane walks on
 // Only for rays that take none of AABB::intersect's special cases (all |d.c| in [1e-6, 1-1e-6]) and start
 // within 4 grid extents of the scene (the error bound of the grid test, occlusion_bvh.cpp).
 __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
@@ -502,35 +505,45 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #define RS_STAT(i, v)
 #endif
     for (;;) {
-        const bool walking = (verify < 0) & (cur != endOff);
-        const unsigned long long smask = __ballot(walking | (verify >= 0));
-        if (!(smask | __ballot(qn > 0))) break;
-        RS_STAT(1, 1);
-        if (__any((qn == kLeafQueue) & (verify < 0)) || smask == 0) {
-            RS_STAT(2, 1);
-            // leaf round: every lane that is not verifying tests the triangles of its newest leaf
-            const bool take = (qn > 0) & (verify < 0);
-            int tri = 0, cnt = 0;
-            if (take) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
-            while (__any(cnt > 0)) {
-                RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot(cnt > 0)));
-                if (cnt > 0) {
-                    const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
-                    const float4 a = p[0], b = p[1], c = p[2];
-                    float bx, by, dist;
-                    tri++; cnt--;
-                    if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit) {
-                        if (cnt > 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tri * 8 + cnt; qn++; cnt = 0; }   // rest of the leaf, should the candidate fail
-                        verify = __float_as_int(a.w) | 0x40000000;
-                    }
+        // walk phase: a tight loop until some lane's leaf queue is full or every walk has ended
+        while (__any(cur != endOff)) {
+            RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
+            if (cur != endOff) {
+                const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+                const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
+                const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
+                const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                const bool pass = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
+                const int meta = (int)n.w;
+                const bool leaf = meta < 0;
+                const bool push = pass & leaf;
+                q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn += push ? 1 : 0;
+                cur = (pass | leaf) ? cur + 16u : (unsigned)meta * 16u;
+            }
+            if (__any(qn == kLeafQueue)) break;
+        }
+        if (!__any(qn > 0)) break;
+        // leaf round: every lane tests the triangles of its newest queued leaf
+        RS_STAT(2, 1);
+        int tri = 0, cnt = 0;
+        if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
+        while (__any(cnt > 0)) {
+            RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot(cnt > 0)));
+            if (cnt > 0) {
+                const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
+                const float4 a = p[0], b = p[1], c = p[2];
+                float bx, by, dist;
+                tri++; cnt--;
+                if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit) {
+                    if (cnt > 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tri * 8 + cnt; qn++; cnt = 0; }   // rest of the leaf, should the candidate fail
+                    verify = __float_as_int(a.w) | 0x40000000;
                 }
             }
-            continue;
         }
-        RS_STAT(5, __any(walking) ? 1 : 0); RS_STAT(6, __popcll(__ballot(walking)));
-        RS_STAT(7, __popcll(__ballot(verify >= 0))); RS_STAT(8, __any(walking) ? 0 : 1);
-        if (__any(verify >= 0)) {
-            RS_STAT(4, 1);
+        // candidates: the reference's own test along the path to the triangle's leaf (normally one step, see below)
+        while (__any(verify >= 0)) {
+            RS_STAT(4, 1); RS_STAT(7, __popcll(__ballot(verify >= 0)));
             if (verify >= 0) {
                 const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
                 const float4 lo = rec[0], hi = rec[1];
@@ -558,19 +571,6 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                 if (done) { occluded = true; cur = endOff; qn = 0; }
                 verify = (open & !done) ? parent : -1;              // closed: the reference never reaches the triangle
             }
-        }
-        if (walking) {
-            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
-            const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
-            const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
-            const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-            const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-            const bool pass = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
-            const int meta = (int)n.w;
-            const bool leaf = meta < 0;
-            const bool push = pass & leaf;
-            q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn += push ? 1 : 0;
-            cur = (pass | leaf) ? cur + 16u : (unsigned)meta * 16u;
         }
     }
 #ifdef RS_WALK_STATS
