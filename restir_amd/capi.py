@@ -218,6 +218,33 @@ class Scene:
         self.handle = C.c_void_p()
         check(lib().rs_scene_build(self.num_prims, _p(v), _p(n), _p(t), _p(m), len(mats), _p(mats), C.byref(self.handle)))
 
+    @classmethod
+    def from_tables(cls, vertices, normals, texcoords, material_ids, materials, tables):
+        """DevScene::create from caller-built tables (rs_scene_create): `tables` as returned by host_desc()."""
+        self = cls.__new__(cls)
+        t = tables
+        self._keep = (np.ascontiguousarray(vertices, np.float32), np.ascontiguousarray(normals, np.float32),
+                      np.ascontiguousarray(texcoords, np.float32), np.ascontiguousarray(material_ids, np.int32),
+                      np.ascontiguousarray(materials, MATERIAL_DTYPE),
+                      np.ascontiguousarray(t["boxes"], np.float32), [np.ascontiguousarray(t["nodes"][k], np.int32) for k in range(6)],
+                      np.ascontiguousarray(t["light_prim_ids"], np.int32), np.ascontiguousarray(t["light_radiance"], np.float32),
+                      np.ascontiguousarray(t["light_prob"], np.float32), np.ascontiguousarray(t["light_fail"], np.int32))
+        v, n, tc, m, mats, boxes, nodes, lp, lr, lpr, lf = self._keep
+        self.num_prims = v.size // 9
+        d = SceneDesc()
+        d.numPrims = self.num_prims
+        d.vertices, d.normals, d.texcoords, d.materialIds = _p(v), _p(n), _p(tc), _p(m)
+        d.numMaterials, d.materials = len(mats), _p(mats)
+        d.bvhSize, d.boundingBoxes = len(boxes), _p(boxes)
+        for k in range(6):
+            d.bvhNodes[k] = _p(nodes[k])
+        d.numLights = len(lp)
+        d.lightPrimIds, d.lightUnitRadiance, d.lightProb, d.lightFailId = _p(lp), _p(lr), _p(lpr), _p(lf)
+        d.sumLightPower = float(t["sum_power"])
+        self.handle = C.c_void_p()
+        check(lib().rs_scene_create(C.byref(d), C.byref(self.handle)))
+        return self
+
     def host_desc(self):
         """numpy views of the arrays the scene was built from (for parity checks of the host build)."""
         d = SceneDesc()

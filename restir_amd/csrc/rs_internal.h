@@ -53,6 +53,7 @@ struct rs_scene {
     // host copies of the source arrays (rs_scene_host_desc)
     std::vector<float> hVertices, hNormals, hTexcoords, hBoxes, hLightRadiance, hLightProb;
     std::vector<int> hMaterialIds, hNodes[6], hLightPrimIds, hLightFailId;
+    std::vector<int> hParent, hLeafOf;   // reference tree: parent by original node id, leaf node of each primitive
     std::vector<rs_material> hMaterials;
     float sumLightPower = 0.f;
     int numPrims = 0, bvhSize = 0, numLights = 0;

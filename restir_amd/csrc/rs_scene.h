@@ -61,6 +61,7 @@ struct DevScene {
     f3 occBase, occScale;         // grid plane q on axis c = occBase.c + q * occScale.c
     f3 occRootLo, occRootHi;      // the reference's root box
     bool occNested;               // every reference box lies inside its parent's (enables the leaf shortcut)
+    bool axisCull;                // boxes contain their children and triangles (enables skip_far_on_axis)
     int occCount;
     unsigned long long* walkStats;   // null unless built with -DRS_WALK_STATS (tools/walk_stats.py)
     int bvhSize;
@@ -150,6 +151,7 @@ struct RayBoxCtx {
     f3 o, d, dinv;
     int mode;          // 0 general, 1/2/3 axis-aligned along x/y/z (abs(d) > 1-1e-6, first match)
     bool zx, zy, zz;   // abs(d.c) < 1e-6
+    bool cull;         // skip_far_on_axis allowed: the box table is a proper hierarchy (DevScene::axisCull)
 };
 
 RS_HD RayBoxCtx make_box_ctx(const Ray& r) {
@@ -159,6 +161,7 @@ RS_HD RayBoxCtx make_box_ctx(const Ray& r) {
     c.dinv = mk3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
     c.mode = gabs(r.d.x) > 1.f - Eps ? 1 : (gabs(r.d.y) > 1.f - Eps ? 2 : (gabs(r.d.z) > 1.f - Eps ? 3 : 0));
     c.zx = gabs(r.d.x) < Eps; c.zy = gabs(r.d.y) < Eps; c.zz = gabs(r.d.z) < Eps;
+    c.cull = true;
     return c;
 }
 
@@ -216,10 +219,12 @@ RS_HD bool box_hit(const RayBoxCtx& c, f3 bmin, f3 bmax, float& tMin) {
     // if the ray stays farther than a generous tolerance from it over the interval it crosses the
     // other two slabs.  A skipped subtree cannot contain a triangle the ray hits (a Moeller-Trumbore
     // hit point lies inside its triangle's box up to rounding << tol), the visiting order of the
-    // remaining nodes is unchanged, so closest hit, ties and occlusion results are identical.
-    if (c.zx && oyz) return slab_max_min(tn.y, tn.z, tf.y, tf.z, tMin) && !skip_far_on_axis(c.o.x, c.d.x, bmin.x, bmax.x, tMin, fminf(tf.y, tf.z));
-    if (c.zy && ozx) return slab_max_min(tn.z, tn.x, tf.z, tf.x, tMin) && !skip_far_on_axis(c.o.y, c.d.y, bmin.y, bmax.y, tMin, fminf(tf.z, tf.x));
-    if (c.zz && oxy) return slab_max_min(tn.x, tn.y, tf.x, tf.y, tMin) && !skip_far_on_axis(c.o.z, c.d.z, bmin.z, bmax.z, tMin, fminf(tf.x, tf.y));
+    // remaining nodes is unchanged, so closest hit, ties and occlusion results are identical.  That argument
+    // needs boxes that contain their triangles and their children, which rs_scene_create checks
+    // (DevScene::axisCull); for any other caller-supplied table the cull is off.
+    if (c.zx && oyz) return slab_max_min(tn.y, tn.z, tf.y, tf.z, tMin) && !(c.cull && skip_far_on_axis(c.o.x, c.d.x, bmin.x, bmax.x, tMin, fminf(tf.y, tf.z)));
+    if (c.zy && ozx) return slab_max_min(tn.z, tn.x, tf.z, tf.x, tMin) && !(c.cull && skip_far_on_axis(c.o.y, c.d.y, bmin.y, bmax.y, tMin, fminf(tf.z, tf.x)));
+    if (c.zz && oxy) return slab_max_min(tn.x, tn.y, tf.x, tf.y, tMin) && !(c.cull && skip_far_on_axis(c.o.z, c.d.z, bmin.z, bmax.z, tMin, fminf(tf.x, tf.y)));
     if (oyz && ozx && oxy)
         return slab_max_min(fmaxf(tn.x, tn.y), tn.z, fminf(tf.x, tf.y), tf.z, tMin);
     return false;
@@ -389,7 +394,8 @@ __device__ __forceinline__ WalkResult walk_paired(const DevScene& s, const Ray& 
 
 template <bool ANYHIT>
 __device__ __forceinline__ WalkResult walk_dispatch(const DevScene& s, const Ray& ray, float limit) {
-    const RayBoxCtx ctx = make_box_ctx(ray);
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
     const bool special = ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x);
     // the special cases are ~1e-6 of the rays: a wave that has none runs the branch-free test
     if (__any(special)) return walk<ANYHIT, false>(s, ray, ctx, limit);
@@ -495,7 +501,6 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                                     fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
                               fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
     unsigned cur = active ? 0u : endOff;
-    int verify = -1;                                            // reference node being checked, -1 = walking
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
     bool occluded = false;
 #ifdef RS_WALK_STATS
@@ -524,52 +529,54 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
             if (__any(qn == kLeafQueue)) break;
         }
         if (!__any(qn > 0)) break;
-        // leaf round: every lane tests the triangles of its newest queued leaf
+        // leaf round: every lane takes its newest queued leaf (so no queue is full when the walk resumes) and
+        // tests its triangles; a hit becomes a candidate, and the rest of the leaf waits for its verdict
         RS_STAT(2, 1);
-        int tri = 0, cnt = 0;
+        int tri = 0, cnt = 0, verify = -1;
         if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
-        while (__any(cnt > 0)) {
-            RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot(cnt > 0)));
-            if (cnt > 0) {
-                const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
-                const float4 a = p[0], b = p[1], c = p[2];
-                float bx, by, dist;
-                tri++; cnt--;
-                if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit) {
-                    if (cnt > 0) { q3 = q2; q2 = q1; q1 = q0; q0 = tri * 8 + cnt; qn++; cnt = 0; }   // rest of the leaf, should the candidate fail
-                    verify = __float_as_int(a.w) | 0x40000000;
+        for (;;) {
+            while (__any((cnt > 0) & (verify < 0))) {
+                RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot((cnt > 0) & (verify < 0))));
+                if ((cnt > 0) & (verify < 0)) {
+                    const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
+                    const float4 a = p[0], b = p[1], c = p[2];
+                    float bx, by, dist;
+                    tri++; cnt--;
+                    if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit)
+                        verify = __float_as_int(a.w) | 0x40000000;          // reference leaf of the candidate, bit 30 = first step
                 }
             }
-        }
-        // candidates: the reference's own test along the path to the triangle's leaf (normally one step, see below)
-        while (__any(verify >= 0)) {
-            RS_STAT(4, 1); RS_STAT(7, __popcll(__ballot(verify >= 0)));
-            if (verify >= 0) {
-                const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
-                const float4 lo = rec[0], hi = rec[1];
-                // the general case of AABB::intersect (box_hit_general), spelled out for the margins below
-                const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
-                const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
-                const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
-                const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
-                const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
-                const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
-                const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
-                const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
-                // Shortcut at the leaf (first record of a chain, flagged in bit 30).  Every ancestor box contains
-                // the leaf box (checked at scene build), so by monotone rounding its near distances are <= and
-                // its far distances >= the leaf's: tMax >= 0, tMax >= tMin and tMin < range carry over exactly.
-                // The three overlap conditions are, in real arithmetic, fy > nz, fz > nx, fx > ny, and those
-                // differences can only grow towards the root; evaluated in float they are off by less than
-                // 2^-20 * tRoot (four roundings of values below 4 * tRoot, tRoot = largest |slab distance| of the
-                // root box, which bounds every ancestor's).  A leaf that clears them by 2^-18 * tRoot therefore
-                // settles the whole path; otherwise the ancestors are tested one by one.
-                const bool first = (verify & 0x40000000) != 0;
-                const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
-                const int parent = __float_as_int(lo.w);
-                const bool done = open & ((parent < 0) | (first & clear & s.occNested));
-                if (done) { occluded = true; cur = endOff; qn = 0; }
-                verify = (open & !done) ? parent : -1;              // closed: the reference never reaches the triangle
+            if (!__any(verify >= 0)) break;
+            // candidates: the reference's own test along the path to the triangle's leaf (normally one step, see below)
+            while (__any(verify >= 0)) {
+                RS_STAT(4, 1); RS_STAT(7, __popcll(__ballot(verify >= 0)));
+                if (verify >= 0) {
+                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
+                    const float4 lo = rec[0], hi = rec[1];
+                    // the general case of AABB::intersect (box_hit_general), spelled out for the margins below
+                    const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
+                    const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
+                    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
+                    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
+                    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+                    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
+                    const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
+                    const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
+                    // Shortcut at the leaf (first record of a chain).  Every ancestor box contains the leaf box
+                    // (checked at scene build), so by monotone rounding its near distances are <= and its far
+                    // distances >= the leaf's: tMax >= 0, tMax >= tMin and tMin < range carry over exactly.  The
+                    // three overlap conditions are, in real arithmetic, fy > nz, fz > nx, fx > ny, and those
+                    // differences can only grow towards the root; evaluated in float they are off by less than
+                    // 2^-20 * tRoot (four roundings of values below 4 * tRoot, tRoot = largest |slab distance| of
+                    // the root box, which bounds every ancestor's).  A leaf that clears them by 2^-18 * tRoot
+                    // therefore settles the whole path; otherwise the ancestors are tested one by one.
+                    const bool first = (verify & 0x40000000) != 0;
+                    const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
+                    const int parent = __float_as_int(lo.w);
+                    const bool done = open & ((parent < 0) | (first & clear & s.occNested));
+                    if (done) { occluded = true; cur = endOff; qn = 0; cnt = 0; }
+                    verify = (open & !done) ? parent : -1;          // closed: the reference never reaches the triangle
+                }
             }
         }
     }
@@ -583,7 +590,8 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 // all 64 lanes of the wave must call this
 template <bool ANYHIT>
 __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active) {
-    const RayBoxCtx ctx = make_box_ctx(ray);
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
     const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
     if (ANYHIT) {
         WalkResult r;
@@ -686,7 +694,8 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
 __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bool active) {
     WalkResult w;
     w.closest = 3.402823466e+38f; w.prim = kNullPrim; w.bx = 0.f; w.by = 0.f; w.any = false;
-    const RayBoxCtx ctx = make_box_ctx(ray);
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
     const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
     const bool anySpecial = __any(special);
     const int order = mtbvh_order(-ray.d);

@@ -34,8 +34,8 @@ int build_occlusion_side(rs_scene* s) {
     for (size_t i = 0; i < nn * 6; i++) if (!std::isfinite(s->hBoxes[i])) return 0;
     for (size_t i = 0; i < nn; i++)
         for (int k = 0; k < 3; k++) if (s->hBoxes[i * 6 + k] > s->hBoxes[i * 6 + 3 + k]) return 0;
-    std::vector<int> parent, leafOf;
-    RS_TRY(rs_reference_chain_tables(s->bvhSize, s->hNodes[0].data(), parent, leafOf, s->numPrims));
+    const std::vector<int>& parent = s->hParent;
+    const std::vector<int>& leafOf = s->hLeafOf;
     std::vector<float> primBoxes(np * 6);
     for (size_t p = 0; p < np; p++) std::memcpy(&primBoxes[p * 6], &s->hBoxes[(size_t)leafOf[p] * 6], 6 * sizeof(float));
     std::vector<BvhNode> nodes;
@@ -63,15 +63,9 @@ int build_occlusion_side(rs_scene* s) {
         std::memcpy(&leafBits, &leafOf[p], 4);
         rec[i] = TriRec{ v0.x, v0.y, v0.z, leafBits, e1.x, e1.y, e1.z, 0.f, e2.x, e2.y, e2.z, 0.f };
     }
-    bool nested = true;
     int root = 0;
-    for (size_t i = 0; i < nn; i++) {
-        if (parent[i] < 0) { root = (int)i; continue; }
-        const float* c = &s->hBoxes[i * 6];
-        const float* q = &s->hBoxes[(size_t)parent[i] * 6];
-        for (int k = 0; k < 3; k++) nested = nested && q[k] <= c[k] && q[3 + k] >= c[3 + k];
-    }
-    s->dev.occNested = nested;
+    for (size_t i = 0; i < nn; i++) if (parent[i] < 0) root = (int)i;
+    s->dev.occNested = s->dev.axisCull;          // a proper hierarchy is in particular nested
     s->dev.occRootLo = ld3(&s->hBoxes[(size_t)root * 6]);
     s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
     RS_TRY(rs_dev_alloc(&s->dOccNodes, no));
@@ -212,6 +206,28 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.occBase = splat(0.f); s->dev.occScale = splat(0.f);
     s->dev.walkStats = nullptr;
     s->dev.occNested = false; s->dev.occRootLo = splat(0.f); s->dev.occRootHi = splat(0.f);
+    // Is the box table a proper hierarchy (finite, min <= max, every box inside its parent's, every leaf box
+    // around its triangle)?  Tables from rs_build_bvh are; the two shortcuts that rely on it (skip_far_on_axis and
+    // the leaf shortcut of the shadow tree) are switched off for any other caller-supplied table.
+    if (int e = rs_reference_chain_tables(s->bvhSize, s->hNodes[0].data(), s->hParent, s->hLeafOf, s->numPrims)) { rs_scene_destroy(s); return e; }
+    {
+        bool proper = true;
+        for (size_t i = 0; i < nn * 6 && proper; i++) proper = std::isfinite(s->hBoxes[i]);
+        for (size_t i = 0; i < nn && proper; i++) {
+            const float* c = &s->hBoxes[i * 6];
+            for (int k = 0; k < 3; k++) proper = proper && c[k] <= c[3 + k];
+            if (s->hParent[i] >= 0) {
+                const float* q = &s->hBoxes[(size_t)s->hParent[i] * 6];
+                for (int k = 0; k < 3; k++) proper = proper && q[k] <= c[k] && q[3 + k] >= c[3 + k];
+            }
+        }
+        for (size_t p = 0; p < np && proper; p++) {
+            const float* c = &s->hBoxes[(size_t)s->hLeafOf[p] * 6];
+            for (int v = 0; v < 3; v++)
+                for (int k = 0; k < 3; k++) { const float x = s->hVertices[p * 9 + v * 3 + k]; proper = proper && c[k] <= x && x <= c[3 + k]; }
+        }
+        s->dev.axisCull = proper;
+    }
 #ifdef RS_WALK_STATS
     if (int e = rs_dev_alloc(&s->dWalkStats, 16)) { rs_scene_destroy(s); return e; }
     (void)hipMemset(s->dWalkStats, 0, 16 * sizeof(unsigned long long));

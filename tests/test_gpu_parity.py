@@ -68,6 +68,97 @@ def test_trace_closest_and_occlusion(hip, name):
     assert 0 < occ.sum() < len(occ)
 
 
+def _shadow_like_segments(sd, n, seed):
+    """Segments of the kinds the shadow pass produces and the corner cases of the occlusion tree: surface point ->
+    light point, random pairs, short, grazing along a triangle's plane, axis-aligned / near-zero directions
+    (reference walk), and origins far outside the scene (beyond the grid test's reach)."""
+    rng = np.random.default_rng(seed)
+    v = sd.vertices.reshape(-1, 3, 3).astype(np.float64)
+    lights = np.nonzero(sd.materials["type"][sd.material_ids] == 4)[0]
+
+    def points_on(tris, k):
+        t = v[rng.choice(tris, k)]
+        u = rng.uniform(size=(k, 2)); flip = u.sum(1) > 1; u[flip] = 1 - u[flip]
+        p = t[:, 0] * (1 - u.sum(1))[:, None] + t[:, 1] * u[:, :1] + t[:, 2] * u[:, 1:]
+        nrm = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+        return p, nrm, t
+
+    a, na, _ = points_on(np.arange(len(v)), n)
+    b, _, _ = points_on(lights if len(lights) else np.arange(len(v)), n)
+    na *= np.sign(np.einsum("ij,ij->i", na, b - a))[:, None]
+    a = a + 1e-4 * na
+    k = n // 8
+    b[k:2 * k] = points_on(np.arange(len(v)), k)[0]                                   # random surface pairs
+    b[2 * k:3 * k] = a[2 * k:3 * k] + rng.normal(size=(k, 3)) * 0.05                      # short
+    g, ng, tg = points_on(np.arange(len(v)), k)                                           # grazing: inside a triangle's plane
+    a[3 * k:4 * k] = g + (tg[:, 0] - g) * 3.0; b[3 * k:4 * k] = g + (tg[:, 1] - g) * 3.0
+    ax = rng.integers(0, 3, k)                                                            # axis-aligned / near-zero components
+    b[4 * k:5 * k] = a[4 * k:5 * k]; b[np.arange(4 * k, 5 * k), ax] += rng.choice([-3.0, 3.0], k)
+    b[4 * k:4 * k + k // 2, (ax[:k // 2] + 1) % 3] += rng.uniform(-2e-6, 2e-6, k // 2)
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    a[5 * k:5 * k + 64] = hi + (hi - lo) * rng.uniform(6, 40, (64, 1))                    # far origins
+    seg = np.ascontiguousarray(np.concatenate([a, b], 1), np.float32)
+    seg[-16:, 3:] = seg[-16:, :3]                                                         # x == y: NaN direction
+    return seg
+
+
+def test_occlusion_tree_equals_reference_walk(hip, monkeypatch):
+    """Shadow rays go through a second tree + ancestor-chain verification (rs_scene.h walk_occlusion_tree); the
+    result must equal DevScene::testOcclusion on the reference's tree for every segment: against the oracle, and at
+    a larger count against the library's own reference walk (RS_NO_OCCLUSION_TREE)."""
+    import torch
+    sd = get_scene("sponza:0.1")
+    seg = _shadow_like_segments(sd, 400000, 11)
+    fast = hip.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+    monkeypatch.setenv("RS_NO_OCCLUSION_TREE", "1")
+    slow = hip.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+    monkeypatch.delenv("RS_NO_OCCLUSION_TREE")
+    dseg = torch.from_numpy(seg).cuda()
+    a = hip.trace_occlusion(fast, dseg).cpu().numpy()
+    b = hip.trace_occlusion(slow, dseg).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert 0.05 < a.mean() < 0.95
+    sub = seg[:: 10]
+    assert np.array_equal(oracle_scene(sd).test_occlusion(sub), a[:: 10])
+
+
+def test_occlusion_tree_with_caller_supplied_boxes(hip, monkeypatch):
+    """rs_scene_create accepts any box table.  Boxes that are not nested in their parents switch the leaf
+    shortcut off (every ancestor is then tested); results must still equal the reference walk on the same table."""
+    import torch
+    sd = get_scene("sponza:0.03")
+    base = hip.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+    t = base.host_desc()
+    rng = np.random.default_rng(5)
+    boxes = t["boxes"].copy()
+    pick = rng.choice(len(boxes), len(boxes) // 3, replace=False)
+    boxes[pick, :3] -= rng.uniform(0, 0.2, (len(pick), 3)).astype(np.float32)      # grow some boxes beyond their parents
+    boxes[pick, 3:] += rng.uniform(0, 0.2, (len(pick), 3)).astype(np.float32)
+    shrink = rng.choice(len(boxes), len(boxes) // 10, replace=False)                 # and make some inner boxes miss their content
+    mid = 0.5 * (boxes[shrink, :3] + boxes[shrink, 3:])
+    boxes[shrink, :3] = 0.5 * (boxes[shrink, :3] + mid); boxes[shrink, 3:] = 0.5 * (boxes[shrink, 3:] + mid)
+    t["boxes"] = boxes
+    args = (sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials, t)
+    fast = hip.Scene.from_tables(*args)
+    monkeypatch.setenv("RS_NO_OCCLUSION_TREE", "1")
+    slow = hip.Scene.from_tables(*args)
+    monkeypatch.delenv("RS_NO_OCCLUSION_TREE")
+    segh = _shadow_like_segments(sd, 200000, 12)
+    seg = torch.from_numpy(segh).cuda()
+    a = hip.trace_occlusion(fast, seg).cpu().numpy()
+    b = hip.trace_occlusion(slow, seg).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert 0.02 < a.mean() < 0.98
+    # and the literal reference walk on the same table (also covers: the near-zero-direction cull is off for such tables)
+    osc = ob.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials,
+                   prebuilt=(t["light_prim_ids"], t["light_radiance"], np.zeros(len(t["light_prim_ids"]), np.float32),
+                             t["light_prob"], t["light_fail"], t["sum_power"], boxes, t["nodes"]))
+    assert np.array_equal(osc.test_occlusion(segh[::20]), a[::20])
+    rays = _random_rays(sd, 20000, 6)
+    prim = osc.intersect(rays)[0]
+    assert np.array_equal(prim, hip.trace_closest(fast, torch.from_numpy(rays).cuda())[0].cpu().numpy())
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 def test_gbuffer(hip, name):
     sd = get_scene(name)
