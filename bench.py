@@ -36,6 +36,18 @@ REUSE = 3                      # ReservoirReuse::Spatiotemporal
 TONEMAP = 2                    # ToneMapping::ACES (Settings default, src/common.cpp:4)
 ALGO_BYTES_PER_PIXEL = 92      # spatial-reuse pass
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per launch from the PMC passes of tools/profile.sh on this same command (FETCH_SIZE x 2 + WRITE_SIZE,
+# the gfx950 correction of MI355X_MICROARCH.md), condensed by tools/summarize_profile.py; counters cannot be read
+# from inside the process, so `roofline.traffic` quotes the committed summary (null if it is absent).
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_hbm_counters.json")
+
+
+def pmc_traffic(kernel):
+    try:
+        with open(PMC_SUMMARY) as fh:
+            return float(json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def host_threads():
@@ -177,7 +189,7 @@ def main():
                        "tiling": f"{world} row strips, 5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0" if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade") if world == 1 else None,
                          "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us},
             "pass_ms": {"primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }

@@ -34,6 +34,7 @@ constexpr int kHalo = RS_SPATIAL_HALO_ROWS;
 // kind of a pixel after the primary hit
 constexpr int kKindMiss = 0, kKindLight = 1, kKindShaded = 2;
 constexpr int kRaySlots = 1024;   // ring of per-frame BVH-walk counters
+constexpr int kRaySub = 64, kRayStride = 8;   // per frame: 64 partial counters, 64 B apart (one hot address cost ~85 us/frame)
 
 struct SurfPlanes {
     float4* posMat;     // pos.xyz, bits(matId | kind << 24)
@@ -91,15 +92,20 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
     if ((threadIdx.x & 63) == 0) {
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
-        if (c) atomicAdd(rayCount, c);
+        if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
     }
 }
 
 // ---- phase A.2: RIS over the light table ----------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
-    const int n0 = y0 * width, n1 = y1 * width;
-    const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= n1) return;
+// Measured with the table in global memory: 32 candidates x (8-byte alias record + 64-byte light record) per
+// pixel are five 64-address gathers per candidate, and the texture addresser was as busy (88 %) as the VALU.
+// Up to kRisLdsLights lights the whole table (72 B per light) is copied into LDS by a 1024-thread block --
+// two such blocks per CU keep 8 waves per SIMD -- and the gathers become ds_read_b128 / ds_read_b64.
+constexpr int kRisThreads = 1024;
+constexpr int kRisLdsLights = 1024;
+
+template <typename AliasPtr, typename LightPtr>
+__device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& sp, AliasPtr alias, LightPtr lights, int index) {
     const float4 pm = sp.posMat[index];
     const int mk = __float_as_int(pm.w);
     if ((mk >> 24) != kKindShaded) return;
@@ -115,7 +121,7 @@ __global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int widt
     float selDist = 0.f, wsum = 0.f;
     for (int i = 0; i < kReservoirSize; i++) {
         f4 r = rng.uniform4();
-        LightSample c = sample_light_nv<const AliasRec*, const LightRec*>(s.alias, s.lights, s.numLights, pos, r);
+        LightSample c = sample_light_nv<AliasPtr, LightPtr>(alias, lights, s.numLights, pos, r);
         f3 g = c.Li * eval_bsdf(m.type, baseColor, m.metallic, m.roughness, norm, wo, c.wi) * sat_dot(norm, c.wi);
         float weight = luminance(g / c.pdf);
         if (is_nan_or_inf(weight) || c.pdf <= 0.f) weight = 0.f;
@@ -126,6 +132,29 @@ __global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int widt
     sp.candLi[index] = make_float4(selLi.x, selLi.y, selLi.z, selDist);
     sp.candWi[index] = make_float4(selWi.x, selWi.y, selWi.z, wsum);
     reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;
+}
+
+__global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
+    const int n0 = y0 * width, n1 = y1 * width;
+    const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= n1) return;
+    ris_pixel<const AliasRec*, const LightRec*>(s, sp, s.alias, s.lights, index);
+}
+
+__global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
+    __shared__ LightRec sLights[kRisLdsLights];
+    __shared__ AliasRec sAlias[kRisLdsLights];
+    {
+        const float4* src = reinterpret_cast<const float4*>(s.lights);
+        float4* dst = reinterpret_cast<float4*>(sLights);
+        for (int i = threadIdx.x; i < s.numLights * 4; i += kRisThreads) dst[i] = src[i];
+        for (int i = threadIdx.x; i < s.numLights; i += kRisThreads) sAlias[i] = s.alias[i];
+    }
+    __syncthreads();
+    const int n0 = y0 * width, n1 = y1 * width;
+    const int index = n0 + blockIdx.x * kRisThreads + threadIdx.x;
+    if (index >= n1) return;
+    ris_pixel<const AliasRec*, const LightRec*>(s, sp, sAlias, sLights, index);
 }
 
 // ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------
@@ -517,9 +546,9 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     if (!e) e = rs_dev_alloc(&r->rngMat, n);
     if (!e) e = rs_dev_alloc(&r->candLi, n);
     if (!e) e = rs_dev_alloc(&r->candWi, n);
-    if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots);
+    if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots * kRaySub * kRayStride);
     if (!e) e = rs_check_hip(hipMemset(r->rngMat, 0, n * 8), "memset");
-    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * kRaySlots), "memset");
+    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * (size_t)kRaySlots * kRaySub * kRayStride), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (e) { rs_restir_free(r); return e; }
     *out = r;
@@ -544,8 +573,8 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     if (y0 < 0) y0 = 0;
     if (y1 > r->height) y1 = r->height;
     r->raySlot = (r->raySlot + 1) % kRaySlots;                  // one counter slot per frame (ring)
-    unsigned long long* rayCounter = r->dRayCount + r->raySlot;
-    RS_HIP(hipMemsetAsync(rayCounter, 0, 8, rs_stream()));
+    unsigned long long* rayCounter = r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride;
+    RS_HIP(hipMemsetAsync(rayCounter, 0, 8 * kRaySub * kRayStride, rs_stream()));
     if (y1 <= y0) return 0;
     const int W = r->width;
     const int tilesX = (W + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
@@ -555,7 +584,10 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     hipLaunchKernelGGL(k_primary, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     mark(r, 1);
     const int npx = (y1 - y0) * W;
-    hipLaunchKernelGGL(k_ris, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+    if (scene->numLights > 0 && scene->numLights <= kRisLdsLights)
+        hipLaunchKernelGGL(k_ris_lds, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+    else
+        hipLaunchKernelGGL(k_ris, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
     mark(r, 2);
     hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
                        r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
@@ -721,17 +753,24 @@ int rs_debug_tap_estimate_error(int n, float* maxErr) {
 int rs_restir_ray_count(rs_restir* r, unsigned long long* rays) {
     if (!r || !rays) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_count: null");
     RS_HIP(hipStreamSynchronize(rs_stream()));
-    RS_HIP(hipMemcpy(rays, r->dRayCount + r->raySlot, 8, hipMemcpyDeviceToHost));
+    unsigned long long h[kRaySub * kRayStride];
+    RS_HIP(hipMemcpy(h, r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride, sizeof h, hipMemcpyDeviceToHost));
+    *rays = 0;
+    for (int i = 0; i < kRaySub; i++) *rays += h[i * kRayStride];
     return 0;
 }
 
 int rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays) {
     if (!r || !rays || frames < 0 || frames > kRaySlots) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_total: frames must be in [0, 1024]");
     RS_HIP(hipStreamSynchronize(rs_stream()));
-    std::vector<unsigned long long> h((size_t)kRaySlots);
-    RS_HIP(hipMemcpy(h.data(), r->dRayCount, 8 * kRaySlots, hipMemcpyDeviceToHost));
+    const size_t per = (size_t)kRaySub * kRayStride;
+    std::vector<unsigned long long> h((size_t)kRaySlots * per);
+    RS_HIP(hipMemcpy(h.data(), r->dRayCount, 8 * h.size(), hipMemcpyDeviceToHost));
     unsigned long long t = 0;
-    for (int i = 0; i < frames; i++) t += h[(size_t)((r->raySlot - i) % kRaySlots + kRaySlots) % kRaySlots];
+    for (int i = 0; i < frames; i++) {
+        const size_t slot = (size_t)((r->raySlot - i) % kRaySlots + kRaySlots) % kRaySlots;
+        for (int k = 0; k < kRaySub; k++) t += h[slot * per + (size_t)k * kRayStride];
+    }
     *rays = t;
     return 0;
 }
