@@ -66,11 +66,11 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
     Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
     if (inside) {
 
-        int kind = kKindMiss, matId = 0;
+        int kind = kKindMiss, matId = 0, type = 0;
         f3 norm = splat(0.f), wo = splat(0.f);
         if (h.primId != kNullPrim) {
             matId = h.matId;
-            const int type = s.materials[matId].type;
+            type = s.materials[matId].type;
             if (type == 4) {
                 kind = kKindLight;
             }
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
         const int mk = matId | (kind << 24);
         sp.posMat[index] = make_float4(h.pos.x, h.pos.y, h.pos.z, __int_as_float(mk));
         sp.norm[index] = make_float4(norm.x, norm.y, norm.z, 0.f);
-        sp.wo[index] = make_float4(wo.x, wo.y, wo.z, 0.f);
+        if (type == 1) sp.wo[index] = make_float4(wo.x, wo.y, wo.z, 0.f);     // only the metallic BSDF reads wo (k_ris, k_spatial_shade)
         sp.rngMat[index] = make_uint2(rng.x, (unsigned)mk);
     }
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
