@@ -297,7 +297,12 @@ __device__ __forceinline__ void load_tri(const TriRec* tris, int prim, f3& v0, f
     v0 = mk3(a.x, a.y, a.z); e1 = mk3(b.x, b.y, b.z); e2 = mk3(c.x, c.y, c.z);
 }
 
-struct WalkResult { float closest; int prim; float bx, by; bool any; };
+struct WalkResult {
+    float closest; int prim; float bx, by; bool any;
+#ifdef RS_WALK_STATS
+    unsigned steps;
+#endif
+};
 
 // One per-lane MTBVH walk.  ANYHIT: stop at the first triangle closer than `limit` (testOcclusion);
 // otherwise keep the closest (intersect).  GENERAL: every lane of the wave is a general-case ray.
@@ -663,10 +668,18 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
     const unsigned end = (unsigned)s.bvhSize;
     unsigned myNext = mine ? 0u : end;
     unsigned c = 0;                                           // wave-uniform
+    // uniform addresses -> scalar loads.  The record after the current one is requested before the current
+    // one is tested: c+1 is the successor whenever any lane enters the node (about half of the steps), and
+    // then the scalar-load latency is off the wave's critical path (it sets the duration of the slowest
+    // tiles, and with it the floor of a kernel on a small strip).  nodes[end] is readable (next order / padding).
+    const float4* np0 = reinterpret_cast<const float4*>(nodes);
+    float4 lo = np0[0], hi = np0[1];
     while (c != end) {
-        // uniform address -> scalar loads
-        const float4* np = reinterpret_cast<const float4*>(nodes + c);
-        const float4 lo = np[0], hi = np[1];
+#ifdef RS_WALK_STATS
+        r.steps++;
+#endif
+        const float4* nq = reinterpret_cast<const float4*>(nodes + c + 1);
+        const float4 plo = nq[0], phi = nq[1];
         const int prim = __float_as_int(lo.w);
         const unsigned nxt = (unsigned)__float_as_int(hi.w);
         const bool part = myNext == c;
@@ -686,7 +699,12 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
         }
         myNext = part ? (entered ? c + 1u : nxt) : myNext;
         // every pending target is > c; if some lane wants c+1 that is the minimum
-        c = __any(myNext == c + 1u) ? c + 1u : wave_min_u32(myNext);
+        if (__any(myNext == c + 1u)) { c = c + 1u; lo = plo; hi = phi; }
+        else {
+            c = wave_min_u32(myNext);
+            const float4* np = reinterpret_cast<const float4*>(nodes + c);
+            lo = np[0]; hi = np[1];
+        }
     }
 }
 
@@ -700,7 +718,14 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     const bool anySpecial = __any(special);
     const int order = mtbvh_order(-ray.d);
     unsigned long long todo = __ballot(active);
+#ifdef RS_WALK_STATS
+    w.steps = 0;
+    unsigned norders = 0;
+#endif
     while (todo) {                                            // one pass per threaded order present in the wave
+#ifdef RS_WALK_STATS
+        norders++;
+#endif
         const int lead = __ffsll((long long)todo) - 1;
         const int k = __builtin_amdgcn_readlane(order, lead);
         const bool mine = active && order == k;
@@ -708,6 +733,14 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
         if (anySpecial) packet_walk_order<false>(s, k, mine, ray, ctx, w);
         else packet_walk_order<true>(s, k, mine, ray, ctx, w);
     }
+#ifdef RS_WALK_STATS
+    if (s.walkStats && __lane_id() == 0) {
+        atomicAdd(&s.walkStats[16], 1ull); atomicAdd(&s.walkStats[17], (unsigned long long)w.steps);
+        atomicMax(&s.walkStats[18], (unsigned long long)w.steps); atomicAdd(&s.walkStats[19], (unsigned long long)norders);
+        atomicAdd(&s.walkStats[20], anySpecial ? 1ull : 0ull);
+        atomicAdd(&s.walkStats[24 + (w.steps ? 31 - __clz((int)w.steps) : 0)], 1ull);
+    }
+#endif
     Hit h;
     h.primId = w.prim;
     h.matId = 0;

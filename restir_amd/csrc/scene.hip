@@ -229,8 +229,8 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
         s->dev.axisCull = proper;
     }
 #ifdef RS_WALK_STATS
-    if (int e = rs_dev_alloc(&s->dWalkStats, 16)) { rs_scene_destroy(s); return e; }
-    (void)hipMemset(s->dWalkStats, 0, 16 * sizeof(unsigned long long));
+    if (int e = rs_dev_alloc(&s->dWalkStats, 64)) { rs_scene_destroy(s); return e; }
+    (void)hipMemset(s->dWalkStats, 0, 64 * sizeof(unsigned long long));
     s->dev.walkStats = s->dWalkStats;
 #endif
     if (int e = build_occlusion_side(s)) { rs_scene_destroy(s); return e; }
@@ -240,10 +240,10 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
 
 #ifdef RS_WALK_STATS
 // measurement builds only (tools/walk_stats.py): wave-level counters of walk_occlusion_tree
-extern "C" int rs_debug_walk_stats(rs_scene* s, unsigned long long* out16, int reset) {
+extern "C" int rs_debug_walk_stats(rs_scene* s, unsigned long long* out64, int reset) {
     RS_HIP(hipDeviceSynchronize());
-    RS_HIP(hipMemcpy(out16, s->dWalkStats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) RS_HIP(hipMemset(s->dWalkStats, 0, 16 * sizeof(unsigned long long)));
+    RS_HIP(hipMemcpy(out64, s->dWalkStats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) RS_HIP(hipMemset(s->dWalkStats, 0, 64 * sizeof(unsigned long long)));
     return 0;
 }
 #endif

@@ -31,6 +31,37 @@ def strip_bounds(height, world, rank):
     return y0, y0 + base + (1 if rank < rem else 0)
 
 
+def rebalance_bounds(bounds, times, height, quantum=8, min_rows=8):
+    """Cost-balanced strips (rows differ in cost, and the slowest strip sets the frame time).
+
+    bounds: current [(y0, y1)] per rank, times: measured cost of each strip (any unit).  The cost per row is taken
+    as constant inside a strip; new boundaries are placed at equal shares of the cumulative cost, rounded to
+    `quantum` rows (the kernels work in 8-row tiles) and kept at least `min_rows` (>= HALO) tall.  Pure function of
+    its arguments, so every rank derives the same bounds from the same all-gathered times."""
+    world = len(bounds)
+    if world == 1:
+        return [(0, height)]
+    row_cost = []
+    for (a, b), t in zip(bounds, times):
+        row_cost += [float(t) / (b - a)] * (b - a)
+    total = sum(row_cost)
+    cuts, acc, y = [], 0.0, 0
+    for k in range(1, world):
+        target = total * k / world
+        while y < height and acc + row_cost[y] <= target:
+            acc += row_cost[y]; y += 1
+        cuts.append(y)
+    lo = max(min_rows, quantum)
+    out, prev = [], 0
+    for k, c in enumerate(cuts):
+        c = int(round(c / quantum)) * quantum
+        c = max(c, prev + lo)                                   # tall enough
+        c = min(c, height - lo * (world - 1 - k))               # leave room for the strips below
+        out.append((prev, c)); prev = c
+    out.append((prev, height))
+    return out
+
+
 class StripRenderer:
     """runCuda (src/main.cpp:146-185) for one rank of a row-strip decomposition.
 
@@ -39,12 +70,16 @@ class StripRenderer:
     history_bytes(rows), history_pack(y0,rows)->tensor, history_unpack(y0,rows,tensor).
     """
 
-    def __init__(self, backend, world, rank, height, dist=None, share_history=False):
+    def __init__(self, backend, world, rank, height, dist=None, share_history=False, bounds=None):
         self.b = backend
         self.world, self.rank, self.height = world, rank, height
         self.dist = dist
         self.share_history = share_history and world > 1
-        self.bounds = [strip_bounds(height, world, r) for r in range(world)]
+        # bounds: optional explicit [(y0, y1)] per rank (cost-balanced strips); must tile [0, height) in rank order
+        self.bounds = list(bounds) if bounds is not None else [strip_bounds(height, world, r) for r in range(world)]
+        if len(self.bounds) != world or self.bounds[0][0] != 0 or self.bounds[-1][1] != height or \
+                any(self.bounds[i][1] != self.bounds[i + 1][0] for i in range(world - 1)):
+            raise ValueError("strip bounds must tile the framebuffer rows in rank order")
         self.y0, self.y1 = self.bounds[rank]
         if world > 1 and min(b[1] - b[0] for b in self.bounds) < HALO:
             raise ValueError("strips must be at least HALO rows tall")

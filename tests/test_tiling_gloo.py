@@ -22,7 +22,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, moving, outdir):
+BALANCED = {3: [(0, 8), (8, 45), (45, 64)]}     # uneven (cost-balanced style) strips: still exact
+
+
+def _worker(rank, world, port, moving, outdir, balanced=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +36,7 @@ def _worker(rank, world, port, moving, outdir):
     sd = get_scene("sponza:0.02")
     cam = ob.camera_update(sd.camera(W, H))
     backend = OracleBackend(oracle_scene(sd), cam, W, H)
-    r = StripRenderer(backend, world, rank, H, dist=dist, share_history=moving)
+    r = StripRenderer(backend, world, rank, H, dist=dist, share_history=moving, bounds=BALANCED[world] if balanced else None)
     for frame in range(FRAMES):
         if moving:
             p = orbit_position(sd.camera_args["position"], frame, radius=0.6)
@@ -67,6 +70,34 @@ def test_strips_equal_full_frame(tmp_path, world, moving):
     ref = _reference(moving)
     assert got.shape == ref.shape
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_uneven_strips_equal_full_frame(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, True, str(tmp_path), True), nprocs=3, join=True)
+    got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(3)])
+    assert np.array_equal(got.view(np.uint32), _reference(True).view(np.uint32))
+
+
+def test_rebalance_bounds():
+    from restir_amd.tiling import HALO, StripRenderer, rebalance_bounds, strip_bounds
+    for height, world in ((1080, 8), (1080, 2), (2160, 8), (64, 3)):
+        b = [strip_bounds(height, world, r) for r in range(world)]
+        rng = np.random.default_rng(world)
+        for _ in range(5):
+            t = rng.uniform(0.2, 2.0, world)
+            nb = rebalance_bounds(b, t, height)
+            assert nb[0][0] == 0 and nb[-1][1] == height
+            assert all(nb[i][1] == nb[i + 1][0] for i in range(world - 1))
+            assert min(y1 - y0 for y0, y1 in nb) >= max(HALO, 8)
+            b = nb
+    # a strip that costs more per row gets fewer rows; equal costs keep an even split (up to the 8-row quantum)
+    nb = rebalance_bounds([(0, 540), (540, 1080)], [2.0, 1.0], 1080)
+    assert nb[0][1] < 540
+    nb = rebalance_bounds([(0, 540), (540, 1080)], [1.0, 1.0], 1080)
+    assert abs(nb[0][1] - 540) <= 8
+    with pytest.raises(ValueError):
+        StripRenderer(None, 2, 0, 64, bounds=[(0, 30), (32, 64)])
 
 
 def test_strip_bounds_cover_and_balance():

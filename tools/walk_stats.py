@@ -17,7 +17,7 @@ backend = HipBackend(capi, scene, cam, W, H)
 strips = StripRenderer(backend, 1, 0, H)
 for _ in range(6):
     strips.frame(3, 0)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 64)()
 L = capi.lib()
 L.rs_debug_walk_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 assert L.rs_debug_walk_stats(scene.handle, out, 1) == 0
@@ -33,3 +33,7 @@ for i, n in enumerate(names):
     print("  %-28s %10.2f" % (n, out[i] / w))
 print("  walking lanes per walk iteration %.1f, verifying lanes per verify iteration %.1f, lanes per triangle iteration %.1f" %
       (out[6] / max(out[5], 1), out[7] / max(out[4], 1), out[9] / max(out[3], 1)))
+pw = out[16]
+print("closest-hit packet walks (G-buffer + primary), per wave: union nodes mean %.1f max %d, orders %.2f, waves on the special-case path %.4f" %
+      (out[17] / pw, out[18], out[19] / pw, out[20] / pw))
+print("  histogram of union nodes per wave (log2 buckets):", " ".join("%d:%d" % (1 << b, out[24 + b]) for b in range(20) if out[24 + b]))
