@@ -35,7 +35,7 @@ typedef struct rs_material {
     float metallic;
     float roughness;
     float ior;
-    int   baseColorMapId;  /* must be -1 (NullTextureId) */
+    int   baseColorMapId;  /* -1 NullTextureId, -2 ProceduralTexId (src/material.h:11-13), else index into rs_scene_desc::textures */
     int   metallicMapId;
     int   roughnessMapId;
     int   normalMapId;
@@ -67,6 +67,13 @@ typedef struct rs_reservoir {
     float weight;
 } rs_reservoir;
 
+/* src/image.h:7-38,76-97 -- a decoded image: linear-RGB float texels, row-major (what Image / DevTextureObj hold;
+ * decoding files stays with the caller, as it does with stb_image in the reference, src/image.cpp:14-31) */
+typedef struct rs_texture {
+    int          width, height;
+    const float* data;            /* 3 floats / texel */
+} rs_texture;
+
 /* Host arrays that define a device scene = the inputs of DevScene::create (src/scene.cpp:435-509),
  * in the layouts Scene::buildDevData leaves them (src/scene.cpp:159-215). */
 typedef struct rs_scene_desc {
@@ -86,6 +93,14 @@ typedef struct rs_scene_desc {
     const float*       lightProb;         /* DiscreteSampler1D::binomDistribs[i].prob   */
     const int*         lightFailId;       /* DiscreteSampler1D::binomDistribs[i].failId */
     float              sumLightPower;     /* lightSampler.sumAll */
+    /* Textures and environment map (src/scene.h:78-99,358-392; src/scene.cpp:136-152,479-498).  With an environment
+     * map the light sampler has one more entry than there are light primitives (src/scene.cpp:151): numLights
+     * counts it, lightProb/lightFailId have numLights entries, lightPrimIds/lightUnitRadiance numLights-1. */
+    int                numTextures;
+    const rs_texture*  textures;
+    int                envMapTexId;        /* Scene::envMapTexId, -1 = none */
+    const float*       envMapProb;         /* envMapSampler alias table, width*height entries (NULL without a map) */
+    const int*         envMapFailId;
 } rs_scene_desc;
 
 typedef struct rs_scene   rs_scene;    /* = Scene::devScene / DevScene      (src/scene.h:64-481)  */
@@ -129,6 +144,13 @@ int  rs_build_alias_table(int n, const float* values, float* prob, int* failId, 
 int  rs_scene_build(int numPrims, const float* vertices, const float* normals, const float* texcoords,
                     const int* materialIds, int numMaterials, const rs_material* materials,
                     rs_scene** scene);
+/* The same with textures and an environment map: adds Scene::createLightSampler's environment-map sampler
+ * (src/scene.cpp:136-152).  envMapTexId: index into textures or -1. */
+int  rs_scene_build_textured(int numPrims, const float* vertices, const float* normals, const float* texcoords,
+                             const int* materialIds, int numMaterials, const rs_material* materials,
+                             int numTextures, const rs_texture* textures, int envMapTexId, rs_scene** scene);
+/* pdf of the environment-map sampler: lum(texel) * sin((.5 + row) / height * Pi) (src/scene.cpp:139-146). */
+int  rs_build_envmap_pdf(int width, int height, const float* data, float* pdf);
 /* DevScene::create (src/scene.cpp:435-509) from prebuilt host arrays. */
 int  rs_scene_create(const rs_scene_desc* desc, rs_scene** scene);
 /* Host copies of the arrays the scene was created from (valid until rs_scene_destroy). */

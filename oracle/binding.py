@@ -51,7 +51,17 @@ class OrcScene(C.Structure):
         ("lightProb", C.c_void_p),
         ("lightFailId", C.c_void_p),
         ("sumLightPowerInv", C.c_float),
+        ("numTextures", C.c_int),
+        ("textures", C.c_void_p),
+        ("envMapTexId", C.c_int),
+        ("envMapSamplerLength", C.c_int),
+        ("envMapProb", C.c_void_p),
+        ("envMapFailId", C.c_void_p),
     ]
+
+
+class OrcTexture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.c_void_p)]
 
 
 class OrcGBuffer(C.Structure):
@@ -96,6 +106,13 @@ def lib():
     L.orc_alias_build.argtypes = [C.c_int, f32p, f32p, i32p, C.POINTER(C.c_float)]
     L.orc_light_table.argtypes = [C.c_int, f32p, i32p, C.c_void_p, i32p, f32p, f32p]
     L.orc_light_table.restype = C.c_int
+    L.orc_envmap_pdf.argtypes = [C.c_int, C.c_int, f32p, f32p]
+    L.orc_set_libm_mode.argtypes = [C.c_int]
+    L.orc_linear_sample.argtypes = [C.POINTER(OrcTexture), C.c_int, f32p, f32p]
+    L.orc_to_sphere.argtypes = [C.c_int, f32p, f32p]
+    L.orc_to_plane.argtypes = [C.c_int, f32p, f32p]
+    L.orc_procedural_texture.argtypes = [C.c_int, f32p, f32p]
+    L.orc_local_to_world.argtypes = [C.c_int, f32p, f32p, f32p]
     L.orc_intersect.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, i32p, i32p, f32p, f32p, f32p]
     L.orc_test_occlusion.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, i32p]
     L.orc_sample_direct_light_nv.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, f32p, f32p, f32p, f32p, f32p]
@@ -160,6 +177,47 @@ def alias_build(values):
     return prob, fail, np.float32(s.value)
 
 
+def envmap_pdf(env):
+    """scene.cpp:139-146 on an (H, W, 3) float32 environment map."""
+    env = np.ascontiguousarray(env, np.float32)
+    pdf = np.zeros(env.shape[0] * env.shape[1], np.float32)
+    lib().orc_envmap_pdf(env.shape[1], env.shape[0], env.reshape(-1), pdf)
+    return pdf
+
+
+def set_libm_mode(correctly_rounded):
+    lib().orc_set_libm_mode(int(bool(correctly_rounded)))
+
+
+def linear_sample(tex, uv):
+    tex = np.ascontiguousarray(tex, np.float32); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    t = OrcTexture(); t.height, t.width = tex.shape[0], tex.shape[1]; t.data = tex.ctypes.data
+    out = np.zeros((len(uv), 3), np.float32)
+    lib().orc_linear_sample(C.byref(t), len(uv), uv.reshape(-1), out.reshape(-1))
+    return out
+
+
+def to_sphere(uv):
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2); out = np.zeros((len(uv), 3), np.float32)
+    lib().orc_to_sphere(len(uv), uv.reshape(-1), out.reshape(-1)); return out
+
+
+def to_plane(d):
+    d = np.ascontiguousarray(d, np.float32).reshape(-1, 3); out = np.zeros((len(d), 2), np.float32)
+    lib().orc_to_plane(len(d), d.reshape(-1), out.reshape(-1)); return out
+
+
+def local_to_world(n, v):
+    n = np.ascontiguousarray(n, np.float32).reshape(-1, 3); v = np.ascontiguousarray(v, np.float32).reshape(-1, 3)
+    out = np.zeros((len(n), 3), np.float32)
+    lib().orc_local_to_world(len(n), n.reshape(-1), v.reshape(-1), out.reshape(-1)); return out
+
+
+def procedural_texture(uv):
+    uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2); out = np.zeros((len(uv), 3), np.float32)
+    lib().orc_procedural_texture(len(uv), uv.reshape(-1), out.reshape(-1)); return out
+
+
 def light_table(vertices, material_ids, materials):
     v = np.ascontiguousarray(vertices, np.float32).reshape(-1)
     n = v.size // 9
@@ -174,7 +232,11 @@ def light_table(vertices, material_ids, materials):
 class Scene:
     """Host image of DevScene, built the way Scene::buildDevData does (scene.cpp:159-215)."""
 
-    def __init__(self, vertices, normals, texcoords, material_ids, materials, prebuilt=None):
+    def __init__(self, vertices, normals, texcoords, material_ids, materials, prebuilt=None, textures=(), env_map_tex=-1):
+        # textures: list of (H, W, 3) float32 linear-RGB arrays; env_map_tex: index of the environment map or -1
+        self.textures = [np.ascontiguousarray(t, np.float32) for t in textures]
+        self.env_map_tex = int(env_map_tex)
+        self.env_prob = np.zeros(0, np.float32); self.env_fail = np.zeros(0, np.int32)
         self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3, 3)
         self.normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3, 3)
         self.texcoords = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 3, 2)
@@ -184,6 +246,10 @@ class Scene:
         if prebuilt is None:
             self.light_prim_ids, self.light_radiance, self.light_power = light_table(
                 self.vertices, self.material_ids, self.materials)
+            if self.env_map_tex >= 0:                       # Scene::createLightSampler (scene.cpp:136-152)
+                env = self.textures[self.env_map_tex]
+                self.env_prob, self.env_fail, env_sum = alias_build(envmap_pdf(env))
+                self.light_power = np.concatenate([self.light_power, np.array([env_sum], np.float32)])
             if len(self.light_power):
                 self.light_prob, self.light_fail, self.sum_power = alias_build(self.light_power)
             else:
@@ -207,13 +273,23 @@ class Scene:
         s.boundingBoxes = self.boxes.ctypes.data
         for i in range(6):
             s.bvhNodes[i] = self.nodes[i].ctypes.data
-        s.numLights = len(self.light_prim_ids)
+        s.numLights = len(self.light_prob)              # sampler length: light primitives (+1 with an environment map)
         s.lightPrimIds = self.light_prim_ids.ctypes.data
         s.lightUnitRadiance = self.light_radiance.ctypes.data
         s.lightProb = self.light_prob.ctypes.data
         s.lightFailId = self.light_fail.ctypes.data
         with np.errstate(divide="ignore"):
             s.sumLightPowerInv = np.float32(1.0) / np.float32(self.sum_power)
+        self._tex = (OrcTexture * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            self._tex[i].height, self._tex[i].width = t.shape[0], t.shape[1]
+            self._tex[i].data = t.ctypes.data
+        s.numTextures = len(self.textures)
+        s.textures = C.cast(self._tex, C.c_void_p)
+        s.envMapTexId = self.env_map_tex
+        s.envMapSamplerLength = len(self.env_prob)
+        s.envMapProb = self.env_prob.ctypes.data
+        s.envMapFailId = self.env_fail.ctypes.data
         self.c = s
 
     # scene services ---------------------------------------------------------------
@@ -361,6 +437,10 @@ def ref_subset():
     R.ref_triangle_misc.argtypes = [C.c_int, f32p, f32p, f32p, f32p, f32p]
     R.ref_tonemap.argtypes = [C.c_int, f32p, C.c_int, f32p]
     R.ref_bvh_build.argtypes = [C.c_int, f32p, f32p, C.POINTER(C.c_void_p * 6)]
+    R.ref_linear_sample.argtypes = [C.c_int, C.c_int, f32p, C.c_int, f32p, f32p]
+    R.ref_to_sphere.argtypes = [C.c_int, f32p, f32p]
+    R.ref_to_plane.argtypes = [C.c_int, f32p, f32p]
+    R.ref_local_to_world.argtypes = [C.c_int, f32p, f32p, f32p]
     R.ref_bvh_build.restype = C.c_int
     return R
 

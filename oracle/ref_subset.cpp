@@ -8,7 +8,7 @@
  * the GPU box; nothing at run time there needs this file's output except as a prebuilt checker.
  *
  * What compiles: the thrust-free subset of the reference -- intersections.h, bvh.h, bvh.cpp,
- * sceneStructs.h, material.h, mathUtil.h -- with plain g++, the reference's vendored GLM 0.9.6.3
+ * sceneStructs.h, material.h, mathUtil.h, image.h -- with plain g++, the reference's vendored GLM 0.9.6.3
  * and the genuine CUDA runtime headers that ship inside this image's Triton wheel (only for the
  * `#include <cuda_runtime.h>` lines and the __host__/__device__ annotations, which g++ ignores).
  * What does not: scene.h / sampler.h / restir.h / gbuffer.h / *.cu need CUDA Thrust and nvcc
@@ -23,6 +23,7 @@
 #include "material.h"
 #include "sceneStructs.h"
 #include "mathUtil.h"
+#include "image.h"           // linearSample / DevTextureObj (templates; Image's methods are only declared)
 
 static inline glm::vec3 ld3(const float* p) { return glm::vec3(p[0], p[1], p[2]); }
 static inline void st3(float* p, glm::vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
@@ -135,6 +136,24 @@ int ref_bvh_build(int numPrims, const float* vertices, float* boxesOut, int* nod
     std::memcpy(boxesOut, boxes.data(), sizeof(AABB) * boxes.size());
     for (int i = 0; i < 6; i++) std::memcpy(nodesOut[i], nodes[i].data(), sizeof(MTBVHNode) * nodes[i].size());
     return size;
+}
+
+// image.h:41-75 through DevTextureObj::linearSample (image.h:89-91)
+void ref_linear_sample(int width, int height, const float* data, int n, const float* uv, float* out) {
+    DevTextureObj tex;
+    tex.width = width; tex.height = height;
+    tex.devData = reinterpret_cast<glm::vec3*>(const_cast<float*>(data));
+    for (int i = 0; i < n; i++) st3(out + 3 * i, tex.linearSample(glm::vec2(uv[2 * i], uv[2 * i + 1])));
+}
+// mathUtil.h:134-155
+void ref_to_sphere(int n, const float* uv, float* dir) {
+    for (int i = 0; i < n; i++) st3(dir + 3 * i, Math::toSphere(glm::vec2(uv[2 * i], uv[2 * i + 1])));
+}
+void ref_to_plane(int n, const float* dir, float* uv) {
+    for (int i = 0; i < n; i++) { glm::vec2 u = Math::toPlane(ld3(dir + 3 * i)); uv[2 * i] = u.x; uv[2 * i + 1] = u.y; }
+}
+void ref_local_to_world(int n, const float* nrm, const float* v, float* out) {
+    for (int i = 0; i < n; i++) st3(out + 3 * i, Math::localToWorld(ld3(nrm + 3 * i), ld3(v + 3 * i)));
 }
 
 } // extern "C"

@@ -26,6 +26,8 @@ typedef struct { float x, y; } v2;
 #define PI_TWO_F  6.2831853071795864769252867665590057683943f  /* mathUtil.h:12 */
 #define GLM_PI_F  ((float)3.14159265358979323846264338327950288) /* glm::pi<float>() */
 #define NULL_PRIM (-1)
+#define NULL_TEXTURE (-1)     /* material.h:11 */
+#define PROCEDURAL_TEX (-2)   /* material.h:13 */
 #define INVALID_PDF (-1.f)
 
 static inline float g_abs(float x) { return x >= 0.f ? x : -x; }           /* func_common.inl:56 */
@@ -435,6 +437,60 @@ static v3 material_bsdf(const orc_material* m, v3 n, v3 wo, v3 wi) { /* :218-228
 }
 
 /* ------------------------------------------------------------------------------------------
+ * libm calls of __device__ code (see orc_set_libm_mode in the header)
+ * ---------------------------------------------------------------------------------------- */
+static int g_libm_cr = 0;
+void orc_set_libm_mode(int correctlyRounded) { g_libm_cr = correctlyRounded != 0; }
+static inline float m_sin(float x) { return g_libm_cr ? (float)sin((double)x) : sinf(x); }
+static inline float m_cos(float x) { return g_libm_cr ? (float)cos((double)x) : cosf(x); }
+static inline float m_atan2(float y, float x) { return g_libm_cr ? (float)atan2((double)y, (double)x) : atan2f(y, x); }
+
+static inline float g_fract(float x) { return x - floorf(x); }                 /* func_common.inl:318-321 */
+
+/* mathUtil.h:134-137 */
+static inline v3 to_sphere(v2 v) {
+    v.x *= PI_TWO_F; v.y *= PI_F;
+    return V3(m_cos(v.x) * m_sin(v.y), m_cos(v.y), m_sin(v.x) * m_sin(v.y));
+}
+/* mathUtil.h:139-144; PiInv is the macro "1.f / Pi" (Q10): x * PiInv * .5f == ((x * 1.f) / Pi) * .5f */
+static inline v2 to_plane(v3 v) {
+    v2 o;
+    o.x = g_fract(((m_atan2(v.z, v.x) * 1.f) / PI_F) * .5f + 1.f);
+    o.y = (m_atan2(sqrtf(v.x * v.x + v.z * v.z), v.y) * 1.f) / PI_F;      /* glm::length(vec2) = sqrt(dot) */
+    return o;
+}
+/* mathUtil.h:146-155 */
+static inline v3 local_to_world(v3 n, v3 v) {
+    v3 t = (g_abs(n.y) > 0.9999f) ? V3(0.f, 0.f, 1.f) : V3(0.f, 1.f, 0.f);
+    v3 b = normalize3(cross(n, t));
+    t = cross(b, n);
+    return normalize3(m3mul(t, b, n, v));
+}
+
+/* image.h:41-75 (T = glm::vec3); float -> int conversions truncate (device semantics via f2i) */
+static v3 linear_sample(const orc_texture* tex, v2 uv) {
+    const float Eps = FLT_MIN;
+    const int width = tex->width, height = tex->height;
+    uv.x = g_fract(uv.x); uv.y = g_fract(uv.y);
+    float fx = uv.x * ((float)width - Eps) + .5f;
+    float fy = uv.y * ((float)height - Eps) + .5f;
+    int ix = f2i(g_fract(fx) > .5f ? fx : fx - 1);
+    if (ix < 0) ix += width;
+    int iy = f2i(g_fract(fy) > .5f ? fy : fy - 1);
+    if (iy < 0) iy += height;
+    int ux = ix + 1;
+    if (ux >= width) ux -= width;
+    int uy = iy + 1;
+    if (uy >= height) uy -= height;
+    float lx = g_fract(fx + .5f);
+    float ly = g_fract(fy + .5f);
+    const float* d = tex->data;
+    v3 c1 = mix3s(ld3(d + ((size_t)iy * width + ix) * 3), ld3(d + ((size_t)iy * width + ux) * 3), lx);
+    v3 c2 = mix3s(ld3(d + ((size_t)uy * width + ix) * 3), ld3(d + ((size_t)uy * width + ux) * 3), lx);
+    return mix3s(c1, c2, ly);
+}
+
+/* ------------------------------------------------------------------------------------------
  * DevScene services (scene.h:101-198,245-316,394-459)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -555,18 +611,79 @@ static int scene_test_occlusion(const orc_scene* s, v3 x, v3 y) {
     return 0;
 }
 
+/* scene.h:68-76 */
+static v3 procedural_texture(v2 uv) {
+    rng_t rng = rng_seed_raw((uint32_t)(f2i(uv.x * 1024.f) * 1024 + f2i(uv.y * 1024.f)));
+    float rx = sample1D(&rng);
+    float ry = sample1D(&rng);
+    float f = (m_sin(uv.x * 10.f * PI_TWO_F + rx * PI_TWO_F) + 1.f) * .5f;
+    float g = (m_sin(uv.y * 10.f * PI_TWO_F + ry * PI_TWO_F) + 1.f) * .5f;
+    return v3s(f * g);
+}
+
+/* scene.h:78-99: material with its maps applied; a normal map also replaces intersec.norm */
+static orc_material textured_material_and_surface(const orc_scene* s, isect_t* it) {
+    orc_material mat = s->materials[it->matId];
+    if (mat.baseColorMapId != NULL_TEXTURE) {
+        st3(mat.baseColor, mat.baseColorMapId == PROCEDURAL_TEX ? procedural_texture(it->uv)
+                                                                : linear_sample(&s->textures[mat.baseColorMapId], it->uv));
+    }
+    if (mat.metallicMapId > NULL_TEXTURE) {
+        mat.metallic = linear_sample(&s->textures[mat.metallicMapId], it->uv).x;
+    }
+    if (mat.roughnessMapId > NULL_TEXTURE) {
+        mat.roughness = linear_sample(&s->textures[mat.roughnessMapId], it->uv).x;
+    }
+    if (mat.normalMapId != NULL_TEXTURE) {
+        v3 mapped = linear_sample(&s->textures[mat.normalMapId], it->uv);
+        v3 localNorm = normalize3(adds(scl(mapped, 1.f), -0.5f));
+        it->norm = local_to_world(it->norm, localNorm);
+    }
+    return mat;
+}
+
+/* radiance seen by a ray that leaves the scene: envMap->linearSample(Math::toPlane(dir)) (restir.cu:134-136) */
+static inline int scene_has_env(const orc_scene* s) { return s->envMapTexId >= 0; }
+static v3 env_radiance(const orc_scene* s, v3 dir) {
+    return linear_sample(&s->textures[s->envMapTexId], to_plane(dir));
+}
+
+/* sampler.h:203-207 on the environment-map table */
+static inline int env_sampler_sample(const orc_scene* s, float r1, float r2) {
+    int passId = i_min(f2i((float)s->envMapSamplerLength * r1), s->envMapSamplerLength - 1);
+    return (r2 < s->envMapProb[passId]) ? passId : s->envMapFailId[passId];
+}
+
+/* scene.h:364-376 (NoVisibility) / :378-392.  `PiInv * PiInv * .5f` is the macro quirk Q10:
+ * x * 1.f / Pi * 1.f / Pi * .5f evaluated left to right. */
+static float sample_environment_map_nv(const orc_scene* s, v2 r, v3* radiance, v3* wi) {
+    const orc_texture* env = &s->textures[s->envMapTexId];
+    int pixId = env_sampler_sample(s, r.x, r.y);
+    int y = pixId / env->width;
+    int x = pixId - y * env->width;
+    *radiance = ld3(env->data + (size_t)pixId * 3);
+    v2 uv = { (.5f + (float)x) / (float)env->width, (.5f + (float)y) / (float)env->height };
+    *wi = to_sphere(uv);
+    return ((((luminance(*radiance) * s->sumLightPowerInv * (float)env->width * (float)env->height * 1.f) / PI_F) * 1.f) / PI_F) * .5f;
+}
+
 /* sampler.h:203-207 */
 static inline int light_sampler_sample(const orc_scene* s, float r1, float r2) {
     int passId = i_min(f2i((float)s->numLights * r1), s->numLights - 1);
     return (r2 < s->lightProb[passId]) ? passId : s->lightFailId[passId];
 }
 
-/* scene.h:394-425 (environment-map branch :400-403 unreachable: envMapSampler.length == 0) */
+/* scene.h:394-425 */
 static float sample_direct_light_nv(const orc_scene* s, v3 pos, v4 r, v3* radiance, v3* wi, float* dist) {
     if (s->numLights == 0) {
         return INVALID_PDF;
     }
     int lightId = light_sampler_sample(s, r.x, r.y);
+    if (lightId == s->numLights - 1 && s->envMapSamplerLength != 0) {     /* :400-403 */
+        *dist = 1e10f;
+        v2 r2 = { r.z, r.w };
+        return sample_environment_map_nv(s, r2, radiance, wi);
+    }
     int primId = s->lightPrimIds[lightId];
     v3 v0, v1, v2_;
     tri_verts(s, primId, &v0, &v1, &v2_);
@@ -592,6 +709,15 @@ static float sample_direct_light(const orc_scene* s, v3 pos, v4 r, v3* radiance,
         return INVALID_PDF;
     }
     int lightId = light_sampler_sample(s, r.x, r.y);
+    if (lightId == s->numLights - 1 && s->envMapSamplerLength != 0) {     /* :433-435 -> sampleEnvironmentMap :378-392 */
+        v2 r2 = { r.z, r.w };
+        float pdf = sample_environment_map_nv(s, r2, radiance, wi);
+        (*walks)++;
+        if (scene_test_occlusion(s, pos, add(pos, scl(*wi, 1e6f)))) {
+            return INVALID_PDF;
+        }
+        return pdf;
+    }
     int primId = s->lightPrimIds[lightId];
     v3 v0, v1, v2_;
     tri_verts(s, primId, &v0, &v1, &v2_);
@@ -704,8 +830,8 @@ void orc_gbuffer_render(const orc_scene* s, const orc_camera* cam, orc_gbuffer* 
                     matId = NULL_PRIM - 1;
                     /* gbuffer.cu:32-36 only rewrites intersec.primId, which is not read again */
                 }
-                const orc_material* material = &s->materials[it.matId]; /* scene.h:78-99, no textures */
-                st3(g->albedo + (size_t)idx * 3, ld3(material->baseColor));
+                orc_material material = textured_material_and_surface(s, &it);   /* scene.h:78-99 */
+                st3(g->albedo + (size_t)idx * 3, ld3(material.baseColor));
                 st3(normal + (size_t)idx * 3, it.norm);
                 primIdPlane[idx] = matId;
                 depth[idx] = length3(sub(ray.origin, it.pos));      /* glm::distance(pos, origin) */
@@ -720,7 +846,11 @@ void orc_gbuffer_render(const orc_scene* s, const orc_camera* cam, orc_gbuffer* 
                 }
             }
             else {
-                st3(g->albedo + (size_t)idx * 3, v3s(0.f));
+                v3 albedo = v3s(0.f);
+                if (scene_has_env(s)) {                                  /* gbuffer.cu:59-62 */
+                    albedo = env_radiance(s, ray.direction);
+                }
+                st3(g->albedo + (size_t)idx * 3, albedo);
                 st3(normal + (size_t)idx * 3, v3s(0.f));
                 primIdPlane[idx] = NULL_PRIM;
                 depth[idx] = 1.f;
@@ -755,8 +885,14 @@ void orc_pt_direct(const orc_scene* s, const orc_camera* cam, float* directIllum
             scene_intersect(s, ray, &it);
             walks++;
 
-            if (it.primId != NULL_PRIM) {
-                const orc_material* material = &s->materials[it.matId];
+            if (it.primId == NULL_PRIM) {
+                if (scene_has_env(s)) {                                  /* pathtrace.cu:295-297 */
+                    direct = env_radiance(s, ray.direction);
+                }
+            }
+            else {
+                orc_material mat = textured_material_and_surface(s, &it); /* :301 */
+                const orc_material* material = &mat;
                 if (material->type == MAT_LIGHT) {
                     direct = ld3(material->baseColor);
                 }
@@ -858,7 +994,7 @@ typedef struct {
     rng_t rng;
     resv_t reservoir;    /* post-temporal (validity-checked when spatial reuse is on) */
     v3    norm, wo;
-    int   matId;
+    orc_material material;   /* with its maps applied and baseColor = 1 (restir.cu:140-141) */
 } pixel_state_t;
 
 #define RESERVOIR_SIZE 32   /* restir.cu:3 */
@@ -894,9 +1030,12 @@ void orc_restir_phase_a(void* state, const orc_scene* s, const orc_camera* cam, 
             total++;
 
             if (it.primId == NULL_PRIM) {
-                continue;                       /* envMap == nullptr -> direct = 0 */
+                if (scene_has_env(s)) {         /* restir.cu:134-136 */
+                    ps->direct = env_radiance(s, ray.direction);
+                }
+                continue;
             }
-            orc_material material = s->materials[it.matId];
+            orc_material material = textured_material_and_surface(s, &it);   /* restir.cu:140 */
             st3(material.baseColor, v3s(1.f));  /* restir.cu:141 */
 
             if (material.type == MAT_LIGHT) {
@@ -951,7 +1090,7 @@ void orc_restir_phase_a(void* state, const orc_scene* s, const orc_camera* cam, 
             ps->reservoir = reservoir;
             ps->norm = it.norm;
             ps->wo = it.wo;
-            ps->matId = it.matId;
+            ps->material = material;
         }
     }
     if (rays) *rays = total;
@@ -975,8 +1114,7 @@ void orc_restir_phase_b(void* state, const orc_scene* s, const orc_camera* cam, 
             if (ps->kind == 1) {
                 rng_t rng = ps->rng;
                 resv_t reservoir = ps->reservoir;
-                orc_material material = s->materials[ps->matId];
-                st3(material.baseColor, v3s(1.f));
+                orc_material material = ps->material;
 
                 if (reuse & 2) {
                     resv_t agg = resv_default();           /* mergeSpatialNeighborDirect :87-100 */
@@ -1432,6 +1570,31 @@ void orc_sample_triangle_uniform(int n, const float* tris, const float* ruv, flo
 void orc_to_concentric_disk(int n, const float* xy, float* out) {
     for (int i = 0; i < n; i++) { v2 p = to_concentric_disk(xy[2 * i], xy[2 * i + 1]); out[2 * i] = p.x; out[2 * i + 1] = p.y; }
 }
+void orc_linear_sample(const orc_texture* tex, int n, const float* uv, float* out) {
+    for (int i = 0; i < n; i++) { v2 u = { uv[i * 2], uv[i * 2 + 1] }; st3(out + (size_t)i * 3, linear_sample(tex, u)); }
+}
+void orc_to_sphere(int n, const float* uv, float* dir) {
+    for (int i = 0; i < n; i++) { v2 u = { uv[i * 2], uv[i * 2 + 1] }; st3(dir + (size_t)i * 3, to_sphere(u)); }
+}
+void orc_to_plane(int n, const float* dir, float* uv) {
+    for (int i = 0; i < n; i++) { v2 u = to_plane(ld3(dir + (size_t)i * 3)); uv[i * 2] = u.x; uv[i * 2 + 1] = u.y; }
+}
+void orc_local_to_world(int n, const float* nrm, const float* v, float* out) {
+    for (int i = 0; i < n; i++) st3(out + (size_t)i * 3, local_to_world(ld3(nrm + (size_t)i * 3), ld3(v + (size_t)i * 3)));
+}
+void orc_procedural_texture(int n, const float* uv, float* out) {
+    for (int i = 0; i < n; i++) { v2 u = { uv[i * 2], uv[i * 2 + 1] }; st3(out + (size_t)i * 3, procedural_texture(u)); }
+}
+/* scene.cpp:139-146 (host code: glibc sinf in every mode) */
+void orc_envmap_pdf(int width, int height, const float* data, float* pdf) {
+    for (int i = 0; i < height; i++) {
+        for (int j = 0; j < width; j++) {
+            int idx = i * width + j;
+            pdf[idx] = luminance(ld3(data + (size_t)idx * 3)) * sinf((.5f + (float)i) / (float)height * PI_F);
+        }
+    }
+}
+
 void orc_intersect(const orc_scene* s, int n, const float* rays, int* primId, int* matId, float* pos, float* norm, float* uv) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int i = 0; i < n; i++) {

@@ -36,7 +36,7 @@ typedef struct orc_material {
     float metallic;
     float roughness;
     float ior;
-    int   baseColorMapId;    /* -1 = none; textures are out of scope and must be -1 */
+    int   baseColorMapId;    /* -1 = none (NullTextureId), -2 = procedural (ProceduralTexId), else texture index */
     int   metallicMapId;
     int   roughnessMapId;
     int   normalMapId;
@@ -68,6 +68,12 @@ typedef struct orc_reservoir {
     float weight;
 } orc_reservoir;
 
+/* reference: src/image.h:76-97 DevTextureObj -- linear RGB float texels, row-major */
+typedef struct orc_texture {
+    int          width, height;
+    const float* data;             /* 3 floats / texel */
+} orc_texture;
+
 /* Host-memory image of DevScene (src/scene.h:461-480). */
 typedef struct orc_scene {
     int           numPrims;
@@ -86,6 +92,15 @@ typedef struct orc_scene {
     const float*  lightProb;       /* alias table: BinomialDistrib.prob   */
     const int*    lightFailId;     /* alias table: BinomialDistrib.failId */
     float         sumLightPowerInv;
+    /* textures and environment map (scene.h:78-99,358-392; scene.cpp:136-152,479-498).  With an environment
+     * map the light sampler has one more entry than there are light primitives: numLights counts it, and
+     * lightPrimIds / lightUnitRadiance hold numLights-1 records (scene.cpp:151, scene.h:400-403). */
+    int           numTextures;
+    const orc_texture* textures;
+    int           envMapTexId;         /* -1 = none */
+    int           envMapSamplerLength; /* width*height of the environment map, 0 = none */
+    const float*  envMapProb;          /* alias table over lum(texel)*sin(theta) */
+    const int*    envMapFailId;
 } orc_scene;
 
 /* Host-memory image of GBuffer (src/gbuffer.h:41-58). */
@@ -132,7 +147,29 @@ void orc_rng_stream_raw(int n, const int* seeds, int m, float* out);
 /* src/mathUtil.h:102-117: mode 0 none, 1 filmic, 2 ACES; then correctGamma; float output */
 void orc_tonemap(int n, const float* in, int mode, float* out);
 
+/* How the libm calls of __device__ code are evaluated (sin/cos/atan2 in toSphere / toPlane / proceduralTexture
+ * / the spatial tap; the reference's CUDA build uses libdevice, which cannot be reproduced here):
+ *   0  glibc sinf/cosf/atan2f -- what a host build of the reference computes (default)
+ *   1  the correctly rounded value (evaluated in double, rounded once) -- what librestir_hip computes for the
+ *      environment-map and procedural-texture paths; used by the bit-exact parity tests of those paths.
+ * The spatial tap (restir.cu:49-56) always uses glibc (mode 0 semantics), see DESIGN.md. */
+void orc_set_libm_mode(int correctlyRounded);
+
+/* src/image.h:41-75 linearSample on n uv pairs */
+void orc_linear_sample(const orc_texture* tex, int n, const float* uv, float* out);
+/* src/mathUtil.h:134-144: toSphere (2 -> 3), toPlane (3 -> 2) */
+void orc_to_sphere(int n, const float* uv, float* dir);
+void orc_to_plane(int n, const float* dir, float* uv);
+/* src/mathUtil.h:146-155 localToWorld(n, v) */
+void orc_local_to_world(int n, const float* nrm, const float* v, float* out);
+/* src/scene.h:68-76 proceduralTexture (value replicated to 3 channels) */
+void orc_procedural_texture(int n, const float* uv, float* out);
+
 /* ---- host scene build -------------------------------------------------------------- */
+
+/* src/scene.cpp:139-146: pdf[i*w+j] = lum(texel) * sin((.5f + i) / h * Pi) -- host code, glibc sinf */
+void orc_envmap_pdf(int width, int height, const float* data, float* pdf);
+
 
 /* src/bvh.cpp:10-202.  boxes: 6*(2n-1) floats; nodes: 6 arrays of 3*(2n-1) ints. Returns BVHSize. */
 int  orc_bvh_build(int numPrims, const float* vertices, float* boxes, int* nodes[6]);

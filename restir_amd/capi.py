@@ -37,7 +37,16 @@ class SceneDesc(C.Structure):
         ("lightProb", C.c_void_p),
         ("lightFailId", C.c_void_p),
         ("sumLightPower", C.c_float),
+        ("numTextures", C.c_int),
+        ("textures", C.c_void_p),
+        ("envMapTexId", C.c_int),
+        ("envMapProb", C.c_void_p),
+        ("envMapFailId", C.c_void_p),
     ]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.c_void_p)]
 
 
 class GBufferView(C.Structure):
@@ -56,7 +65,7 @@ class GBufferView(C.Structure):
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
     "rs_last_error", "rs_init", "rs_set_stream", "rs_set_sync", "rs_synchronize",
-    "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_scene_build", "rs_scene_create",
+    "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
@@ -95,6 +104,8 @@ def lib():
     L.rs_build_light_table.argtypes = [ci, vp, vp, ci, vp, C.POINTER(ci), vp, vp, vp]
     L.rs_build_alias_table.argtypes = [ci, vp, vp, vp, C.POINTER(cf)]
     L.rs_scene_build.argtypes = [ci, vp, vp, vp, vp, ci, vp, C.POINTER(vp)]
+    L.rs_scene_build_textured.argtypes = [ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, C.POINTER(vp)]
+    L.rs_build_envmap_pdf.argtypes = [ci, ci, vp, vp]
     L.rs_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     L.rs_scene_host_desc.argtypes = [vp, C.POINTER(SceneDesc)]
     L.rs_scene_destroy.argtypes = [vp]
@@ -204,25 +215,47 @@ def build_light_table(vertices, material_ids, materials):
     return ids[:k.value].copy(), rad[:k.value].copy(), power[:k.value].copy()
 
 
+def build_envmap_pdf(env):
+    """Scene::createLightSampler's environment-map pdf (src/scene.cpp:139-146) for an (H, W, 3) float32 map."""
+    env = np.ascontiguousarray(env, np.float32)
+    pdf = np.zeros(env.shape[0] * env.shape[1], np.float32)
+    check(lib().rs_build_envmap_pdf(env.shape[1], env.shape[0], _p(env), _p(pdf)))
+    return pdf
+
+
+def _texture_table(textures):
+    keep = [np.ascontiguousarray(t, np.float32) for t in textures]
+    arr = (Texture * max(1, len(keep)))()
+    for i, t in enumerate(keep):
+        assert t.ndim == 3 and t.shape[2] == 3, "textures are (H, W, 3) float32"
+        arr[i].height, arr[i].width, arr[i].data = t.shape[0], t.shape[1], t.ctypes.data
+    return keep, arr
+
+
 # ---- device objects ---------------------------------------------------------------------------------
 class Scene:
     """Scene::buildDevData + DevScene (src/scene.cpp:159-215): builds light table, alias table and the
     MTBVH on the host (C++ in the library) and uploads the CDNA4 layout."""
 
-    def __init__(self, vertices, normals, texcoords, material_ids, materials):
+    def __init__(self, vertices, normals, texcoords, material_ids, materials, textures=(), env_map_tex=-1):
+        """textures: (H, W, 3) float32 linear-RGB arrays (what Image holds, src/image.h); env_map_tex: index or -1."""
         self._keep = (np.ascontiguousarray(vertices, np.float32), np.ascontiguousarray(normals, np.float32),
                       np.ascontiguousarray(texcoords, np.float32), np.ascontiguousarray(material_ids, np.int32),
                       np.ascontiguousarray(materials, MATERIAL_DTYPE))
         v, n, t, m, mats = self._keep
         self.num_prims = v.size // 9
         self.handle = C.c_void_p()
-        check(lib().rs_scene_build(self.num_prims, _p(v), _p(n), _p(t), _p(m), len(mats), _p(mats), C.byref(self.handle)))
+        self._tex, tex = _texture_table(textures)
+        check(lib().rs_scene_build_textured(self.num_prims, _p(v), _p(n), _p(t), _p(m), len(mats), _p(mats),
+                                            len(self._tex), C.cast(tex, C.c_void_p), int(env_map_tex), C.byref(self.handle)))
 
     @classmethod
-    def from_tables(cls, vertices, normals, texcoords, material_ids, materials, tables):
-        """DevScene::create from caller-built tables (rs_scene_create): `tables` as returned by host_desc()."""
+    def from_tables(cls, vertices, normals, texcoords, material_ids, materials, tables, textures=(), env_map_tex=-1, env_sampler=None):
+        """DevScene::create from caller-built tables (rs_scene_create): `tables` as returned by host_desc();
+        env_sampler = (prob, failId) of the environment map's alias table when env_map_tex >= 0."""
         self = cls.__new__(cls)
         t = tables
+        self._tex, tex = _texture_table(textures)
         self._keep = (np.ascontiguousarray(vertices, np.float32), np.ascontiguousarray(normals, np.float32),
                       np.ascontiguousarray(texcoords, np.float32), np.ascontiguousarray(material_ids, np.int32),
                       np.ascontiguousarray(materials, MATERIAL_DTYPE),
@@ -238,9 +271,13 @@ class Scene:
         d.bvhSize, d.boundingBoxes = len(boxes), _p(boxes)
         for k in range(6):
             d.bvhNodes[k] = _p(nodes[k])
-        d.numLights = len(lp)
+        d.numLights = len(lpr)                      # sampler length (light primitives + 1 with an environment map)
         d.lightPrimIds, d.lightUnitRadiance, d.lightProb, d.lightFailId = _p(lp), _p(lr), _p(lpr), _p(lf)
         d.sumLightPower = float(t["sum_power"])
+        d.numTextures = len(self._tex); d.textures = C.cast(tex, C.c_void_p); d.envMapTexId = int(env_map_tex)
+        if env_sampler is not None:
+            self._env = (np.ascontiguousarray(env_sampler[0], np.float32), np.ascontiguousarray(env_sampler[1], np.int32))
+            d.envMapProb, d.envMapFailId = _p(self._env[0]), _p(self._env[1])
         self.handle = C.c_void_p()
         check(lib().rs_scene_create(C.byref(d), C.byref(self.handle)))
         return self
@@ -250,6 +287,11 @@ class Scene:
         d = SceneDesc()
         check(lib().rs_scene_host_desc(self.handle, C.byref(d)))
         n, s, l = d.numPrims, d.bvhSize, d.numLights
+        lp = l - (1 if d.envMapTexId >= 0 else 0)       # light primitives; the environment map is the last sampler entry
+        ne = 0
+        if d.envMapTexId >= 0:
+            t = C.cast(d.textures, C.POINTER(Texture))[d.envMapTexId]
+            ne = t.width * t.height
 
         def arr(ptr, ctype, count, shape):
             if count == 0:
@@ -259,11 +301,13 @@ class Scene:
         return dict(
             boxes=arr(d.boundingBoxes, np.float32, s * 6, (s, 6)),
             nodes=np.stack([arr(d.bvhNodes[k], np.int32, s * 3, (s, 3)) for k in range(6)]),
-            light_prim_ids=arr(d.lightPrimIds, np.int32, l, (l,)),
-            light_radiance=arr(d.lightUnitRadiance, np.float32, l * 3, (l, 3)),
+            light_prim_ids=arr(d.lightPrimIds, np.int32, lp, (lp,)),
+            light_radiance=arr(d.lightUnitRadiance, np.float32, lp * 3, (lp, 3)),
             light_prob=arr(d.lightProb, np.float32, l, (l,)),
             light_fail=arr(d.lightFailId, np.int32, l, (l,)),
             sum_power=np.float32(d.sumLightPower), num_lights=l, bvh_size=s, num_prims=n,
+            env_map_tex=d.envMapTexId,
+            env_prob=arr(d.envMapProb, np.float32, ne, (ne,)), env_fail=arr(d.envMapFailId, np.int32, ne, (ne,)),
         )
 
     def destroy(self):

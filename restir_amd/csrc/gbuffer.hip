@@ -13,6 +13,8 @@ struct GBufWrite {
     float* albedo; int* motion; float* normal; int* primId; float* depth;
 };
 
+// TEX: the scene has texture maps or an environment map (getTexturedMaterialAndSurface, gbuffer.cu:38,59-62)
+template <bool TEX>
 __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
                                                         int y0, int y1, int tilesX) {
     // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels
@@ -29,10 +31,11 @@ __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams ca
 
     if (h.primId != kNullPrim) {
         int matId = h.matId;
-        const rs_material m = s.materials[h.matId];
-        if (m.type == 4) matId = kNullPrim - 1;          // lights -> -2 (gbuffer.cu:30-31)
-        st3(g.albedo + (size_t)idx * 3, ld3(m.baseColor));
-        st3(g.normal + (size_t)idx * 3, h.norm);
+        f3 norm = h.norm;
+        const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+        if (m.type == 4) matId = kNullPrim - 1;          // lights -> -2 (gbuffer.cu:30-31; the map lookup cannot change the type)
+        st3(g.albedo + (size_t)idx * 3, m.baseColor);
+        st3(g.normal + (size_t)idx * 3, norm);
         g.primId[idx] = matId;
         g.depth[idx] = length(ray.o - h.pos);            // glm::distance(pos, origin) = length(origin - pos)
         int lx, ly;
@@ -40,7 +43,7 @@ __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams ca
         g.motion[idx] = (lx >= 0 && lx < cam.width && ly >= 0 && ly < cam.height) ? ly * cam.width + lx : -1;
     }
     else {
-        st3(g.albedo + (size_t)idx * 3, splat(0.f));
+        st3(g.albedo + (size_t)idx * 3, (TEX && s.envTex >= 0) ? env_radiance(s, ray.d) : splat(0.f));
         st3(g.normal + (size_t)idx * 3, splat(0.f));
         g.primId[idx] = kNullPrim;
         g.depth[idx] = 1.f;
@@ -95,8 +98,12 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
     if (y1 <= y0) return 0;
     GBufWrite w{ g->devAlbedo, g->devMotion, g->devNormal[g->frameIdx], g->devPrimId[g->frameIdx], g->devDepth[g->frameIdx] };
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
-    hipLaunchKernelGGL(k_render_gbuffer, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(),
-                       scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
+    if (scene->textured)
+        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(),
+                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
+    else
+        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(),
+                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
     return rs_after_launch("renderGBuffer");
 }
 

@@ -9,8 +9,10 @@ namespace {
 
 // sampleDirectLight (src/scene.h:427-459): like the NoVisibility form, but with an occlusion test to
 // the sampled point before the single-sided test.
+// With an environment map the last sampler entry is sampleEnvironmentMap (:378-392): occlusion towards pos + wi * 1e6.
+template <bool ENV>
 __device__ inline float sample_light_visible(const DevScene& s, f3 pos, f4 r, f3& Li, f3& wi, int& walks) {
-    LightSample c = sample_light_nv<const AliasRec*, const LightRec*>(s.alias, s.lights, s.numLights, pos, r);
+    LightSample c = sample_light_nv<ENV, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
     if (s.numLights == 0) return kInvalidPdf;
     walks++;
     if (trace_occluded(s, pos, c.point)) return kInvalidPdf;
@@ -18,6 +20,8 @@ __device__ inline float sample_light_visible(const DevScene& s, f3 pos, f4 r, f3
     return c.pdf;
 }
 
+// TEX: the scene has texture maps or an environment map
+template <bool TEX>
 __global__ void __launch_bounds__(256) k_pt_direct(DevScene s, CamParams cam, float* __restrict__ directIllum,
                                                    int looper, int iter, int tilesX, unsigned long long* rayCount) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,22 +38,26 @@ __global__ void __launch_bounds__(256) k_pt_direct(DevScene s, CamParams cam, fl
     if (inside) {
         f3 direct = splat(0.f);
         walks = 1;
-        if (h.primId != kNullPrim) {
-            const rs_material m = s.materials[h.matId];
+        if (h.primId == kNullPrim) {
+            if (TEX && s.envTex >= 0) direct = env_radiance(s, ray.d);          // pathtrace.cu:295-297
+        }
+        else {
+            f3 norm = h.norm;
+            const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);    // pathtrace.cu:301
             if (m.type == 4) {
-                direct = ld3(m.baseColor);
+                direct = m.baseColor;
             }
             else {
                 f3 wo = -ray.d;
-                f3 norm = h.norm;
                 const bool delta = m.type == 2;
                 if (!delta && dot(norm, wo) < 0.f) norm = -norm;
                 if (!delta) {
                     f3 Li = splat(0.f), wi = splat(0.f);
                     f4 rl = rng.uniform4();
-                    float pdf = sample_light_visible(s, h.pos, rl, Li, wi, walks);
+                    float pdf = (TEX && s.envTex >= 0) ? sample_light_visible<true>(s, h.pos, rl, Li, wi, walks)
+                                                       : sample_light_visible<false>(s, h.pos, rl, Li, wi, walks);
                     if (pdf > 0.f)
-                        direct = ((Li * eval_bsdf(m.type, ld3(m.baseColor), m.metallic, m.roughness, norm, wo, wi)) * sat_dot(norm, wi)) / pdf;
+                        direct = ((Li * eval_bsdf(m.type, m.baseColor, m.metallic, m.roughness, norm, wo, wi)) * sat_dot(norm, wi)) / pdf;
                 }
             }
         }
@@ -104,8 +112,12 @@ int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* dev
     RS_HIP(hipMemsetAsync(g_ptRayCount, 0, 8, rs_stream()));
     const int W = cam->resolution[0], H = cam->resolution[1];
     const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
-    hipLaunchKernelGGL(k_pt_direct, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
-                       devDirectIllum, looper, iter, tilesX, g_ptRayCount);
+    if (scene->textured)
+        hipLaunchKernelGGL(k_pt_direct<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
+                           devDirectIllum, looper, iter, tilesX, g_ptRayCount);
+    else
+        hipLaunchKernelGGL(k_pt_direct<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
+                           devDirectIllum, looper, iter, tilesX, g_ptRayCount);
     RS_TRY(rs_after_launch("pathTrace"));
     if (rays) {
         RS_HIP(hipStreamSynchronize(rs_stream()));

@@ -33,13 +33,16 @@ constexpr int kHalo = RS_SPATIAL_HALO_ROWS;
 
 // kind of a pixel after the primary hit
 constexpr int kKindMiss = 0, kKindLight = 1, kKindShaded = 2;
+// per-pixel tag: material id (24 bits) | kind << 24 (2 bits) | Material::Type << 26 (3 bits)
+__device__ __forceinline__ int mk_kind(int mk) { return (mk >> 24) & 3; }
+__device__ __forceinline__ int mk_type(int mk) { return (mk >> 26) & 7; }
 constexpr int kRaySlots = 1024;   // ring of per-frame BVH-walk counters
 constexpr int kRaySub = 64, kRayStride = 8;   // per frame: 64 partial counters, 64 B apart (one hot address cost ~85 us/frame)
 
 struct SurfPlanes {
-    float4* posMat;     // pos.xyz, bits(matId | kind << 24)
-    float4* norm;       // shading normal xyz (flipped to the wo side), w unused
-    float4* wo;         // wo.xyz, 0
+    float4* posMat;     // pos.xyz (radiance of the environment map for a miss pixel of an env-mapped scene), bits(tag)
+    float4* norm;       // shading normal xyz (normal-mapped, flipped to the wo side), w = metallic (after its map)
+    float4* wo;         // wo.xyz, w = roughness (after its map); written and read only for the metallic BSDF
     uint2*  rngMat;     // { RNG state carried from pass to pass, matId | kind << 24 }: all the spatial pass needs for a Lambertian pixel
     float4* candLi;     // RIS winner Li.xyz, dist
     float4* candWi;     // RIS winner wi.xyz, reservoir weight
@@ -53,6 +56,7 @@ __device__ __forceinline__ void pixel_of_lane(int tilesX, int y0, int& x, int& y
 }
 
 // ---- phase A.1: primary hit ---------------------------------------------------------------------
+template <bool TEX>
 __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
     int x, y;
@@ -67,25 +71,31 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
     if (inside) {
 
         int kind = kKindMiss, matId = 0, type = 0;
-        f3 norm = splat(0.f), wo = splat(0.f);
+        f3 norm = splat(0.f), wo = splat(0.f), p = h.pos;
+        float metallic = 0.f, roughness = 0.f;
         if (h.primId != kNullPrim) {
             matId = h.matId;
-            type = s.materials[matId].type;
+            norm = h.norm;
+            const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, matId);    // restir.cu:140 (baseColor is then forced to 1)
+            type = m.type; metallic = m.metallic; roughness = m.roughness;
             if (type == 4) {
                 kind = kKindLight;
+                norm = splat(0.f);
             }
             else {
                 kind = kKindShaded;
                 wo = -ray.d;
-                norm = h.norm;
                 if (type != 2 && dot(norm, wo) < 0.f) norm = -norm;     // restir.cu:150-153
                 shaded = 1;
             }
         }
-        const int mk = matId | (kind << 24);
-        sp.posMat[index] = make_float4(h.pos.x, h.pos.y, h.pos.z, __int_as_float(mk));
-        sp.norm[index] = make_float4(norm.x, norm.y, norm.z, 0.f);
-        if (type == 1) sp.wo[index] = make_float4(wo.x, wo.y, wo.z, 0.f);     // only the metallic BSDF reads wo (k_ris, k_spatial_shade)
+        else if (TEX && s.envTex >= 0) {
+            p = env_radiance(s, ray.d);                                 // restir.cu:134-136: the pixel's radiance
+        }
+        const int mk = matId | (kind << 24) | (type << 26);
+        sp.posMat[index] = make_float4(p.x, p.y, p.z, __int_as_float(mk));
+        sp.norm[index] = make_float4(norm.x, norm.y, norm.z, metallic);
+        if (type == 1) sp.wo[index] = make_float4(wo.x, wo.y, wo.z, roughness);     // only the metallic BSDF reads wo (k_ris, k_spatial_shade)
         sp.rngMat[index] = make_uint2(rng.x, (unsigned)mk);
     }
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
@@ -104,24 +114,24 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
 constexpr int kRisThreads = 1024;
 constexpr int kRisLdsLights = 1024;
 
-template <typename AliasPtr, typename LightPtr>
+template <bool ENV, typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& sp, AliasPtr alias, LightPtr lights, int index) {
     const float4 pm = sp.posMat[index];
     const int mk = __float_as_int(pm.w);
-    if ((mk >> 24) != kKindShaded) return;
+    if (mk_kind(mk) != kKindShaded) return;
     const float4 nr = sp.norm[index];
     const f3 pos = mk3(pm.x, pm.y, pm.z), norm = mk3(nr.x, nr.y, nr.z);
-    const rs_material m = s.materials[mk & 0xffffff];
+    struct { int type; float metallic, roughness; } m = { mk_type(mk), nr.w, 0.f };     // the material after its maps (k_primary)
     const f3 baseColor = splat(1.f);                       // material.baseColor = 1 (restir.cu:141)
     f3 wo = splat(0.f);
-    if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); }
+    if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); m.roughness = w4.w; }
 
     Rng rng; rng.x = sp.rngMat[index].x;
     f3 selLi = splat(0.f), selWi = splat(0.f);
     float selDist = 0.f, wsum = 0.f;
     for (int i = 0; i < kReservoirSize; i++) {
         f4 r = rng.uniform4();
-        LightSample c = sample_light_nv<AliasPtr, LightPtr>(alias, lights, s.numLights, pos, r);
+        LightSample c = sample_light_nv<ENV, AliasPtr, LightPtr>(s, alias, lights, s.numLights, pos, r);
         f3 g = c.Li * eval_bsdf(m.type, baseColor, m.metallic, m.roughness, norm, wo, c.wi) * sat_dot(norm, c.wi);
         float weight = luminance(g / c.pdf);
         if (is_nan_or_inf(weight) || c.pdf <= 0.f) weight = 0.f;
@@ -134,11 +144,12 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
     reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;
 }
 
+template <bool ENV>
 __global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
     const int n0 = y0 * width, n1 = y1 * width;
     const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= n1) return;
-    ris_pixel<const AliasRec*, const LightRec*>(s, sp, s.alias, s.lights, index);
+    ris_pixel<ENV, const AliasRec*, const LightRec*>(s, sp, s.alias, s.lights, index);
 }
 
 __global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
@@ -154,7 +165,7 @@ __global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes 
     const int n0 = y0 * width, n1 = y1 * width;
     const int index = n0 + blockIdx.x * kRisThreads + threadIdx.x;
     if (index >= n1) return;
-    ris_pixel<const AliasRec*, const LightRec*>(s, sp, sAlias, sLights, index);
+    ris_pixel<false, const AliasRec*, const LightRec*>(s, sp, sAlias, sLights, index);
 }
 
 // ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------
@@ -177,7 +188,7 @@ __global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes 
     const bool inside = x < g.width && y < y1;
     const int index = inside ? y * g.width + x : 0;
     const float4 pm = inside ? sp.posMat[index] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool shaded = inside && (__float_as_int(pm.w) >> 24) == kKindShaded;
+    const bool shaded = inside && mk_kind(__float_as_int(pm.w)) == kKindShaded;
     float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
     if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
     const f3 pos = mk3(pm.x, pm.y, pm.z);
@@ -351,10 +362,14 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
                                               int x, int y, int index, uint2 rm, f3 albedo, f3 prev) {
     const int W = g.width, H = g.height;
     const int mk = (int)rm.y;
-    const int kind = mk >> 24;
+    const int kind = mk_kind(mk);
 
     f3 direct = splat(0.f);
     if (kind == kKindLight) direct = splat(1.f);               // restir.cu:143-146 (baseColor forced to 1)
+    if (kind == kKindMiss && s.envTex >= 0) {                  // restir.cu:134-136: looked up by k_primary
+        const float4 e = sp.posMat[index];
+        direct = mk3(e.x, e.y, e.z);
+    }
     if (kind == kKindShaded) {
         Rng rng; rng.x = rm.x;
 
@@ -415,13 +430,15 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
                 const float4 a = spatial ? temp.li[src] : own.li[src], b = spatial ? temp.wi[src] : own.wi[src];
                 Li = mk3(a.x, a.y, a.z); wi = mk3(b.x, b.y, b.z);
             }
-            const rs_material m = s.materials[mk & 0xffffff];
+            const int type = mk_type(mk);
             f3 wo = splat(0.f), norm = splat(0.f);
-            if (m.type == 1) {                                         // only the metallic BSDF looks at n and wo
+            float metallic = 0.f, roughness = 0.f;
+            if (type == 1) {                                           // only the metallic BSDF looks at n, wo and the two scalars
                 const float4 w4 = sp.wo[index], n4 = sp.norm[index];
                 wo = mk3(w4.x, w4.y, w4.z); norm = mk3(n4.x, n4.y, n4.z);
+                metallic = n4.w; roughness = w4.w;
             }
-            const f3 LiBSDF = Li * eval_bsdf(m.type, splat(1.f), m.metallic, m.roughness, norm, wo, wi);
+            const f3 LiBSDF = Li * eval_bsdf(type, splat(1.f), metallic, roughness, norm, wo, wi);
             direct = ((LiBSDF / luminance(LiBSDF)) * W0) / (float)M0;       // restir.cu:220-221
         }
         if (any_nan_or_inf(direct)) direct = splat(0.f);
@@ -581,13 +598,18 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     const SurfPlanes sp = surf_of(r);
     const CamParams cp = rs_make_cam_params(cam);
     mark(r, 0);
-    hipLaunchKernelGGL(k_primary, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+    if (scene->textured)
+        hipLaunchKernelGGL(k_primary<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+    else
+        hipLaunchKernelGGL(k_primary<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     mark(r, 1);
     const int npx = (y1 - y0) * W;
-    if (scene->numLights > 0 && scene->numLights <= kRisLdsLights)
+    if (scene->envMapTexId >= 0)       // the environment map is one more light (scene.h:400-403)
+        hipLaunchKernelGGL(k_ris<true>, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+    else if (scene->numLights > 0 && scene->numLights <= kRisLdsLights)
         hipLaunchKernelGGL(k_ris_lds, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), 0, rs_stream(), scene->dev, sp, W, y0, y1);
     else
-        hipLaunchKernelGGL(k_ris, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+        hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
     mark(r, 2);
     hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
                        r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);

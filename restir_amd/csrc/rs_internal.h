@@ -46,6 +46,16 @@ struct rs_scene {
     rs_material* dMaterials = nullptr;
     rs::LightRec* dLights = nullptr;
     rs::AliasRec* dAlias = nullptr;
+    rs::TexRec* dTextures = nullptr;
+    float* dTexcoords = nullptr;
+    rs::AliasRec* dEnvAlias = nullptr;
+    std::vector<float*> dTexData;                 // one device array per texture
+    std::vector<std::vector<float>> hTexData;     // host copies (rs_scene_host_desc)
+    std::vector<rs_texture> hTextures;
+    std::vector<float> hEnvProb;
+    std::vector<int> hEnvFail;
+    int envMapTexId = -1;
+    bool textured = false;                        // any material map or an environment map: kernels take the textured variant
     uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;

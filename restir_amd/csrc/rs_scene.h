@@ -45,16 +45,22 @@ struct __attribute__((aligned(16))) LightRec {
     float Lx, Ly, Lz, pdfArea;
 };
 struct AliasRec { float prob; int failId; };
+struct TexRec { const float* data; int width, height; };       // DevTextureObj (src/image.h:76-97): packed float[3] texels
 
 struct DevScene {
     const BvhNode* nodesAll;      // 6 * bvhSize records (+1 padding record): order k starts at k * bvhSize
     const TriRec*  tris;
     const float*   vertices;
     const float*   normals;
+    const float*   texcoords;     // 6 floats / triangle; null unless the scene has texture maps
     const int*     materialIds;
     const rs_material* materials;
     const LightRec* lights;
     const AliasRec* alias;
+    const TexRec*  textures;      // null unless the scene has texture maps or an environment map
+    const AliasRec* envAlias;     // envMapSampler (src/scene.h:364-376), envLen = width*height of the map, 0 = none
+    int envTex, envLen;           // envMap = textures + envTex (src/scene.cpp:495-498), -1 = none
+    float sumLightPowerInv;       // src/scene.cpp:489
     const uint4*   occNodes;
     const BvhNode* occChain;
     const TriRec*  occTris;
@@ -77,6 +83,7 @@ struct Hit {
     int matId;
     f3  pos;
     f3  norm;
+    float bx, by;     // barycentrics of the hit (for the texture coordinates of textured scenes)
 };
 
 // ---- camera (src/sceneStructs.h:22-86) ---------------------------------------------------------
@@ -623,6 +630,7 @@ __device__ inline Hit trace_closest(const DevScene& s, const Ray& ray) {
     h.matId = 0;
     h.pos = splat(0.f);
     h.norm = splat(0.f);
+    h.bx = w.bx; h.by = w.by;
     if (w.prim != kNullPrim) {             // getIntersecGeomInfo (scene.h:135-151)
         const float* v = s.vertices + (size_t)w.prim * 9;
         const float* n = s.normals + (size_t)w.prim * 9;
@@ -746,6 +754,7 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     h.matId = 0;
     h.pos = splat(0.f);
     h.norm = splat(0.f);
+    h.bx = w.bx; h.by = w.by;
     if (w.prim != kNullPrim) {             // getIntersecGeomInfo (scene.h:135-151)
         const float* v = s.vertices + (size_t)w.prim * 9;
         const float* n = s.normals + (size_t)w.prim * 9;
@@ -816,34 +825,11 @@ struct LightSample { float pdf; f3 Li, wi; float dist; f3 point; int id; };
 // sampleDirectLightNoVisibility; `lights`/`alias` may point to global memory or to an LDS copy.
 // Bit-exact shortcuts: dot(x-y, x-y) == dot(y-x, y-x) and normalize(x-y) == -normalize(y-x), so
 // the pdf conversion (mathUtil.h:182-185) reuses wi and dist instead of re-deriving them.
-template <typename AliasPtr, typename LightPtr>
-__device__ __forceinline__ LightSample sample_light_nv(AliasPtr alias, LightPtr lights, int numLights, f3 pos, f4 r) {
-    LightSample o;
-    o.pdf = kInvalidPdf; o.Li = splat(0.f); o.wi = splat(0.f); o.dist = 0.f; o.point = splat(0.f); o.id = 0;
-    if (numLights == 0) return o;
-    int pass = imin(f2i((float)numLights * r.x), numLights - 1);      // DevDiscreteSampler1D::sample
-    AliasRec al = alias[pass];
-    int id = r.y < al.prob ? pass : al.failId;
-    o.id = id;
-    const float4* lp = reinterpret_cast<const float4*>(&lights[id]);
-    float4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
-    f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
-    f3 nrm = mk3(a.w, b.w, c.w);
-    float sr = sqrtf(r.w);                         // sampleTriangleUniform(v0,v1,v2, ru=r.z, rv=r.w)
-    float u = 1.f - sr;
-    float v = r.z * sr;
-    f3 sampled = v1 * u + v2 * v + v0 * (1.f - u - v);
-    o.point = sampled;
-    f3 toS = sampled - pos;
-    if (dot(nrm, toS) > -1e-6f) return o;          // SCENE_LIGHT_SINGLE_SIDED
-    float dd = dot(toS, toS);
-    float len = sqrtf(dd);
-    o.Li = mk3(d.x, d.y, d.z);
-    o.wi = toS * (1.f / len);
-    o.dist = len;
-    o.pdf = d.w * dd / gabs(-dot(nrm, o.wi));
-    return o;
-}
+template <bool ENV, typename AliasPtr, typename LightPtr>
+__device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasPtr alias, LightPtr lights, int numLights, f3 pos, f4 r);
 #endif
 
 }  // namespace rs
+
+#include "rs_surface.h"
+

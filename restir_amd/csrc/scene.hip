@@ -10,10 +10,16 @@ using namespace rs;
 
 namespace {
 
-int check_materials(int n, const rs_material* m) {
+// Map ids as getTexturedMaterialAndSurface reads them (src/scene.h:78-99): baseColor -1 none / -2 procedural / index;
+// metallic and roughness are used only when > -1; a normal map id other than -1 indexes `textures` directly.
+int check_materials(int n, const rs_material* m, int numTextures, bool* anyMap) {
+    *anyMap = false;
     for (int i = 0; i < n; i++) {
-        if (m[i].baseColorMapId != -1 || m[i].metallicMapId != -1 || m[i].roughnessMapId != -1 || m[i].normalMapId != -1)
-            return rs_fail(RS_ERR_UNSUPPORTED, "material textures are outside the scope of this path (DESIGN.md); map ids must be -1");
+        const int ids[4] = { m[i].baseColorMapId, m[i].metallicMapId, m[i].roughnessMapId, m[i].normalMapId };
+        for (int k = 0; k < 4; k++)
+            if (ids[k] >= numTextures) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: material map id beyond the texture table");
+        if (ids[0] < -2 || ids[3] < -1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: invalid material map id");
+        if (ids[0] != -1 || ids[1] > -1 || ids[2] > -1 || ids[3] != -1) *anyMap = true;
     }
     return 0;
 }
@@ -88,6 +94,8 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
+    rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords);
+    for (float*& p : s->dTexData) rs_dev_free(p);
     delete s;
     return 0;
 }
@@ -100,9 +108,20 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: inconsistent scene description");
     for (int k = 0; k < 6; k++)
         if (!d->bvhNodes[k]) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: missing BVH order");
-    RS_TRY(check_materials(d->numMaterials, d->materials));
+    bool anyMap = false;
+    if (d->numTextures < 0 || (d->numTextures > 0 && !d->textures) || d->envMapTexId < -1 || d->envMapTexId >= d->numTextures)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: inconsistent texture table");
+    for (int i = 0; i < d->numTextures; i++)
+        if (d->textures[i].width <= 0 || d->textures[i].height <= 0 || !d->textures[i].data)
+            return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: empty texture");
+    RS_TRY(check_materials(d->numMaterials, d->materials, d->numTextures, &anyMap));
+    const bool hasEnv = d->envMapTexId >= 0;
+    if (hasEnv && (!d->envMapProb || !d->envMapFailId || d->numLights < 1))
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: an environment map needs its sampler table and its light-sampler entry");
+    if (anyMap && !d->texcoords) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: texture maps need texcoords");
 
     const size_t np = (size_t)d->numPrims, nn = (size_t)d->bvhSize, nl = (size_t)(d->numLights > 0 ? d->numLights : 0);
+    const size_t nlp = nl - (hasEnv ? 1 : 0);          // light primitives; the environment map is the last sampler entry
     rs_scene* s = new rs_scene();
     s->numPrims = d->numPrims; s->bvhSize = d->bvhSize; s->numLights = (int)nl;
     s->sumLightPower = d->sumLightPower;
@@ -114,10 +133,28 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->hBoxes.assign(d->boundingBoxes, d->boundingBoxes + nn * 6);
     for (int k = 0; k < 6; k++) s->hNodes[k].assign(d->bvhNodes[k], d->bvhNodes[k] + nn * 3);
     if (nl) {
-        s->hLightPrimIds.assign(d->lightPrimIds, d->lightPrimIds + nl);
-        s->hLightRadiance.assign(d->lightUnitRadiance, d->lightUnitRadiance + nl * 3);
+        if (nlp) {
+            s->hLightPrimIds.assign(d->lightPrimIds, d->lightPrimIds + nlp);
+            s->hLightRadiance.assign(d->lightUnitRadiance, d->lightUnitRadiance + nlp * 3);
+        }
         s->hLightProb.assign(d->lightProb, d->lightProb + nl);
         s->hLightFailId.assign(d->lightFailId, d->lightFailId + nl);
+    }
+    s->envMapTexId = d->envMapTexId;
+    s->textured = anyMap || hasEnv;
+    s->hTexData.resize((size_t)d->numTextures);
+    s->hTextures.resize((size_t)d->numTextures);
+    for (int i = 0; i < d->numTextures; i++) {
+        const size_t n = (size_t)d->textures[i].width * d->textures[i].height * 3;
+        s->hTexData[i].assign(d->textures[i].data, d->textures[i].data + n);
+        s->hTextures[i] = rs_texture{ d->textures[i].width, d->textures[i].height, s->hTexData[i].data() };
+    }
+    if (hasEnv) {
+        const size_t n = (size_t)d->textures[d->envMapTexId].width * d->textures[d->envMapTexId].height;
+        s->hEnvProb.assign(d->envMapProb, d->envMapProb + n);
+        s->hEnvFail.assign(d->envMapFailId, d->envMapFailId + n);
+        for (size_t i = 0; i < n; i++)
+            if (s->hEnvFail[i] < 0 || (size_t)s->hEnvFail[i] >= n) { delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: environment sampler index out of range"); }
     }
 
     // validate indices the kernels will chase (a bad link would walk off the arrays on the GPU)
@@ -131,7 +168,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
             }
         }
     for (size_t i = 0; i < nl; i++)
-        if (s->hLightPrimIds[i] < 0 || s->hLightPrimIds[i] >= d->numPrims || s->hLightFailId[i] < 0 || s->hLightFailId[i] >= (int)nl) {
+        if ((i < nlp && (s->hLightPrimIds[i] < 0 || s->hLightPrimIds[i] >= d->numPrims)) || s->hLightFailId[i] < 0 || s->hLightFailId[i] >= (int)nl) {
             delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: light table index out of range");
         }
 
@@ -170,6 +207,9 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
         std::vector<AliasRec> al(nl);
         const float sumInv = 1.f / d->sumLightPower;                       // scene.cpp:489
         for (size_t i = 0; i < nl; i++) {
+            al[i].prob = s->hLightProb[i];
+            al[i].failId = s->hLightFailId[i];
+            if (i >= nlp) { rec[i] = LightRec{}; continue; }          // the environment map's sampler entry has no triangle
             const float* t = &s->hVertices[(size_t)s->hLightPrimIds[i] * 9];
             f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
             f3 c = cross(v1 - v0, v2 - v0);
@@ -179,8 +219,6 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
             float power = luminance(Le) / (area * 2.f * kGlmPi);
             rec[i] = LightRec{ v0.x, v0.y, v0.z, nrm.x, v1.x, v1.y, v1.z, nrm.y, v2.x, v2.y, v2.z, nrm.z,
                                Le.x, Le.y, Le.z, power * sumInv };
-            al[i].prob = s->hLightProb[i];
-            al[i].failId = s->hLightFailId[i];
         }
         if (int e = upload(&s->dLights, rec)) { rs_scene_destroy(s); return e; }
         if (int e = upload(&s->dAlias, al)) { rs_scene_destroy(s); return e; }
@@ -189,6 +227,29 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     if (int e = upload(&s->dNormals, s->hNormals)) { rs_scene_destroy(s); return e; }
     if (int e = upload(&s->dMaterialIds, s->hMaterialIds)) { rs_scene_destroy(s); return e; }
     if (int e = upload(&s->dMaterials, s->hMaterials)) { rs_scene_destroy(s); return e; }
+
+    // textures (DevScene::create, src/scene.cpp:479-498)
+    if (!s->hTextures.empty()) {
+        std::vector<TexRec> recs(s->hTextures.size());
+        s->dTexData.assign(s->hTextures.size(), nullptr);
+        for (size_t i = 0; i < s->hTextures.size(); i++) {
+            if (int e = upload(&s->dTexData[i], s->hTexData[i])) { rs_scene_destroy(s); return e; }
+            recs[i] = TexRec{ s->dTexData[i], s->hTextures[i].width, s->hTextures[i].height };
+        }
+        if (int e = upload(&s->dTextures, recs)) { rs_scene_destroy(s); return e; }
+    }
+    if (hasEnv) {
+        std::vector<AliasRec> al(s->hEnvProb.size());
+        for (size_t i = 0; i < al.size(); i++) { al[i].prob = s->hEnvProb[i]; al[i].failId = s->hEnvFail[i]; }
+        if (int e = upload(&s->dEnvAlias, al)) { rs_scene_destroy(s); return e; }
+    }
+    if (s->textured) { if (int e = upload(&s->dTexcoords, s->hTexcoords)) { rs_scene_destroy(s); return e; } }
+    s->dev.texcoords = s->dTexcoords;
+    s->dev.sumLightPowerInv = 1.f / d->sumLightPower;                      // scene.cpp:489
+    s->dev.textures = s->dTextures;
+    s->dev.envAlias = s->dEnvAlias;
+    s->dev.envTex = s->envMapTexId;
+    s->dev.envLen = hasEnv ? (int)s->hEnvProb.size() : 0;
 
     s->dev.nodesAll = s->dNodesAll;
     s->dev.tris = s->dTris;
@@ -250,7 +311,15 @@ extern "C" int rs_debug_walk_stats(rs_scene* s, unsigned long long* out64, int r
 
 extern "C" int rs_scene_build(int numPrims, const float* vertices, const float* normals, const float* texcoords,
                               const int* materialIds, int numMaterials, const rs_material* materials, rs_scene** out) {
+    return rs_scene_build_textured(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials, 0, nullptr, -1, out);
+}
+
+extern "C" int rs_scene_build_textured(int numPrims, const float* vertices, const float* normals, const float* texcoords,
+                                       const int* materialIds, int numMaterials, const rs_material* materials,
+                                       int numTextures, const rs_texture* textures, int envMapTexId, rs_scene** out) {
     if (!out) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_build: null output");
+    if (numTextures < 0 || (numTextures > 0 && !textures) || envMapTexId < -1 || envMapTexId >= numTextures)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_build: inconsistent texture table");
     *out = nullptr;
     if (numPrims <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_build: no mesh data");   // scene.cpp:192-195
     const size_t np = (size_t)numPrims, nn = 2 * np - 1;
@@ -260,6 +329,22 @@ extern "C" int rs_scene_build(int numPrims, const float* vertices, const float* 
     std::vector<float> lightRad(np * 3), lightPower(np);
     RS_TRY(rs_build_light_table(numPrims, vertices, materialIds, numMaterials, materials, &numLights,
                                 lightPrim.data(), lightRad.data(), lightPower.data()));
+    // Scene::createLightSampler (src/scene.cpp:136-157): the environment map, if any, is one more light
+    std::vector<float> envProb;
+    std::vector<int> envFail;
+    if (envMapTexId >= 0) {
+        const rs_texture& env = textures[envMapTexId];
+        if (env.width <= 0 || env.height <= 0 || !env.data) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_build: empty environment map");
+        const size_t n = (size_t)env.width * env.height;
+        std::vector<float> pdf(n);
+        RS_TRY(rs_build_envmap_pdf(env.width, env.height, env.data, pdf.data()));
+        envProb.resize(n); envFail.resize(n);
+        float envSum = 0.f;
+        RS_TRY(rs_build_alias_table((int)n, pdf.data(), envProb.data(), envFail.data(), &envSum));
+        lightPower.resize((size_t)numLights + 1);
+        lightPower[(size_t)numLights] = envSum;
+        numLights++;
+    }
     std::vector<float> prob((size_t)numLights);
     std::vector<int> fail((size_t)numLights);
     float sumAll = 0.f;
@@ -280,6 +365,8 @@ extern "C" int rs_scene_build(int numPrims, const float* vertices, const float* 
     for (int k = 0; k < 6; k++) d.bvhNodes[k] = nodes[k].data();
     d.numLights = numLights; d.lightPrimIds = lightPrim.data(); d.lightUnitRadiance = lightRad.data();
     d.lightProb = prob.data(); d.lightFailId = fail.data(); d.sumLightPower = sumAll;
+    d.numTextures = numTextures; d.textures = textures; d.envMapTexId = envMapTexId;
+    d.envMapProb = envProb.empty() ? nullptr : envProb.data(); d.envMapFailId = envFail.empty() ? nullptr : envFail.data();
     return rs_scene_create(&d, out);
 }
 
@@ -294,6 +381,8 @@ extern "C" int rs_scene_host_desc(const rs_scene* s, rs_scene_desc* d) {
     d->numLights = s->numLights; d->lightPrimIds = s->hLightPrimIds.data();
     d->lightUnitRadiance = s->hLightRadiance.data(); d->lightProb = s->hLightProb.data();
     d->lightFailId = s->hLightFailId.data(); d->sumLightPower = s->sumLightPower;
+    d->numTextures = (int)s->hTextures.size(); d->textures = s->hTextures.data(); d->envMapTexId = s->envMapTexId;
+    d->envMapProb = s->hEnvProb.data(); d->envMapFailId = s->hEnvFail.data();
     return 0;
 }
 

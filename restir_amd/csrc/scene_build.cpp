@@ -218,6 +218,17 @@ extern "C" int rs_build_light_table(int numPrims, const float* vertices, const i
     return 0;
 }
 
+// pdf of Scene::createLightSampler's environment-map sampler (src/scene.cpp:139-146); host code in the reference too
+extern "C" int rs_build_envmap_pdf(int width, int height, const float* data, float* pdf) {
+    if (width <= 0 || height <= 0 || !data || !pdf) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_build_envmap_pdf: bad argument");
+    for (int i = 0; i < height; i++)
+        for (int j = 0; j < width; j++) {
+            const int idx = i * width + j;
+            pdf[idx] = luminance(ld3(data + (size_t)idx * 3)) * sinf((.5f + (float)i) / (float)height * kPi);
+        }
+    return 0;
+}
+
 extern "C" int rs_camera_update(rs_camera* c) {
     if (!c) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_camera_update: null camera");
     float yaw = radians(c->rotation[0]);

@@ -76,6 +76,14 @@ struct Scene {
                       const int* materialIds, int numMaterials, const Material* materials) {
         rsc::check(rs_scene_build(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials, &devScene), "Dev Scene");
     }
+    // the same with the decoded images of Scene::textures and Scene::envMapTexId (src/scene.h:518-521;
+    // createLightSampler's environment-map sampler, src/scene.cpp:136-152, is built by the library)
+    void buildDevData(int numPrims, const float* vertices, const float* normals, const float* texcoords,
+                      const int* materialIds, int numMaterials, const Material* materials,
+                      int numTextures, const rs_texture* textures, int envMapTexId) {
+        rsc::check(rs_scene_build_textured(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials,
+                                           numTextures, textures, envMapTexId, &devScene), "Dev Scene");
+    }
     void clear() { rs_scene_destroy(devScene); devScene = nullptr; }     // src/scene.cpp:217-220
 };
 

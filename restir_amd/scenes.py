@@ -79,11 +79,13 @@ class TriangleSoup:
 
 
 class SceneData:
-    def __init__(self, name, soup, materials, camera_args):
+    def __init__(self, name, soup, materials, camera_args, textures=(), env_map_tex=-1):
         self.name = name
         self.vertices, self.normals, self.texcoords, self.material_ids = soup.finish()
         self.materials = materials
         self.camera_args = camera_args       # dict(position=, rotation=, fov_y=, focal_dist=)
+        self.textures = list(textures)       # (H, W, 3) float32 linear-RGB images (what Image holds, src/image.h)
+        self.env_map_tex = env_map_tex       # Scene::envMapTexId
 
     @property
     def num_prims(self):
@@ -134,6 +136,61 @@ def cornell_box():
     s.add_quad((-0.25, 1.98, -0.25), (0.25, 1.98, -0.25), (0.25, 1.98, 0.25), (-0.25, 1.98, 0.25), 3)
     assert s.count() == 36
     return SceneData("cornell", s, mats, dict(position=(0.0, 1.0, 3.5), rotation=(-90.0, 0.0, 0.0), fov_y=19.5, focal_dist=1.0))
+
+
+def cornell_textured(seed=3, env=True):
+    """The Cornell box of config 1/2 with everything getTexturedMaterialAndSurface and the environment-map light
+    can do (src/scene.h:78-99,358-403): a base-colour map, the procedural texture, metallic / roughness / normal
+    maps on a MetallicWorkflow box, a normal map on a Lambertian box, and (env=True) an HDR environment map with a
+    small bright sun that is visible through the open front and is the last entry of the light sampler.
+    Texture coordinates are a planar projection that leaves [0,1] (exercises the wrap of linearSample)."""
+    base = cornell_box()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    checker = np.indices((16, 32)).sum(0) % 2
+    tex_base = (0.25 + 0.6 * checker[..., None] * np.array([1.0, 0.9, 0.7]) + 0.1 * rng.uniform(size=(16, 32, 3))).astype(np.float32)
+    tex_metal = np.repeat(rng.uniform(0.0, 1.0, (16, 16, 1)), 3, axis=2).astype(np.float32)
+    tex_rough = np.repeat(rng.uniform(0.15, 0.9, (8, 8, 1)), 3, axis=2).astype(np.float32)
+    bump = rng.uniform(-0.2, 0.2, (16, 16, 2))
+    tex_normal = np.concatenate([0.5 + bump, np.full((16, 16, 1), 1.0)], axis=2).astype(np.float32)
+    textures = [tex_base, tex_metal, tex_rough, tex_normal]
+    env_id = -1
+    if env:
+        h, w = 32, 64
+        yy, xx = np.mgrid[0:h, 0:w]
+        sky = 0.3 + 0.4 * (1.0 - yy / h)
+        envmap = np.stack([sky * 0.6, sky * 0.8, sky * 1.0], axis=2)
+        envmap[6:9, 14:18] = (60.0, 55.0, 40.0)                   # the sun
+        envmap += 0.02 * rng.uniform(size=envmap.shape)
+        textures.append(envmap.astype(np.float32))
+        env_id = len(textures) - 1
+    mats = make_materials([
+        dict(type=LAMBERTIAN, baseColor=(0.73, 0.73, 0.73)),                       # 0 walls: base-colour map
+        dict(type=LAMBERTIAN, baseColor=(0.65, 0.05, 0.05)),                       # 1 red wall: procedural texture
+        dict(type=LAMBERTIAN, baseColor=(0.12, 0.45, 0.15)),                       # 2 green wall: plain
+        dict(type=LIGHT, baseColor=(10.0, 10.0, 10.0)),                            # 3 light
+        dict(type=METALLIC_WORKFLOW, baseColor=(0.9, 0.8, 0.5), metallic=0.5, roughness=0.4),   # 4 tall box: all maps
+        dict(type=LAMBERTIAN, baseColor=(0.7, 0.7, 0.9)),                          # 5 short box: normal map only
+    ])
+    mats[0]["baseColorMapId"] = 0
+    mats[1]["baseColorMapId"] = -2
+    mats[4]["baseColorMapId"] = 0; mats[4]["metallicMapId"] = 1; mats[4]["roughnessMapId"] = 2; mats[4]["normalMapId"] = 3
+    mats[5]["normalMapId"] = 3
+    sd = SceneData.__new__(SceneData)
+    sd.name = "cornell_textured"
+    sd.vertices, sd.normals, sd.material_ids = base.vertices, base.normals, base.material_ids.copy()
+    # triangles 10..21 = tall box, 22..33 = short box (cornell_box order: 5 quads, 2 boxes, light)
+    sd.material_ids[10:22] = 4
+    sd.material_ids[22:34] = 5
+    v = sd.vertices
+    t = np.zeros((v.shape[0], 3, 2), np.float32)
+    t[:, :, 0] = v[:, :, 0] * 0.7 + v[:, :, 2] * 0.3 + 0.13
+    t[:, :, 1] = v[:, :, 1] * 0.6 - v[:, :, 2] * 0.2 - 0.21
+    sd.texcoords = np.ascontiguousarray(t)
+    sd.materials = mats
+    sd.camera_args = dict(base.camera_args, fov_y=27.0)      # wide enough to see past the box: environment-map pixels
+    sd.textures = textures
+    sd.env_map_tex = env_id
+    return sd
 
 
 def _column(soup, cx, cz, radius, height, nseg, nring, mat, flute=0.03):

@@ -27,12 +27,22 @@ def mismatch_fraction(a, b):
 
 
 def oracle_scene(sd):
-    return ob.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+    return ob.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials,
+                    textures=sd.textures, env_map_tex=sd.env_map_tex)
+
+
+def hip_scene(capi, sd):
+    return capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials,
+                      textures=sd.textures, env_map_tex=sd.env_map_tex)
 
 
 def get_scene(name):
     if name == "cornell":
         return scenes.cornell_box()
+    if name == "cornell_textured":
+        return scenes.cornell_textured(env=True)
+    if name == "cornell_maps":
+        return scenes.cornell_textured(env=False)
     if name.startswith("sponza"):
         return scenes.sponza_class(1, float(name.split(":")[1]))
     if name.startswith("bistro"):
@@ -78,7 +88,7 @@ class HipRenderer:
         self.torch = torch
         self.capi = capi
         self.sd = sd
-        self.scene = scene or capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+        self.scene = scene or hip_scene(capi, sd)
         self.W, self.H = width, height
         self.cam = capi.camera_update(sd.camera(width, height))
         self.gbuf = capi.GBuffer(width, height)

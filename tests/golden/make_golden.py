@@ -3,7 +3,7 @@
 
 Expected outputs come from
   * oracle/_ref/libref_subset.so : the reference's own functions compiled from /root/reference/src
-    (intersectTriangle, AABB::intersect, BVHBuilder::build, Camera::*, Material::BSDF, Math::*);
+    (intersectTriangle, AABB::intersect, BVHBuilder::build, Camera::*, Material::BSDF, Math::*, linearSample);
   * oracle/_ref/libthrust_probe.so : rocThrust's minstd_rand + uniform_real_distribution<float>.
 Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
 The GPU box has no /root/reference; tests/test_oracle_golden.py replays these vectors there and here.
@@ -118,6 +118,21 @@ def main():
         bb, nn = ob.bvh_build(v, R.ref_bvh_build)
         g.update({f"bvh_{name}_verts": v, f"bvh_{name}_boxes": bb, f"bvh_{name}_nodes": nn})
 
+    # image.h linearSample, mathUtil.h toSphere / toPlane / localToWorld (the texture and environment-map paths)
+    tex = rng.uniform(0, 2, (13, 21, 3)).astype(np.float32)
+    uv = rng.uniform(-3, 3, (3000, 2)).astype(np.float32)
+    uv[:200] = rng.integers(-2, 3, (200, 2)).astype(np.float32)                     # texel borders / wrap
+    uv[200:400] = (rng.integers(0, 21, (200, 2)) / np.float32(21)).astype(np.float32)
+    ls = np.zeros((len(uv), 3), np.float32); R.ref_linear_sample(21, 13, tex.reshape(-1), len(uv), uv.reshape(-1), ls.reshape(-1))
+    u01 = rng.uniform(0, 1, (3000, 2)).astype(np.float32)
+    sph = np.zeros((len(u01), 3), np.float32); R.ref_to_sphere(len(u01), u01.reshape(-1), sph.reshape(-1))
+    dirs = unit(rng, 3000); dirs[:50, 0] = 0; dirs[50:100, 2] = 0; dirs[100:150] = [0, 1, 0]; dirs[150:200] = [0, -1, 0]
+    pl = np.zeros((len(dirs), 2), np.float32); R.ref_to_plane(len(dirs), dirs.reshape(-1), pl.reshape(-1))
+    nn_ = unit(rng, 3000); nn_[:50] = [0, 1, 0]; nn_[50:100] = [0, -1, 0]
+    lv = rng.uniform(-1, 1, (3000, 3)).astype(np.float32)
+    l2w = np.zeros((3000, 3), np.float32); R.ref_local_to_world(3000, nn_.reshape(-1), lv.reshape(-1), l2w.reshape(-1))
+    g.update(tex=tex, tex_uv=uv, tex_sample=ls, sph_uv=u01, sph_dir=sph, plane_dir=dirs, plane_uv=pl, l2w_n=nn_, l2w_v=lv, l2w_out=l2w)
+
     np.savez_compressed(os.path.join(OUT, "functions_ref.npz"), **g)
     print("functions_ref.npz", os.path.getsize(os.path.join(OUT, "functions_ref.npz")), "bytes,", len(g), "arrays")
 
@@ -136,6 +151,15 @@ def main():
     o.gbuf.c.frameIdx ^= 1
     fr["cornell64_gbuf_id"] = o.gbuf.prim_id[o.gbuf.frame_idx].copy()
     fr["cornell64_gbuf_depth"] = o.gbuf.depth[o.gbuf.frame_idx].copy()
+    for name in ("cornell_textured", "cornell_maps"):      # texture / environment-map paths, both libm modes
+        for mode in (0, 1):
+            ob.set_libm_mode(mode)
+            o = OracleRenderer(get_scene(name), 64, 48)
+            for frame in range(2):
+                img = o.frame(3)
+            fr[f"{name}_libm{mode}_frame1"] = img.copy()
+            fr[f"{name}_libm{mode}_albedo"] = o.gbuf.albedo.copy()
+    ob.set_libm_mode(0)
     np.savez_compressed(os.path.join(OUT, "frames_oracle.npz"), **fr)
     print("frames_oracle.npz", os.path.getsize(os.path.join(OUT, "frames_oracle.npz")), "bytes")
 

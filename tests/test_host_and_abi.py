@@ -44,6 +44,23 @@ def test_scene_build_matches_oracle(name):
     assert bits_equal(aa[0], ab[0]) and np.array_equal(aa[1], ab[1]) and aa[2] == ab[2]
 
 
+def test_environment_map_sampler_build_matches_oracle():
+    """Scene::createLightSampler (src/scene.cpp:136-157): pdf = lum * sin(theta) per texel, alias table over it, and
+    the map's total as one more entry of the light sampler."""
+    sd = get_scene("cornell_textured")
+    env = sd.textures[sd.env_map_tex]
+    pa, pb = capi.build_envmap_pdf(env), ob.envmap_pdf(env)
+    assert bits_equal(pa, pb) and pa.shape == (env.shape[0] * env.shape[1],)
+    aa, ab = capi.build_alias_table(pa), ob.alias_build(pb)
+    assert bits_equal(aa[0], ab[0]) and np.array_equal(aa[1], ab[1]) and aa[2] == ab[2]
+    osc = ob.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials, textures=sd.textures, env_map_tex=sd.env_map_tex)
+    la = capi.build_light_table(sd.vertices, sd.material_ids, sd.materials)
+    power = np.concatenate([la[2], [aa[2]]]).astype(np.float32)
+    al = capi.build_alias_table(power)
+    assert bits_equal(al[0], osc.light_prob) and np.array_equal(al[1], osc.light_fail) and al[2] == osc.sum_power
+    assert len(osc.light_prob) == len(osc.light_prim_ids) + 1
+
+
 def test_bvh_degenerate_inputs():
     rng = np.random.default_rng(3)
     one = rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32)
@@ -100,6 +117,24 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("a GPU is present")
     with pytest.raises(capi.RestirHipError):
         capi.init(0)
+
+
+def test_texture_table_is_validated_before_any_device_work():
+    """Map ids a material may carry (src/scene.h:78-99) are checked on the host; the errors need no GPU."""
+    sd = get_scene("cornell_maps")
+    ok = dict(vertices=sd.vertices, normals=sd.normals, texcoords=sd.texcoords, material_ids=sd.material_ids)
+
+    def build(mats, textures, env=-1):
+        return capi.Scene(ok["vertices"], ok["normals"], ok["texcoords"], ok["material_ids"], mats, textures=textures, env_map_tex=env)
+
+    bad = sd.materials.copy(); bad[0]["baseColorMapId"] = len(sd.textures)          # beyond the table
+    with pytest.raises(capi.RestirHipError, match="texture table"):
+        build(bad, sd.textures)
+    bad = sd.materials.copy(); bad[5]["normalMapId"] = -2                            # ProceduralTexId is not a normal map
+    with pytest.raises(capi.RestirHipError, match="map id"):
+        build(bad, sd.textures)
+    with pytest.raises(capi.RestirHipError, match="texture table"):
+        build(sd.materials, sd.textures, env=len(sd.textures))                       # environment map id out of range
 
 
 def test_procedural_scene_budgets():

@@ -96,6 +96,23 @@ def test_math_helpers(g):
     assert bits_equal(area, g["tri_area"]) and bits_equal(nrm, g["tri_normal"]) and bits_equal(pdf, g["tri_pdf"])
 
 
+def test_texture_and_environment_helpers(g):
+    """image.h linearSample and mathUtil.h toSphere / toPlane / localToWorld against the reference's own code
+    (default libm mode = glibc, which is what the reference's host-compiled functions call)."""
+    assert bits_equal(ob.linear_sample(g["tex"], g["tex_uv"]), g["tex_sample"])
+    assert bits_equal(ob.to_sphere(g["sph_uv"]), g["sph_dir"])
+    assert bits_equal(ob.to_plane(g["plane_dir"]), g["plane_uv"])
+    assert bits_equal(ob.local_to_world(g["l2w_n"], g["l2w_v"]), g["l2w_out"])
+    # the correctly rounded mode differs from glibc by at most one ulp, and only for a small fraction of arguments
+    ob.set_libm_mode(1)
+    try:
+        d = ob.to_sphere(g["sph_uv"])
+    finally:
+        ob.set_libm_mode(0)
+    ulp = np.abs(d.view(np.int32).astype(np.int64) - g["sph_dir"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 4 and (ulp > 0).mean() < 0.1
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_tonemap(g, mode):
     o = np.zeros_like(g["tonemap_in"])
@@ -122,6 +139,17 @@ def test_frames_regression_pin():
         assert np.array_equal(o.restir.last["numSamples"], fr[f"cornell64_reuse{reuse}_M"])
     o = OracleRenderer(sd, 64, 64)
     assert bits_equal(o.frame(0, use_reservoir=False), fr["cornell64_ptdirect"])
+    for name in ("cornell_textured", "cornell_maps"):
+        for mode in (0, 1):
+            ob.set_libm_mode(mode)
+            try:
+                o = OracleRenderer(get_scene(name), 64, 48)
+                for _ in range(2):
+                    img = o.frame(3)
+            finally:
+                ob.set_libm_mode(0)
+            assert bits_equal(img, fr[f"{name}_libm{mode}_frame1"]), (name, mode)
+            assert bits_equal(o.gbuf.albedo, fr[f"{name}_libm{mode}_albedo"]), (name, mode)
 
 
 def test_config1_cornell_256_host_loop():

@@ -101,3 +101,26 @@ def test_camera():
         ob.lib().orc_camera_sample(C.byref(b), k, xy.reshape(-1), r4.reshape(-1), ra.reshape(-1))
         R.ref_camera_sample(C.byref(b), k, xy.reshape(-1), r4.reshape(-1), rb.reshape(-1))
         assert bits_equal(ra, rb)
+
+
+@needs_ref
+def test_texture_and_environment_helpers():
+    """image.h linearSample (through DevTextureObj) and mathUtil.h toSphere / toPlane / localToWorld, 2e5 inputs each."""
+    rng = np.random.default_rng(5)
+    tex = rng.uniform(0, 2, (37, 53, 3)).astype(np.float32)
+    uv = rng.uniform(-3, 3, (200000, 2)).astype(np.float32)
+    uv[:1000] = rng.integers(-2, 3, (1000, 2)).astype(np.float32)
+    uv[1000:2000] = (rng.integers(0, 53, (1000, 2)) / np.float32(53)).astype(np.float32)
+    b = np.zeros((len(uv), 3), np.float32); R.ref_linear_sample(53, 37, tex.reshape(-1), len(uv), uv.reshape(-1), b.reshape(-1))
+    assert bits_equal(ob.linear_sample(tex, uv), b)
+    u2 = rng.uniform(0, 1, (200000, 2)).astype(np.float32)
+    b = np.zeros((len(u2), 3), np.float32); R.ref_to_sphere(len(u2), u2.reshape(-1), b.reshape(-1))
+    assert bits_equal(ob.to_sphere(u2), b)
+    d = rng.normal(size=(200000, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:100, 0] = 0; d[100:200, 2] = 0; d[200:300] = [0, 1, 0]
+    b = np.zeros((len(d), 2), np.float32); R.ref_to_plane(len(d), d.reshape(-1), b.reshape(-1))
+    assert bits_equal(ob.to_plane(d), b)
+    n = rng.normal(size=(200000, 3)).astype(np.float32); n /= np.linalg.norm(n, axis=1, keepdims=True); n[:100] = [0, 1, 0]
+    v = rng.uniform(-1, 1, (200000, 3)).astype(np.float32)
+    b = np.zeros((len(n), 3), np.float32); R.ref_local_to_world(len(n), n.reshape(-1), v.reshape(-1), b.reshape(-1))
+    assert bits_equal(ob.local_to_world(n, v), b)
