@@ -249,6 +249,11 @@ int  rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* de
 /* ---- display conversion (src/pathtrace.h:8) ---------------------------------------------- */
 /* copyImageToPBO(uchar4*, glm::vec3*, w, h, toneMapping, scale) (src/pathtrace.cu:108-113) */
 int  rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int height, int toneMapping, float scale);
+/* the debug-view overloads copyImageToPBO(uchar4*, glm::vec2* / float* / int*, w, h) (src/pathtrace.h:9-11,
+ * src/pathtrace.cu:58-106,115-134): gamma only; the int form shows a pixel-index plane such as devMotion */
+int  rs_copy_image2_to_pbo(void* devPBO, const float* devImage, int width, int height);
+int  rs_copy_imagef_to_pbo(void* devPBO, const float* devImage, int width, int height);
+int  rs_copy_imagei_to_pbo(void* devPBO, const int* devImage, int width, int height);
 
 /* ---- EAW denoiser (src/denoiser.h:33-43,72-74) -------------------------------------------- */
 int  rs_eaw_create(int width, int height, int level, rs_eaw** f);   /* LeveledEAWFilter::create */

@@ -135,6 +135,7 @@ def lib():
         C.c_int, C.c_int, C.c_int, C.c_int,
     ]
     L.orc_send_image_to_pbo.argtypes = [C.c_int, C.c_int, f32p, C.c_int, C.c_float, u8p]
+    L.orc_send_debug_to_pbo.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, u8p]
     L.orc_eaw_level.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_int]
     L.orc_eaw_filter.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, f32p]
     L.orc_eaw_filter.restype = C.c_void_p
@@ -402,6 +403,14 @@ def pt_direct(scene, cam, direct_illum, iter_, looper):
 def send_image_to_pbo(image, w, h, tone_mapping, scale=1.0):
     out = np.zeros((h * w, 4), np.uint8)
     lib().orc_send_image_to_pbo(w, h, np.ascontiguousarray(image, np.float32).reshape(-1), tone_mapping, scale, out.reshape(-1))
+    return out
+
+
+def send_debug_to_pbo(image, w, h, kind):
+    """kind 0: (N,2) float32, 1: (N,) float32, 2: (N,) int32 pixel indices (pathtrace.cu:58-106)."""
+    image = np.ascontiguousarray(image, np.int32 if kind == 2 else np.float32)
+    out = np.zeros((h * w, 4), np.uint8)
+    lib().orc_send_debug_to_pbo(w, h, image.ctypes.data_as(C.c_void_p), kind, out.reshape(-1))
     return out
 
 

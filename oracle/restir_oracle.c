@@ -1197,6 +1197,26 @@ void orc_send_image_to_pbo(int w, int h, const float* image, int toneMapping, fl
     }
 }
 
+/* pathtrace.cu:58-106: the vec2 / float / int overloads (kind 0 / 1 / 2): correctGamma only.  The int form turns a
+ * pixel index into (idx % width, idx / HEIGHT) / (width, height) -- `/ height` as written in the reference (:100). */
+void orc_send_debug_to_pbo(int w, int h, const void* image, int kind, unsigned char* rgba) {
+    for (int i = 0; i < w * h; i++) {
+        v3 color;
+        if (kind == 0) color = V3(((const float*)image)[2 * i], ((const float*)image)[2 * i + 1], 0.f);
+        else if (kind == 1) color = v3s(((const float*)image)[i]);
+        else {
+            int v = ((const int*)image)[i];
+            int px = v % w, py = v / h;
+            color = V3((float)px / (float)w, (float)py / (float)h, 0.f);
+        }
+        color = tonemap(color, 0);                      /* mode 0 = Math::correctGamma only */
+        rgba[4 * i + 0] = (unsigned char)i_clamp(f2i(color.x * 255.f), 0, 255);
+        rgba[4 * i + 1] = (unsigned char)i_clamp(f2i(color.y * 255.f), 0, 255);
+        rgba[4 * i + 2] = (unsigned char)i_clamp(f2i(color.z * 255.f), 0, 255);
+        rgba[4 * i + 3] = 0;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * EAW a-trous (denoiser.cu:18-24,64-134,463-477), modulate / add (denoiser.cu:218-248)
  * ---------------------------------------------------------------------------------------- */

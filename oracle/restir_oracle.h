@@ -228,6 +228,9 @@ void  orc_restir_phase_b(void* state, const orc_scene* s, const orc_camera* cam,
 void orc_send_image_to_pbo(int w, int h, const float* image, int toneMapping, float scale,
                            unsigned char* rgba);
 
+/* src/pathtrace.cu:58-106: the vec2 (kind 0) / float (1) / int (2) overloads of sendImageToPBO */
+void orc_send_debug_to_pbo(int w, int h, const void* image, int kind, unsigned char* rgba);
+
 /* src/denoiser.cu:64-134: one EAW level */
 void orc_eaw_level(const orc_gbuffer* g, const orc_camera* cam, const float* colorIn,
                    float* colorOut, float sigDepth, float sigNormal, float sigLumin, int level);

@@ -72,7 +72,7 @@ EXPORTS = [
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
     "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
-    "rs_copy_image_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
+    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
 ]
 
@@ -146,6 +146,8 @@ def lib():
     L.rs_restir_enable_timing.argtypes = [vp, ci]
     L.rs_path_trace_direct.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, C.POINTER(C.c_ulonglong)]
     L.rs_copy_image_to_pbo.argtypes = [vp, vp, ci, ci, ci, cf]
+    for name in ("rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo"):
+        getattr(L, name).argtypes = [vp, vp, ci, ci]
     L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
     L.rs_eaw_destroy.argtypes = [vp]
     L.rs_eaw_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
@@ -504,6 +506,12 @@ def path_trace_direct(scene, cam, dev_direct_illum_ptr, iter_, looper):
 
 def copy_image_to_pbo(dev_pbo_ptr, dev_image_ptr, width, height, tone_mapping, scale=1.0):
     check(lib().rs_copy_image_to_pbo(dev_pbo_ptr, dev_image_ptr, width, height, tone_mapping, scale))
+
+
+def copy_debug_image_to_pbo(dev_pbo_ptr, dev_image_ptr, width, height, kind):
+    """The vec2 (kind 0) / float (1) / int (2) overloads of copyImageToPBO."""
+    fn = (lib().rs_copy_image2_to_pbo, lib().rs_copy_imagef_to_pbo, lib().rs_copy_imagei_to_pbo)[kind]
+    check(fn(dev_pbo_ptr, dev_image_ptr, width, height))
 
 
 def trace_closest(scene, rays_t):

@@ -94,7 +94,34 @@ __global__ void __launch_bounds__(256) k_send_image_to_pbo(uchar4* __restrict__ 
                          (unsigned char)iclamp(f2i(c.z * 255.f), 0, 255), 0);
 }
 
+// The debug-view overloads (pathtrace.cu:58-106): gamma only, no tone map.  kind 0: vec2 image -> (x, y, 0);
+// kind 1: float image -> grey; kind 2: int image (a pixel index, e.g. devMotion) -> (idx % width, idx / HEIGHT) / (width, height)
+// -- the reference divides by height where the row length is width (pathtrace.cu:100); kept as is.
+__global__ void __launch_bounds__(256) k_send_debug_to_pbo(uchar4* __restrict__ pbo, const void* __restrict__ image,
+                                                            int width, int height, int kind) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    f3 c;
+    if (kind == 0) { const float* p = (const float*)image + (size_t)i * 2; c = mk3(p[0], p[1], 0.f); }
+    else if (kind == 1) c = splat(((const float*)image)[i]);
+    else {
+        const int v = ((const int*)image)[i];
+        const int px = v % width, py = v / height;
+        c = mk3((float)px / (float)width, (float)py / (float)height, 0.f);
+    }
+    c = mk3(gamma_pow(c.x), gamma_pow(c.y), gamma_pow(c.z));
+    pbo[i] = make_uchar4((unsigned char)iclamp(f2i(c.x * 255.f), 0, 255), (unsigned char)iclamp(f2i(c.y * 255.f), 0, 255),
+                         (unsigned char)iclamp(f2i(c.z * 255.f), 0, 255), 0);
+}
+
 unsigned long long* g_ptRayCount = nullptr;
+
+int copy_debug(void* devPBO, const void* devImage, int width, int height, int kind) {
+    if (!devPBO || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "copyImageToPBO: bad argument");
+    const int n = width * height;
+    hipLaunchKernelGGL(k_send_debug_to_pbo, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, width, height, kind);
+    return rs_after_launch("copyImageToPBO");
+}
 
 }  // namespace
 
@@ -132,5 +159,9 @@ int rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int hei
     hipLaunchKernelGGL(k_send_image_to_pbo, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
     return rs_after_launch("copyImageToPBO");
 }
+
+int rs_copy_image2_to_pbo(void* devPBO, const float* devImage, int width, int height) { return copy_debug(devPBO, devImage, width, height, 0); }
+int rs_copy_imagef_to_pbo(void* devPBO, const float* devImage, int width, int height) { return copy_debug(devPBO, devImage, width, height, 1); }
+int rs_copy_imagei_to_pbo(void* devPBO, const int* devImage, int width, int height) { return copy_debug(devPBO, devImage, width, height, 2); }
 
 }  // extern "C"

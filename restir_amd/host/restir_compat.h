@@ -126,6 +126,17 @@ struct uchar4_t { unsigned char x, y, z, w; };
 inline void copyImageToPBO(void* devPBO, rsc::vec3* devImage, int width, int height, int toneMapping, float scale = 1.f) {
     rsc::check(rs_copy_image_to_pbo(devPBO, reinterpret_cast<const float*>(devImage), width, height, toneMapping, scale), "copyImageToPBO");
 }
+// the debug-view overloads (src/pathtrace.h:9-11); vec2 is two packed floats
+namespace rsc { struct vec2 { float x, y; }; }
+inline void copyImageToPBO(void* devPBO, rsc::vec2* devImage, int width, int height) {
+    rsc::check(rs_copy_image2_to_pbo(devPBO, reinterpret_cast<const float*>(devImage), width, height), "copyImageToPBO");
+}
+inline void copyImageToPBO(void* devPBO, float* devImage, int width, int height) {
+    rsc::check(rs_copy_imagef_to_pbo(devPBO, devImage, width, height), "copyImageToPBO");
+}
+inline void copyImageToPBO(void* devPBO, int* devImage, int width, int height) {
+    rsc::check(rs_copy_imagei_to_pbo(devPBO, devImage, width, height), "copyImageToPBO");
+}
 
 // ---- src/denoiser.h:33-43,72-74 -------------------------------------------------------------------------
 struct LeveledEAWFilter {

@@ -381,6 +381,23 @@ def test_copy_image_to_pbo(hip, mode):
     assert np.mean(diff > 0) <= 1e-4
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_copy_debug_image_to_pbo(hip, kind):
+    """The vec2 / float / int overloads of copyImageToPBO (pathtrace.cu:58-106), e.g. the motion-vector view."""
+    import torch
+    rng = np.random.default_rng(8 + kind)
+    W, H = 200, 100
+    if kind == 2:
+        img = rng.integers(-1, W * H, W * H).astype(np.int32)                 # devMotion holds pixel indices or -1
+    else:
+        img = rng.uniform(-0.2, 1.5, (W * H, 2) if kind == 0 else (W * H,)).astype(np.float32)
+    ref = ob.send_debug_to_pbo(img, W, H, kind)
+    out = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")
+    hip.copy_debug_image_to_pbo(out.data_ptr(), torch.from_numpy(img).cuda().data_ptr(), W, H, kind)
+    diff = np.abs(ref.astype(np.int32) - out.cpu().numpy().astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff > 0) <= 1e-4
+
+
 def test_eaw_filter(hip):
     import torch
     sd = get_scene("sponza:0.03")
