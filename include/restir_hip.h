@@ -107,6 +107,7 @@ typedef struct rs_scene   rs_scene;    /* = Scene::devScene / DevScene      (src
 typedef struct rs_gbuffer rs_gbuffer;  /* = GBuffer                          (src/gbuffer.h:15-59) */
 typedef struct rs_restir  rs_restir;   /* = module statics of restir.cu      (src/restir.cu:8-18)  */
 typedef struct rs_eaw     rs_eaw;      /* = LeveledEAWFilter                 (src/denoiser.h:33-43) */
+typedef struct rs_svgf    rs_svgf;     /* = SpatioTemporalFilter             (src/denoiser.h:45-70) */
 
 /* Device pointers of a GBuffer's planes (src/gbuffer.h:41-58). */
 typedef struct rs_gbuffer_view {
@@ -261,6 +262,27 @@ int  rs_eaw_destroy(rs_eaw* f);
 /* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
  * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
 int  rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);
+/* ---- SVGF (src/denoiser.h:45-70) ---------------------------------------------------------- */
+/* SpatioTemporalFilter::create / destroy (src/denoiser.cu:479-504); wavelet sigmas 4 / 128 / 1 as in the reference */
+int  rs_svgf_create(int width, int height, int level, rs_svgf** f);
+int  rs_svgf_destroy(rs_svgf* f);
+/* SpatioTemporalFilter::filter (src/denoiser.cu:532-564): temporal accumulation (alpha .2), variance estimate, five
+ * variance-guided a-trous levels.  *devColorOut is the reference's `glm::vec3*& devColorOut`: it is swapped with the
+ * filter's buffers (the level-0 result becomes the history), so the caller continues with the pointer it gets back
+ * and, as in the reference, buffers on both sides must come from hipMalloc: rs_svgf_destroy frees what the filter
+ * holds at that time, the caller frees the pointer it holds. */
+int  rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);
+int  rs_svgf_next_frame(rs_svgf* f);                                                  /* ::nextFrame (:566-568) */
+/* Device pointers of the filter's state (devAccumColor / devAccumMoment / devVariance, src/denoiser.h:60-63). */
+typedef struct rs_svgf_view {
+    float* devAccumColor[2];
+    float* devAccumMoment[2];
+    float* devVariance;
+    int    frameIdx;
+    int    width, height;
+} rs_svgf_view;
+int  rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* view);
+
 int  rs_modulate_albedo(float* devImage, const rs_gbuffer* g);                        /* src/denoiser.cu:405-411 */
 int  rs_add_image(float* devImage, const float* devIn, int width, int height);       /* :413-418 */
 int  rs_add_image3(float* devOut, const float* devIn1, const float* devIn2, int width, int height); /* :420-425 */

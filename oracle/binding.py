@@ -136,6 +136,12 @@ def lib():
     ]
     L.orc_send_image_to_pbo.argtypes = [C.c_int, C.c_int, f32p, C.c_int, C.c_float, u8p]
     L.orc_send_debug_to_pbo.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, u8p]
+    L.orc_svgf_create.argtypes = [C.c_int, C.c_int]
+    L.orc_svgf_destroy.argtypes = [C.c_void_p]
+    L.orc_svgf_filter.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OrcGBuffer), C.POINTER(Camera)]
+    L.orc_svgf_next_frame.argtypes = [C.c_void_p]
+    for _n in ("orc_svgf_variance", "orc_svgf_accum_color", "orc_svgf_accum_moment"):
+        getattr(L, _n).argtypes = [C.c_void_p]
     L.orc_eaw_level.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_int]
     L.orc_eaw_filter.argtypes = [C.POINTER(OrcGBuffer), C.POINTER(Camera), f32p, f32p, f32p]
     L.orc_eaw_filter.restype = C.c_void_p
@@ -412,6 +418,40 @@ def send_debug_to_pbo(image, w, h, kind):
     out = np.zeros((h * w, 4), np.uint8)
     lib().orc_send_debug_to_pbo(w, h, image.ctypes.data_as(C.c_void_p), kind, out.reshape(-1))
     return out
+
+
+class SVGF:
+    """SpatioTemporalFilter (denoiser.h:45-70) on the CPU oracle."""
+
+    def __init__(self, width, height):
+        self.n = width * height
+        L = lib()
+        L.orc_svgf_create.restype = C.c_void_p
+        for name in ("orc_svgf_filter", "orc_svgf_variance", "orc_svgf_accum_color", "orc_svgf_accum_moment"):
+            getattr(L, name).restype = C.POINTER(C.c_float)
+        self.h = C.c_void_p(L.orc_svgf_create(width, height))
+
+    def _grab(self, ptr, count):
+        return np.ctypeslib.as_array(ptr, (count,)).copy()
+
+    def filter(self, color_in, gbuf, cam):
+        p = lib().orc_svgf_filter(self.h, np.ascontiguousarray(color_in, np.float32).reshape(-1).ctypes.data_as(C.c_void_p), C.byref(gbuf.c), C.byref(cam))
+        return self._grab(p, self.n * 3).reshape(self.n, 3)
+
+    def next_frame(self):
+        lib().orc_svgf_next_frame(self.h)
+
+    def state(self):
+        L = lib()
+        return dict(variance=self._grab(L.orc_svgf_variance(self.h), self.n),
+                    accum_color=self._grab(L.orc_svgf_accum_color(self.h), self.n * 3).reshape(self.n, 3),
+                    accum_moment=self._grab(L.orc_svgf_accum_moment(self.h), self.n * 3).reshape(self.n, 3))
+
+    def __del__(self):
+        try:
+            lib().orc_svgf_destroy(self.h)
+        except Exception:
+            pass
 
 
 def eaw_filter(gbuf, cam, color_in):

@@ -1298,6 +1298,211 @@ float* orc_eaw_filter(const orc_gbuffer* g, const orc_camera* cam, const float* 
     return a;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * SVGF: SpatioTemporalFilter (denoiser.cu:136-216,250-371,479-568)
+ * ---------------------------------------------------------------------------------------- */
+static const float Gaussian3x3[3][3] = {          /* denoiser.cu:11-15 */
+    { .075f, .124f, .075f },
+    { .124f, .204f, .124f },
+    { .075f, .124f, .075f }
+};
+
+typedef struct {
+    int width, height;
+    float* accumColor[2]; float* accumMoment[2];
+    float* variance; float* tempColor; float* tempVariance; float* filteredVariance;
+    float* colorOut;     /* the caller's `devColorOut` of the reference: swapped with the filter's buffers by filter() */
+    int firstTime, frameIdx;
+} svgf_t;
+
+void* orc_svgf_create(int width, int height) {        /* :479-493 */
+    svgf_t* f = (svgf_t*)calloc(1, sizeof(svgf_t));
+    size_t n = (size_t)width * height;
+    f->width = width; f->height = height;
+    for (int i = 0; i < 2; i++) { f->accumColor[i] = (float*)calloc(n * 3, 4); f->accumMoment[i] = (float*)calloc(n * 3, 4); }
+    f->variance = (float*)calloc(n, 4); f->tempVariance = (float*)calloc(n, 4); f->filteredVariance = (float*)calloc(n, 4);
+    f->tempColor = (float*)calloc(n * 3, 4); f->colorOut = (float*)calloc(n * 3, 4);
+    f->firstTime = 1; f->frameIdx = 0;
+    return f;
+}
+void orc_svgf_destroy(void* p) {
+    svgf_t* f = (svgf_t*)p;
+    if (!f) return;
+    for (int i = 0; i < 2; i++) { free(f->accumColor[i]); free(f->accumMoment[i]); }
+    free(f->variance); free(f->tempVariance); free(f->filteredVariance); free(f->tempColor); free(f->colorOut);
+    free(f);
+}
+void orc_svgf_next_frame(void* p) { ((svgf_t*)p)->frameIdx ^= 1; }          /* :566-568 */
+const float* orc_svgf_variance(void* p) { return ((svgf_t*)p)->variance; }
+const float* orc_svgf_accum_color(void* p) { svgf_t* f = (svgf_t*)p; return f->accumColor[f->frameIdx]; }
+const float* orc_svgf_accum_moment(void* p) { svgf_t* f = (svgf_t*)p; return f->accumMoment[f->frameIdx]; }
+
+/* temporalAccumulate (:250-305).  lastColor / lastMoment are read at lastIdx before `diff` is looked at in the
+ * reference (also at lastIdx = -1); they only matter when !diff. */
+static void svgf_temporal(float* colorOut, const float* colorAccIn, float* momentOut, const float* momentAccIn,
+                          const float* colorIn, const orc_gbuffer* g, int first) {
+    const float Alpha = .2f;
+    const int* primIdPlane = g->primId[g->frameIdx];
+    const int* lastPrimId = g->primId[g->frameIdx ^ 1];
+    const float* normal = g->normal[g->frameIdx];
+    const float* lastNormal = g->normal[g->frameIdx ^ 1];
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < g->width * g->height; idx++) {
+        int primId = primIdPlane[idx];
+        int lastIdx = g->motion[idx];
+        int diff = first;
+        if (lastIdx < 0) diff = 1;
+        else if (primId <= NULL_PRIM) diff = 1;
+        else if (lastPrimId[lastIdx] != primId) diff = 1;
+        else {
+            v3 norm = ld3(normal + (size_t)idx * 3), lastNorm = ld3(lastNormal + (size_t)lastIdx * 3);
+            if (g_abs(dot(norm, lastNorm)) < .1f) diff = 1;
+        }
+        v3 color = ld3(colorIn + (size_t)idx * 3);
+        float lum = luminance(color);
+        v3 accumColor, accumMoment;
+        if (diff) {
+            accumColor = color;
+            accumMoment = V3(lum, lum * lum, 0.f);
+        }
+        else {
+            v3 lastColor = ld3(colorAccIn + (size_t)lastIdx * 3), lastMoment = ld3(momentAccIn + (size_t)lastIdx * 3);
+            accumColor = mix3s(lastColor, color, Alpha);
+            accumMoment = V3(mixf(lastMoment.x, lum, Alpha), mixf(lastMoment.y, lum * lum, Alpha), lastMoment.z + 1.f);
+        }
+        st3(colorOut + (size_t)idx * 3, accumColor);
+        st3(momentOut + (size_t)idx * 3, accumMoment);
+    }
+}
+
+/* estimateVariance (:307-343) */
+static void svgf_estimate_variance(float* variance, const float* moment, int width, int height) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            int idx = y * width + x;
+            v3 m = ld3(moment + (size_t)idx * 3);
+            if (m.z > 3.5f) { variance[idx] = m.y - m.x * m.x; continue; }
+            v2 sumMoment = { 0.f, 0.f };
+            int numPixel = 0;
+            for (int i = -1; i <= 1; i++) {
+                for (int j = -1; j <= 1; j++) {
+                    int qx = x + j, qy = y + i;
+                    if (qx < 0 || qx >= width || qy < 0 || qy >= height) continue;
+                    int idxQ = qy * width + qx;
+                    sumMoment.x += moment[(size_t)idxQ * 3]; sumMoment.y += moment[(size_t)idxQ * 3 + 1];
+                    numPixel++;
+                }
+            }
+            sumMoment.x /= (float)numPixel; sumMoment.y /= (float)numPixel;
+            variance[idx] = sumMoment.y - sumMoment.x * sumMoment.x;
+        }
+    }
+}
+
+/* filterVariance (:345-371): qx follows the outer loop variable */
+static void svgf_filter_variance(float* out, const float* in, int width, int height) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            float sum = 0.f, sumWeight = 0.f;
+            for (int i = -1; i <= 1; i++) {
+                for (int j = -1; j <= 1; j++) {
+                    int qx = x + i, qy = y + j;
+                    if (qx < 0 || qx >= width || qy < 0 || qy >= height) continue;
+                    float weight = Gaussian3x3[i + 1][j + 1];
+                    sum += in[qy * width + qx] * weight;
+                    sumWeight += weight;
+                }
+            }
+            out[y * width + x] = sum / sumWeight;
+        }
+    }
+}
+
+/* waveletFilter, SVGF form (:139-216) */
+static void svgf_wavelet(float* colorOut, const float* colorIn, float* varOut, const float* varIn, const float* varFiltered,
+                         const orc_gbuffer* g, const orc_camera* cam, float sigDepth, float sigNormal, float sigLuminance, int level) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    const int step = 1 << level;
+    const int* primIdPlane = g->primId[g->frameIdx];
+    const float* normal = g->normal[g->frameIdx];
+    const float* depth = g->depth[g->frameIdx];
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            int idxP = y * W + x;
+            int primIdP = primIdPlane[idxP];
+            if (primIdP <= NULL_PRIM) {
+                st3(colorOut + (size_t)idxP * 3, ld3(colorIn + (size_t)idxP * 3));
+                varOut[idxP] = varIn[idxP];
+                continue;
+            }
+            v3 normP = ld3(normal + (size_t)idxP * 3);
+            v3 colorP = ld3(colorIn + (size_t)idxP * 3);
+            v3 posP = camera_get_position(cam, x, y, depth[idxP]);
+            v3 sumColor = v3s(0.f);
+            float sumVariance = 0.f, sumWeight = 0.f, sumWeight2 = 0.f;
+            for (int i = -2; i <= 2; i++) {
+                for (int j = -2; j <= 2; j++) {
+                    int qx = x + j * step, qy = y + i * step;
+                    int idxQ = qy * W + qx;
+                    if (qx >= W || qy >= H || qx < 0 || qy < 0) continue;
+                    if (primIdPlane[idxQ] != primIdP) continue;
+                    v3 normQ = ld3(normal + (size_t)idxQ * 3);
+                    v3 colorQ = ld3(colorIn + (size_t)idxQ * 3);
+                    v3 posQ = camera_get_position(cam, qx, qy, depth[idxQ]);
+                    float varQ = varIn[idxQ];
+                    v3 dp = sub(posP, posQ);
+                    float distPos2 = dot(dp, dp);
+                    float wPos = expf(-distPos2 / sigDepth) + 1e-4f;
+                    float wNorm = powf(sat_dot(normP, normQ), sigNormal) + 1e-4f;
+                    float denom = sigLuminance * sqrtf(g_max(varFiltered[idxQ], 0.f)) + 1e-4f;
+                    float wColor = expf(-g_abs(luminance(colorP) - luminance(colorQ)) / denom) + 1e-4f;
+                    float weight = wColor * wNorm * wPos * Gaussian5x5[i + 2][j + 2];
+                    float weight2 = weight * weight;
+                    sumColor = add(sumColor, scl(colorQ, weight));
+                    sumVariance += varQ * weight2;
+                    sumWeight += weight;
+                    sumWeight2 += weight2;
+                }
+            }
+            st3(colorOut + (size_t)idxP * 3, (sumWeight < FLT_EPSILON) ? ld3(colorIn + (size_t)idxP * 3) : dvs(sumColor, sumWeight));
+            varOut[idxP] = (sumWeight2 < FLT_EPSILON) ? varIn[idxP] : sumVariance / sumWeight2;
+        }
+    }
+}
+
+#define SWAP_PTR(a, b) do { float* t_ = (a); (a) = (b); (b) = t_; } while (0)
+
+/* SpatioTemporalFilter::filter (:532-564); the state's colorOut plays the caller's `glm::vec3*& devColorOut`
+ * carried from call to call.  Returns the buffer that holds the result. */
+const float* orc_svgf_filter(void* p, const float* colorIn, const orc_gbuffer* g, const orc_camera* cam) {
+    svgf_t* f = (svgf_t*)p;
+    const float sigLumin = 4.f, sigNormal = 128.f, sigDepth = 1.f;          /* :488 */
+    const int W = f->width, H = f->height, fi = f->frameIdx;
+    svgf_temporal(f->accumColor[fi], f->accumColor[fi ^ 1], f->accumMoment[fi], f->accumMoment[fi ^ 1], colorIn, g, f->firstTime);
+    f->firstTime = 0;
+    svgf_estimate_variance(f->variance, f->accumMoment[fi], W, H);
+
+    svgf_filter_variance(f->filteredVariance, f->variance, W, H);
+    svgf_wavelet(f->colorOut, f->accumColor[fi], f->tempVariance, f->variance, f->filteredVariance, g, cam, sigDepth, sigNormal, sigLumin, 0);
+    SWAP_PTR(f->colorOut, f->accumColor[fi]);
+    SWAP_PTR(f->tempVariance, f->variance);
+
+    svgf_filter_variance(f->filteredVariance, f->variance, W, H);
+    svgf_wavelet(f->colorOut, f->accumColor[fi], f->tempVariance, f->variance, f->filteredVariance, g, cam, sigDepth, sigNormal, sigLumin, 1);
+    SWAP_PTR(f->tempVariance, f->variance);
+
+    for (int level = 2; level <= 4; level++) {
+        svgf_filter_variance(f->filteredVariance, f->variance, W, H);
+        svgf_wavelet(f->tempColor, f->colorOut, f->tempVariance, f->variance, f->filteredVariance, g, cam, sigDepth, sigNormal, sigLumin, level);
+        SWAP_PTR(f->tempColor, f->colorOut);
+        SWAP_PTR(f->tempVariance, f->variance);
+    }
+    return f->colorOut;
+}
+
 void orc_modulate(int w, int h, float* image, const float* albedo) {   /* denoiser.cu:218-228 */
     for (int i = 0; i < w * h; i++) {
         v3 color = ld3(image + (size_t)i * 3);

@@ -238,6 +238,17 @@ void orc_eaw_level(const orc_gbuffer* g, const orc_camera* cam, const float* col
  * pointer (out or tmp) that holds the final image, mirroring the pointer swap of the reference. */
 float* orc_eaw_filter(const orc_gbuffer* g, const orc_camera* cam, const float* colorIn,
                       float* out, float* tmp);
+/* src/denoiser.cu:136-216,250-371,479-568: SpatioTemporalFilter (SVGF).  The state object also holds the caller's
+ * `devColorOut` buffer of the reference (it is swapped with the filter's buffers by every filter() call);
+ * orc_svgf_filter returns the buffer that holds the result of this call. */
+void* orc_svgf_create(int width, int height);
+void  orc_svgf_destroy(void* f);
+const float* orc_svgf_filter(void* f, const float* colorIn, const orc_gbuffer* g, const orc_camera* cam);
+void  orc_svgf_next_frame(void* f);
+const float* orc_svgf_variance(void* f);
+const float* orc_svgf_accum_color(void* f);
+const float* orc_svgf_accum_moment(void* f);
+
 /* src/denoiser.cu:218-248 */
 void orc_modulate(int w, int h, float* image, const float* albedo);
 void orc_add(int w, int h, float* image, const float* in);

@@ -49,6 +49,17 @@ class Texture(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.c_void_p)]
 
 
+class SVGFView(C.Structure):
+    _fields_ = [
+        ("devAccumColor", C.c_void_p * 2),
+        ("devAccumMoment", C.c_void_p * 2),
+        ("devVariance", C.c_void_p),
+        ("frameIdx", C.c_int),
+        ("width", C.c_int),
+        ("height", C.c_int),
+    ]
+
+
 class GBufferView(C.Structure):
     _fields_ = [
         ("devAlbedo", C.c_void_p),
@@ -72,6 +83,7 @@ EXPORTS = [
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
     "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
 ]
@@ -145,6 +157,11 @@ def lib():
     L.rs_restir_pass_times.argtypes = [vp, C.POINTER(cf * 4)]
     L.rs_restir_enable_timing.argtypes = [vp, ci]
     L.rs_path_trace_direct.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, C.POINTER(C.c_ulonglong)]
+    L.rs_svgf_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
+    L.rs_svgf_destroy.argtypes = [vp]
+    L.rs_svgf_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
+    L.rs_svgf_next_frame.argtypes = [vp]
+    L.rs_svgf_get_view.argtypes = [vp, C.POINTER(SVGFView)]
     L.rs_copy_image_to_pbo.argtypes = [vp, vp, ci, ci, ci, cf]
     for name in ("rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo"):
         getattr(L, name).argtypes = [vp, vp, ci, ci]
@@ -388,11 +405,30 @@ class GBuffer:
 _hip = None
 
 
-def hip_memcpy_d2d(dst, src, nbytes):
+def _hiprt():
     global _hip
     if _hip is None:
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip.hipFree.argtypes = [C.c_void_p]
+    return _hip
+
+
+def hip_malloc(nbytes):
+    p = C.c_void_p()
+    e = _hiprt().hipMalloc(C.byref(p), nbytes)
+    if e != 0:
+        raise RestirHipError(f"hipMalloc failed: {e}")
+    return p.value
+
+
+def hip_free(ptr):
+    _hiprt().hipFree(ptr)
+
+
+def hip_memcpy_d2d(dst, src, nbytes):
+    _hiprt()
     synchronize()
     e = _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
     if e != 0:
@@ -495,6 +531,38 @@ class EAWFilter:
     def destroy(self):
         if self.handle:
             lib().rs_eaw_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class SVGFFilter:
+    """SpatioTemporalFilter (src/denoiser.h:45-70).  The caller-side `devColorOut` buffer of the reference is kept
+    here: it comes from hipMalloc and is swapped with the filter's buffers by every call, as in the reference."""
+
+    def __init__(self, width, height, level=5):
+        self.n = width * height
+        self.handle = C.c_void_p()
+        check(lib().rs_svgf_create(width, height, level, C.byref(self.handle)))
+        self.out_ptr = hip_malloc(self.n * 12)
+
+    def filter(self, in_ptr, gbuf, cam):
+        """Returns the device pointer that holds the filtered image."""
+        p = C.c_void_p(self.out_ptr)
+        check(lib().rs_svgf_filter(self.handle, C.byref(p), in_ptr, gbuf.handle, C.byref(cam)))
+        self.out_ptr = p.value
+        return self.out_ptr
+
+    def next_frame(self):
+        check(lib().rs_svgf_next_frame(self.handle))
+
+    def view(self):
+        v = SVGFView()
+        check(lib().rs_svgf_get_view(self.handle, C.byref(v)))
+        return v
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_svgf_destroy(self.handle)
+            hip_free(self.out_ptr)
             self.handle = C.c_void_p()
 
 

@@ -1,4 +1,4 @@
-// denoiser.hip -- the EAW a-trous path of src/denoiser.cu:
+// denoiser.hip -- src/denoiser.cu: the EAW a-trous path and SVGF (SpatioTemporalFilter, second half of this file):
 //   waveletFilter (colour)         src/denoiser.cu:64-134    (one level)
 //   EAWaveletFilter::filter        src/denoiser.cu:427-437
 //   LeveledEAWFilter               src/denoiser.cu:453-477   (5 levels, sigma 64 / .2 / 1, ping-pong)
@@ -84,6 +84,134 @@ __global__ void __launch_bounds__(256) k_add(float* __restrict__ out, const floa
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// ---- SVGF: SpatioTemporalFilter (src/denoiser.cu:136-216,250-371,479-568) ---------------------------------
+__constant__ float kGaussian3x3[3][3] = {        // src/denoiser.cu:11-15
+    { .075f, .124f, .075f },
+    { .124f, .204f, .124f },
+    { .075f, .124f, .075f }
+};
+
+// temporalAccumulate (:250-305), Alpha = .2.  The reference reads the history at lastIdx before it looks at
+// `diff` (also for lastIdx = -1); the values are only used when !diff, so they are only loaded then.
+__global__ void __launch_bounds__(256) k_svgf_temporal(float* __restrict__ colorOut, const float* __restrict__ colorAccIn,
+                                                       float* __restrict__ momentOut, const float* __restrict__ momentAccIn,
+                                                       const float* __restrict__ colorIn, GBufView g, int first) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.width * g.height) return;
+    const int primId = g.primId[idx];
+    const int lastIdx = g.motion[idx];
+    bool diff = first != 0;
+    if (lastIdx < 0) diff = true;
+    else if (primId <= kNullPrim) diff = true;
+    else if (g.lastPrimId[lastIdx] != primId) diff = true;
+    else {
+        const f3 norm = ld3(g.normal + (size_t)idx * 3), lastNorm = ld3(g.lastNormal + (size_t)lastIdx * 3);
+        if (gabs(dot(norm, lastNorm)) < .1f) diff = true;
+    }
+    const f3 color = ld3(colorIn + (size_t)idx * 3);
+    const float lum = luminance(color);
+    f3 accColor, accMoment;
+    if (diff) {
+        accColor = color;
+        accMoment = mk3(lum, lum * lum, 0.f);
+    }
+    else {
+        const f3 lastColor = ld3(colorAccIn + (size_t)lastIdx * 3), lastMoment = ld3(momentAccIn + (size_t)lastIdx * 3);
+        accColor = mix(lastColor, color, .2f);
+        accMoment = mk3(mixf(lastMoment.x, lum, .2f), mixf(lastMoment.y, lum * lum, .2f), lastMoment.z + 1.f);
+    }
+    st3(colorOut + (size_t)idx * 3, accColor);
+    st3(momentOut + (size_t)idx * 3, accMoment);
+}
+
+// estimateVariance (:307-343): temporal variance after 4 accumulated frames, else the 3x3 spatial estimate
+__global__ void __launch_bounds__(256) k_svgf_variance(float* __restrict__ variance, const float* __restrict__ moment, int W, int H) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const int idx = y * W + x;
+    const f3 m = ld3(moment + (size_t)idx * 3);
+    if (m.z > 3.5f) { variance[idx] = m.y - m.x * m.x; return; }
+    float sx = 0.f, sy = 0.f;
+    int n = 0;
+    for (int i = -1; i <= 1; i++)
+        for (int j = -1; j <= 1; j++) {
+            const int qx = x + j, qy = y + i;
+            if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+            const float* q = moment + (size_t)(qy * W + qx) * 3;
+            sx += q[0]; sy += q[1];
+            n++;
+        }
+    sx /= (float)n; sy /= (float)n;
+    variance[idx] = sy - sx * sx;
+}
+
+// filterVariance (:345-371); the reference walks qx with the OUTER loop variable (:358-359), kept for the summation order
+__global__ void __launch_bounds__(256) k_svgf_filter_variance(float* __restrict__ out, const float* __restrict__ in, int W, int H) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    float sum = 0.f, sumW = 0.f;
+#pragma unroll
+    for (int i = -1; i <= 1; i++) {
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+            const int qx = x + i, qy = y + j;
+            if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+            const float w = kGaussian3x3[i + 1][j + 1];
+            sum += in[qy * W + qx] * w;
+            sumW += w;
+        }
+    }
+    out[y * W + x] = sum / sumW;
+}
+
+// waveletFilter, SVGF form (:139-216): colour and variance filtered together, luminance weight scaled by the
+// 3x3-filtered variance.  Positions come from the per-call plane (see the header comment).
+__global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorOut, const float* __restrict__ colorIn,
+                                                      float* __restrict__ varOut, const float* __restrict__ varIn,
+                                                      const float* __restrict__ varFiltered,
+                                                      const int* __restrict__ primId, const float* __restrict__ normal,
+                                                      const float* __restrict__ pos, int W, int H,
+                                                      float sigDepth, float sigNormal, float sigLumin, int level) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const int step = 1 << level;
+    const int idxP = y * W + x;
+    const int idP = primId[idxP];
+    const f3 colorP = ld3(colorIn + (size_t)idxP * 3);
+    if (idP <= kNullPrim) { st3(colorOut + (size_t)idxP * 3, colorP); varOut[idxP] = varIn[idxP]; return; }
+    const f3 normP = ld3(normal + (size_t)idxP * 3);
+    const f3 posP = ld3(pos + (size_t)idxP * 3);
+    const float lumP = luminance(colorP);
+
+    f3 sumColor = splat(0.f);
+    float sumVar = 0.f, sumW = 0.f, sumW2 = 0.f;
+#pragma unroll
+    for (int i = -2; i <= 2; i++) {
+#pragma unroll
+        for (int j = -2; j <= 2; j++) {
+            const int qx = x + j * step, qy = y + i * step;
+            if (qx >= W || qy >= H || qx < 0 || qy < 0) continue;
+            const int idxQ = qy * W + qx;
+            if (primId[idxQ] != idP) continue;
+            const f3 normQ = ld3(normal + (size_t)idxQ * 3);
+            const f3 colorQ = ld3(colorIn + (size_t)idxQ * 3);
+            const f3 dp = posP - ld3(pos + (size_t)idxQ * 3);
+            const float wPos = expf(-dot(dp, dp) / sigDepth) + 1e-4f;
+            const float wNorm = powf(sat_dot(normP, normQ), sigNormal) + 1e-4f;
+            const float denom = sigLumin * sqrtf(gmax(varFiltered[idxQ], 0.f)) + 1e-4f;
+            const float wColor = expf(-gabs(lumP - luminance(colorQ)) / denom) + 1e-4f;
+            const float w = wColor * wNorm * wPos * kGaussian5x5[i + 2][j + 2];
+            const float w2 = w * w;
+            sumColor = sumColor + colorQ * w;
+            sumVar += varIn[idxQ] * w2;
+            sumW += w;
+            sumW2 += w2;
+        }
+    }
+    st3(colorOut + (size_t)idxP * 3, sumW < 1.1920928955078125e-7f ? colorP : sumColor / sumW);
+    varOut[idxP] = sumW2 < 1.1920928955078125e-7f ? varIn[idxP] : sumVar / sumW2;
+}
+
 int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer* g, int level) {
     dim3 grid((f->width + 31) / 32, (f->height + 7) / 8);
     hipLaunchKernelGGL(k_wavelet, grid, dim3(256), 0, rs_stream(), out, in, g->devPrimId[g->frameIdx], g->devNormal[g->frameIdx],
@@ -130,6 +258,86 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
         float* t = *devColorOut; *devColorOut = f->devTempImg; f->devTempImg = t;
     }
     return 0;
+}
+
+// ---- SpatioTemporalFilter (src/denoiser.cu:479-568) -----------------------------------------------------------
+int rs_svgf_destroy(rs_svgf* f) {
+    if (!f) return 0;
+    for (int i = 0; i < 2; i++) { rs_dev_free(f->devAccumColor[i]); rs_dev_free(f->devAccumMoment[i]); }
+    rs_dev_free(f->devVariance); rs_dev_free(f->devTempVariance); rs_dev_free(f->devFilteredVariance);
+    rs_dev_free(f->devTempColor); rs_dev_free(f->devPos);
+    delete f;
+    return 0;
+}
+
+int rs_svgf_create(int width, int height, int level, rs_svgf** out) {
+    if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_create: bad size");
+    *out = nullptr;
+    rs_svgf* f = new rs_svgf();
+    f->width = width; f->height = height; f->level = level;
+    const size_t n = (size_t)width * height;
+    int e = 0;
+    for (int i = 0; i < 2 && !e; i++) {
+        e = rs_dev_alloc(&f->devAccumColor[i], n * 3);
+        if (!e) e = rs_dev_alloc(&f->devAccumMoment[i], n * 3);
+    }
+    if (!e) e = rs_dev_alloc(&f->devVariance, n);
+    if (!e) e = rs_dev_alloc(&f->devTempVariance, n);
+    if (!e) e = rs_dev_alloc(&f->devFilteredVariance, n);
+    if (!e) e = rs_dev_alloc(&f->devTempColor, n * 3);
+    if (!e) e = rs_dev_alloc(&f->devPos, n * 3);
+    if (e) { rs_svgf_destroy(f); return e; }
+    *out = f;
+    return 0;
+}
+
+int rs_svgf_next_frame(rs_svgf* f) {                          // SpatioTemporalFilter::nextFrame (:566-568)
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_next_frame: null filter");
+    f->frameIdx ^= 1;
+    return 0;
+}
+
+int rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* v) {
+    if (!f || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_get_view: null argument");
+    for (int i = 0; i < 2; i++) { v->devAccumColor[i] = f->devAccumColor[i]; v->devAccumMoment[i] = f->devAccumMoment[i]; }
+    v->devVariance = f->devVariance; v->frameIdx = f->frameIdx; v->width = f->width; v->height = f->height;
+    return 0;
+}
+
+// SpatioTemporalFilter::filter (:532-564).  *devColorOut is the reference's `glm::vec3*& devColorOut`: after level 0
+// it is swapped with devAccumColor[frameIdx], so the caller's buffer becomes the filter's history and the caller
+// continues with one of the filter's buffers; as in the reference the caller must keep using the pointer it gets back.
+int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
+    if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
+    if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: size mismatch");
+    const int W = f->width, H = f->height, n = W * H;
+    const int fi = f->frameIdx;
+    const dim3 grid2((W + 31) / 32, (H + 7) / 8);
+    const GBufView gv = gbuf_view(g);
+    hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
+                       g->devDepth[g->frameIdx], g->devPrimId[g->frameIdx], f->devPos);
+    // temporalAccumulate (:506-519), estimateVariance (:521-527)
+    hipLaunchKernelGGL(k_svgf_temporal, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), f->devAccumColor[fi], f->devAccumColor[fi ^ 1],
+                       f->devAccumMoment[fi], f->devAccumMoment[fi ^ 1], devColorIn, gv, f->firstTime ? 1 : 0);
+    f->firstTime = false;
+    hipLaunchKernelGGL(k_svgf_variance, grid2, dim3(256), 0, rs_stream(), f->devVariance, f->devAccumMoment[fi], W, H);
+    RS_TRY(rs_after_launch("SpatioTemporalFilter::temporalAccumulate"));
+
+    auto level = [&](float* out, const float* in, int lv) {
+        hipLaunchKernelGGL(k_svgf_filter_variance, grid2, dim3(256), 0, rs_stream(), f->devFilteredVariance, f->devVariance, W, H);
+        hipLaunchKernelGGL(k_svgf_wavelet, grid2, dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, f->devFilteredVariance,
+                           gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, lv);
+        float* t = f->devTempVariance; f->devTempVariance = f->devVariance; f->devVariance = t;      // std::swap(devTempVariance, devVariance)
+    };
+    level(*devColorOut, f->devAccumColor[fi], 0);
+    { float* t = *devColorOut; *devColorOut = f->devAccumColor[fi]; f->devAccumColor[fi] = t; }       // the filtered colour is the new history
+    level(*devColorOut, f->devAccumColor[fi], 1);
+    for (int lv = 2; lv <= 4; lv++) {
+        level(f->devTempColor, *devColorOut, lv);
+        float* t = f->devTempColor; f->devTempColor = *devColorOut; *devColorOut = t;
+    }
+    return rs_after_launch("SpatioTemporalFilter::filter");
 }
 
 int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {

@@ -155,6 +155,21 @@ struct rs_eaw {
     float* devPos = nullptr;        // per-pixel cam.getPosition(x,y,depth), computed once per filter call
 };
 
+// SpatioTemporalFilter (src/denoiser.h:45-70); EAWaveletFilter(width, height, 4, 128, 1) (src/denoiser.cu:488)
+struct rs_svgf {
+    int width = 0, height = 0, level = 0;
+    float sigLumin = 4.f, sigNormal = 128.f, sigDepth = 1.f;
+    float* devAccumColor[2] = { nullptr, nullptr };
+    float* devAccumMoment[2] = { nullptr, nullptr };
+    float* devVariance = nullptr;
+    float* devTempColor = nullptr;
+    float* devTempVariance = nullptr;
+    float* devFilteredVariance = nullptr;
+    float* devPos = nullptr;                  // per-pixel cam.getPosition(x,y,depth), once per filter call
+    bool firstTime = true;
+    int frameIdx = 0;
+};
+
 rs::CamParams rs_make_cam_params(const rs_camera* cam);
 
 // occlusion_bvh.cpp

@@ -150,6 +150,19 @@ struct LeveledEAWFilter {
         devColorOut = reinterpret_cast<rsc::vec3*>(out);
     }
 };
+// src/denoiser.h:45-70 (filter / nextFrame; the three sub-steps are internal to rs_svgf_filter)
+struct SpatioTemporalFilter {
+    rs_svgf* impl = nullptr;
+    int level = 0;
+    void create(int width, int height, int lv) { level = lv; rsc::check(rs_svgf_create(width, height, lv, &impl), "SVGF create"); }
+    void destroy() { rs_svgf_destroy(impl); impl = nullptr; }
+    void filter(rsc::vec3*& devColorOut, rsc::vec3* devColorIn, const GBuffer& gBuffer, const Camera& cam) {
+        float* out = reinterpret_cast<float*>(devColorOut);
+        rsc::check(rs_svgf_filter(impl, &out, reinterpret_cast<const float*>(devColorIn), gBuffer.impl, &cam), "SpatioTemporalFilter::filter");
+        devColorOut = reinterpret_cast<rsc::vec3*>(out);
+    }
+    void nextFrame() { rsc::check(rs_svgf_next_frame(impl), "SpatioTemporalFilter::nextFrame"); }
+};
 inline void modulateAlbedo(rsc::vec3* devImage, const GBuffer& gBuffer) {
     rsc::check(rs_modulate_albedo(reinterpret_cast<float*>(devImage), gBuffer.impl), "modulate");
 }

@@ -422,6 +422,48 @@ def test_eaw_filter(hip):
     assert np.abs(ref - a).max() > 1e-3               # the filter did something
 
 
+def test_svgf_filter(hip):
+    """SpatioTemporalFilter (denoiser.cu:136-216,250-371,479-568) on an orbiting camera: temporal accumulation through
+    devMotion, spatial then (from the fifth frame on) temporal variance, five variance-guided a-trous levels, and
+    the pointer hand-over of filter(); filtered image and filter state against the oracle every frame."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.03")
+    W, H = 160, 96
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    fo = ob.SVGF(W, H)
+    fh = hip.SVGFFilter(W, H, 5)
+
+    def grab(ptr, count):
+        t = torch.empty(count, dtype=torch.float32, device="cuda")
+        hip.hip_memcpy_d2d(t.data_ptr(), ptr, count * 4)
+        return t.cpu().numpy()
+
+    for frame in range(7):
+        p = orbit_position(sd.camera_args["position"], frame, radius=0.3)
+        o.set_camera_position(p); h.set_camera_position(p)
+        # runCuda order: G-buffer, shading, (denoise here), gBuffer.update
+        o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+        o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, o.looper, 1)
+        h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 1)
+        o.looper += 1; h.looper += 1
+        ref = fo.filter(o.image, o.gbuf, o.cam)
+        got = grab(fh.filter(h.image.data_ptr(), h.gbuf, h.cam), W * H * 3).reshape(-1, 3)
+        assert np.allclose(ref, got, rtol=3e-5, atol=2e-6), (frame, float(np.abs(ref - got).max()))
+        st = fo.state(); v = fh.view()
+        assert v.frameIdx == frame % 2
+        assert np.allclose(st["variance"], grab(v.devVariance, W * H), rtol=3e-5, atol=1e-6), frame
+        assert np.allclose(st["accum_moment"], grab(v.devAccumMoment[v.frameIdx], W * H * 3).reshape(-1, 3), rtol=1e-6, atol=1e-7), frame
+        assert np.allclose(st["accum_color"], grab(v.devAccumColor[v.frameIdx], W * H * 3).reshape(-1, 3), rtol=3e-5, atol=2e-6), frame
+        if frame >= 5:
+            assert (st["accum_moment"][:, 2] > 3.5).mean() > 0.3          # the temporal-variance branch is exercised
+        fo.next_frame(); fh.next_frame()
+        o.gbuf.update(o.cam); h.gbuf.update(h.cam)
+    assert np.abs(ref - o.image).max() > 1e-3                              # the filter did something
+    fh.destroy()
+
+
 def test_modulate_and_add(hip):
     import torch
     sd = get_scene("cornell")

@@ -152,6 +152,32 @@ def test_frames_regression_pin():
             assert bits_equal(o.gbuf.albedo, fr[f"{name}_libm{mode}_albedo"]), (name, mode)
 
 
+def test_svgf_oracle_properties():
+    """SpatioTemporalFilter on the oracle: a static camera accumulates history (moment count grows, variance of a
+    noisy input falls), and misses / light pixels pass through unfiltered."""
+    sd = get_scene("cornell")
+    W, H = 64, 64
+    o = OracleRenderer(sd, W, H)
+    f = ob.SVGF(W, H)
+    var = []
+    for frame in range(6):
+        o.gbuf.render(o.scene, o.cam)
+        o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, o.looper, 0)
+        o.looper += 1
+        out = f.filter(o.image, o.gbuf, o.cam)
+        st = f.state()
+        shaded = o.gbuf.prim_id[o.gbuf.frame_idx] > -1
+        assert np.isfinite(out).all()
+        assert np.array_equal(out[~shaded], o.image[~shaded])              # primId <= NullPrimitive: copied
+        assert st["accum_moment"][shaded, 2].max() == float(frame)
+        var.append(float(st["variance"][shaded].mean()))
+        f.next_frame()
+        o.gbuf.update(o.cam)
+    assert var[-1] < var[0]
+    noisy = np.abs(o.image[shaded] - out[shaded]).mean()
+    assert noisy > 1e-3
+
+
 def test_config1_cornell_256_host_loop():
     """BASELINE config 1: Cornell box, 256x256, 1 spp raw direct path trace, looper 0 (host loop)."""
     sd = get_scene("cornell")
