@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""tools/bench_denoisers.py -- 1080p timings of the two denoisers of src/denoiser.cu on the bench scene's G-buffer:
+LeveledEAWFilter (5 a-trous levels) and SpatioTemporalFilter (SVGF).  Algorithmic bytes per pixel:
+EAW level = read colour 12 + G-buffer {id 4, normal 12, depth 4} + write 12 = 44 B; SVGF level adds variance in/out/filtered
+(12 B) and the 3x3 variance pre-filter (8 B); temporal accumulation reads colour 12 + motion 4 + 2 x {id 4, normal 12} +
+history colour/moment 24 and writes 24 = 96 B; variance estimate 12 + 4 B."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from restir_amd import capi, scenes
+from restir_amd.tiling import HipBackend
+
+W, H = 1920, 1080
+capi.init(0)
+sd = scenes.sponza_class(seed=1, scale=1.0)
+scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+cam = capi.camera_update(sd.camera(W, H))
+b = HipBackend(capi, scene, cam, W, H)
+capi.set_sync(False)
+for i in range(3):
+    b.gbuffer_render(0, H); b.phase_a(i, 3, 0, H); b.phase_b(0, 3, 0, H); b.restir.end_frame()
+torch.cuda.synchronize()
+N = W * H
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+eaw = capi.EAWFilter(W, H, 5)
+out = torch.zeros_like(b.image)
+state = {"p": out.data_ptr()}
+t = timed(lambda: state.update(p=eaw.filter(state["p"], b.image.data_ptr(), b.gbuf, cam)))
+bytes_eaw = N * (5 * 44 + 16 + 12)            # + the position plane: read depth/id 8 + ... write 12
+print("LeveledEAWFilter   %.1f us / frame, algorithmic %.0f MB -> %.0f GB/s (%.2f of 8 TB/s)" % (t, bytes_eaw / 1e6, bytes_eaw / t / 1e3, bytes_eaw / t / 1e3 / 8000))
+svgf = capi.SVGFFilter(W, H, 5)
+def svgf_frame():
+    svgf.filter(b.image.data_ptr(), b.gbuf, cam); svgf.next_frame()
+t = timed(svgf_frame)
+bytes_svgf = N * (96 + 16 + 5 * (44 + 12 + 8) + 20)
+print("SpatioTemporalFilter %.1f us / frame, algorithmic %.0f MB -> %.0f GB/s (%.2f of 8 TB/s)" % (t, bytes_svgf / 1e6, bytes_svgf / t / 1e3, bytes_svgf / t / 1e3 / 8000))
