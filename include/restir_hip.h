@@ -74,6 +74,15 @@ typedef struct rs_texture {
     const float* data;            /* 3 floats / texel */
 } rs_texture;
 
+/* src/restir.h:13-27,114-116 -- Reservoir<IndirectLiSample>, identical 68-byte layout */
+typedef struct rs_indirect_reservoir {
+    float Lo[3];
+    float xv[3], nv[3];
+    float xs[3], ns[3];
+    int   numSamples;
+    float weight;
+} rs_indirect_reservoir;
+
 /* Host arrays that define a device scene = the inputs of DevScene::create (src/scene.cpp:435-509),
  * in the layouts Scene::buildDevData leaves them (src/scene.cpp:159-215). */
 typedef struct rs_scene_desc {
@@ -246,6 +255,19 @@ int  rs_path_trace_free(void);            /* pathTraceFree (:27-28) */
 /* pathTraceDirect (src/pathtrace.cu:457-476) -> PTDirectKernel (:279-328) */
 int  rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum,
                           int iter, int looper, unsigned long long* rays);
+
+/* pathTrace(direct, indirect, iter) -> singleKernelPT (src/pathtrace.cu:156-277,434-455) and pathTraceIndirect ->
+ * PTIndirectKernel (:330-432,478-497); maxDepth = Settings::traceDepth */
+int  rs_path_trace(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, float* devIndirectIllum,
+                   int iter, int looper, int maxDepth, unsigned long long* rays);
+int  rs_path_trace_indirect(const rs_scene* scene, const rs_camera* cam, float* devIndirectIllum,
+                            int iter, int looper, int maxDepth, unsigned long long* rays);
+/* ReSTIRIndirect(devIndirectIllum, iter, gBuffer) (src/restir.cu:233-416,448-476): one path per pixel into a
+ * Reservoir<IndirectLiSample>, temporal reuse (reuse bit 0), clamp<20>; shares the first-frame flag with rs_restir_direct. */
+int  rs_restir_indirect(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, float* devIndirectIllum,
+                        int iter, int looper, int reuse, int maxDepth, unsigned long long* rays);
+/* which: 0 = the buffer the next call writes, 1 = the one the last call wrote (devIndLastTemporalReservoir) */
+int  rs_restir_download_indirect(rs_restir* r, int which, rs_indirect_reservoir* host);
 
 /* ---- display conversion (src/pathtrace.h:8) ---------------------------------------------- */
 /* copyImageToPBO(uchar4*, glm::vec3*, w, h, toneMapping, scale) (src/pathtrace.cu:108-113) */

@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from restir_amd.ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE
+from restir_amd.ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE, INDIRECT_RESERVOIR_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
@@ -113,6 +113,8 @@ def lib():
     L.orc_to_plane.argtypes = [C.c_int, f32p, f32p]
     L.orc_procedural_texture.argtypes = [C.c_int, f32p, f32p]
     L.orc_local_to_world.argtypes = [C.c_int, f32p, f32p, f32p]
+    L.orc_material_sample.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, u32p]
+    L.orc_material_pdf.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
     L.orc_intersect.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, i32p, i32p, f32p, f32p, f32p]
     L.orc_test_occlusion.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, i32p]
     L.orc_sample_direct_light_nv.argtypes = [C.POINTER(OrcScene), C.c_int, f32p, f32p, f32p, f32p, f32p, f32p]
@@ -123,6 +125,10 @@ def lib():
         C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), f32p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong),
     ]
+    L.orc_path_trace.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), f32p, f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    L.orc_pt_indirect.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    L.orc_restir_indirect.argtypes = [C.POINTER(OrcScene), C.POINTER(Camera), C.POINTER(OrcGBuffer), f32p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
     L.orc_restir_state_create.argtypes = [C.c_int, C.c_int]
     L.orc_restir_state_create.restype = C.c_void_p
     L.orc_restir_state_destroy.argtypes = [C.c_void_p]
@@ -218,6 +224,23 @@ def local_to_world(n, v):
     n = np.ascontiguousarray(n, np.float32).reshape(-1, 3); v = np.ascontiguousarray(v, np.float32).reshape(-1, 3)
     out = np.zeros((len(n), 3), np.float32)
     lib().orc_local_to_world(len(n), n.reshape(-1), v.reshape(-1), out.reshape(-1)); return out
+
+
+def material_sample(mats, nrm, wo, r3, fn=None):
+    """Material::sample on n inputs -> dir (n,3), bsdf (n,3), pdf (n,), type (n,) uint32."""
+    mats = np.ascontiguousarray(mats); n = len(mats)
+    nrm = np.ascontiguousarray(nrm, np.float32); wo = np.ascontiguousarray(wo, np.float32); r3 = np.ascontiguousarray(r3, np.float32)
+    d = np.zeros((n, 3), np.float32); b = np.zeros((n, 3), np.float32); p = np.zeros(n, np.float32); t = np.zeros(n, np.uint32)
+    (fn or lib().orc_material_sample)(n, mats.ctypes.data_as(C.c_void_p), nrm.reshape(-1), wo.reshape(-1), r3.reshape(-1), d.reshape(-1), b.reshape(-1), p, t)
+    return d, b, p, t
+
+
+def material_pdf(mats, nrm, wo, wi, fn=None):
+    mats = np.ascontiguousarray(mats); n = len(mats)
+    p = np.zeros(n, np.float32)
+    (fn or lib().orc_material_pdf)(n, mats.ctypes.data_as(C.c_void_p), np.ascontiguousarray(nrm, np.float32).reshape(-1),
+                                   np.ascontiguousarray(wo, np.float32).reshape(-1), np.ascontiguousarray(wi, np.float32).reshape(-1), p)
+    return p
 
 
 def procedural_texture(uv):
@@ -366,8 +389,20 @@ class ReSTIR:
         self.reservoir = np.zeros(n, RESERVOIR_DTYPE)       # devDirectReservoir
         self.last = np.zeros(n, RESERVOIR_DTYPE)            # devLastDirectReservoir
         self.temp = np.zeros(n, RESERVOIR_DTYPE)            # devDirectTemp
+        self.ind_reservoir = np.zeros(n, INDIRECT_RESERVOIR_DTYPE)   # devIndTemporalReservoir (restir.cu:13-14)
+        self.ind_last = np.zeros(n, INDIRECT_RESERVOIR_DTYPE)        # devIndLastTemporalReservoir
         self.first = True
         self.rays = 0
+
+    def indirect(self, scene, cam, gbuf, indirect_illum, iter_, looper, reuse, max_depth):
+        """ReSTIRIndirect (restir.cu:448-476); shares ReSTIRFirstFrame with direct()."""
+        rays = C.c_ulonglong(0)
+        lib().orc_restir_indirect(C.byref(scene.c), C.byref(cam), C.byref(gbuf.c), indirect_illum.reshape(-1),
+                                  _ptr(self.ind_reservoir), _ptr(self.ind_last), looper, iter_, max_depth, int(self.first), reuse, C.byref(rays))
+        self.ind_reservoir, self.ind_last = self.ind_last, self.ind_reservoir
+        self.first = False
+        self.rays = rays.value
+        return rays.value
 
     def reset(self):
         self.first = True
@@ -403,6 +438,20 @@ class ReSTIR:
 def pt_direct(scene, cam, direct_illum, iter_, looper):
     rays = C.c_ulonglong(0)
     lib().orc_pt_direct(C.byref(scene.c), C.byref(cam), direct_illum.reshape(-1), looper, iter_, C.byref(rays))
+    return rays.value
+
+
+def path_trace(scene, cam, direct_illum, indirect_illum, iter_, looper, max_depth):
+    """pathTrace = singleKernelPT (pathtrace.cu:156-277,434-455)."""
+    rays = C.c_ulonglong(0)
+    lib().orc_path_trace(C.byref(scene.c), C.byref(cam), direct_illum.reshape(-1), indirect_illum.reshape(-1), looper, iter_, max_depth, C.byref(rays))
+    return rays.value
+
+
+def pt_indirect(scene, cam, indirect_illum, iter_, looper, max_depth):
+    """pathTraceIndirect = PTIndirectKernel (pathtrace.cu:330-432,478-497)."""
+    rays = C.c_ulonglong(0)
+    lib().orc_pt_indirect(C.byref(scene.c), C.byref(cam), indirect_illum.reshape(-1), looper, iter_, max_depth, C.byref(rays))
     return rays.value
 
 
@@ -486,6 +535,8 @@ def ref_subset():
     R.ref_triangle_misc.argtypes = [C.c_int, f32p, f32p, f32p, f32p, f32p]
     R.ref_tonemap.argtypes = [C.c_int, f32p, C.c_int, f32p]
     R.ref_bvh_build.argtypes = [C.c_int, f32p, f32p, C.POINTER(C.c_void_p * 6)]
+    R.ref_material_sample.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p, f32p, f32p, u32p]
+    R.ref_material_pdf.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
     R.ref_linear_sample.argtypes = [C.c_int, C.c_int, f32p, C.c_int, f32p, f32p]
     R.ref_to_sphere.argtypes = [C.c_int, f32p, f32p]
     R.ref_to_plane.argtypes = [C.c_int, f32p, f32p]

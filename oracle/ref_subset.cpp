@@ -138,6 +138,20 @@ int ref_bvh_build(int numPrims, const float* vertices, float* boxesOut, int* nod
     return size;
 }
 
+// material.h:230-256.  Fields the reference leaves unwritten for an Invalid sample are reported as 0.
+void ref_material_sample(int n, const Material* mats, const float* nrm, const float* wo, const float* r3,
+                         float* dir, float* bsdf, float* pdf, uint32_t* type) {
+    for (int i = 0; i < n; i++) {
+        BSDFSample sp; sp.dir = glm::vec3(0.f); sp.bsdf = glm::vec3(0.f); sp.pdf = 0.f; sp.type = Invalid;
+        mats[i].sample(ld3(nrm + 3 * i), ld3(wo + 3 * i), ld3(r3 + 3 * i), sp);
+        if (sp.type == Invalid) { sp.dir = glm::vec3(0.f); sp.bsdf = glm::vec3(0.f); sp.pdf = 0.f; }
+        st3(dir + 3 * i, sp.dir); st3(bsdf + 3 * i, sp.bsdf); pdf[i] = sp.pdf; type[i] = sp.type;
+    }
+}
+void ref_material_pdf(int n, const Material* mats, const float* nrm, const float* wo, const float* wi, float* pdf) {
+    for (int i = 0; i < n; i++) pdf[i] = mats[i].pdf(ld3(nrm + 3 * i), ld3(wo + 3 * i), ld3(wi + 3 * i));
+}
+
 // image.h:41-75 through DevTextureObj::linearSample (image.h:89-91)
 void ref_linear_sample(int width, int height, const float* data, int n, const float* uv, float* out) {
     DevTextureObj tex;

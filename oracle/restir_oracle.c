@@ -436,6 +436,18 @@ static v3 material_bsdf(const orc_material* m, v3 n, v3 wo, v3 wi) { /* :218-228
     return v3s(0.f);
 }
 
+/* glm::inverse(mat3) (func_matrix.inl compute_inverse<tmat3x3>), columns in / columns out */
+static inline void m3_inverse(v3 c0, v3 c1, v3 c2, v3* o0, v3* o1, v3* o2) {
+    const float m[3][3] = { { c0.x, c0.y, c0.z }, { c1.x, c1.y, c1.z }, { c2.x, c2.y, c2.z } };
+    float ood = 1.f / (
+        + m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2])
+        - m[1][0] * (m[0][1] * m[2][2] - m[2][1] * m[0][2])
+        + m[2][0] * (m[0][1] * m[1][2] - m[1][1] * m[0][2]));
+    *o0 = V3(+ (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * ood, - (m[0][1] * m[2][2] - m[2][1] * m[0][2]) * ood, + (m[0][1] * m[1][2] - m[1][1] * m[0][2]) * ood);
+    *o1 = V3(- (m[1][0] * m[2][2] - m[2][0] * m[1][2]) * ood, + (m[0][0] * m[2][2] - m[2][0] * m[0][2]) * ood, - (m[0][0] * m[1][2] - m[1][0] * m[0][2]) * ood);
+    *o2 = V3(+ (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * ood, - (m[0][0] * m[2][1] - m[2][0] * m[0][1]) * ood, + (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * ood);
+}
+
 /* ------------------------------------------------------------------------------------------
  * libm calls of __device__ code (see orc_set_libm_mode in the header)
  * ---------------------------------------------------------------------------------------- */
@@ -488,6 +500,141 @@ static v3 linear_sample(const orc_texture* tex, v2 uv) {
     v3 c1 = mix3s(ld3(d + ((size_t)iy * width + ix) * 3), ld3(d + ((size_t)iy * width + ux) * 3), lx);
     v3 c2 = mix3s(ld3(d + ((size_t)uy * width + ix) * 3), ld3(d + ((size_t)uy * width + ux) * 3), lx);
     return mix3s(c1, c2, ly);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Material::sample / pdf (material.h:42-62,82-121,126-170,186-256), the sampling half of the BSDFs
+ * ---------------------------------------------------------------------------------------- */
+enum { BS_DIFFUSE = 1 << 0, BS_GLOSSY = 1 << 1, BS_SPECULAR = 1 << 2, BS_REFLECTION = 1 << 4, BS_TRANSMISSION = 1 << 5, BS_INVALID = 1 << 15 };
+typedef struct { v3 dir, bsdf; float pdf; uint32_t type; } bsdf_sample_t;
+
+/* mathUtil.h:128-132 with the libm mode of __device__ code (the spatial tap keeps to_concentric_disk) */
+static inline v2 to_concentric_disk_m(float x, float y) {
+    float r = sqrtf(x);
+    float theta = y * PI_F * 2.0f;
+    v2 o = { m_cos(theta) * r, m_sin(theta) * r };
+    return o;
+}
+/* mathUtil.h:157-161 */
+static inline v3 sample_hemisphere_cosine(v3 n, float rx, float ry) {
+    v2 d = to_concentric_disk_m(rx, ry);
+    float z = sqrtf(1.f - (d.x * d.x + d.y * d.y));
+    return local_to_world(n, V3(d.x, d.y, z));
+}
+/* mathUtil.h:163-180 */
+static inline int math_refract(v3 n, v3 wi, float ior, v3* wt) {
+    float cosIn = dot(n, wi);
+    if (cosIn < 0) ior = 1.f / ior;
+    float sin2In = g_max(0.f, 1.f - cosIn * cosIn);
+    float sin2Tr = sin2In / (ior * ior);
+    if (sin2Tr >= 1.f) return 0;
+    float cosTr = sqrtf(1.f - sin2Tr);
+    if (cosIn < 0) cosTr = -cosTr;
+    *wt = normalize3(add(dvs(neg(wi), ior), scl(n, cosIn / ior - cosTr)));
+    return 1;
+}
+static inline v3 glm_reflect(v3 I, v3 N) { return sub(I, mul(scl(N, dot(N, I)), v3s(2.f))); }   /* func_geometric.inl:176-179 */
+static inline float power_heuristic(float f, float g) { float f2 = f * f; return f2 / (f2 + g * g); }   /* mathUtil.h:81-84 */
+static inline v3 hdr_to_ldr(v3 c) { return scl(dvv(c, adds(c, 1.f)), 1.f); }                         /* mathUtil.h:36-38 */
+
+/* material.h:42-61 (MATERIAL_DIELECTRIC_USE_SCHLICK_APPROX is not defined -> the exact form) */
+static float fresnel_dielectric(float cosIn, float ior) {
+    if (cosIn < 0) { ior = 1.f / ior; cosIn = -cosIn; }
+    float sinIn = sqrtf(1.f - cosIn * cosIn);
+    float sinTr = sinIn / ior;
+    if (sinTr >= 1.f) return 1.f;
+    float cosTr = sqrtf(1.f - sinTr * sinTr);
+    float a = (cosIn - ior * cosTr) / (cosIn + ior * cosTr), b = (ior * cosIn - cosTr) / (ior * cosIn + cosTr);
+    return (a * a + b * b) * .5f;
+}
+/* material.h:82-85 */
+static inline float gtr2_pdf(v3 n, v3 m, v3 wo, float alpha) {
+    return gtr2_distrib(dot(n, m), alpha) * schlick_g(dot(n, wo), alpha) * abs_dot(m, wo) / abs_dot(n, wo);
+}
+/* material.h:94-112: GGX visible-normal sampling */
+static v3 gtr2_sample(v3 n, v3 wo, float alpha, float rx, float ry) {
+    v3 t0 = (g_abs(n.y) > 0.9999f) ? V3(0.f, 0.f, 1.f) : V3(0.f, 1.f, 0.f);      /* Math::localRefMatrix */
+    v3 b0 = normalize3(cross(n, t0));
+    t0 = cross(b0, n);
+    v3 i0, i1, i2;
+    m3_inverse(t0, b0, n, &i0, &i1, &i2);
+    v3 vh = normalize3(mul(m3mul(i0, i1, i2, wo), V3(alpha, alpha, 1.f)));
+    float lenSq = vh.x * vh.x + vh.y * vh.y;
+    v3 t = lenSq > 0.f ? dvs(V3(-vh.y, vh.x, 0.f), sqrtf(lenSq)) : V3(1.f, 0.f, 0.f);
+    v3 b = cross(vh, t);
+    v2 p = to_concentric_disk_m(rx, ry);
+    float s = 0.5f * (vh.z + 1.f);
+    p.y = (1.f - s) * sqrtf(1.f - p.x * p.x) + s * p.y;
+    v3 h = add(add(scl(t, p.x), scl(b, p.y)), scl(vh, sqrtf(g_max(0.f, 1.f - (p.x * p.x + p.y * p.y)))));
+    h = V3(h.x * alpha, h.y * alpha, g_max(0.f, h.z));
+    return normalize3(m3mul(t0, b0, n, h));
+}
+/* material.h:186-193 */
+static float metallic_workflow_pdf(const orc_material* m, v3 n, v3 wo, v3 wi) {
+    v3 h = normalize3(add(wo, wi));
+    return mixf((sat_dot(n, wi) * 1.f) / PI_F,
+                gtr2_pdf(n, h, wo, m->roughness * m->roughness) / (4.f * abs_dot(h, wo)),
+                1.f / (2.f - m->metallic));
+}
+/* Material::pdf (material.h:230-240) */
+static float material_pdf(const orc_material* m, v3 n, v3 wo, v3 wi) {
+    switch (m->type) {
+    case MAT_LAMBERTIAN: return (sat_dot(n, wi) * 1.f) / PI_F;                   /* :126-128 */
+    case MAT_METALLIC:   return metallic_workflow_pdf(m, n, wo, wi);
+    case MAT_DIELECTRIC: return 0.f;
+    }
+    return 0.f;
+}
+/* Material::sample (material.h:242-256).  Fields the reference leaves unwritten (pdf / dir of an Invalid sample) are 0 here. */
+static void material_sample(const orc_material* m, v3 n, v3 wo, v3 r, bsdf_sample_t* sp) {
+    sp->dir = v3s(0.f); sp->bsdf = v3s(0.f); sp->pdf = 0.f; sp->type = BS_INVALID;
+    switch (m->type) {
+    case MAT_LAMBERTIAN:                                                          /* :130-135 */
+        sp->dir = sample_hemisphere_cosine(n, r.x, r.y);
+        sp->bsdf = dvs(scl(ld3(m->baseColor), 1.f), PI_F);
+        sp->pdf = (sat_dot(n, sp->dir) * 1.f) / PI_F;
+        sp->type = BS_DIFFUSE | BS_REFLECTION;
+        break;
+    case MAT_METALLIC: {                                                          /* :195-213 */
+        float alpha = m->roughness * m->roughness;
+        if (r.z > (1.f / (2.f - m->metallic))) {
+            sp->dir = sample_hemisphere_cosine(n, r.x, r.y);
+        }
+        else {
+            v3 h = gtr2_sample(n, wo, alpha, r.x, r.y);
+            sp->dir = neg(glm_reflect(wo, h));
+        }
+        if (dot(n, sp->dir) < 0.f) {
+            sp->type = BS_INVALID;
+        }
+        else {
+            sp->bsdf = metallic_workflow_bsdf(m, n, wo, sp->dir);
+            sp->pdf = metallic_workflow_pdf(m, n, wo, sp->dir);
+            sp->type = BS_GLOSSY | BS_REFLECTION;
+        }
+        break;
+    }
+    case MAT_DIELECTRIC: {                                                        /* :145-169 */
+        float pdfRefl = fresnel_dielectric(dot(n, wo), m->ior);
+        sp->bsdf = ld3(m->baseColor);
+        if (r.z < pdfRefl) {
+            sp->dir = glm_reflect(neg(wo), n);
+            sp->type = BS_SPECULAR | BS_REFLECTION;
+            sp->pdf = 1.f;
+        }
+        else {
+            if (!math_refract(n, wo, m->ior, &sp->dir)) { sp->type = BS_INVALID; break; }
+            float eta = m->ior;
+            if (dot(n, wo) < 0) eta = 1.f / eta;
+            sp->bsdf = dvs(sp->bsdf, eta * eta);
+            sp->type = BS_SPECULAR | BS_TRANSMISSION;
+            sp->pdf = 1.f;
+        }
+        break;
+    }
+    default:
+        sp->type = BS_INVALID;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -923,10 +1070,201 @@ void orc_pt_direct(const orc_scene* s, const orc_camera* cam, float* directIllum
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-bounce path tracing: singleKernelPT / PTIndirectKernel (pathtrace.cu:156-277,330-432)
+ * ---------------------------------------------------------------------------------------- */
+/* scene.h:358-362 */
+static float environment_map_pdf(const orc_scene* s, v3 w) {
+    const orc_texture* env = &s->textures[s->envMapTexId];
+    v3 radiance = linear_sample(env, to_plane(w));
+    return luminance(radiance) * s->sumLightPowerInv * (float)env->width * (float)env->height * .5f;
+}
+/* scene.h:121-126 */
+static float primitive_area(const orc_scene* s, int primId) {
+    v3 v0, v1, v2_;
+    tri_verts(s, primId, &v0, &v1, &v2_);
+    return length3(cross(sub(v1, v0), sub(v2_, v0))) * .5f;
+}
+static inline v3 sample3D(rng_t* r) { v3 o; o.x = sample1D(r); o.y = sample1D(r); o.z = sample1D(r); return o; }   /* sampler.h:55-57 */
+
+/* One step that the three kernels share: next-event estimation at the current vertex
+ * (pathtrace.cu:203-213 / 365-376, restir.cu:291-302).  Returns the contribution (zero if none). */
+static v3 nee_contribution(const orc_scene* s, const orc_material* material, const isect_t* it, v3 throughput, rng_t* rng, int* walks) {
+    v3 radiance = v3s(0.f), wi = v3s(0.f);
+    v4 r = sample4D(rng);
+    float lightPdf = sample_direct_light(s, it->pos, r, &radiance, &wi, walks);
+    if (lightPdf > 0.f) {
+        float BSDFPdf = material_pdf(material, it->norm, it->wo, wi);
+        /* throughput * BSDF * radiance * satDot / lightPdf * powerHeuristic, left to right */
+        v3 c = mul(mul(throughput, material_bsdf(material, it->norm, it->wo, wi)), radiance);
+        c = scl(c, sat_dot(it->norm, wi));
+        c = dvs(c, lightPdf);
+        return scl(c, power_heuristic(lightPdf, BSDFPdf));
+    }
+    return v3s(0.f);
+}
+
+/* What happens when the continuation ray has been traced (pathtrace.cu:234-269 / 395-424, restir.cu:333-367):
+ * returns 1 if the path ends here; *add receives the radiance picked up (environment map or an emitter). */
+static int path_end_contribution(const orc_scene* s, isect_t* it, ray_t ray, v3 curPos, v3 throughput, const bsdf_sample_t* sample,
+                                 int deltaSample, int firstBounceUnweighted, orc_material* material, v3* add_, int* hitLight) {
+    *add_ = v3s(0.f);
+    *hitLight = 0;
+    if (it->primId == NULL_PRIM) {
+        if (scene_has_env(s)) {
+            v3 radiance = mul(env_radiance(s, ray.direction), throughput);
+            float weight = deltaSample ? 1.f : power_heuristic(sample->pdf, environment_map_pdf(s, ray.direction));
+            *add_ = scl(radiance, weight);
+        }
+        return 1;
+    }
+    *material = textured_material_and_surface(s, it);
+    if (material->type == MAT_LIGHT) {
+        if (dot(it->norm, ray.direction) < 0.f) {      /* SCENE_LIGHT_SINGLE_SIDED */
+            return 1;
+        }
+        v3 radiance = ld3(material->baseColor);
+        float weight = (deltaSample || firstBounceUnweighted) ? 1.f : power_heuristic(sample->pdf,
+            pdf_area_to_solid_angle(luminance(radiance) * s->sumLightPowerInv * primitive_area(s, it->primId), curPos, it->pos, it->norm));
+        *add_ = scl(mul(radiance, throughput), weight);
+        *hitLight = 1;
+        return 1;
+    }
+    return 0;
+}
+
+/* singleKernelPT (pathtrace.cu:156-277); DENOISER_DEMODULATE is true: the primary material's baseColor is 1 */
+void orc_path_trace(const orc_scene* s, const orc_camera* cam, float* directIllum, float* indirectIllum,
+                    int looper, int iter, int maxDepth, unsigned long long* rays) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    unsigned long long total = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            v3 direct = v3s(0.f), indirect = v3s(0.f);
+            int index = y * W + x;
+            int walks = 0;
+            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            ray_t ray = camera_sample(cam, x, y, sample4D(&rng));
+            isect_t it;
+            scene_intersect(s, ray, &it);
+            walks++;
+            if (it.primId == NULL_PRIM) {
+                direct = v3s(1.f);
+            }
+            else {
+                orc_material material = textured_material_and_surface(s, &it);
+                st3(material.baseColor, v3s(1.f));
+                if (material.type == MAT_LIGHT) {
+                    direct = v3s(1.f);
+                }
+                else {
+                    v3 throughput = v3s(1.f);
+                    it.wo = neg(ray.direction);
+                    for (int depth = 1; depth <= maxDepth; depth++) {
+                        int deltaBSDF = (material.type == MAT_DIELECTRIC);
+                        if (material.type != MAT_DIELECTRIC && dot(it.norm, it.wo) < 0.f) it.norm = neg(it.norm);
+                        if (!deltaBSDF) {
+                            v3 c = nee_contribution(s, &material, &it, throughput, &rng, &walks);
+                            if (depth == 1) direct = add(direct, c); else indirect = add(indirect, c);
+                        }
+                        bsdf_sample_t sample;
+                        material_sample(&material, it.norm, it.wo, sample3D(&rng), &sample);
+                        if (sample.type == BS_INVALID) break;
+                        else if (sample.pdf < 1e-8f) break;
+                        int deltaSample = (sample.type & BS_SPECULAR) != 0;
+                        throughput = mul(throughput, scl(dvs(sample.bsdf, sample.pdf), deltaSample ? 1.f : abs_dot(it.norm, sample.dir)));
+                        ray = make_offseted_ray(it.pos, sample.dir);
+                        v3 curPos = it.pos;
+                        scene_intersect(s, ray, &it);
+                        walks++;
+                        it.wo = neg(ray.direction);
+                        v3 c; int hitLight;
+                        if (path_end_contribution(s, &it, ray, curPos, throughput, &sample, deltaSample, 0, &material, &c, &hitLight)) {
+                            indirect = add(indirect, c);
+                            break;
+                        }
+                    }
+                }
+            }
+            if (has_nan_or_inf(direct)) direct = v3s(0.f);
+            if (has_nan_or_inf(indirect)) indirect = v3s(0.f);
+            direct = hdr_to_ldr(direct);
+            indirect = hdr_to_ldr(indirect);
+            float* od = directIllum + (size_t)index * 3; float* oi = indirectIllum + (size_t)index * 3;
+            st3(od, dvs(add(scl(ld3(od), (float)iter), direct), (float)(iter + 1)));
+            st3(oi, dvs(add(scl(ld3(oi), (float)iter), indirect), (float)(iter + 1)));
+            total += (unsigned long long)walks;
+        }
+    }
+    if (rays) *rays = total;
+}
+
+/* PTIndirectKernel (pathtrace.cu:330-432) */
+void orc_pt_indirect(const orc_scene* s, const orc_camera* cam, float* indirectIllum,
+                     int looper, int iter, int maxDepth, unsigned long long* rays) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    unsigned long long total = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            v3 indirect = v3s(0.f);
+            int index = y * W + x;
+            int walks = 0;
+            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            ray_t ray = camera_sample(cam, x, y, sample4D(&rng));
+            isect_t it;
+            scene_intersect(s, ray, &it);
+            walks++;
+            if (it.primId != NULL_PRIM) {
+                orc_material material = textured_material_and_surface(s, &it);
+                if (material.type != MAT_LIGHT) {
+                    v3 throughput = v3s(1.f);
+                    it.wo = neg(ray.direction);
+                    for (int depth = 1; depth <= maxDepth; depth++) {
+                        int deltaBSDF = (material.type == MAT_DIELECTRIC);
+                        if (material.type != MAT_DIELECTRIC && dot(it.norm, it.wo) < 0.f) it.norm = neg(it.norm);
+                        if (!deltaBSDF && depth > 1) {
+                            indirect = add(indirect, nee_contribution(s, &material, &it, throughput, &rng, &walks));
+                        }
+                        bsdf_sample_t sample;
+                        material_sample(&material, it.norm, it.wo, sample3D(&rng), &sample);
+                        if (sample.type == BS_INVALID) break;
+                        else if (sample.pdf < 1e-8f) break;
+                        int deltaSample = (sample.type & BS_SPECULAR) != 0;
+                        throughput = mul(throughput, scl(dvs(sample.bsdf, sample.pdf), deltaSample ? 1.f : abs_dot(it.norm, sample.dir)));
+                        ray = make_offseted_ray(it.pos, sample.dir);
+                        v3 curPos = it.pos;
+                        scene_intersect(s, ray, &it);
+                        walks++;
+                        it.wo = neg(ray.direction);
+                        v3 c; int hitLight;
+                        if (path_end_contribution(s, &it, ray, curPos, throughput, &sample, deltaSample, 0, &material, &c, &hitLight)) {
+                            indirect = add(indirect, c);
+                            break;
+                        }
+                    }
+                }
+            }
+            if (has_nan_or_inf(indirect)) indirect = v3s(0.f);
+            float* oi = indirectIllum + (size_t)index * 3;
+            st3(oi, dvs(add(scl(ld3(oi), (float)iter), indirect), (float)(iter + 1)));
+            total += (unsigned long long)walks;
+        }
+    }
+    if (rays) *rays = total;
+}
+
+/* ------------------------------------------------------------------------------------------
  * ReSTIRDirectKernel (restir.cu:20-100,111-231), two-phase contract
  * ---------------------------------------------------------------------------------------- */
 /* restir.cu:20-45 */
+static int temporal_neighbor_index(int idx, const orc_gbuffer* g);
 static resv_t find_temporal_neighbor(const orc_reservoir* reservoir, int idx, const orc_gbuffer* g) {
+    int lastIdx = temporal_neighbor_index(idx, g);
+    return lastIdx < 0 ? resv_default() : resv_load(&reservoir[lastIdx]);
+}
+/* the neighbour test of findTemporalNeighbor (restir.cu:20-45): the index to reuse, or -1 for `T()` */
+static int temporal_neighbor_index(int idx, const orc_gbuffer* g) {
     const int cur = g->frameIdx, last = g->frameIdx ^ 1;
     int primId = g->primId[cur][idx];
     int lastIdx = g->motion[idx];
@@ -950,7 +1288,7 @@ static resv_t find_temporal_neighbor(const orc_reservoir* reservoir, int idx, co
             diff = 1;
         }
     }
-    return diff ? resv_default() : resv_load(&reservoir[lastIdx]);
+    return diff ? -1 : lastIdx;
 }
 
 /* restir.cu:47-85 */
@@ -1158,6 +1496,123 @@ void orc_restir_direct(const orc_scene* s, const orc_camera* cam, const orc_gbuf
     orc_restir_phase_a(st, s, cam, g, reservoirOut, reservoirIn, reservoirTemp, looper, first, reuse, 0, H, rays);
     orc_restir_phase_b(st, s, cam, g, directIllum, reservoirTemp, iter, reuse, 0, H);
     orc_restir_state_destroy(st);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ReSTIRIndirectKernel (restir.cu:233-416): one path per pixel into a Reservoir<IndirectLiSample>, temporal reuse
+ * ---------------------------------------------------------------------------------------- */
+/* IndirectLiSample members the reference leaves uninitialised (xv, nv, xs, ns; restir.h:13-27) start at 0 here. */
+static inline orc_indirect_reservoir ires_default(void) { orc_indirect_reservoir r; memset(&r, 0, sizeof r); return r; }
+static inline int ires_invalid(const orc_indirect_reservoir* r) { return is_nan_or_inf(r->weight) || r->weight < 0.f; }
+
+void orc_restir_indirect(const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g, float* indirectIllum,
+                         orc_indirect_reservoir* temporalReservoir, const orc_indirect_reservoir* lastTemporalReservoir,
+                         int looper, int iter, int maxDepth, int first, int reuse, unsigned long long* rays) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    unsigned long long total = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            orc_indirect_reservoir smp = ires_default();     /* indirectSample lives in .Lo/.xv/.nv/.xs/.ns of this record */
+            int index = y * W + x;
+            int walks = 0;
+            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            ray_t ray = camera_sample(cam, x, y, sample4D(&rng));
+            isect_t it;
+            scene_intersect(s, ray, &it);
+            walks++;
+            float primSamplePdf = 0.f;
+            int primSampleDelta = 0;
+            v3 primWo = neg(ray.direction);
+            orc_material primMaterial; memset(&primMaterial, 0, sizeof primMaterial);
+            v3 Lo = v3s(0.f);
+
+            if (it.primId != NULL_PRIM) {
+                orc_material material = textured_material_and_surface(s, &it);
+                if (material.type != MAT_LIGHT) {
+                    v3 throughput = v3s(1.f);
+                    it.wo = neg(ray.direction);
+                    primMaterial = material;
+                    for (int depth = 1; depth <= maxDepth; depth++) {
+                        int deltaBSDF = (material.type == MAT_DIELECTRIC);
+                        if (material.type != MAT_DIELECTRIC && dot(it.norm, it.wo) < 0.f) it.norm = neg(it.norm);
+                        if (!deltaBSDF && depth > 1) {
+                            Lo = add(Lo, nee_contribution(s, &material, &it, throughput, &rng, &walks));
+                        }
+                        bsdf_sample_t sample;
+                        material_sample(&material, it.norm, it.wo, sample3D(&rng), &sample);
+                        if (sample.type == BS_INVALID) break;
+                        else if (sample.pdf < 1e-8f) break;
+                        int deltaSample = (sample.type & BS_SPECULAR) != 0;
+                        if (depth > 1) {
+                            throughput = mul(throughput, scl(dvs(sample.bsdf, sample.pdf), deltaSample ? 1.f : abs_dot(it.norm, sample.dir)));
+                        }
+                        else {
+                            primSamplePdf = sample.pdf;
+                            primSampleDelta = deltaSample;
+                            st3(smp.xv, it.pos);
+                            st3(smp.nv, it.norm);
+                        }
+                        ray = make_offseted_ray(it.pos, sample.dir);
+                        v3 curPos = it.pos;
+                        scene_intersect(s, ray, &it);
+                        walks++;
+                        it.wo = neg(ray.direction);
+                        v3 c; int hitLight;
+                        if (path_end_contribution(s, &it, ray, curPos, throughput, &sample, deltaSample, depth == 1, &material, &c, &hitLight)) {
+                            Lo = add(Lo, c);
+                            if (hitLight && depth == 1) { st3(smp.xs, it.pos); st3(smp.ns, it.norm); }     /* :360-363 */
+                            break;
+                        }
+                        if (depth == 1) { st3(smp.xs, it.pos); st3(smp.ns, it.norm); }                     /* :367-370 */
+                    }
+                }
+            }
+            st3(smp.Lo, Lo);
+            /* WriteSample (:372-416) */
+            orc_indirect_reservoir reservoir = ires_default();
+            float sampleWeight = 0.f;
+            if (!(luminance(Lo) < 1e-8f)) {                                   /* !indirectSample.invalid() */
+                sampleWeight = luminance(dvs(Lo, primSamplePdf));             /* toScalar(pHatIndirect(...) / primSamplePdf), pHat = Lo (:234) */
+                if (isnan(sampleWeight) || sampleWeight < 0.f) sampleWeight = 0.f;
+            }
+            {   /* reservoir.update(indirectSample, sampleWeight, sample1D(rng)) */
+                float r = sample1D(&rng);
+                reservoir.weight += sampleWeight;
+                reservoir.numSamples++;
+                if (r * reservoir.weight < sampleWeight) { memcpy(&reservoir, &smp, 15 * sizeof(float)); }
+            }
+            if (!first && (reuse & 1)) {
+                int lastIdx = temporal_neighbor_index(index, g);
+                orc_indirect_reservoir temp = lastIdx < 0 ? ires_default() : lastTemporalReservoir[lastIdx];
+                if (!ires_invalid(&temp)) {
+                    float r = sample1D(&rng);                                  /* merge (restir.h:61-68) */
+                    reservoir.weight += temp.weight;
+                    reservoir.numSamples += temp.numSamples;
+                    if (r * reservoir.weight < temp.weight) { memcpy(&reservoir, &temp, 15 * sizeof(float)); }
+                }
+            }
+            v3 indirect = v3s(0.f);
+            orc_indirect_reservoir picked = reservoir;                         /* IndirectLiSample sample = reservoir.sample */
+            if (reservoir.numSamples > 20) {                                   /* clamp<20>() (restir.h:79-86) */
+                reservoir.weight *= (float)20 / (float)reservoir.numSamples;
+                reservoir.numSamples = 20;
+            }
+            if (!ires_invalid(&reservoir)) {
+                v3 primWi = normalize3(sub(ld3(picked.xs), ld3(picked.xv)));
+                v3 rl = ld3(reservoir.Lo);
+                indirect = dvs(scl(dvs(rl, luminance(rl)), reservoir.weight), (float)reservoir.numSamples);
+                indirect = mul(indirect, scl(material_bsdf(&primMaterial, ld3(picked.nv), primWo, primWi),
+                                             primSampleDelta ? 1.f : sat_dot(ld3(picked.nv), primWi)));
+            }
+            if (has_nan_or_inf(indirect)) indirect = v3s(0.f);
+            temporalReservoir[index] = reservoir;
+            float* oi = indirectIllum + (size_t)index * 3;
+            st3(oi, dvs(add(scl(ld3(oi), (float)iter), indirect), (float)(iter + 1)));
+            total += (unsigned long long)walks;
+        }
+    }
+    if (rays) *rays = total;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1803,6 +2258,19 @@ void orc_to_sphere(int n, const float* uv, float* dir) {
 }
 void orc_to_plane(int n, const float* dir, float* uv) {
     for (int i = 0; i < n; i++) { v2 u = to_plane(ld3(dir + (size_t)i * 3)); uv[i * 2] = u.x; uv[i * 2 + 1] = u.y; }
+}
+/* Material::sample / pdf on n inputs: r3 = sample3D; out dir[3], bsdf[3], pdf, type */
+void orc_material_sample(int n, const orc_material* mats, const float* nrm, const float* wo, const float* r3,
+                         float* dir, float* bsdf, float* pdf, uint32_t* type) {
+    for (int i = 0; i < n; i++) {
+        bsdf_sample_t sp;
+        material_sample(&mats[i], ld3(nrm + (size_t)i * 3), ld3(wo + (size_t)i * 3), ld3(r3 + (size_t)i * 3), &sp);
+        if (sp.type == BS_INVALID) { sp.dir = v3s(0.f); sp.bsdf = v3s(0.f); sp.pdf = 0.f; }
+        st3(dir + (size_t)i * 3, sp.dir); st3(bsdf + (size_t)i * 3, sp.bsdf); pdf[i] = sp.pdf; type[i] = sp.type;
+    }
+}
+void orc_material_pdf(int n, const orc_material* mats, const float* nrm, const float* wo, const float* wi, float* pdf) {
+    for (int i = 0; i < n; i++) pdf[i] = material_pdf(&mats[i], ld3(nrm + (size_t)i * 3), ld3(wo + (size_t)i * 3), ld3(wi + (size_t)i * 3));
 }
 void orc_local_to_world(int n, const float* nrm, const float* v, float* out) {
     for (int i = 0; i < n; i++) st3(out + (size_t)i * 3, local_to_world(ld3(nrm + (size_t)i * 3), ld3(v + (size_t)i * 3)));

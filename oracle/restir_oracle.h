@@ -9,13 +9,15 @@
  *   - pinned bit-for-bit against the reference's own code compiled here (oracle/_ref, built by
  *     oracle/Makefile from /root/reference/src with g++): intersectTriangle, AABB::intersect,
  *     BVHBuilder::build/buildMTBVH, Camera::{update,sample,getRasterCoord,getPosition},
- *     Material::BSDF, Math::* helpers, tone-map operators;
+ *     Material::BSDF / sample / pdf, Math::* helpers (incl. toSphere / toPlane / localToWorld), linearSample,
+ *     tone-map operators;
  *   - pinned against the third-party dependency itself (rocThrust 2.8.5 minstd_rand +
  *     uniform_real_distribution compiled by hipcc host-only): the RNG stream;
  *   - PARITY UNPINNED (restated from source text only; the reference's scene.h / sampler.h /
  *     restir.h / *.cu cannot be compiled in this image without CUDA Thrust + nvcc):
  *     DevScene::intersect / testOcclusion loops, sampleDirectLight*, DiscreteSampler1D,
- *     Reservoir<>, and the kernel glue of restir.cu / gbuffer.cu / pathtrace.cu / denoiser.cu.
+ *     Reservoir<>, and the kernel glue of restir.cu / gbuffer.cu / pathtrace.cu / denoiser.cu (DI, GI, path tracing,
+ *     EAW, SVGF).
  *
  * All arithmetic is FP32, compiled with -ffp-contract=off; operation order follows GLM 0.9.6.3.
  * Layout-compatible with include/restir_hip.h (rs_material / rs_camera / rs_reservoir).
@@ -73,6 +75,15 @@ typedef struct orc_texture {
     int          width, height;
     const float* data;             /* 3 floats / texel */
 } orc_texture;
+
+/* reference: src/restir.h:13-27,114-116 -- Reservoir<IndirectLiSample> (68 bytes) */
+typedef struct orc_indirect_reservoir {
+    float Lo[3];
+    float xv[3], nv[3];
+    float xs[3], ns[3];
+    int   numSamples;
+    float weight;
+} orc_indirect_reservoir;
 
 /* Host-memory image of DevScene (src/scene.h:461-480). */
 typedef struct orc_scene {
@@ -160,6 +171,10 @@ void orc_linear_sample(const orc_texture* tex, int n, const float* uv, float* ou
 /* src/mathUtil.h:134-144: toSphere (2 -> 3), toPlane (3 -> 2) */
 void orc_to_sphere(int n, const float* uv, float* dir);
 void orc_to_plane(int n, const float* dir, float* uv);
+/* src/material.h:230-256: Material::sample (r3 = sample3D; an Invalid sample reports dir = bsdf = 0, pdf = 0) and ::pdf */
+void orc_material_sample(int n, const orc_material* mats, const float* nrm, const float* wo, const float* r3,
+                         float* dir, float* bsdf, float* pdf, uint32_t* type);
+void orc_material_pdf(int n, const orc_material* mats, const float* nrm, const float* wo, const float* wi, float* pdf);
 /* src/mathUtil.h:146-155 localToWorld(n, v) */
 void orc_local_to_world(int n, const float* nrm, const float* v, float* out);
 /* src/scene.h:68-76 proceduralTexture (value replicated to 3 channels) */
@@ -201,6 +216,17 @@ void orc_gbuffer_update(orc_gbuffer* g, const orc_camera* cam);
 /* src/pathtrace.cu:279-328 */
 void orc_pt_direct(const orc_scene* s, const orc_camera* cam, float* directIllum,
                    int looper, int iter, unsigned long long* rays);
+
+/* src/pathtrace.cu:156-277 singleKernelPT (pathTrace) and :330-432 PTIndirectKernel (pathTraceIndirect) */
+void orc_path_trace(const orc_scene* s, const orc_camera* cam, float* directIllum, float* indirectIllum,
+                    int looper, int iter, int maxDepth, unsigned long long* rays);
+void orc_pt_indirect(const orc_scene* s, const orc_camera* cam, float* indirectIllum,
+                     int looper, int iter, int maxDepth, unsigned long long* rays);
+/* src/restir.cu:233-416 ReSTIRIndirectKernel: temporalReservoir is written, lastTemporalReservoir read (the launcher
+ * swaps them afterwards, :463).  reuse bit0 = temporal. */
+void orc_restir_indirect(const orc_scene* s, const orc_camera* cam, const orc_gbuffer* g, float* indirectIllum,
+                         orc_indirect_reservoir* temporalReservoir, const orc_indirect_reservoir* lastTemporalReservoir,
+                         int looper, int iter, int maxDepth, int first, int reuse, unsigned long long* rays);
 
 /* src/restir.cu:111-231 with the two-phase contract of SURVEY.md Q1:
  * phase A (primary, RIS, shadow, temporal, publish) for all pixels, grid barrier,

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE, copy_camera
+from .ctypes_structs import Camera, Material, Reservoir, MATERIAL_DTYPE, RESERVOIR_DTYPE, INDIRECT_RESERVOIR_DTYPE, copy_camera
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RESTIR_HIP_LIB") or os.path.join(_HERE, "librestir_hip.so")   # env override: A/B builds
@@ -83,6 +83,7 @@ EXPORTS = [
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
     "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
@@ -157,6 +158,10 @@ def lib():
     L.rs_restir_pass_times.argtypes = [vp, C.POINTER(cf * 4)]
     L.rs_restir_enable_timing.argtypes = [vp, ci]
     L.rs_path_trace_direct.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, C.POINTER(C.c_ulonglong)]
+    L.rs_path_trace.argtypes = [vp, C.POINTER(Camera), vp, vp, ci, ci, ci, C.POINTER(C.c_ulonglong)]
+    L.rs_path_trace_indirect.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, ci, C.POINTER(C.c_ulonglong)]
+    L.rs_restir_indirect.argtypes = [vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci, ci, C.POINTER(C.c_ulonglong)]
+    L.rs_restir_download_indirect.argtypes = [vp, ci, vp]
     L.rs_svgf_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
     L.rs_svgf_destroy.argtypes = [vp]
     L.rs_svgf_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
@@ -449,6 +454,17 @@ class ReSTIR:
     def direct(self, scene, cam, gbuf, dev_direct_illum_ptr, iter_, looper, reuse):
         check(lib().rs_restir_direct(self.handle, scene.handle, C.byref(cam), gbuf.handle, dev_direct_illum_ptr, iter_, looper, reuse))
 
+    def indirect(self, scene, cam, gbuf, dev_indirect_illum_ptr, iter_, looper, reuse, max_depth):
+        """ReSTIRIndirect (src/restir.cu:448-476); returns the number of BVH walks."""
+        n = C.c_ulonglong(0)
+        check(lib().rs_restir_indirect(self.handle, scene.handle, C.byref(cam), gbuf.handle, dev_indirect_illum_ptr, iter_, looper, reuse, max_depth, C.byref(n)))
+        return n.value
+
+    def download_indirect(self, which):
+        out = np.zeros(self.width * self.height, INDIRECT_RESERVOIR_DTYPE)
+        check(lib().rs_restir_download_indirect(self.handle, which, _p(out)))
+        return out
+
     def phase_a(self, scene, cam, gbuf, looper, reuse, y0, y1):
         check(lib().rs_restir_phase_a(self.handle, scene.handle, C.byref(cam), gbuf.handle, looper, reuse, y0, y1))
 
@@ -564,6 +580,18 @@ class SVGFFilter:
             lib().rs_svgf_destroy(self.handle)
             hip_free(self.out_ptr)
             self.handle = C.c_void_p()
+
+
+def path_trace(scene, cam, dev_direct_ptr, dev_indirect_ptr, iter_, looper, max_depth):
+    n = C.c_ulonglong(0)
+    check(lib().rs_path_trace(scene.handle, C.byref(cam), dev_direct_ptr, dev_indirect_ptr, iter_, looper, max_depth, C.byref(n)))
+    return n.value
+
+
+def path_trace_indirect(scene, cam, dev_indirect_ptr, iter_, looper, max_depth):
+    n = C.c_ulonglong(0)
+    check(lib().rs_path_trace_indirect(scene.handle, C.byref(cam), dev_indirect_ptr, iter_, looper, max_depth, C.byref(n)))
+    return n.value
 
 
 def path_trace_direct(scene, cam, dev_direct_illum_ptr, iter_, looper):

@@ -1,0 +1,316 @@
+// gi.hip -- the multi-bounce half of the reference:
+//   singleKernelPT / pathTrace             src/pathtrace.cu:156-277,434-455
+//   PTIndirectKernel / pathTraceIndirect   src/pathtrace.cu:330-432,478-497
+//   ReSTIRIndirectKernel / ReSTIRIndirect  src/restir.cu:233-416,448-476   (Reservoir<IndirectLiSample>, temporal reuse)
+//
+// One lane per pixel, 8x8 pixel tile per wave.  The primary ray is coherent and uses the wave-cooperative packet
+// walk; after the first bounce rays are incoherent and lanes leave the loop at different depths, so the
+// continuation and shadow rays use the per-lane walks of the reference's tree (trace_closest / trace_occluded).
+// The three kernels share one path loop (path_loop below); what differs is cited at each switch.
+#include "rs_internal.h"
+#include "rs_bsdf.h"
+
+using namespace rs;
+
+namespace {
+
+enum { kModePT = 0, kModePTIndirect = 1, kModeReSTIR = 2 };
+
+// scene.h:358-362
+__device__ inline float environment_map_pdf(const DevScene& s, f3 w) {
+    const TexRec env = s.textures[s.envTex];
+    float u, v;
+    to_plane(w, u, v);
+    return luminance(linear_sample(env, u, v)) * s.sumLightPowerInv * (float)env.width * (float)env.height * .5f;
+}
+// scene.h:121-126
+__device__ inline float primitive_area(const DevScene& s, int prim) {
+    const float* t = s.vertices + (size_t)prim * 9;
+    const f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+    return length(cross(v1 - v0, v2 - v0)) * .5f;
+}
+
+struct PathState {
+    f3 direct, indirect;          // kModePT: direct / indirect; others: indirect only (ReSTIR: the sample's Lo)
+    // ReSTIR-GI bookkeeping (restir.cu:273-281,316-321)
+    float primSamplePdf; bool primSampleDelta; f3 primWo; SurfMat primMaterial;
+    f3 xv, nv, xs, ns;
+    int walks;
+};
+
+// next-event estimation at the current vertex (pathtrace.cu:203-213 / 365-376, restir.cu:291-302)
+template <bool ENV>
+__device__ inline f3 nee_contribution(const DevScene& s, const SurfMat& m, f3 pos, f3 norm, f3 wo, f3 throughput, Rng& rng, int& walks) {
+    f3 radiance = splat(0.f), wi = splat(0.f);
+    const f4 r = rng.uniform4();
+    const float lightPdf = sample_light_visible<ENV>(s, pos, r, radiance, wi, walks);
+    if (lightPdf > 0.f) {
+        const float bsdfPdf = material_pdf(m, norm, wo, wi);
+        return ((((throughput * material_bsdf(m, norm, wo, wi)) * radiance) * sat_dot(norm, wi)) / lightPdf) * power_heuristic(lightPdf, bsdfPdf);
+    }
+    return splat(0.f);
+}
+
+// The loop of the three kernels from the first shaded hit on.  `h`, `material`, `ray` describe the primary hit.
+template <int MODE, bool TEX>
+__device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Rng& rng, int maxDepth, PathState& st) {
+    f3 throughput = splat(1.f);
+    f3 norm = h.norm, pos = h.pos;
+    f3 wo = -ray.d;
+    const bool env = TEX && s.envTex >= 0;
+    for (int depth = 1; depth <= maxDepth; depth++) {
+        const bool deltaBSDF = material.type == 2;
+        if (material.type != 2 && dot(norm, wo) < 0.f) norm = -norm;
+        if (!deltaBSDF && (MODE == kModePT || depth > 1)) {          // pathtrace.cu:203 vs :365, restir.cu:291
+            const f3 c = env ? nee_contribution<true>(s, material, pos, norm, wo, throughput, rng, st.walks)
+                             : nee_contribution<false>(s, material, pos, norm, wo, throughput, rng, st.walks);
+            if (MODE == kModePT && depth == 1) st.direct = st.direct + c; else st.indirect = st.indirect + c;
+        }
+        const f3 r3 = mk3(rng.uniform(), rng.uniform(), rng.uniform());        // sample3D
+        const BsdfSample sample = material_sample(material, norm, wo, r3);
+        if (sample.type == kBsInvalid) break;
+        else if (sample.pdf < 1e-8f) break;
+        const bool deltaSample = (sample.type & kBsSpecular) != 0;
+        if (MODE != kModeReSTIR || depth > 1) {                                 // restir.cu:315-325
+            throughput = throughput * ((sample.bsdf / sample.pdf) * (deltaSample ? 1.f : abs_dot(norm, sample.dir)));
+        }
+        else {
+            st.primSamplePdf = sample.pdf;
+            st.primSampleDelta = deltaSample;
+            st.xv = pos; st.nv = norm;
+        }
+        ray.o = pos + sample.dir * 1e-5f; ray.d = sample.dir;                   // makeOffsetedRay
+        const f3 curPos = pos;
+        h = trace_closest(s, ray);
+        st.walks++;
+        wo = -ray.d;
+        if (h.primId == kNullPrim) {
+            if (env) {
+                const f3 radiance = env_radiance(s, ray.d) * throughput;
+                const float weight = deltaSample ? 1.f : power_heuristic(sample.pdf, environment_map_pdf(s, ray.d));
+                st.indirect = st.indirect + radiance * weight;
+            }
+            break;
+        }
+        pos = h.pos; norm = h.norm;
+        material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+        if (material.type == 4) {
+            if (dot(norm, ray.d) < 0.f) break;                                  // SCENE_LIGHT_SINGLE_SIDED
+            const f3 radiance = material.baseColor;
+            const bool unweighted = deltaSample || (MODE == kModeReSTIR && depth == 1);          // restir.cu:353
+            const float weight = unweighted ? 1.f : power_heuristic(sample.pdf,
+                (luminance(radiance) * s.sumLightPowerInv * primitive_area(s, h.primId)) * dot(curPos - pos, curPos - pos) /
+                    abs_dot(norm, normalize(curPos - pos)));                     // Math::pdfAreaToSolidAngle (mathUtil.h:182-185)
+            st.indirect = st.indirect + (radiance * throughput) * weight;
+            if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+            break;
+        }
+        if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+    }
+}
+
+__device__ __forceinline__ void accumulate(float* image, int index, f3 v, int iter) {
+    float* o = image + (size_t)index * 3;
+    st3(o, (ld3(o) * (float)iter + v) / (float)(iter + 1));
+}
+
+struct IndResv { f3 Lo, xv, nv, xs, ns; int M; float W; };            // Reservoir<IndirectLiSample>, 68 B at the boundary
+__device__ inline IndResv ind_load(const rs_indirect_reservoir* p) {
+    const float* f = reinterpret_cast<const float*>(p);
+    IndResv r;
+    r.Lo = ld3(f); r.xv = ld3(f + 3); r.nv = ld3(f + 6); r.xs = ld3(f + 9); r.ns = ld3(f + 12);
+    r.M = __float_as_int(f[15]); r.W = f[16];
+    return r;
+}
+__device__ inline void ind_store(rs_indirect_reservoir* p, const IndResv& r) {
+    float* f = reinterpret_cast<float*>(p);
+    st3(f, r.Lo); st3(f + 3, r.xv); st3(f + 6, r.nv); st3(f + 9, r.xs); st3(f + 12, r.ns);
+    f[15] = __int_as_float(r.M); f[16] = r.W;
+}
+__device__ inline bool ind_invalid(float W) { return is_nan_or_inf(W) || W < 0.f; }
+
+template <int MODE, bool TEX>
+__global__ void __launch_bounds__(256) k_path(DevScene s, CamParams cam, float* __restrict__ directIllum, float* __restrict__ indirectIllum,
+                                              rs_indirect_reservoir* __restrict__ resvOut, const rs_indirect_reservoir* __restrict__ resvIn,
+                                              GBufView g, int looper, int iter, int maxDepth, int first, int reuse, int tilesX,
+                                              unsigned long long* rayCount) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const int x = bx * 32 + wave * 8 + (lane & 7);
+    const int y = by * 8 + (lane >> 3);
+    const bool inside = x < cam.width && y < cam.height;
+    const int index = y * cam.width + x;
+    Rng rng = seeded_rng(looper, index, 0);
+    const f4 r = rng.uniform4();
+    const Ray ray = camera_sample(cam, x, y, r.x, r.y);
+    const Hit h = trace_closest_packet(s, ray, inside);                // all 64 lanes take part in the wave's walk
+    PathState st;
+    st.direct = splat(0.f); st.indirect = splat(0.f); st.primSamplePdf = 0.f; st.primSampleDelta = false; st.primWo = -ray.d;
+    st.primMaterial = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
+    st.xv = st.nv = st.xs = st.ns = splat(0.f);
+    st.walks = 0;
+    if (inside) {
+        st.walks = 1;
+        if (h.primId == kNullPrim) {
+            if (MODE == kModePT) st.direct = splat(1.f);                               // pathtrace.cu:175-178
+        }
+        else {
+            f3 norm = h.norm;
+            SurfMat material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+            if (MODE == kModePT) material.baseColor = splat(1.f);                      // DENOISER_DEMODULATE (:181-185)
+            if (material.type == 4) {
+                if (MODE == kModePT) st.direct = splat(1.f);                           // :187-190
+            }
+            else {
+                Hit hh = h; hh.norm = norm;
+                st.primMaterial = material;
+                path_loop<MODE, TEX>(s, hh, material, ray, rng, maxDepth, st);
+            }
+        }
+
+        if (MODE == kModePT) {
+            if (any_nan_or_inf(st.direct)) st.direct = splat(0.f);
+            if (any_nan_or_inf(st.indirect)) st.indirect = splat(0.f);
+            accumulate(directIllum, index, hdr_to_ldr(st.direct), iter);                // Math::HDRToLDR (:273-276)
+            accumulate(indirectIllum, index, hdr_to_ldr(st.indirect), iter);
+        }
+        else if (MODE == kModePTIndirect) {
+            if (any_nan_or_inf(st.indirect)) st.indirect = splat(0.f);
+            accumulate(indirectIllum, index, st.indirect, iter);
+        }
+        else {
+            // WriteSample (restir.cu:372-416)
+            IndResv smp; smp.Lo = st.indirect; smp.xv = st.xv; smp.nv = st.nv; smp.xs = st.xs; smp.ns = st.ns; smp.M = 0; smp.W = 0.f;
+            IndResv rv; rv.Lo = rv.xv = rv.nv = rv.xs = rv.ns = splat(0.f); rv.M = 0; rv.W = 0.f;
+            float sampleWeight = 0.f;
+            if (!(luminance(smp.Lo) < 1e-8f)) {                                         // !indirectSample.invalid()
+                sampleWeight = luminance(smp.Lo / st.primSamplePdf);                    // toScalar(pHatIndirect / primSamplePdf), pHat = Lo
+                if ((sampleWeight != sampleWeight) || sampleWeight < 0.f) sampleWeight = 0.f;
+            }
+            {
+                const float u = rng.uniform();                                          // Reservoir::update
+                rv.W += sampleWeight; rv.M++;
+                if (u * rv.W < sampleWeight) { rv.Lo = smp.Lo; rv.xv = smp.xv; rv.nv = smp.nv; rv.xs = smp.xs; rv.ns = smp.ns; }
+            }
+            if (!first && (reuse & 1)) {                                                // findTemporalNeighbor (restir.cu:20-45)
+                const int primId = g.primId[index];
+                const int lastIdx = g.motion[index];
+                bool diff = false;
+                if (lastIdx < 0) diff = true;
+                else if (primId <= kNullPrim) diff = true;
+                else if (g.lastPrimId[lastIdx] != primId) diff = true;
+                else {
+                    const f3 n = ld3(g.normal + (size_t)index * 3), ln = ld3(g.lastNormal + (size_t)lastIdx * 3);
+                    const float depth = g.depth[index], pdepth = g.lastDepth[lastIdx];
+                    if (abs_dot(n, ln) < .9f || gabs(pdepth - depth) > depth * .1f) diff = true;
+                }
+                IndResv t; t.Lo = t.xv = t.nv = t.xs = t.ns = splat(0.f); t.M = 0; t.W = 0.f;
+                if (!diff) t = ind_load(resvIn + lastIdx);
+                if (!ind_invalid(t.W)) {
+                    const float u = rng.uniform();                                      // Reservoir::merge (restir.h:61-68)
+                    rv.W += t.W; rv.M += t.M;
+                    if (u * rv.W < t.W) { rv.Lo = t.Lo; rv.xv = t.xv; rv.nv = t.nv; rv.xs = t.xs; rv.ns = t.ns; }
+                }
+            }
+            f3 indirect = splat(0.f);
+            if (rv.M > 20) { rv.W *= (float)20 / (float)rv.M; rv.M = 20; }            // clamp<20>() (restir.h:79-86)
+            if (!ind_invalid(rv.W)) {
+                const f3 primWi = normalize(rv.xs - rv.xv);
+                indirect = ((rv.Lo / luminance(rv.Lo)) * rv.W) / (float)rv.M;
+                indirect = indirect * (material_bsdf(st.primMaterial, rv.nv, st.primWo, primWi) * (st.primSampleDelta ? 1.f : sat_dot(rv.nv, primWi)));
+            }
+            if (any_nan_or_inf(indirect)) indirect = splat(0.f);
+            ind_store(resvOut + index, rv);
+            accumulate(indirectIllum, index, indirect, iter);
+        }
+    }
+    // BVH walks for the Mrays/s metric: wave-level sum, one atomic per wave
+    int walks = st.walks;
+    for (int off = 32; off > 0; off >>= 1) walks += __shfl_down(walks, off);
+    if (lane == 0 && walks) atomicAdd(rayCount + (blockIdx.x % 64) * 8, (unsigned long long)walks);
+}
+
+unsigned long long* g_giRayCount = nullptr;     // 64 partial counters, 64 B apart
+
+int gi_counters() {
+    if (!g_giRayCount) RS_TRY(rs_dev_alloc(&g_giRayCount, 64 * 8));
+    RS_HIP(hipMemsetAsync(g_giRayCount, 0, 64 * 8 * sizeof(unsigned long long), rs_stream()));
+    return 0;
+}
+int gi_read_rays(unsigned long long* rays) {
+    if (!rays) return 0;
+    unsigned long long h[64 * 8];
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(h, g_giRayCount, sizeof h, hipMemcpyDeviceToHost));
+    *rays = 0;
+    for (int i = 0; i < 64; i++) *rays += h[i * 8];
+    return 0;
+}
+
+template <int MODE>
+int launch_path(const rs_scene* scene, const rs_camera* cam, float* direct, float* indirect, rs_indirect_reservoir* out,
+                const rs_indirect_reservoir* in, const GBufView& g, int looper, int iter, int maxDepth, int first, int reuse) {
+    const int W = cam->resolution[0], H = cam->resolution[1];
+    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
+    const CamParams cp = rs_make_cam_params(cam);
+    if (scene->textured)
+        hipLaunchKernelGGL((k_path<MODE, true>), dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, direct, indirect, out, in, g,
+                           looper, iter, maxDepth, first, reuse, tilesX, g_giRayCount);
+    else
+        hipLaunchKernelGGL((k_path<MODE, false>), dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, direct, indirect, out, in, g,
+                           looper, iter, maxDepth, first, reuse, tilesX, g_giRayCount);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_path_trace(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, float* devIndirectIllum,
+                  int iter, int looper, int maxDepth, unsigned long long* rays) {
+    if (!scene || !cam || !devDirectIllum || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTrace: null argument");
+    RS_TRY(gi_counters());
+    GBufView none{};
+    RS_TRY(launch_path<kModePT>(scene, cam, devDirectIllum, devIndirectIllum, nullptr, nullptr, none, looper, iter, maxDepth, 0, 0));
+    RS_TRY(rs_after_launch("pathTrace"));
+    return gi_read_rays(rays);
+}
+
+int rs_path_trace_indirect(const rs_scene* scene, const rs_camera* cam, float* devIndirectIllum, int iter, int looper, int maxDepth,
+                           unsigned long long* rays) {
+    if (!scene || !cam || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceIndirect: null argument");
+    RS_TRY(gi_counters());
+    GBufView none{};
+    RS_TRY(launch_path<kModePTIndirect>(scene, cam, nullptr, devIndirectIllum, nullptr, nullptr, none, looper, iter, maxDepth, 0, 0));
+    RS_TRY(rs_after_launch("pathTrace"));
+    return gi_read_rays(rays);
+}
+
+int rs_restir_indirect(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, float* devIndirectIllum,
+                       int iter, int looper, int reuse, int maxDepth, unsigned long long* rays) {
+    if (!r || !scene || !cam || !g || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRIndirect: null argument");
+    if (cam->resolution[0] != r->width || cam->resolution[1] != r->height || g->width != r->width || g->height != r->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRIndirect: size mismatch");
+    const size_t n = (size_t)r->width * r->height;
+    for (int i = 0; i < 2; i++)
+        if (!r->indResv[i]) {                                   // devIndTemporalReservoir / devIndLastTemporalReservoir (restir.cu:13-14,491-494)
+            RS_TRY(rs_dev_alloc(&r->indResv[i], n));
+            RS_HIP(hipMemsetAsync(r->indResv[i], 0, n * sizeof(rs_indirect_reservoir), rs_stream()));
+        }
+    RS_TRY(gi_counters());
+    RS_TRY(launch_path<kModeReSTIR>(scene, cam, nullptr, devIndirectIllum, r->indResv[0], r->indResv[1], gbuf_view(g), looper, iter, maxDepth,
+                                    r->firstFrame ? 1 : 0, reuse));
+    { rs_indirect_reservoir* t = r->indResv[0]; r->indResv[0] = r->indResv[1]; r->indResv[1] = t; }      // std::swap (:463)
+    r->firstFrame = false;                                                                                    // ReSTIRFirstFrame (:465-467)
+    RS_TRY(rs_after_launch("ReSTIR Indirect"));
+    return gi_read_rays(rays);
+}
+
+int rs_restir_download_indirect(rs_restir* r, int which, rs_indirect_reservoir* host) {
+    if (!r || !host || which < 0 || which > 1 || !r->indResv[which]) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_download_indirect: bad argument");
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(host, r->indResv[which], (size_t)r->width * r->height * sizeof(rs_indirect_reservoir), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -537,6 +537,7 @@ int rs_restir_free(rs_restir* r) {
     rs_dev_free(r->temp.li); rs_dev_free(r->temp.wi); rs_dev_free(r->temp.tap);
     rs_dev_free(r->surfPosKind); rs_dev_free(r->surfNorm); rs_dev_free(r->surfWo); rs_dev_free(r->rngMat);
     rs_dev_free(r->candLi); rs_dev_free(r->candWi); rs_dev_free(r->dRayCount);
+    rs_dev_free(r->indResv[0]); rs_dev_free(r->indResv[1]);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     delete r;
     return 0;

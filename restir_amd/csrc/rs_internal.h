@@ -132,6 +132,7 @@ struct rs_restir {
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
     TempPlanes temp;     // devDirectTemp           (published for the spatial pass)
+    rs_indirect_reservoir* indResv[2] = { nullptr, nullptr };   // devIndTemporalReservoir / devIndLastTemporalReservoir (gi.hip), allocated on first use
     bool firstFrame = true;
     // per-pixel state carried between the passes of one frame (implementation bytes, not in the
     // reference: its single fused kernel keeps these in registers)

@@ -79,11 +79,11 @@ __device__ inline f3 local_to_world(f3 n, f3 v) {
 }
 
 // what the kernels need of a Material after getTexturedMaterialAndSurface
-struct SurfMat { int type; f3 baseColor; float metallic, roughness; };
+struct SurfMat { int type; f3 baseColor; float metallic, roughness, ior; };
 
 __device__ inline SurfMat plain_material(const DevScene& s, int matId) {
     const rs_material m = s.materials[matId];
-    SurfMat o; o.type = m.type; o.baseColor = ld3(m.baseColor); o.metallic = m.metallic; o.roughness = m.roughness;
+    SurfMat o; o.type = m.type; o.baseColor = ld3(m.baseColor); o.metallic = m.metallic; o.roughness = m.roughness; o.ior = m.ior;
     return o;
 }
 
@@ -98,7 +98,7 @@ __device__ inline void hit_uv(const DevScene& s, const Hit& h, float& u, float& 
 // scene.h:78-99; a normal map also replaces the interpolated normal
 __device__ inline SurfMat textured_material(const DevScene& s, const Hit& h, f3& norm) {
     const rs_material m = s.materials[h.matId];
-    SurfMat o; o.type = m.type; o.baseColor = ld3(m.baseColor); o.metallic = m.metallic; o.roughness = m.roughness;
+    SurfMat o; o.type = m.type; o.baseColor = ld3(m.baseColor); o.metallic = m.metallic; o.roughness = m.roughness; o.ior = m.ior;
     if (m.baseColorMapId == kNullTexture && m.metallicMapId <= kNullTexture && m.roughnessMapId <= kNullTexture && m.normalMapId == kNullTexture)
         return o;
     float u, v;
@@ -172,6 +172,19 @@ __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasP
     o.dist = len;
     o.pdf = d.w * dd / gabs(-dot(nrm, o.wi));
     return o;
+}
+
+// sampleDirectLight (src/scene.h:427-459): like the NoVisibility form, but with an occlusion test to
+// the sampled point before the single-sided test.
+// With an environment map the last sampler entry is sampleEnvironmentMap (:378-392): occlusion towards pos + wi * 1e6.
+template <bool ENV>
+__device__ inline float sample_light_visible(const DevScene& s, f3 pos, f4 r, f3& Li, f3& wi, int& walks) {
+    LightSample c = sample_light_nv<ENV, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
+    if (s.numLights == 0) return kInvalidPdf;
+    walks++;
+    if (trace_occluded(s, pos, c.point)) return kInvalidPdf;
+    Li = c.Li; wi = c.wi;
+    return c.pdf;
 }
 #endif  // __HIPCC__
 

@@ -73,7 +73,12 @@ MATERIAL_DTYPE = np.dtype(
 RESERVOIR_DTYPE = np.dtype(
     [("Li", "<f4", (3,)), ("wi", "<f4", (3,)), ("dist", "<f4"), ("numSamples", "<i4"), ("weight", "<f4")]
 )
-assert MATERIAL_DTYPE.itemsize == 44 and RESERVOIR_DTYPE.itemsize == 36
+# Reservoir<IndirectLiSample> (src/restir.h:13-27,114-116), 68 bytes
+INDIRECT_RESERVOIR_DTYPE = np.dtype(
+    [("Lo", "<f4", (3,)), ("xv", "<f4", (3,)), ("nv", "<f4", (3,)), ("xs", "<f4", (3,)), ("ns", "<f4", (3,)),
+     ("numSamples", "<i4"), ("weight", "<f4")]
+)
+assert MATERIAL_DTYPE.itemsize == 44 and RESERVOIR_DTYPE.itemsize == 36 and INDIRECT_RESERVOIR_DTYPE.itemsize == 68
 
 # Material::Type (src/material.h:114-120)
 LAMBERTIAN, METALLIC_WORKFLOW, DIELECTRIC, DISNEY, LIGHT = range(5)

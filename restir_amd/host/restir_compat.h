@@ -122,6 +122,23 @@ inline void pathTraceDirect(rsc::vec3* devDirectIllum, int iter) {              
                                     iter, State::looper, nullptr), "pathTrace");
     State::looper++;
 }
+// multi-bounce kernels (src/pathtrace.h:12-16, src/restir.h:133); Settings::traceDepth is the reference's global
+inline void pathTrace(rsc::vec3* devDirectIllum, rsc::vec3* devIndirectIllum, int iter) {  // src/pathtrace.cu:434-455
+    rsc::check(rs_path_trace(State::scene->devScene, &State::scene->camera, reinterpret_cast<float*>(devDirectIllum),
+                             reinterpret_cast<float*>(devIndirectIllum), iter, State::looper, Settings::traceDepth, nullptr), "pathTrace");
+    State::looper++;
+}
+inline void pathTraceIndirect(rsc::vec3* devIndirectIllum, int iter) {                     // src/pathtrace.cu:478-497
+    rsc::check(rs_path_trace_indirect(State::scene->devScene, &State::scene->camera, reinterpret_cast<float*>(devIndirectIllum),
+                                      iter, State::looper, Settings::traceDepth, nullptr), "pathTrace");
+    State::looper++;
+}
+inline void ReSTIRIndirect(rsc::vec3* devIndirectIllum, int iter, const GBuffer& gBuffer) {   // src/restir.cu:448-476
+    rsc::check(rs_restir_indirect(rsc::g_restir, State::scene->devScene, &State::scene->camera, gBuffer.impl,
+                                  reinterpret_cast<float*>(devIndirectIllum), iter, State::looper, Settings::reservoirReuse,
+                                  Settings::traceDepth, nullptr), "ReSTIR Indirect");
+    State::looper++;
+}
 struct uchar4_t { unsigned char x, y, z, w; };
 inline void copyImageToPBO(void* devPBO, rsc::vec3* devImage, int width, int height, int toneMapping, float scale = 1.f) {
     rsc::check(rs_copy_image_to_pbo(devPBO, reinterpret_cast<const float*>(devImage), width, height, toneMapping, scale), "copyImageToPBO");

@@ -133,6 +133,19 @@ def main():
     l2w = np.zeros((3000, 3), np.float32); R.ref_local_to_world(3000, nn_.reshape(-1), lv.reshape(-1), l2w.reshape(-1))
     g.update(tex=tex, tex_uv=uv, tex_sample=ls, sph_uv=u01, sph_dir=sph, plane_dir=dirs, plane_uv=pl, l2w_n=nn_, l2w_v=lv, l2w_out=l2w)
 
+    # Material::sample / pdf (material.h:230-256) for every type, poles and degenerate parameters included
+    nm = 6000
+    ms = np.zeros(nm, MATERIAL_DTYPE)
+    ms["type"] = rng.integers(0, 5, nm); ms["baseColor"] = rng.uniform(0, 1, (nm, 3))
+    ms["metallic"] = rng.uniform(0, 1, nm); ms["roughness"] = rng.uniform(0.02, 1, nm); ms["ior"] = rng.uniform(1.0, 2.5, nm)
+    ms["metallic"][:100] = 0; ms["metallic"][100:200] = 1; ms["roughness"][200:300] = 0
+    mn, mwo, mwi = unit(rng, nm), unit(rng, nm), unit(rng, nm)
+    mn[:60] = [0, 1, 0]; mwo[60:120] = mn[60:120]
+    mr = rng.uniform(0, 1, (nm, 3)).astype(np.float32); mr[:10] = 0; mr[10:20] = 1
+    sd_, sb_, sp_, st_ = ob.material_sample(ms, mn, mwo, mr, R.ref_material_sample)
+    g.update(ms_mats=ms, ms_n=mn, ms_wo=mwo, ms_wi=mwi, ms_r=mr, ms_dir=sd_, ms_bsdf=sb_, ms_pdf=sp_, ms_type=st_,
+             ms_pdf_eval=ob.material_pdf(ms, mn, mwo, mwi, R.ref_material_pdf))
+
     np.savez_compressed(os.path.join(OUT, "functions_ref.npz"), **g)
     print("functions_ref.npz", os.path.getsize(os.path.join(OUT, "functions_ref.npz")), "bytes,", len(g), "arrays")
 
@@ -160,6 +173,15 @@ def main():
             fr[f"{name}_libm{mode}_frame1"] = img.copy()
             fr[f"{name}_libm{mode}_albedo"] = o.gbuf.albedo.copy()
     ob.set_libm_mode(0)
+    # multi-bounce kernels (singleKernelPT, PTIndirectKernel, ReSTIRIndirectKernel)
+    o = OracleRenderer(get_scene("cornell"), 48, 48)
+    d = np.zeros((48 * 48, 3), np.float32); i1 = np.zeros_like(d); i2 = np.zeros_like(d); i3 = np.zeros_like(d)
+    ob.path_trace(o.scene, o.cam, d, i1, 0, 0, 4)
+    ob.pt_indirect(o.scene, o.cam, i2, 0, 1, 4)
+    for frame in range(3):
+        o.gbuf.render(o.scene, o.cam); o.restir.indirect(o.scene, o.cam, o.gbuf, i3, 0, frame, 1, 4); o.gbuf.update(o.cam)
+    fr.update(cornell48_pt_direct=d, cornell48_pt_indirect=i1, cornell48_ptind=i2, cornell48_gi=i3,
+              cornell48_gi_M=o.restir.ind_last["numSamples"].copy())
     np.savez_compressed(os.path.join(OUT, "frames_oracle.npz"), **fr)
     print("frames_oracle.npz", os.path.getsize(os.path.join(OUT, "frames_oracle.npz")), "bytes")
 

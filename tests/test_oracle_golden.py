@@ -113,6 +113,15 @@ def test_texture_and_environment_helpers(g):
     assert ulp.max() <= 4 and (ulp > 0).mean() < 0.1
 
 
+def test_material_sample_and_pdf(g):
+    """Material::sample / pdf (material.h:230-256: cosine hemisphere, GGX visible normals, dielectric reflect / refract)."""
+    d, b, p, t = ob.material_sample(g["ms_mats"], g["ms_n"], g["ms_wo"], g["ms_r"])
+    assert np.array_equal(t, g["ms_type"])
+    assert bits_equal(d, g["ms_dir"]) and bits_equal(b, g["ms_bsdf"]) and bits_equal(p, g["ms_pdf"])
+    assert bits_equal(ob.material_pdf(g["ms_mats"], g["ms_n"], g["ms_wo"], g["ms_wi"]), g["ms_pdf_eval"])
+    assert set(np.unique(t)) >= {1 | 16, 2 | 16, 4 | 16, 4 | 32, 1 << 15}      # diffuse, glossy, specular R / T, invalid
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_tonemap(g, mode):
     o = np.zeros_like(g["tonemap_in"])
@@ -139,6 +148,15 @@ def test_frames_regression_pin():
         assert np.array_equal(o.restir.last["numSamples"], fr[f"cornell64_reuse{reuse}_M"])
     o = OracleRenderer(sd, 64, 64)
     assert bits_equal(o.frame(0, use_reservoir=False), fr["cornell64_ptdirect"])
+    o = OracleRenderer(sd, 48, 48)
+    d = np.zeros((48 * 48, 3), np.float32); i1 = np.zeros_like(d); i2 = np.zeros_like(d); i3 = np.zeros_like(d)
+    ob.path_trace(o.scene, o.cam, d, i1, 0, 0, 4)
+    ob.pt_indirect(o.scene, o.cam, i2, 0, 1, 4)
+    for frame in range(3):
+        o.gbuf.render(o.scene, o.cam); o.restir.indirect(o.scene, o.cam, o.gbuf, i3, 0, frame, 1, 4); o.gbuf.update(o.cam)
+    assert bits_equal(d, fr["cornell48_pt_direct"]) and bits_equal(i1, fr["cornell48_pt_indirect"])
+    assert bits_equal(i2, fr["cornell48_ptind"]) and bits_equal(i3, fr["cornell48_gi"])
+    assert np.array_equal(o.restir.ind_last["numSamples"], fr["cornell48_gi_M"])
     for name in ("cornell_textured", "cornell_maps"):
         for mode in (0, 1):
             ob.set_libm_mode(mode)

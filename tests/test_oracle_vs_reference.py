@@ -124,3 +124,21 @@ def test_texture_and_environment_helpers():
     v = rng.uniform(-1, 1, (200000, 3)).astype(np.float32)
     b = np.zeros((len(n), 3), np.float32); R.ref_local_to_world(len(n), n.reshape(-1), v.reshape(-1), b.reshape(-1))
     assert bits_equal(ob.local_to_world(n, v), b)
+
+
+@needs_ref
+def test_material_sample_and_pdf():
+    """Material::sample / pdf against the reference's material.h on 3e5 random inputs of every type."""
+    rng = np.random.default_rng(3)
+    n = 300000
+    mats = np.zeros(n, MATERIAL_DTYPE)
+    mats["type"] = rng.integers(0, 5, n); mats["baseColor"] = rng.uniform(0, 1, (n, 3))
+    mats["metallic"] = rng.uniform(0, 1, n); mats["roughness"] = rng.uniform(0.02, 1, n); mats["ior"] = rng.uniform(1.0, 2.5, n)
+    mats["metallic"][:1000] = 0; mats["metallic"][1000:2000] = 1; mats["roughness"][2000:3000] = 0
+    nrm, wo, wi = unit(rng, n), unit(rng, n), unit(rng, n)
+    nrm[:500] = [0, 1, 0]; wo[500:1000] = nrm[500:1000]
+    r3 = rng.uniform(0, 1, (n, 3)).astype(np.float32); r3[:50] = 0; r3[50:100] = 1
+    a = ob.material_sample(mats, nrm, wo, r3); b = ob.material_sample(mats, nrm, wo, r3, R.ref_material_sample)
+    assert np.array_equal(a[3], b[3])
+    assert bits_equal(a[0], b[0]) and bits_equal(a[1], b[1]) and bits_equal(a[2], b[2])
+    assert bits_equal(ob.material_pdf(mats, nrm, wo, wi), ob.material_pdf(mats, nrm, wo, wi, R.ref_material_pdf))
