@@ -4,8 +4,9 @@
 //   ReSTIRIndirectKernel / ReSTIRIndirect  src/restir.cu:233-416,448-476   (Reservoir<IndirectLiSample>, temporal reuse)
 //
 // One lane per pixel, 8x8 pixel tile per wave.  The primary ray is coherent and uses the wave-cooperative packet
-// walk; after the first bounce rays are incoherent and lanes leave the loop at different depths, so the
-// continuation and shadow rays use the per-lane walks of the reference's tree (trace_closest / trace_occluded).
+// walk; after the first bounce rays are incoherent, so continuation rays use the pair-cooperative per-lane walk of
+// the reference's tree and shadow rays the shadow tree -- both wave-level services, which is why the path loop is
+// run by the whole wave with per-lane `alive` flags instead of lanes breaking out of it.
 // The three kernels share one path loop (path_loop below); what differs is cited at each switch.
 #include "rs_internal.h"
 #include "rs_bsdf.h"
@@ -38,74 +39,95 @@ struct PathState {
     int walks;
 };
 
-// next-event estimation at the current vertex (pathtrace.cu:203-213 / 365-376, restir.cu:291-302)
-template <bool ENV>
-__device__ inline f3 nee_contribution(const DevScene& s, const SurfMat& m, f3 pos, f3 norm, f3 wo, f3 throughput, Rng& rng, int& walks) {
-    f3 radiance = splat(0.f), wi = splat(0.f);
-    const f4 r = rng.uniform4();
-    const float lightPdf = sample_light_visible<ENV>(s, pos, r, radiance, wi, walks);
-    if (lightPdf > 0.f) {
-        const float bsdfPdf = material_pdf(m, norm, wo, wi);
-        return ((((throughput * material_bsdf(m, norm, wo, wi)) * radiance) * sat_dot(norm, wi)) / lightPdf) * power_heuristic(lightPdf, bsdfPdf);
-    }
-    return splat(0.f);
-}
-
-// The loop of the three kernels from the first shaded hit on.  `h`, `material`, `ray` describe the primary hit.
+// The loop of the three kernels from the first shaded hit on, run by the WHOLE wave: lanes whose path has ended
+// (or never started: `alive` false) stay in the loop with their flag down, so that the shadow rays can use the
+// wave-level shadow-tree walk (trace_occluded_wave) and the continuation rays the pair-cooperative walk
+// (trace_closest_wave) instead of per-lane walks inside a divergent loop.  Per lane the sequence of
+// random draws and arithmetic is that of the reference.
 template <int MODE, bool TEX>
-__device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Rng& rng, int maxDepth, PathState& st) {
+__device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Rng& rng, int maxDepth, bool alive, PathState& st) {
     f3 throughput = splat(1.f);
     f3 norm = h.norm, pos = h.pos;
     f3 wo = -ray.d;
     const bool env = TEX && s.envTex >= 0;
     for (int depth = 1; depth <= maxDepth; depth++) {
+        if (!__any(alive)) break;
         const bool deltaBSDF = material.type == 2;
-        if (material.type != 2 && dot(norm, wo) < 0.f) norm = -norm;
-        if (!deltaBSDF && (MODE == kModePT || depth > 1)) {          // pathtrace.cu:203 vs :365, restir.cu:291
-            const f3 c = env ? nee_contribution<true>(s, material, pos, norm, wo, throughput, rng, st.walks)
-                             : nee_contribution<false>(s, material, pos, norm, wo, throughput, rng, st.walks);
-            if (MODE == kModePT && depth == 1) st.direct = st.direct + c; else st.indirect = st.indirect + c;
+        if (alive && material.type != 2 && dot(norm, wo) < 0.f) norm = -norm;
+
+        // next-event estimation (pathtrace.cu:203-213 / 365-376, restir.cu:291-302): sampleDirectLight = light sample,
+        // occlusion test towards it, then the single-sided / pdf part
+        const bool nee = alive && !deltaBSDF && (MODE == kModePT || depth > 1) && s.numLights > 0;    // pathtrace.cu:203 vs :365, restir.cu:291
+        LightSample c;
+        c.pdf = kInvalidPdf; c.Li = splat(0.f); c.wi = splat(0.f); c.dist = 0.f; c.point = pos; c.id = 0;
+        if (alive && !deltaBSDF && (MODE == kModePT || depth > 1)) {
+            const f4 r = rng.uniform4();                                        // drawn even without lights (sample4D is an argument)
+            if (nee) c = env ? sample_light_nv<true, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r)
+                             : sample_light_nv<false, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
         }
-        const f3 r3 = mk3(rng.uniform(), rng.uniform(), rng.uniform());        // sample3D
-        const BsdfSample sample = material_sample(material, norm, wo, r3);
-        if (sample.type == kBsInvalid) break;
-        else if (sample.pdf < 1e-8f) break;
-        const bool deltaSample = (sample.type & kBsSpecular) != 0;
-        if (MODE != kModeReSTIR || depth > 1) {                                 // restir.cu:315-325
-            throughput = throughput * ((sample.bsdf / sample.pdf) * (deltaSample ? 1.f : abs_dot(norm, sample.dir)));
-        }
-        else {
-            st.primSamplePdf = sample.pdf;
-            st.primSampleDelta = deltaSample;
-            st.xv = pos; st.nv = norm;
-        }
-        ray.o = pos + sample.dir * 1e-5f; ray.d = sample.dir;                   // makeOffsetedRay
-        const f3 curPos = pos;
-        h = trace_closest(s, ray);
-        st.walks++;
-        wo = -ray.d;
-        if (h.primId == kNullPrim) {
-            if (env) {
-                const f3 radiance = env_radiance(s, ray.d) * throughput;
-                const float weight = deltaSample ? 1.f : power_heuristic(sample.pdf, environment_map_pdf(s, ray.d));
-                st.indirect = st.indirect + radiance * weight;
+        const bool occluded = trace_occluded_wave(s, pos, c.point, nee);
+        if (nee) {
+            st.walks++;
+            const float lightPdf = occluded ? kInvalidPdf : c.pdf;
+            if (lightPdf > 0.f) {
+                const float bsdfPdf = material_pdf(material, norm, wo, c.wi);
+                const f3 add = ((((throughput * material_bsdf(material, norm, wo, c.wi)) * c.Li) * sat_dot(norm, c.wi)) / lightPdf) * power_heuristic(lightPdf, bsdfPdf);
+                if (MODE == kModePT && depth == 1) st.direct = st.direct + add; else st.indirect = st.indirect + add;
             }
-            break;
         }
-        pos = h.pos; norm = h.norm;
-        material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
-        if (material.type == 4) {
-            if (dot(norm, ray.d) < 0.f) break;                                  // SCENE_LIGHT_SINGLE_SIDED
-            const f3 radiance = material.baseColor;
-            const bool unweighted = deltaSample || (MODE == kModeReSTIR && depth == 1);          // restir.cu:353
-            const float weight = unweighted ? 1.f : power_heuristic(sample.pdf,
-                (luminance(radiance) * s.sumLightPowerInv * primitive_area(s, h.primId)) * dot(curPos - pos, curPos - pos) /
-                    abs_dot(norm, normalize(curPos - pos)));                     // Math::pdfAreaToSolidAngle (mathUtil.h:182-185)
-            st.indirect = st.indirect + (radiance * throughput) * weight;
-            if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
-            break;
+
+        BsdfSample sample;
+        sample.dir = splat(0.f); sample.bsdf = splat(0.f); sample.pdf = 0.f; sample.type = kBsInvalid;
+        bool deltaSample = false;
+        if (alive) {
+            const f3 r3 = mk3(rng.uniform(), rng.uniform(), rng.uniform());    // sample3D
+            sample = material_sample(material, norm, wo, r3);
+            if (sample.type == kBsInvalid) alive = false;
+            else if (sample.pdf < 1e-8f) alive = false;
         }
-        if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+        const f3 curPos = pos;
+        if (alive) {
+            deltaSample = (sample.type & kBsSpecular) != 0;
+            if (MODE != kModeReSTIR || depth > 1) {                             // restir.cu:315-325
+                throughput = throughput * ((sample.bsdf / sample.pdf) * (deltaSample ? 1.f : abs_dot(norm, sample.dir)));
+            }
+            else {
+                st.primSamplePdf = sample.pdf;
+                st.primSampleDelta = deltaSample;
+                st.xv = pos; st.nv = norm;
+            }
+            ray.o = pos + sample.dir * 1e-5f; ray.d = sample.dir;               // makeOffsetedRay
+        }
+        h = trace_closest_wave(s, ray, alive);
+        if (alive) {
+            st.walks++;
+            wo = -ray.d;
+            if (h.primId == kNullPrim) {
+                if (env) {
+                    const f3 radiance = env_radiance(s, ray.d) * throughput;
+                    const float weight = deltaSample ? 1.f : power_heuristic(sample.pdf, environment_map_pdf(s, ray.d));
+                    st.indirect = st.indirect + radiance * weight;
+                }
+                alive = false;
+            }
+            else {
+                pos = h.pos; norm = h.norm;
+                material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+                if (material.type == 4) {
+                    if (!(dot(norm, ray.d) < 0.f)) {                            // SCENE_LIGHT_SINGLE_SIDED: the back side ends the path silently
+                        const f3 radiance = material.baseColor;
+                        const bool unweighted = deltaSample || (MODE == kModeReSTIR && depth == 1);      // restir.cu:353
+                        const float weight = unweighted ? 1.f : power_heuristic(sample.pdf,
+                            (luminance(radiance) * s.sumLightPowerInv * primitive_area(s, h.primId)) * dot(curPos - pos, curPos - pos) /
+                                abs_dot(norm, normalize(curPos - pos)));         // Math::pdfAreaToSolidAngle (mathUtil.h:182-185)
+                        st.indirect = st.indirect + (radiance * throughput) * weight;
+                        if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+                    }
+                    alive = false;
+                }
+                else if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+            }
+        }
     }
 }
 
@@ -149,6 +171,10 @@ __global__ void __launch_bounds__(256) k_path(DevScene s, CamParams cam, float* 
     st.primMaterial = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
     st.xv = st.nv = st.xs = st.ns = splat(0.f);
     st.walks = 0;
+    // primary hit (pathtrace.cu:172-190 / 343-350, restir.cu:259-270); lanes that end here keep alive = false
+    bool alive = false;
+    Hit hh = h;
+    SurfMat material = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
     if (inside) {
         st.walks = 1;
         if (h.primId == kNullPrim) {
@@ -156,18 +182,20 @@ __global__ void __launch_bounds__(256) k_path(DevScene s, CamParams cam, float* 
         }
         else {
             f3 norm = h.norm;
-            SurfMat material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+            material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
             if (MODE == kModePT) material.baseColor = splat(1.f);                      // DENOISER_DEMODULATE (:181-185)
             if (material.type == 4) {
                 if (MODE == kModePT) st.direct = splat(1.f);                           // :187-190
             }
             else {
-                Hit hh = h; hh.norm = norm;
+                hh.norm = norm;
                 st.primMaterial = material;
-                path_loop<MODE, TEX>(s, hh, material, ray, rng, maxDepth, st);
+                alive = true;
             }
         }
-
+    }
+    path_loop<MODE, TEX>(s, hh, material, ray, rng, maxDepth, alive, st);                // every lane of the wave takes part
+    if (inside) {
         if (MODE == kModePT) {
             if (any_nan_or_inf(st.direct)) st.direct = splat(0.f);
             if (any_nan_or_inf(st.indirect)) st.indirect = splat(0.f);

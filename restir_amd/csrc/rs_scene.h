@@ -766,6 +766,27 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     return h;
 }
 
+// closest hit for a whole wave of INCOHERENT rays (bounce rays): per-lane walks of the reference's tree with the
+// pair-cooperative node fetch; every lane of the wave must call it, `active` false where there is no ray
+__device__ inline Hit trace_closest_wave(const DevScene& s, const Ray& ray, bool active) {
+    const WalkResult w = walk_dispatch_paired<false>(s, ray, 3.402823466e+38f, active);
+    Hit h;
+    h.primId = active ? w.prim : kNullPrim;
+    h.matId = 0;
+    h.pos = splat(0.f);
+    h.norm = splat(0.f);
+    h.bx = w.bx; h.by = w.by;
+    if (h.primId != kNullPrim) {           // getIntersecGeomInfo (scene.h:135-151)
+        const float* v = s.vertices + (size_t)w.prim * 9;
+        const float* n = s.normals + (size_t)w.prim * 9;
+        float wgt = 1.f - w.bx - w.by;
+        h.pos = ld3(v + 3) * w.bx + ld3(v + 6) * w.by + ld3(v) * wgt;
+        h.norm = normalize(ld3(n + 3) * w.bx + ld3(n + 6) * w.by + ld3(n) * wgt);
+        h.matId = s.materialIds[w.prim];
+    }
+    return h;
+}
+
 // testOcclusion for a whole wave of (incoherent) segments with the pair-cooperative fetch; every lane of
 // the wave must call it, `active` false where there is no segment
 __device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool active) {

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""tools/bench_gi.py -- 1080p timings of the multi-bounce kernels (gi.hip) on the bench scene: pathTrace (singleKernelPT),
+pathTraceIndirect and ReSTIRIndirect at Settings::traceDepth = 4; Mrays/s = BVH walks (closest-hit + shadow) per second."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from restir_amd import capi, scenes
+
+W, H, DEPTH = 1920, 1080, 4
+capi.init(0)
+sd = scenes.sponza_class(seed=1, scale=1.0)
+scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+cam = capi.camera_update(sd.camera(W, H))
+gbuf = capi.GBuffer(W, H); restir = capi.ReSTIR(W, H)
+d = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda"); i = torch.zeros_like(d)
+gbuf.render(scene, cam)
+
+
+def run(name, fn, frames=10):
+    fn(0); torch.cuda.synchronize()
+    t0 = time.perf_counter(); rays = 0
+    for f in range(1, frames + 1):
+        rays += fn(f)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    print("%-18s %.2f ms / frame, %.2f M walks / frame -> %.0f Mrays/s" % (name, dt * 1e3, rays / frames / 1e6, rays / frames / dt / 1e6))
+
+
+run("pathTrace", lambda f: capi.path_trace(scene, cam, d.data_ptr(), i.data_ptr(), 0, f, DEPTH))
+run("pathTraceIndirect", lambda f: capi.path_trace_indirect(scene, cam, i.data_ptr(), 0, f, DEPTH))
+run("ReSTIRIndirect", lambda f: restir.indirect(scene, cam, gbuf, i.data_ptr(), 0, f, 1, DEPTH))
