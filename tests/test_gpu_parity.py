@@ -17,7 +17,7 @@ import pytest
 
 from oracle import binding as ob
 from restir_amd.ctypes_structs import RESERVOIR_DTYPE
-from tests.common import (HipRenderer, OracleRenderer, bits_equal, get_scene, mismatch_fraction, oracle_scene,
+from tests.common import (HipRenderer, OracleRenderer, bits_equal, get_scene, hip_scene, mismatch_fraction, oracle_scene,
                           radiance_stats)
 
 pytestmark = pytest.mark.gpu
@@ -608,6 +608,37 @@ def test_strip_tiling_equals_full_frame(hip):
         hip.synchronize()
         got = np.concatenate([ranks[0].image.cpu().numpy()[:bounds[0][1] * W], ranks[1].image.cpu().numpy()[bounds[1][0] * W:]])
         assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
+
+
+def test_config4_4k_eight_strips_equal_full_frame(hip):
+    """BASELINE config 4: the bench scene at 3840x2160 cut into 8 row strips with the 5-row reservoir halo -- the
+    eight ranks are run one after the other on this GPU -- against the full-frame result, bit for bit."""
+    import torch
+    from restir_amd.tiling import HALO, HipBackend, strip_bounds
+    sd = get_scene("sponza:1.0")
+    W, H, N = 3840, 2160, 8
+    scene = hip_scene(hip, sd)
+    cam = hip.camera_update(sd.camera(W, H))
+    full = HipBackend(hip, scene, cam, W, H)
+    ranks = [HipBackend(hip, scene, cam, W, H) for _ in range(N)]
+    bounds = [strip_bounds(H, N, r) for r in range(N)]
+    for frame in range(2):
+        full.gbuffer_render(0, H); full.phase_a(frame, 3, 0, H); full.phase_b(0, 3, 0, H); full.end_frame()
+        for b, (y0, y1) in zip(ranks, bounds):
+            b.gbuffer_render(max(0, y0 - HALO), min(H, y1 + HALO))
+            b.phase_a(frame, 3, y0, y1)
+        for r in range(N - 1):                                       # neighbours r (above) and r+1 (below)
+            edge = bounds[r][1]
+            down = ranks[r].halo_pack(edge - HALO, HALO); up = ranks[r + 1].halo_pack(edge, HALO)
+            ranks[r + 1].halo_unpack(edge - HALO, HALO, down); ranks[r].halo_unpack(edge, HALO, up)
+        for b, (y0, y1) in zip(ranks, bounds):
+            b.phase_b(0, 3, y0, y1); b.end_frame()
+        hip.synchronize()
+        ref = full.image.cpu().numpy()
+        got = np.concatenate([b.image[y0 * W:y1 * W].cpu().numpy() for b, (y0, y1) in zip(ranks, bounds)])
+        assert np.isfinite(ref).all() and ref.max() > 0
+        assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
+        assert full.restir.ray_count() == sum(b.restir.ray_count() for b in ranks)      # primary + shadow walks of the own rows
 
 
 def test_full_size_properties(hip):
