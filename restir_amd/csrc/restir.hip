@@ -4,22 +4,23 @@
 // grid-wide dependency.  Here the frame is four launches on one stream, which gives
 // the two-phase contract by construction (stream order is the grid barrier):
 //
-//   phase A  k_primary          jittered primary ray, closest-hit MTBVH walk          restir.cu:127-153
-//            k_ris              32-candidate RIS over the light table (no rays)       restir.cu:155-170
-//            k_shadow_temporal  shadow ray on the RIS winner, temporal merge,
-//                               publish reservoirs                                    restir.cu:172-194,211-212
+//   phase A  k_primary          jittered primary ray, wave-cooperative packet walk of
+//                               the MTBVH, material after its texture maps            restir.cu:127-153
+//            k_ris / k_ris_lds  32-candidate RIS over the light table (no rays)       restir.cu:155-170
+//            k_shadow_temporal  shadow ray on the RIS winner (shadow tree), temporal
+//                               merge, publish reservoirs                             restir.cu:172-194,211-212
 //   phase B  k_spatial_shade    5-tap spatial reuse from an LDS-staged tile+halo,
 //                               shade, accumulate                                     restir.cu:196-230
 //
 // Splitting the walk-bound passes from the ALU-bound RIS loop keeps the traversal kernels at low
-// register counts (many waves per SIMD to hide the dependent node fetches) and lets the RIS kernel
-// run without divergence.  The price is ~100 B/px of per-pixel state between passes (surf*/cand*
-// planes below), which is small next to the walks.
+// register counts (8 waves per SIMD) and lets the RIS kernel run without divergence.  The price is
+// ~90 B/px of per-pixel state between passes (SurfPlanes below), which is small next to the walks.
 //
-// Reservoir storage is four planes (rs_internal.h ResvPlanes).  The spatial pass stages only the
-// planes its neighbour tests need -- weight, M, G-buffer id / normal / depth -- for a 32x8 tile
-// plus a 5-pixel halo into LDS (21 KB), tracks the SOURCE PIXEL of the surviving sample through the
-// merges, and gathers that one sample (32 B) at the end instead of staging Li/wi for 756 pixels.
+// Reservoir storage is four planes (rs_internal.h ResvPlanes); what the spatial pass gathers from is
+// one 16-byte tap record per pixel {W, M, G-buffer id, depth} (TempPlanes).  The spatial pass stages
+// tap record + normal for a 32x16 tile plus a 5-pixel halo into LDS (35 KB), tracks the SOURCE PIXEL
+// of the surviving sample through the merges, and gathers that one sample (32 B) at the end instead
+// of staging Li / wi for 1092 pixels.
 #include <cstring>
 
 #include "rs_internal.h"
