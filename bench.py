@@ -12,7 +12,8 @@ shading ray per pixel + 1 shadow ray per shaded pixel; c
 N > 1: the 1920x1080 framebuffer is cut into N row strips (strong scaling: the total work is fixed).
 Every rank renders its strip (+5 G-buffer halo rows), exchanges 5 rows of published reservoirs with
 its strip neighbours over RCCL point-to-point between phase A and phase B (restir_amd/tiling.py),
-tone-maps its strip, and the RGBA8 strips are gathered on rank 0 -- all inside the timed region.
+tone-maps its strip, and the RGBA8 strips are gathered on rank 0 (asynchronously: the gather of one frame overlaps
+the next frame's kernels; the last gathers are waited for before the clock stops) -- all inside the timed region.
 
 One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its
@@ -99,14 +100,20 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank per GPU")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no fallback"
-    torch.cuda.set_device(local_rank)
+    # rehearsal of the N > 1 path on a one-GPU box: BENCH_DIST_BACKEND=gloo BENCH_DEVICE=0 puts every rank on one card
+    device = int(os.environ.get("BENCH_DEVICE", local_rank))
+    backend_name = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend_name)
 
     from restir_amd import capi, scenes
     from restir_amd.scenes import orbit_position
     from restir_amd.tiling import HipBackend, StripRenderer
-    capi.init(local_rank)
+    capi.init(device)
 
     sd = scenes.sponza_class(seed=1, scale=1.0)
     scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
@@ -116,8 +123,12 @@ def main():
     strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit)
     y0, y1 = strips.y0, strips.y1
     rows = y1 - y0
-    pbo = torch.zeros((strips.max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda")
-    gather_out = [torch.empty_like(pbo) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # RGBA8 strip of this rank; with N > 1 two sets of buffers, so that the gather of frame f (asynchronous, on RCCL's
+    # stream) overlaps the kernels of frame f + 1 and is only waited for before its buffers are written again
+    pbos = [torch.zeros((strips.max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+    gather_outs = [[torch.empty_like(pbos[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in pbos]
+    pending = [None] * len(pbos)
+    frame_no = [0]
 
     base_pos = sd.camera_args["position"]
     capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
@@ -129,11 +140,17 @@ def main():
                 cam.position[i] = float(p[i])
             capi.camera_update(cam)
         strips.frame(REUSE, 0)             # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), GBuffer::update
-        capi.copy_image_to_pbo(pbo.data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+        k = frame_no[0] % len(pbos); frame_no[0] += 1
+        if pending[k] is not None:
+            pending[k].wait(); pending[k] = None
+        capi.copy_image_to_pbo(pbos[k].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
         if world > 1:
-            dist.gather(pbo, gather_out, dst=0)
+            pending[k] = dist.gather(pbos[k], gather_outs[k], dst=0, async_op=True)
 
     def barrier():
+        for k in range(len(pending)):      # every frame's image has reached rank 0 before the clock stops
+            if pending[k] is not None:
+                pending[k].wait(); pending[k] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -147,7 +164,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     counted = min(args.steps, 1024)
-    local_rays = backend.restir.ray_total(counted) / counted * args.steps + (strips.gy1 - strips.gy0 if world > 1 else HEIGHT) * WIDTH * args.steps
+    # G-buffer rays: only the strip's own rows count (the +-5 halo rows a strip re-renders are overhead, not throughput)
+    local_rays = backend.restir.ray_total(counted) / counted * args.steps + rows * WIDTH * args.steps
 
     # per-pass times of a few extra (untimed) frames, HIP events on the library's stream
     spatial_ms, pass_ms = [], np.zeros(4)
@@ -190,7 +208,8 @@ def main():
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade") if world == 1 else None,
-                         "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us},
+                         "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us,
+                         "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
             "pass_ms": {"primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }
         if world == 1 and args.cpu_frames > 0:

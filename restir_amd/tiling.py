@@ -7,7 +7,8 @@ rank (one process per GPU, torch.distributed over RCCL/xGMI) does
     phase A on its rows                    (primary hit, RIS, shadow ray, temporal merge, publish)
     exchange HALO rows of published reservoirs with the strip above and below   <- point-to-point
                                             send/recv, 40 B/px: 384 KB per edge at 1080p
-    phase B on its rows                    (spatial reuse, shade, accumulate)
+    phase B on its rows                    (spatial reuse, shade, accumulate): the interior rows while the
+                                            halo is in flight, the two 5-row border bands after it arrived
 
 The spatial taps reach y-4..y+5 (src/restir.cu:49-56), so HALO = 5 rows is exact.
 
@@ -89,7 +90,8 @@ class StripRenderer:
         self.max_rows = max(b[1] - b[0] for b in self.bounds)
         self.looper = 0
 
-    def exchange_halo(self):
+    def start_halo_exchange(self):
+        """Pack the strip's border rows and post the sends / receives; returns what finish_halo_exchange needs."""
         d = self.dist
         ops, recvs = [], []
         if self.up is not None:
@@ -102,11 +104,33 @@ class StripRenderer:
             recv = self.b.empty(send.numel())
             ops += [d.P2POp(d.isend, send, self.down), d.P2POp(d.irecv, recv, self.down)]
             recvs.append((self.y1, recv))
-        if ops:
-            for w in d.batch_isend_irecv(ops):
-                w.wait()
+        works = d.batch_isend_irecv(ops) if ops else []
+        return works, recvs, ops                 # ops keeps the send buffers alive until the wait
+
+    def finish_halo_exchange(self, pending):
+        works, recvs, _ = pending
+        for w in works:
+            w.wait()
         for y, buf in recvs:
             self.b.halo_unpack(y, HALO, buf)
+
+    def exchange_halo(self):
+        self.finish_halo_exchange(self.start_halo_exchange())
+
+    def phase_b_overlapped(self, iteration, reuse):
+        """Phase B with the halo exchange in flight: the interior rows (whose +-5-row taps stay inside the strip)
+        run while the border rows of the neighbours travel; the two border bands follow once they have arrived."""
+        b = self.b
+        pending = self.start_halo_exchange()
+        top_end = min(self.y0 + HALO, self.y1) if self.up is not None else self.y0
+        bot_start = max(self.y1 - HALO, top_end) if self.down is not None else self.y1
+        if bot_start > top_end:
+            b.phase_b(iteration, reuse, top_end, bot_start)
+        self.finish_halo_exchange(pending)
+        if top_end > self.y0:
+            b.phase_b(iteration, reuse, self.y0, top_end)
+        if self.y1 > bot_start:
+            b.phase_b(iteration, reuse, bot_start, self.y1)
 
     def exchange_history(self):
         """All-gather of the rows this frame produced that the next frame's temporal merge may read."""
@@ -132,8 +156,9 @@ class StripRenderer:
             b.gbuffer_render(self.gy0, self.gy1)
             b.phase_a(self.looper, reuse, self.y0, self.y1)
             if reuse & 2:
-                self.exchange_halo()
-            b.phase_b(iteration, reuse, self.y0, self.y1)
+                self.phase_b_overlapped(iteration, reuse)
+            else:
+                b.phase_b(iteration, reuse, self.y0, self.y1)
         b.end_frame()
         if self.share_history and (reuse & 1):
             self.exchange_history()

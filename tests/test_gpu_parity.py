@@ -610,6 +610,27 @@ def test_strip_tiling_equals_full_frame(hip):
         assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
 
 
+def test_phase_b_in_row_bands_equals_one_call(hip):
+    """The overlapped multi-GPU schedule runs phase B as interior rows + two 5-row border bands (tiling.py); any split
+    of the rows into bands must give the image of a single call."""
+    from restir_amd.tiling import HipBackend
+    sd = get_scene("sponza:0.03")
+    W, H = 160, 96
+    scene = hip_scene(hip, sd)
+    cam = hip.camera_update(sd.camera(W, H))
+    one, bands = HipBackend(hip, scene, cam, W, H), HipBackend(hip, scene, cam, W, H)
+    for frame in range(3):
+        for b in (one, bands):
+            b.gbuffer_render(0, H); b.phase_a(frame, 3, 0, H)
+        one.phase_b(frame, 3, 0, H)                      # iter = frame: the accumulating form (restir.cu:230)
+        for y0, y1 in ((5, 91), (0, 5), (91, 96)) if frame != 1 else ((37, 38), (0, 37), (38, 96)):
+            bands.phase_b(frame, 3, y0, y1)
+        for b in (one, bands):
+            b.end_frame()
+        hip.synchronize()
+        assert bits_equal(one.image.cpu().numpy(), bands.image.cpu().numpy()), frame
+
+
 def test_config4_4k_eight_strips_equal_full_frame(hip):
     """BASELINE config 4: the bench scene at 3840x2160 cut into 8 row strips with the 5-row reservoir halo -- the
     eight ranks are run one after the other on this GPU -- against the full-frame result, bit for bit."""
