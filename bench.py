@@ -175,6 +175,14 @@ def main():
         ms = backend.restir.pass_times()
         spatial_ms.append(ms[3]); pass_ms += np.array(ms)
     pass_ms /= len(spatial_ms)
+    # the two passes outside ReSTIRDirect (the library enqueues on the null stream, which is torch's current stream here)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    gb_ms, pbo_ms = [], []
+    for _ in range(10):
+        ev[0].record(); backend.gbuffer_render(strips.gy0 if world > 1 else 0, strips.gy1 if world > 1 else HEIGHT); ev[1].record()
+        ev[2].record(); capi.copy_image_to_pbo(pbos[0].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0); ev[3].record()
+        torch.cuda.synchronize()
+        gb_ms.append(ev[0].elapsed_time(ev[1])); pbo_ms.append(ev[2].elapsed_time(ev[3]))
 
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -210,7 +218,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade") if world == 1 else None,
                          "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us,
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
-            "pass_ms": {"primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
+            "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(sd, args.cpu_frames)
