@@ -1,6 +1,8 @@
 // pathtrace.hip -- the non-ReSTIR baseline pass and the display conversion of src/pathtrace.cu:
 //   PTDirectKernel / pathTraceDirect   (src/pathtrace.cu:279-328,457-476)
 //   sendImageToPBO / copyImageToPBO    (src/pathtrace.cu:30-56,108-113; tone-map ops mathUtil.h:102-117)
+#include <cstdlib>
+
 #include "rs_internal.h"
 
 using namespace rs;
@@ -63,6 +65,22 @@ __device__ __forceinline__ float filmic_curve(float c) {
 // quantisation below sees the correctly rounded float power.
 __device__ __forceinline__ float gamma_pow(float c) { return (float)pow((double)c, (double)(1.f / 2.2f)); }
 
+// clamp(int(pow(c, 1/2.2) * 255), 0, 255) -- the only use of the power in sendImageToPBO (pathtrace.cu:50-55).  Three
+// double-precision pows per pixel made this streaming kernel VALU-bound at 0.9 TB/s; the integer only changes at the
+// 255 boundaries, so exp2(log2(c) / 2.2) (v_log_f32 / v_exp_f32, tests: test_fast_gamma_equals_exact) decides the byte
+// unless c^(1/2.2) * 255 lies within 2e-3 of an integer (8x the error bound), and only then the exact power is evaluated.
+template <bool EXACT>
+__device__ __forceinline__ int gamma_byte(float c) {
+    if (!EXACT && c >= 0.f && c < 1e-6f) return 0;              // (1e-6)^(1/2.2) * 255 = 0.48: the power is monotone, the byte is 0
+    if (!EXACT && c >= 1e-6f && c < 1e6f) {                       // |log2 c| <= 20: total relative error < 1e-6, 2.6e-4 in v
+        const float v = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.f / 2.2f)) * 255.f;
+        if (v >= 256.f) return 255;
+        if (gabs(v - rintf(v)) > 2e-3f) return f2i(v);          // v < 256: no clamp needed; truncation as in the reference
+    }
+    return iclamp(f2i(gamma_pow(c) * 255.f), 0, 255);
+}
+
+template <bool EXACT>
 __global__ void __launch_bounds__(256) k_send_image_to_pbo(uchar4* __restrict__ pbo, const float* __restrict__ image,
                                                            int n, int toneMapping, float scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,9 +94,7 @@ __global__ void __launch_bounds__(256) k_send_image_to_pbo(uchar4* __restrict__ 
     else if (toneMapping == 2) {                                       // Math::ACES
         c = (c * (c * 2.51f + 0.03f)) / (c * (c * 2.43f + 0.59f) + 0.14f);
     }
-    c = mk3(gamma_pow(c.x), gamma_pow(c.y), gamma_pow(c.z));
-    pbo[i] = make_uchar4((unsigned char)iclamp(f2i(c.x * 255.f), 0, 255), (unsigned char)iclamp(f2i(c.y * 255.f), 0, 255),
-                         (unsigned char)iclamp(f2i(c.z * 255.f), 0, 255), 0);
+    pbo[i] = make_uchar4((unsigned char)gamma_byte<EXACT>(c.x), (unsigned char)gamma_byte<EXACT>(c.y), (unsigned char)gamma_byte<EXACT>(c.z), 0);
 }
 
 // The debug-view overloads (pathtrace.cu:58-106): gamma only, no tone map.  kind 0: vec2 image -> (x, y, 0);
@@ -143,7 +159,10 @@ int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* dev
 int rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int height, int toneMapping, float scale) {
     if (!devPBO || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "copyImageToPBO: bad argument");
     const int n = width * height;
-    hipLaunchKernelGGL(k_send_image_to_pbo, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
+    if (std::getenv("RS_EXACT_GAMMA"))      // test switch: every pixel through the double-precision power
+        hipLaunchKernelGGL(k_send_image_to_pbo<true>, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
+    else
+        hipLaunchKernelGGL(k_send_image_to_pbo<false>, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
     return rs_after_launch("copyImageToPBO");
 }
 

@@ -474,6 +474,34 @@ def test_copy_image_to_pbo(hip, mode):
     assert np.mean(diff > 0) <= 1e-4
 
 
+def test_fast_gamma_equals_exact(hip, monkeypatch):
+    """copyImageToPBO decides the byte with exp2(log2(c)/2.2) and falls back to the double-precision power near the 255
+    integer boundaries; the result must equal the all-exact kernel (RS_EXACT_GAMMA) on every value: dense logarithmic
+    sweep over 24 decades, values straddling every byte boundary, zeros, negatives, NaN and infinities."""
+    import torch
+    rng = np.random.default_rng(21)
+    n = 6_000_000
+    x = np.exp(rng.uniform(np.log(1e-12), np.log(1e12), n)).astype(np.float32)
+    b = (np.arange(1, 256, dtype=np.float64) / 255.0) ** 2.2                                 # c with c^(1/2.2) * 255 = integer
+    near = (b[None, :] * (1.0 + rng.uniform(-3e-6, 3e-6, (2000, 255)))).astype(np.float32).reshape(-1)
+    x[:near.size] = near
+    x[near.size:near.size + 8] = [0.0, -0.0, -1.0, np.nan, np.inf, -np.inf, 1e-7, 1.0]
+    img = np.ascontiguousarray(x[: (n // 3) * 3].reshape(-1, 3))
+    W, H = 1000, img.shape[0] // 1000
+    img = img[: W * H]
+    t = torch.from_numpy(img).cuda()
+    outs = []
+    for exact in (False, True):
+        if exact:
+            monkeypatch.setenv("RS_EXACT_GAMMA", "1")
+        o = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")
+        hip.copy_image_to_pbo(o.data_ptr(), t.data_ptr(), W, H, 0, 1.0)
+        outs.append(o.cpu().numpy())
+    monkeypatch.delenv("RS_EXACT_GAMMA")
+    assert np.array_equal(outs[0], outs[1])
+    assert len(np.unique(outs[0][:, :3])) == 256
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_copy_debug_image_to_pbo(hip, kind):
     """The vec2 / float / int overloads of copyImageToPBO (pathtrace.cu:58-106), e.g. the motion-vector view."""
