@@ -1298,7 +1298,7 @@ static resv_t find_spatial_neighbor_disk(const orc_reservoir* reservoir, int x, 
     const int cur = g->frameIdx;
     int idx = y * g->width + x;
 
-    v2 p = to_concentric_disk(r.x, r.y);
+    v2 p = to_concentric_disk_m(r.x, r.y);         /* cos / sin follow the libm mode (orc_set_libm_mode) */
     p.x *= Radius; p.y *= Radius;
     int px = f2i((float)x + .5f + p.x);
     int py = f2i((float)y + .5f + p.y);

@@ -161,9 +161,11 @@ void orc_tonemap(int n, const float* in, int mode, float* out);
 /* How the libm calls of __device__ code are evaluated (sin/cos/atan2 in toSphere / toPlane / proceduralTexture
  * / the spatial tap; the reference's CUDA build uses libdevice, which cannot be reproduced here):
  *   0  glibc sinf/cosf/atan2f -- what a host build of the reference computes (default)
- *   1  the correctly rounded value (evaluated in double, rounded once) -- what librestir_hip computes for the
- *      environment-map and procedural-texture paths; used by the bit-exact parity tests of those paths.
- * The spatial tap (restir.cu:49-56) always uses glibc (mode 0 semantics), see DESIGN.md. */
+ *   1  the correctly rounded value (evaluated in double, rounded once) -- what librestir_hip computes wherever a
+ *      libm result matters (spatial tap position, environment map, procedural texture, BSDF sampling).
+ * In mode 1 the device and the oracle agree bit for bit everywhere; in mode 0 a pixel differs where glibc's result
+ * is one ulp off the correctly rounded one AND that ulp changes an integer (spatial tap: ~2e-8 of the pixels) or a
+ * path. */
 void orc_set_libm_mode(int correctlyRounded);
 
 /* src/image.h:41-75 linearSample on n uv pairs */
