@@ -17,7 +17,7 @@ names = ["cornell", "sponza:0.05", "bistro:0.03", "cornell_textured"]
 scenes = {n: get_scene(n) for n in names}
 osc = {n: oracle_scene(s) for n, s in scenes.items()}
 hsc = {n: hip_scene(capi, s) for n, s in scenes.items()}
-t0 = time.time(); runs = 0; px = 0; bad = 0; worst = 0.0
+t0 = time.time(); runs = 0; px = 0; bad = 0; worst = 0.0; gi_px = 0; gi_bad = 0
 W, H = 192, 108
 while time.time() - t0 < budget:
     n = names[runs % len(names)]
@@ -42,6 +42,22 @@ while time.time() - t0 < budget:
         if ne.any():
             worst = max(worst, float(np.abs(a - b).sum(1).max()))
             print("mismatch: scene %s run %d frame %d pixels %d maxL1 %.3g" % (n, runs, frame, int(ne.sum()), worst), flush=True)
+    if mode == 1:                                   # multi-bounce kernels (their BSDF sampling needs the correctly rounded mode)
+        import torch
+        d0 = np.zeros((W * H, 3), np.float32); i0 = np.zeros_like(d0); i1 = np.zeros_like(d0)
+        d1 = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda"); j0 = torch.zeros_like(d1); j1 = torch.zeros_like(d1)
+        depth = int(rng.integers(1, 6)); lp = int(rng.integers(0, 1 << 20))
+        ra = ob.path_trace(o.scene, o.cam, d0, i0, 0, lp, depth); rb = capi.path_trace(h.scene, h.cam, d1.data_ptr(), j0.data_ptr(), 0, lp, depth)
+        o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+        rc = o.restir.indirect(o.scene, o.cam, o.gbuf, i1, 0, lp + 1, 1, depth); rd = h.restir.indirect(h.scene, h.cam, h.gbuf, j1.data_ptr(), 0, lp + 1, 1, depth)
+        for name_, a_, b_ in (("pathTrace direct", d0, d1), ("pathTrace indirect", i0, j0), ("ReSTIRIndirect", i1, j1)):
+            ne = (a_.view(np.uint32) != b_.cpu().numpy().view(np.uint32)).any(axis=1)
+            gi_px += len(ne); gi_bad += int(ne.sum())
+            if ne.any():
+                print("mismatch: scene %s run %d %s pixels %d" % (n, runs, name_, int(ne.sum())), flush=True)
+        if ra != rb or rc != rd:
+            print("ray-count mismatch: scene %s run %d" % (n, runs), flush=True); gi_bad += 1
     runs += 1
 ob.set_libm_mode(0)
+print("multi-bounce kernels: %d pixel-images, %d with different bits" % (gi_px, gi_bad))
 print("libm mode %d;" % mode, "soak: %d runs, %d pixel-frames, %d with different bits (worst L1 %.3g) in %.0f s" % (runs, px, bad, worst, time.time() - t0))
