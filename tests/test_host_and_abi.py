@@ -137,6 +137,29 @@ def test_texture_table_is_validated_before_any_device_work():
         build(sd.materials, sd.textures, env=len(sd.textures))                       # environment map id out of range
 
 
+def test_argument_errors_are_reported_not_crashed():
+    """Entry points validate their arguments before any device work: 0 sizes, null pointers, inconsistent tables."""
+    import ctypes as C
+    L = capi.lib()
+    h = C.c_void_p()
+    for fn, args in ((L.rs_gbuffer_create, (0, 16, C.byref(h))), (L.rs_gbuffer_create, (16, -1, C.byref(h))),
+                     (L.rs_restir_init, (0, 0, C.byref(h))), (L.rs_eaw_create, (0, 8, 5, C.byref(h))), (L.rs_svgf_create, (8, 0, 5, C.byref(h)))):
+        assert fn(*args) != 0 and h.value is None and len(L.rs_last_error()) > 0
+    assert L.rs_scene_create(None, C.byref(h)) != 0
+    assert L.rs_build_envmap_pdf(0, 4, None, None) != 0
+    v = np.zeros(9, np.float32)
+    n = C.c_int(0)
+    assert L.rs_build_bvh(0, v.ctypes.data_as(C.c_void_p), None, None, C.byref(n)) != 0
+    with pytest.raises(capi.RestirHipError):
+        capi.check(L.rs_build_alias_table(-1, None, None, None, None))
+    # a scene description whose BVH size does not match its triangle count
+    sd = get_scene("cornell")
+    with pytest.raises(capi.RestirHipError):
+        t = dict(boxes=np.zeros((3, 6), np.float32), nodes=np.zeros((6, 3, 3), np.int32), light_prim_ids=np.zeros(0, np.int32),
+                 light_radiance=np.zeros((0, 3), np.float32), light_prob=np.zeros(0, np.float32), light_fail=np.zeros(0, np.int32), sum_power=0.0)
+        capi.Scene.from_tables(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials, t)
+
+
 def test_procedural_scene_budgets():
     sd = scenes.sponza_class(1, 1.0)
     assert sd.num_prims == 262144
