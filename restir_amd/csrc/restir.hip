@@ -181,7 +181,8 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
     p.m[i] = r.M;
 }
 
-__global__ void __launch_bounds__(256) k_shadow_temporal(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last,
+// 8 blocks per CU = 8 waves per SIMD: caps the kernel at 64 VGPRs (it wants 69; the 5 spilled dwords are outside the walk)
+__global__ void __launch_bounds__(256, 8) k_shadow_temporal(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last,
                                                          ResvPlanes cur, TempPlanes temp, int first, int reuse,
                                                          int y0, int y1, int tilesX) {
     int x, y;
