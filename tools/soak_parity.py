@@ -17,8 +17,9 @@ names = ["cornell", "sponza:0.05", "bistro:0.03", "cornell_textured"]
 scenes = {n: get_scene(n) for n in names}
 osc = {n: oracle_scene(s) for n, s in scenes.items()}
 hsc = {n: hip_scene(capi, s) for n, s in scenes.items()}
+last_note = time.time()
 t0 = time.time(); runs = 0; px = 0; bad = 0; worst = 0.0; gi_px = 0; gi_bad = 0
-W, H = 192, 108
+W, H = int(os.environ.get("RS_W", 192)), int(os.environ.get("RS_H", 108))
 while time.time() - t0 < budget:
     n = names[runs % len(names)]
     sd = scenes[n]
@@ -58,6 +59,9 @@ while time.time() - t0 < budget:
         if ra != rb or rc != rd:
             print("ray-count mismatch: scene %s run %d" % (n, runs), flush=True); gi_bad += 1
     runs += 1
+    if time.time() - last_note > 45:
+        last_note = time.time()
+        print("... %d runs, %d pixel-frames, %d differing" % (runs, px, bad + gi_bad), flush=True)
 ob.set_libm_mode(0)
 print("multi-bounce kernels: %d pixel-images, %d with different bits" % (gi_px, gi_bad))
 print("libm mode %d;" % mode, "soak: %d runs, %d pixel-frames, %d with different bits (worst L1 %.3g) in %.0f s" % (runs, px, bad, worst, time.time() - t0))
