@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RS_ERR_INVALID_ARGUMENT 10001
-#define RS_ERR_UNSUPPORTED      10002   /* textures / environment map: out of scope */
+#define RS_ERR_UNSUPPORTED      10002   /* e.g. an image or mesh format the scene-file reader does not decode */
 
 /* src/material.h:258-267 -- identical 44-byte layout */
 typedef struct rs_material {
@@ -170,6 +170,40 @@ int  rs_scene_destroy(rs_scene* scene);
 
 /* Camera::update (src/sceneStructs.h:88-102): view/right/up/rotationMatInv from rotation. */
 int  rs_camera_update(rs_camera* cam);
+
+/* ---- scene files (host only; no GPU call) ------------------------------------------------------
+ * Scene::Scene(filename) (src/scene.cpp:96-131) with loadMaterial (:371-433), loadModel (:222-283), loadCamera
+ * (:285-354), Resource::loadOBJMesh (:27-61) and the instance baking of buildDevData (:161-176): parses the
+ * reference's text scene format and returns the flat arrays rs_scene_build_textured takes.  Image files named in
+ * the scene must be binary PPM (P6, 8 bit) -- PNG / JPG / HDR decoding (stb_image in the reference) stays with the
+ * caller, who can build the arrays directly; glTF meshes are not read.  Pointers in the view stay valid until
+ * rs_scene_file_free. */
+typedef struct rs_scene_file rs_scene_file;
+typedef struct rs_scene_file_view {
+    int                numPrims;
+    const float*       vertices;      /* 9 floats / triangle, transformed (scene.cpp:167) */
+    const float*       normals;       /* 9 floats / triangle, normalize(normalMat * n) (:168) */
+    const float*       texcoords;     /* 6 floats / triangle */
+    const int*         materialIds;   /* 1 / triangle */
+    int                numMaterials;
+    const rs_material* materials;
+    int                numTextures;
+    const rs_texture*  textures;
+    int                envMapTexId;   /* -1: none */
+    rs_camera          camera;        /* after Camera::update */
+    int                iterations;    /* "Sample" */
+    int                traceDepth;    /* "Depth" (Settings::traceDepth) */
+    const char*        imageName;     /* "File" */
+    int                numSkippedObjects;   /* objects whose mesh file could not be opened ("[Fail to load, skipped]", scene.cpp:234-240) */
+} rs_scene_file_view;
+int  rs_scene_file_load(const char* path, rs_scene_file** file);
+int  rs_scene_file_get(const rs_scene_file* file, rs_scene_file_view* view);
+int  rs_scene_file_free(rs_scene_file* file);
+/* Math::buildTransformationMatrix (src/mathUtil.cpp:13-20): column-major 4x4, rotation in degrees. */
+int  rs_build_transformation_matrix(const float* translation, const float* rotation, const float* scale, float* out16);
+/* scene.cpp:167-168 for one instance: vec3(transform * vec4(v, 1)) and normalize(transpose(mat3(inverse(transform))) * n). */
+int  rs_bake_instance(const float* translation, const float* rotation, const float* scale, int n,
+                      const float* vertsIn, const float* normalsIn, float* vertsOut, float* normalsOut);
 
 /* ---- scene services, batched (for parity tests of DevScene::intersect / testOcclusion) */
 /* DevScene::intersect (src/scene.h:245-284): n rays of 6 floats (origin, direction), device ptrs.

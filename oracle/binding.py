@@ -154,6 +154,10 @@ def lib():
     L.orc_modulate.argtypes = [C.c_int, C.c_int, f32p, f32p]
     L.orc_add.argtypes = [C.c_int, C.c_int, f32p, f32p]
     L.orc_add3.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p]
+    L.orc_build_transformation_matrix.argtypes = [f32p, f32p, f32p, f32p]
+    L.orc_bake_instance.argtypes = [f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p]
+    L.orc_tanf.argtypes = [C.c_float]; L.orc_tanf.restype = C.c_float
+    L.orc_atanf.argtypes = [C.c_float]; L.orc_atanf.restype = C.c_float
     _lib = L
     return L
 
@@ -515,6 +519,30 @@ def camera_update(cam):
     return cam
 
 
+def build_transformation_matrix(t, r, s):
+    """Math::buildTransformationMatrix (src/mathUtil.cpp:13-20) -> (4, 4) float32, [column][row]."""
+    out = np.zeros(16, np.float32)
+    lib().orc_build_transformation_matrix(*(np.ascontiguousarray(a, np.float32) for a in (t, r, s)), out)
+    return out.reshape(4, 4)
+
+
+def bake_instance(t, r, s, vertices, normals):
+    """scene.cpp:167-168 for (n, 3) vertices / normals of one instance."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1)
+    n = np.ascontiguousarray(normals, np.float32).reshape(-1)
+    vo, no = np.zeros_like(v), np.zeros_like(n)
+    lib().orc_bake_instance(*(np.ascontiguousarray(a, np.float32) for a in (t, r, s)), len(v) // 3, v, n, vo, no)
+    return vo.reshape(-1, 3), no.reshape(-1, 3)
+
+
+def tanf(x):
+    return np.float32(lib().orc_tanf(float(x)))
+
+
+def atanf(x):
+    return np.float32(lib().orc_atanf(float(x)))
+
+
 # ---------------------------------------------------------------------------------------------
 # reference-derived checkers (this container only)
 # ---------------------------------------------------------------------------------------------
@@ -542,6 +570,20 @@ def ref_subset():
     R.ref_to_plane.argtypes = [C.c_int, f32p, f32p]
     R.ref_local_to_world.argtypes = [C.c_int, f32p, f32p, f32p]
     R.ref_bvh_build.restype = C.c_int
+    R.ref_build_transformation_matrix.argtypes = [f32p, f32p, f32p, f32p]
+    R.ref_bake_instance.argtypes = [f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p]
+    return R
+
+
+def ref_loaders():
+    """The reference's own file loaders (oracle/ref_loaders.cpp); None when not built."""
+    path = os.path.join(os.path.dirname(REF_SUBSET_PATH), "libref_loaders.so")
+    if not os.path.exists(path):
+        return None
+    R = C.CDLL(path)
+    R.ref_image_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int]
+    R.ref_obj_load.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_read_lines.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     return R
 
 

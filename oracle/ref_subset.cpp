@@ -24,6 +24,8 @@
 #include "sceneStructs.h"
 #include "mathUtil.h"
 #include "image.h"           // linearSample / DevTextureObj (templates; Image's methods are only declared)
+#include <glm/gtc/matrix_transform.hpp>
+#include <glm/gtc/matrix_inverse.hpp>
 
 static inline glm::vec3 ld3(const float* p) { return glm::vec3(p[0], p[1], p[2]); }
 static inline void st3(float* p, glm::vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
@@ -150,6 +152,23 @@ void ref_material_sample(int n, const Material* mats, const float* nrm, const fl
 }
 void ref_material_pdf(int n, const Material* mats, const float* nrm, const float* wo, const float* wi, float* pdf) {
     for (int i = 0; i < n; i++) pdf[i] = mats[i].pdf(ld3(nrm + 3 * i), ld3(wo + 3 * i), ld3(wi + 3 * i));
+}
+
+// mathUtil.cpp:13-20 and the per-vertex expressions of Scene::buildDevData (scene.cpp:169-170) / loadModel (:276-278),
+// written with the same GLM calls (scene.cpp itself needs thrust and cannot be compiled here)
+void ref_build_transformation_matrix(const float* t, const float* r, const float* s, float* out16) {
+    glm::mat4 m = Math::buildTransformationMatrix(ld3(t), ld3(r), ld3(s));
+    std::memcpy(out16, &m[0][0], sizeof(float) * 16);
+}
+void ref_bake_instance(const float* t, const float* r, const float* s, int n, const float* vertsIn, const float* normalsIn,
+                       float* vertsOut, float* normalsOut) {
+    glm::mat4 transform = Math::buildTransformationMatrix(ld3(t), ld3(r), ld3(s));
+    glm::mat4 transfInv = glm::inverse(transform);
+    glm::mat3 normalMat = glm::transpose(glm::mat3(transfInv));
+    for (int i = 0; i < n; i++) {
+        st3(vertsOut + 3 * i, glm::vec3(transform * glm::vec4(ld3(vertsIn + 3 * i), 1.f)));
+        st3(normalsOut + 3 * i, glm::normalize(normalMat * ld3(normalsIn + 3 * i)));
+    }
 }
 
 // image.h:41-75 through DevTextureObj::linearSample (image.h:89-91)

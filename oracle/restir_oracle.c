@@ -2187,6 +2187,118 @@ int orc_light_table(int numPrims, const float* vertices, const int* materialIds,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Instance baking of Scene::buildDevData (scene.cpp:161-171): Math::buildTransformationMatrix (mathUtil.cpp:13-20) with
+ * glm::translate / rotate / scale (gtc/matrix_transform.inl:40-134), mat4 product and inverse (type_mat4x4.inl:37-92,
+ * 686-704), normalMat = transpose(mat3(inverse)) (scene.cpp:276-278).  Host code in the reference: glibc cosf / sinf.
+ * Matrices are column-major float[16].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float c[4][4]; } m4;     /* c[col][row] */
+static m4 m4_identity(void) { m4 m; memset(&m, 0, sizeof m); m.c[0][0] = m.c[1][1] = m.c[2][2] = m.c[3][3] = 1.f; return m; }
+static m4 m4_mul(m4 a, m4 b) {           /* type_mat4x4.inl:686-704: Result[j] = A0*B[j][0] + A1*B[j][1] + A2*B[j][2] + A3*B[j][3] */
+    m4 r;
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 4; k++)
+            r.c[j][k] = ((a.c[0][k] * b.c[j][0] + a.c[1][k] * b.c[j][1]) + a.c[2][k] * b.c[j][2]) + a.c[3][k] * b.c[j][3];
+    return r;
+}
+static m4 glm_translate(m4 m, v3 v) {     /* :40-49 */
+    m4 r = m;
+    for (int k = 0; k < 4; k++) r.c[3][k] = ((m.c[0][k] * v.x + m.c[1][k] * v.y) + m.c[2][k] * v.z) + m.c[3][k];
+    return r;
+}
+static m4 glm_rotate(m4 m, float angle, v3 v) {   /* :52-85 */
+    const float c = cosf(angle), s = sinf(angle);
+    v3 axis = normalize3(v);
+    v3 temp = scl(axis, 1.f - c);
+    float R[3][3];
+    R[0][0] = c + temp.x * axis.x;
+    R[0][1] = 0 + temp.x * axis.y + s * axis.z;
+    R[0][2] = 0 + temp.x * axis.z - s * axis.y;
+    R[1][0] = 0 + temp.y * axis.x - s * axis.z;
+    R[1][1] = c + temp.y * axis.y;
+    R[1][2] = 0 + temp.y * axis.z + s * axis.x;
+    R[2][0] = 0 + temp.z * axis.x + s * axis.y;
+    R[2][1] = 0 + temp.z * axis.y - s * axis.x;
+    R[2][2] = c + temp.z * axis.z;
+    m4 r;
+    for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 4; k++) r.c[j][k] = (m.c[0][k] * R[j][0] + m.c[1][k] * R[j][1]) + m.c[2][k] * R[j][2];
+    for (int k = 0; k < 4; k++) r.c[3][k] = m.c[3][k];
+    return r;
+}
+static m4 glm_scale(m4 m, v3 v) {         /* :122-134 */
+    m4 r;
+    for (int k = 0; k < 4; k++) { r.c[0][k] = m.c[0][k] * v.x; r.c[1][k] = m.c[1][k] * v.y; r.c[2][k] = m.c[2][k] * v.z; r.c[3][k] = m.c[3][k]; }
+    return r;
+}
+static m4 build_transformation_matrix(v3 translation, v3 rotation, v3 scale) {      /* mathUtil.cpp:13-20 */
+    m4 translationMat = glm_translate(m4_identity(), translation);
+    m4 rotationMat = glm_rotate(m4_identity(), rotation.x * PI_F / 180.f, V3(1.f, 0.f, 0.f));
+    rotationMat = m4_mul(rotationMat, glm_rotate(m4_identity(), rotation.y * PI_F / 180.f, V3(0.f, 1.f, 0.f)));
+    rotationMat = m4_mul(rotationMat, glm_rotate(m4_identity(), rotation.z * PI_F / 180.f, V3(0.f, 0.f, 1.f)));
+    m4 scaleMat = glm_scale(m4_identity(), scale);
+    return m4_mul(m4_mul(translationMat, rotationMat), scaleMat);
+}
+static m4 m4_inverse(m4 mm) {             /* type_mat4x4.inl:37-92 */
+#define M(c_, r_) mm.c[c_][r_]
+    float Coef00 = M(2,2) * M(3,3) - M(3,2) * M(2,3), Coef02 = M(1,2) * M(3,3) - M(3,2) * M(1,3), Coef03 = M(1,2) * M(2,3) - M(2,2) * M(1,3);
+    float Coef04 = M(2,1) * M(3,3) - M(3,1) * M(2,3), Coef06 = M(1,1) * M(3,3) - M(3,1) * M(1,3), Coef07 = M(1,1) * M(2,3) - M(2,1) * M(1,3);
+    float Coef08 = M(2,1) * M(3,2) - M(3,1) * M(2,2), Coef10 = M(1,1) * M(3,2) - M(3,1) * M(1,2), Coef11 = M(1,1) * M(2,2) - M(2,1) * M(1,2);
+    float Coef12 = M(2,0) * M(3,3) - M(3,0) * M(2,3), Coef14 = M(1,0) * M(3,3) - M(3,0) * M(1,3), Coef15 = M(1,0) * M(2,3) - M(2,0) * M(1,3);
+    float Coef16 = M(2,0) * M(3,2) - M(3,0) * M(2,2), Coef18 = M(1,0) * M(3,2) - M(3,0) * M(1,2), Coef19 = M(1,0) * M(2,2) - M(2,0) * M(1,2);
+    float Coef20 = M(2,0) * M(3,1) - M(3,0) * M(2,1), Coef22 = M(1,0) * M(3,1) - M(3,0) * M(1,1), Coef23 = M(1,0) * M(2,1) - M(2,0) * M(1,1);
+    const float Fac0[4] = { Coef00, Coef00, Coef02, Coef03 }, Fac1[4] = { Coef04, Coef04, Coef06, Coef07 }, Fac2[4] = { Coef08, Coef08, Coef10, Coef11 };
+    const float Fac3[4] = { Coef12, Coef12, Coef14, Coef15 }, Fac4[4] = { Coef16, Coef16, Coef18, Coef19 }, Fac5[4] = { Coef20, Coef20, Coef22, Coef23 };
+    const float Vec0[4] = { M(1,0), M(0,0), M(0,0), M(0,0) }, Vec1[4] = { M(1,1), M(0,1), M(0,1), M(0,1) };
+    const float Vec2[4] = { M(1,2), M(0,2), M(0,2), M(0,2) }, Vec3[4] = { M(1,3), M(0,3), M(0,3), M(0,3) };
+    const float SignA[4] = { +1, -1, +1, -1 }, SignB[4] = { -1, +1, -1, +1 };
+    m4 inv;
+    for (int k = 0; k < 4; k++) {
+        inv.c[0][k] = ((Vec1[k] * Fac0[k] - Vec2[k] * Fac1[k]) + Vec3[k] * Fac2[k]) * SignA[k];
+        inv.c[1][k] = ((Vec0[k] * Fac0[k] - Vec2[k] * Fac3[k]) + Vec3[k] * Fac4[k]) * SignB[k];
+        inv.c[2][k] = ((Vec0[k] * Fac1[k] - Vec1[k] * Fac3[k]) + Vec3[k] * Fac5[k]) * SignA[k];
+        inv.c[3][k] = ((Vec0[k] * Fac2[k] - Vec1[k] * Fac4[k]) + Vec2[k] * Fac5[k]) * SignB[k];
+    }
+    const float d0 = M(0,0) * inv.c[0][0], d1 = M(0,1) * inv.c[1][0], d2 = M(0,2) * inv.c[2][0], d3 = M(0,3) * inv.c[3][0];
+    const float Dot1 = (d0 + d1) + (d2 + d3);
+    const float ood = 1.f / Dot1;
+    for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) inv.c[j][k] = inv.c[j][k] * ood;
+#undef M
+    return inv;
+}
+
+/* the float libm calls of Scene::loadCamera (scene.cpp:344-348), as this host's libm evaluates them */
+float orc_tanf(float x) { return tanf(x); }
+float orc_atanf(float x) { return atanf(x); }
+
+void orc_build_transformation_matrix(const float* t, const float* r, const float* sc, float* out16) {
+    m4 m = build_transformation_matrix(ld3(t), ld3(r), ld3(sc));
+    memcpy(out16, &m, sizeof m);
+}
+/* transform, then scene.cpp:169-170 on n vertices / normals: vec3(transform * vec4(v, 1)), normalize(normalMat * n) */
+void orc_bake_instance(const float* t, const float* r, const float* sc, int n, const float* vertsIn, const float* normalsIn,
+                       float* vertsOut, float* normalsOut) {
+    m4 tr = build_transformation_matrix(ld3(t), ld3(r), ld3(sc));
+    m4 inv = m4_inverse(tr);
+    /* normalMat = transpose(mat3(transfInv)): column j of normalMat = row j of the upper-left 3x3 of inv */
+    float nm[3][3];
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) nm[j][k] = inv.c[k][j];
+    for (int i = 0; i < n; i++) {
+        v3 v = ld3(vertsIn + (size_t)i * 3), nn = ld3(normalsIn + (size_t)i * 3);
+        /* mat4 * vec4 (type_mat4x4.inl:612-628): (m0*v0 + m1*v1) + (m2*v2 + m3*v3) */
+        v3 o;
+        o.x = (tr.c[0][0] * v.x + tr.c[1][0] * v.y) + (tr.c[2][0] * v.z + tr.c[3][0] * 1.f);
+        o.y = (tr.c[0][1] * v.x + tr.c[1][1] * v.y) + (tr.c[2][1] * v.z + tr.c[3][1] * 1.f);
+        o.z = (tr.c[0][2] * v.x + tr.c[1][2] * v.y) + (tr.c[2][2] * v.z + tr.c[3][2] * 1.f);
+        st3(vertsOut + (size_t)i * 3, o);
+        v3 q = V3(nm[0][0] * nn.x + nm[1][0] * nn.y + nm[2][0] * nn.z,
+                  nm[0][1] * nn.x + nm[1][1] * nn.y + nm[2][1] * nn.z,
+                  nm[0][2] * nn.x + nm[1][2] * nn.y + nm[2][2] * nn.z);
+        st3(normalsOut + (size_t)i * 3, normalize3(q));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * function-level entry points
  * ---------------------------------------------------------------------------------------- */
 static inline ray_t ld_ray(const float* p) { ray_t r; r.origin = ld3(p); r.direction = ld3(p + 3); return r; }

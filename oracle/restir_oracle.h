@@ -182,6 +182,15 @@ void orc_local_to_world(int n, const float* nrm, const float* v, float* out);
 /* src/scene.h:68-76 proceduralTexture (value replicated to 3 channels) */
 void orc_procedural_texture(int n, const float* uv, float* out);
 
+/* src/mathUtil.cpp:13-20 buildTransformationMatrix (column-major float[16]) and the instance baking of
+ * Scene::buildDevData (src/scene.cpp:161-171, normalMat from :276-278): host code, glibc cosf / sinf */
+void orc_build_transformation_matrix(const float* t, const float* r, const float* s, float* out16);
+void orc_bake_instance(const float* t, const float* r, const float* s, int n, const float* vertsIn, const float* normalsIn,
+                       float* vertsOut, float* normalsOut);
+/* tan / atan of Scene::loadCamera (src/scene.cpp:344-348) as the host libm evaluates them in float */
+float orc_tanf(float x);
+float orc_atanf(float x);
+
 /* ---- host scene build -------------------------------------------------------------- */
 
 /* src/scene.cpp:139-146: pdf[i*w+j] = lum(texel) * sin((.5f + i) / h * Pi) -- host code, glibc sinf */

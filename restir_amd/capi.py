@@ -49,6 +49,26 @@ class Texture(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.c_void_p)]
 
 
+class SceneFileView(C.Structure):
+    _fields_ = [
+        ("numPrims", C.c_int),
+        ("vertices", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("texcoords", C.c_void_p),
+        ("materialIds", C.c_void_p),
+        ("numMaterials", C.c_int),
+        ("materials", C.c_void_p),
+        ("numTextures", C.c_int),
+        ("textures", C.c_void_p),
+        ("envMapTexId", C.c_int),
+        ("camera", Camera),
+        ("iterations", C.c_int),
+        ("traceDepth", C.c_int),
+        ("imageName", C.c_char_p),
+        ("numSkippedObjects", C.c_int),
+    ]
+
+
 class SVGFView(C.Structure):
     _fields_ = [
         ("devAccumColor", C.c_void_p * 2),
@@ -87,6 +107,7 @@ EXPORTS = [
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
+    "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
 
 _lib = None
@@ -120,6 +141,11 @@ def lib():
     L.rs_scene_build_textured.argtypes = [ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, C.POINTER(vp)]
     L.rs_build_envmap_pdf.argtypes = [ci, ci, vp, vp]
     L.rs_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.rs_scene_file_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rs_scene_file_get.argtypes = [vp, C.POINTER(SceneFileView)]
+    L.rs_scene_file_free.argtypes = [vp]
+    L.rs_build_transformation_matrix.argtypes = [vp, vp, vp, vp]
+    L.rs_bake_instance.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp]
     L.rs_scene_host_desc.argtypes = [vp, C.POINTER(SceneDesc)]
     L.rs_scene_destroy.argtypes = [vp]
     L.rs_camera_update.argtypes = [C.POINTER(Camera)]
@@ -245,6 +271,59 @@ def build_envmap_pdf(env):
     pdf = np.zeros(env.shape[0] * env.shape[1], np.float32)
     check(lib().rs_build_envmap_pdf(env.shape[1], env.shape[0], _p(env), _p(pdf)))
     return pdf
+
+
+def build_transformation_matrix(translation, rotation, scale):
+    """Math::buildTransformationMatrix (src/mathUtil.cpp:13-20): (4, 4) float32, [column][row]."""
+    t, r, sc = (np.ascontiguousarray(a, np.float32) for a in (translation, rotation, scale))
+    out = np.zeros((4, 4), np.float32)
+    check(lib().rs_build_transformation_matrix(_p(t), _p(r), _p(sc), _p(out)))
+    return out
+
+
+def bake_instance(translation, rotation, scale, vertices, normals):
+    """Instance baking of Scene::buildDevData (src/scene.cpp:167-168) for (n, 3) vertices / normals."""
+    t, r, sc = (np.ascontiguousarray(a, np.float32) for a in (translation, rotation, scale))
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    vo, no = np.zeros_like(v), np.zeros_like(n)
+    check(lib().rs_bake_instance(_p(t), _p(r), _p(sc), len(v), _p(v), _p(n), _p(vo), _p(no)))
+    return vo, no
+
+
+class SceneFile:
+    """Scene::Scene(filename) (src/scene.cpp:96-131): the parsed scene as flat host arrays (copies)."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        check(lib().rs_scene_file_load(os.fsencode(path), C.byref(h)))
+        try:
+            v = SceneFileView()
+            check(lib().rs_scene_file_get(h, C.byref(v)))
+            n = v.numPrims
+
+            def arr(ptr, count, dtype):
+                return np.frombuffer(C.string_at(ptr, count * np.dtype(dtype).itemsize), dtype=dtype).copy() if count else np.zeros(0, dtype)
+            self.vertices = arr(v.vertices, n * 9, np.float32).reshape(n, 3, 3)
+            self.normals = arr(v.normals, n * 9, np.float32).reshape(n, 3, 3)
+            self.texcoords = arr(v.texcoords, n * 6, np.float32).reshape(n, 3, 2)
+            self.material_ids = arr(v.materialIds, n, np.int32)
+            self.materials = arr(v.materials, v.numMaterials, MATERIAL_DTYPE)
+            tex = C.cast(v.textures, C.POINTER(Texture))
+            self.textures = [arr(tex[i].data, tex[i].width * tex[i].height * 3, np.float32).reshape(tex[i].height, tex[i].width, 3)
+                             for i in range(v.numTextures)]
+            self.env_map_tex = v.envMapTexId
+            self.camera = copy_camera(v.camera)
+            self.iterations, self.trace_depth = v.iterations, v.traceDepth
+            self.image_name = (v.imageName or b"").decode()
+            self.num_skipped_objects = v.numSkippedObjects
+        finally:
+            lib().rs_scene_file_free(h)
+
+    def build(self):
+        """Scene::buildDevData + DevScene::create of the parsed scene."""
+        return Scene(self.vertices, self.normals, self.texcoords, self.material_ids, self.materials,
+                     textures=self.textures, env_map_tex=self.env_map_tex)
 
 
 def _texture_table(textures):

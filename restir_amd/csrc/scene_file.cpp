@@ -1,0 +1,532 @@
+// scene_file.cpp -- the reference's scene-file front end on the host:
+//   Scene::Scene(filename)        src/scene.cpp:96-131      line-oriented text format (Material / Object / Camera / EnvMap)
+//   Scene::loadMaterial           src/scene.cpp:371-433
+//   Scene::loadModel              src/scene.cpp:222-283     OBJ file, material link, Translate / Rotate / Scale
+//   Scene::loadCamera             src/scene.cpp:285-354
+//   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
+//   instance baking of buildDevData   src/scene.cpp:161-176
+//   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
+// What it does not do: decode PNG / JPG / HDR (stb_image in the reference).  Texture and environment-map files must be
+// binary PPM (P6, 8 bit): stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1) (src/scene.cpp:97), rows
+// flipped for textures (stbi_set_flip_vertically_on_load(true), :98) and not for the environment map (:124-126).
+// glTF (Resource::loadGLTFMesh) is not read either.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rs_internal.h"
+
+using namespace rs;
+
+namespace {
+
+// ---- GLM 0.9.6.3 matrix arithmetic in its operation order (column-major, c[col][row]) --------------------------
+struct M4 { float c[4][4]; };
+M4 identity() { M4 m; std::memset(&m, 0, sizeof m); m.c[0][0] = m.c[1][1] = m.c[2][2] = m.c[3][3] = 1.f; return m; }
+M4 mul(const M4& a, const M4& b) {                                   // type_mat4x4.inl:686-704
+    M4 r;
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 4; k++)
+            r.c[j][k] = ((a.c[0][k] * b.c[j][0] + a.c[1][k] * b.c[j][1]) + a.c[2][k] * b.c[j][2]) + a.c[3][k] * b.c[j][3];
+    return r;
+}
+M4 translate(const M4& m, f3 v) {                                     // gtc/matrix_transform.inl:40-49
+    M4 r = m;
+    for (int k = 0; k < 4; k++) r.c[3][k] = ((m.c[0][k] * v.x + m.c[1][k] * v.y) + m.c[2][k] * v.z) + m.c[3][k];
+    return r;
+}
+M4 rotate(const M4& m, float angle, f3 v) {                           // :52-85
+    const float c = cosf(angle), s = sinf(angle);
+    const f3 axis = normalize(v);
+    const f3 temp = axis * (1.f - c);
+    float R[3][3];
+    R[0][0] = c + temp.x * axis.x;
+    R[0][1] = 0 + temp.x * axis.y + s * axis.z;
+    R[0][2] = 0 + temp.x * axis.z - s * axis.y;
+    R[1][0] = 0 + temp.y * axis.x - s * axis.z;
+    R[1][1] = c + temp.y * axis.y;
+    R[1][2] = 0 + temp.y * axis.z + s * axis.x;
+    R[2][0] = 0 + temp.z * axis.x + s * axis.y;
+    R[2][1] = 0 + temp.z * axis.y - s * axis.x;
+    R[2][2] = c + temp.z * axis.z;
+    M4 r;
+    for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 4; k++) r.c[j][k] = (m.c[0][k] * R[j][0] + m.c[1][k] * R[j][1]) + m.c[2][k] * R[j][2];
+    for (int k = 0; k < 4; k++) r.c[3][k] = m.c[3][k];
+    return r;
+}
+M4 scale(const M4& m, f3 v) {                                         // :122-134
+    M4 r;
+    for (int k = 0; k < 4; k++) { r.c[0][k] = m.c[0][k] * v.x; r.c[1][k] = m.c[1][k] * v.y; r.c[2][k] = m.c[2][k] * v.z; r.c[3][k] = m.c[3][k]; }
+    return r;
+}
+M4 build_transformation_matrix(f3 translation, f3 rotation, f3 scl) {  // mathUtil.cpp:13-20
+    const M4 translationMat = translate(identity(), translation);
+    M4 rotationMat = rotate(identity(), rotation.x * kPi / 180.f, mk3(1.f, 0.f, 0.f));
+    rotationMat = mul(rotationMat, rotate(identity(), rotation.y * kPi / 180.f, mk3(0.f, 1.f, 0.f)));
+    rotationMat = mul(rotationMat, rotate(identity(), rotation.z * kPi / 180.f, mk3(0.f, 0.f, 1.f)));
+    const M4 scaleMat = scale(identity(), scl);
+    return mul(mul(translationMat, rotationMat), scaleMat);
+}
+M4 inverse(const M4& mm) {                                            // type_mat4x4.inl:37-92
+#define M(c_, r_) mm.c[c_][r_]
+    const float Coef00 = M(2,2) * M(3,3) - M(3,2) * M(2,3), Coef02 = M(1,2) * M(3,3) - M(3,2) * M(1,3), Coef03 = M(1,2) * M(2,3) - M(2,2) * M(1,3);
+    const float Coef04 = M(2,1) * M(3,3) - M(3,1) * M(2,3), Coef06 = M(1,1) * M(3,3) - M(3,1) * M(1,3), Coef07 = M(1,1) * M(2,3) - M(2,1) * M(1,3);
+    const float Coef08 = M(2,1) * M(3,2) - M(3,1) * M(2,2), Coef10 = M(1,1) * M(3,2) - M(3,1) * M(1,2), Coef11 = M(1,1) * M(2,2) - M(2,1) * M(1,2);
+    const float Coef12 = M(2,0) * M(3,3) - M(3,0) * M(2,3), Coef14 = M(1,0) * M(3,3) - M(3,0) * M(1,3), Coef15 = M(1,0) * M(2,3) - M(2,0) * M(1,3);
+    const float Coef16 = M(2,0) * M(3,2) - M(3,0) * M(2,2), Coef18 = M(1,0) * M(3,2) - M(3,0) * M(1,2), Coef19 = M(1,0) * M(2,2) - M(2,0) * M(1,2);
+    const float Coef20 = M(2,0) * M(3,1) - M(3,0) * M(2,1), Coef22 = M(1,0) * M(3,1) - M(3,0) * M(1,1), Coef23 = M(1,0) * M(2,1) - M(2,0) * M(1,1);
+    const float Fac0[4] = { Coef00, Coef00, Coef02, Coef03 }, Fac1[4] = { Coef04, Coef04, Coef06, Coef07 }, Fac2[4] = { Coef08, Coef08, Coef10, Coef11 };
+    const float Fac3[4] = { Coef12, Coef12, Coef14, Coef15 }, Fac4[4] = { Coef16, Coef16, Coef18, Coef19 }, Fac5[4] = { Coef20, Coef20, Coef22, Coef23 };
+    const float Vec0[4] = { M(1,0), M(0,0), M(0,0), M(0,0) }, Vec1[4] = { M(1,1), M(0,1), M(0,1), M(0,1) };
+    const float Vec2[4] = { M(1,2), M(0,2), M(0,2), M(0,2) }, Vec3[4] = { M(1,3), M(0,3), M(0,3), M(0,3) };
+    const float SignA[4] = { +1, -1, +1, -1 }, SignB[4] = { -1, +1, -1, +1 };
+    M4 inv;
+    for (int k = 0; k < 4; k++) {
+        inv.c[0][k] = ((Vec1[k] * Fac0[k] - Vec2[k] * Fac1[k]) + Vec3[k] * Fac2[k]) * SignA[k];
+        inv.c[1][k] = ((Vec0[k] * Fac0[k] - Vec2[k] * Fac3[k]) + Vec3[k] * Fac4[k]) * SignB[k];
+        inv.c[2][k] = ((Vec0[k] * Fac1[k] - Vec1[k] * Fac3[k]) + Vec3[k] * Fac5[k]) * SignA[k];
+        inv.c[3][k] = ((Vec0[k] * Fac2[k] - Vec1[k] * Fac4[k]) + Vec2[k] * Fac5[k]) * SignB[k];
+    }
+    const float d0 = M(0,0) * inv.c[0][0], d1 = M(0,1) * inv.c[1][0], d2 = M(0,2) * inv.c[2][0], d3 = M(0,3) * inv.c[3][0];
+    const float ood = 1.f / ((d0 + d1) + (d2 + d3));
+    for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) inv.c[j][k] = inv.c[j][k] * ood;
+#undef M
+    return inv;
+}
+
+// scene.cpp:169-170 with transform / normalMat of loadModel (:273-278)
+void bake(const M4& tr, int n, const float* vertsIn, const float* normalsIn, float* vertsOut, float* normalsOut) {
+    const M4 inv = inverse(tr);
+    float nm[3][3];                                                   // transpose(mat3(transfInv)), columns
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) nm[j][k] = inv.c[k][j];
+    for (int i = 0; i < n; i++) {
+        const f3 v = ld3(vertsIn + (size_t)i * 3), nn = ld3(normalsIn + (size_t)i * 3);
+        f3 o;                                                         // mat4 * vec4 (type_mat4x4.inl:612-628)
+        o.x = (tr.c[0][0] * v.x + tr.c[1][0] * v.y) + (tr.c[2][0] * v.z + tr.c[3][0] * 1.f);
+        o.y = (tr.c[0][1] * v.x + tr.c[1][1] * v.y) + (tr.c[2][1] * v.z + tr.c[3][1] * 1.f);
+        o.z = (tr.c[0][2] * v.x + tr.c[1][2] * v.y) + (tr.c[2][2] * v.z + tr.c[3][2] * 1.f);
+        st3(vertsOut + (size_t)i * 3, o);
+        const f3 q = mk3(nm[0][0] * nn.x + nm[1][0] * nn.y + nm[2][0] * nn.z,
+                         nm[0][1] * nn.x + nm[1][1] * nn.y + nm[2][1] * nn.z,
+                         nm[0][2] * nn.x + nm[1][2] * nn.y + nm[2][2] * nn.z);
+        st3(normalsOut + (size_t)i * 3, normalize(q));
+    }
+}
+
+// ---- text input ----------------------------------------------------------------------------------------------------
+// The reference reads its files with utilityCore::safeGetline on an ifstream and splits lines with tokenizeString
+// (src/utilities.cpp:57-95).  Here the file is read whole and walked in memory; what has to match is observable behaviour:
+// a line ends at "\n", "\r\n" or a lone "\r"; a last line without terminator is still returned; `good()` turns false only
+// when a read finds nothing at all left (so a file ending in a newline yields one more, empty, line first); tokens are maximal
+// runs of non-whitespace as operator>> sees them (space, \t, \v, \f and stray \r / \n).
+class Lines {
+public:
+    bool open(const std::string& path) {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return false;
+        char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) text_.append(buf, got);
+        std::fclose(f);
+        return true;
+    }
+    bool good() const { return !exhausted_; }
+    const std::string& next() {
+        line_.clear();
+        if (exhausted_) return line_;                                  // reads on a failed stream return nothing
+        size_t end = at_;
+        while (end < text_.size() && text_[end] != '\n' && text_[end] != '\r') end++;
+        line_.assign(text_, at_, end - at_);
+        if (end == text_.size()) { if (line_.empty()) exhausted_ = true; at_ = end; }
+        else at_ = end + ((text_[end] == '\r' && end + 1 < text_.size() && text_[end + 1] == '\n') ? 2 : 1);
+        return line_;
+    }
+private:
+    std::string text_, line_;
+    size_t at_ = 0;
+    bool exhausted_ = false;
+};
+
+std::vector<std::string> tokenize(const std::string& str) {
+    std::vector<std::string> out;
+    size_t i = 0;
+    const auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+    while (i < str.size()) {
+        while (i < str.size() && blank(str[i])) i++;
+        size_t j = i;
+        while (j < str.size() && !blank(str[j])) j++;
+        if (j > i) out.emplace_back(str, i, j - i);
+        i = j;
+    }
+    return out;
+}
+
+struct Mesh { std::vector<float> v, n, t; };                          // de-indexed: 3 / 3 / 2 floats per corner
+
+// Number syntax of the OBJ reader the reference links (tinyobjloader 2.0, external/include/tiny_obj_loader.h:866-1010,
+// "tryParseDouble"): digits are accumulated in double -- integer part by *10 + d, fraction digit k by d * 10^-k, a decimal
+// exponent e as ldexp(m * 5^e, e) -- and the result is narrowed to float.  It is not strtof: for long decimals the two can
+// differ in the last float bit, so the same accumulation is done here.  Unparsable text reads as 0.
+float obj_real(const std::string& tok) {
+    const char* c = tok.c_str();
+    const char* end = c + tok.size();
+    if (c == end) return 0.f;
+    double mant = 0.0;
+    int expo = 0, got = 0;
+    bool neg = false, expNeg = false, leadingDot = false;
+    auto digit = [&](const char* q) { return q != end && *q >= '0' && *q <= '9'; };
+    if (*c == '+' || *c == '-') { neg = *c == '-'; c++; if (c != end && *c == '.') leadingDot = true; }
+    else if (digit(c)) {}
+    else if (*c == '.') leadingDot = true;
+    else return 0.f;
+    if (!leadingDot) {
+        while (digit(c)) { mant *= 10; mant += (int)(*c - '0'); c++; got++; }
+        if (got == 0) return 0.f;
+    }
+    if (c != end && *c == '.') {
+        static const double lut[] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
+        c++;
+        int k = 1;
+        while (digit(c)) { mant += (int)(*c - '0') * (k < 8 ? lut[k] : std::pow(10.0, -k)); k++; c++; }
+    }
+    else if (c != end && *c != 'e' && *c != 'E') c = end;            // trailing text after the integer part: the number so far
+    if (c != end && (*c == 'e' || *c == 'E')) {
+        c++;
+        if (c != end && (*c == '+' || *c == '-')) { expNeg = *c == '-'; c++; }
+        else if (!digit(c)) return 0.f;
+        got = 0;
+        while (digit(c)) { if (expo > 2147483647 / 10) return 0.f; expo = expo * 10 + (int)(*c - '0'); c++; got++; }
+        if (expNeg) expo = -expo;
+        if (got == 0) return 0.f;
+    }
+    const double val = (neg ? -1 : 1) * (expo ? std::ldexp(mant * std::pow(5.0, expo), expo) : mant);
+    return (float)val;
+}
+
+// The subset of Wavefront OBJ the reference gets through tinyobj::LoadObj (triangulate = true): v / vn / vt / f with 1-based and
+// negative indices; a quad is split along its shorter diagonal (tiny_obj_loader.h:1429-1524); other statements (o, g, s, usemtl,
+// mtllib, comments) do not change the flattened corner order.  Polygons with more than four corners (ear clipping there) are not
+// accepted.  Every corner needs a normal (the reference indexes attrib.normals unconditionally, scene.cpp:44).
+// returns 0, an error, or -1 when the file cannot be opened (the caller skips the object, as scene.cpp:234-240 does)
+int load_obj(const std::string& path, Mesh& m) {
+    Lines in;
+    if (!in.open(path)) return -1;
+    std::vector<float> pv, pn, pt;
+    struct Corner { int v, t, n; };
+    std::vector<Corner> flat;
+    while (in.good()) {
+        const std::vector<std::string> tok = tokenize(in.next());
+        if (tok.empty()) continue;
+        auto real = [&](size_t k) { return k < tok.size() ? obj_real(tok[k]) : 0.f; };
+        if (tok[0] == "v") for (size_t k = 1; k <= 3; k++) pv.push_back(real(k));
+        else if (tok[0] == "vn") for (size_t k = 1; k <= 3; k++) pn.push_back(real(k));
+        else if (tok[0] == "vt") for (size_t k = 1; k <= 2; k++) pt.push_back(real(k));
+        else if (tok[0] == "f") {
+            std::vector<Corner> cs;
+            for (size_t k = 1; k < tok.size(); k++) {
+                int raw[3] = { 0, 0, 0 };
+                bool have[3] = { false, false, false };
+                int field = 0; std::string cur;
+                const std::string str = tok[k] + "/";
+                for (char ch : str) {
+                    if (ch == '/') {
+                        if (!cur.empty() && field < 3) { raw[field] = std::atoi(cur.c_str()); have[field] = true; }
+                        cur.clear(); field++;
+                    }
+                    else cur += ch;
+                }
+                auto fix = [](bool present, int idx, size_t count) { return !present ? -1 : idx > 0 ? idx - 1 : idx < 0 ? (int)count + idx : -2; };
+                Corner c{ fix(have[0], raw[0], pv.size() / 3), fix(have[1], raw[1], pt.size() / 2), fix(have[2], raw[2], pn.size() / 3) };
+                if (c.v < 0 || (size_t)c.v >= pv.size() / 3) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("bad vertex index in " + path).c_str());
+                if (c.n < 0 || (size_t)c.n >= pn.size() / 3) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("OBJ face corner without a valid normal in " + path).c_str());
+                if (c.t < -1 || (c.t >= 0 && (size_t)c.t >= pt.size() / 2)) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("bad texcoord index in " + path).c_str());
+                cs.push_back(c);
+            }
+            if (cs.size() < 3) continue;                              // "Degenerated face": dropped
+            if (cs.size() == 3) flat.insert(flat.end(), cs.begin(), cs.end());
+            else if (cs.size() == 4) {
+                const float* a = &pv[(size_t)cs[0].v * 3]; const float* b = &pv[(size_t)cs[1].v * 3];
+                const float* c = &pv[(size_t)cs[2].v * 3]; const float* d = &pv[(size_t)cs[3].v * 3];
+                const float e02x = c[0] - a[0], e02y = c[1] - a[1], e02z = c[2] - a[2];
+                const float e13x = d[0] - b[0], e13y = d[1] - b[1], e13z = d[2] - b[2];
+                const float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
+                const float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
+                if (sqr02 < sqr13) for (int q : { 0, 1, 2, 0, 2, 3 }) flat.push_back(cs[q]);
+                else for (int q : { 0, 1, 3, 1, 2, 3 }) flat.push_back(cs[q]);
+            }
+            else return rs_fail(RS_ERR_UNSUPPORTED, ("polygon with more than four corners in " + path + ": triangulate the mesh first").c_str());
+        }
+    }
+    const bool hasTexcoord = !pt.empty();                              // scene.cpp:39,46-49
+    for (const Corner& c : flat) {
+        if (hasTexcoord && c.t < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("OBJ face corner without a texcoord in a file that has vt lines: " + path).c_str());
+        for (int d = 0; d < 3; d++) { m.v.push_back(pv[(size_t)c.v * 3 + d]); m.n.push_back(pn[(size_t)c.n * 3 + d]); }
+        for (int d = 0; d < 2; d++) m.t.push_back(hasTexcoord ? pt[(size_t)c.t * 2 + d] : 0.f);
+    }
+    return 0;
+}
+
+// binary PPM (P6, maxval 255) -> linear float RGB, value / 255
+int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (only binary PPM P6 / 8 bit is decoded here; decode other formats in the caller)").c_str()); };
+    auto token = [&](std::string& out) {
+        out.clear();
+        int c = std::fgetc(f);
+        for (;;) {
+            while (c == ' ' || c == '\n' || c == '\r' || c == '\t') c = std::fgetc(f);
+            if (c == '#') { while (c != '\n' && c != EOF) c = std::fgetc(f); continue; }
+            break;
+        }
+        while (c != EOF && c != ' ' && c != '\n' && c != '\r' && c != '\t') { out += (char)c; c = std::fgetc(f); }
+        return !out.empty();
+    };
+    std::string t;
+    if (!token(t) || t != "P6") return fail("not a binary PPM");
+    int maxv = 0;
+    if (!token(t)) return fail("truncated header"); w = std::atoi(t.c_str());
+    if (!token(t)) return fail("truncated header"); h = std::atoi(t.c_str());
+    if (!token(t)) return fail("truncated header"); maxv = std::atoi(t.c_str());
+    if (w <= 0 || h <= 0 || maxv != 255) return fail("unsupported PPM header");
+    std::vector<unsigned char> raw((size_t)w * h * 3);
+    if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) return fail("truncated pixel data");
+    std::fclose(f);
+    data.resize(raw.size());
+    for (int y = 0; y < h; y++) {
+        const int sy = flipRows ? h - 1 - y : y;
+        for (int i = 0; i < w * 3; i++) data[((size_t)y * w) * 3 + i] = (float)raw[((size_t)sy * w) * 3 + i] / 255.f;
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct rs_scene_file {
+    std::vector<float> vertices, normals, texcoords;
+    std::vector<int> materialIds;
+    std::vector<rs_material> materials;
+    std::vector<std::vector<float>> texData;
+    std::vector<rs_texture> textures;
+    std::map<std::string, int> textureIds, materialMap;
+    int envMapTexId = -1;
+    rs_camera camera{};
+    int iterations = 0, traceDepth = 0;
+    std::string imageName;
+    std::vector<std::string> skipped;                                  // objects whose mesh file could not be opened
+};
+
+namespace {
+
+// The reference opens the names as written, i.e. relative to the working directory; a name that is not there is also tried next to
+// the scene file.
+std::string resolve(const std::string& dir, const std::string& name) {
+    if (name.empty() || name[0] == '/' || dir.empty()) return name;
+    if (FILE* f = std::fopen(name.c_str(), "rb")) { std::fclose(f); return name; }
+    return dir + name;
+}
+
+int add_texture(rs_scene_file* s, const std::string& dir, const std::string& name, bool flip, int* id) {   // Scene::addTexture (:356-369)
+    auto it = s->textureIds.find(name);
+    if (it != s->textureIds.end()) { *id = it->second; return 0; }
+    std::vector<float> data; int w = 0, h = 0;
+    RS_TRY(load_ppm(resolve(dir, name), flip, data, w, h));
+    s->texData.push_back(std::move(data));
+    *id = (int)s->texData.size() - 1;
+    s->textureIds[name] = *id;
+    s->textures.push_back(rs_texture{ w, h, nullptr });
+    return 0;
+}
+
+rs_material default_material() {                                      // src/material.h:258-267
+    rs_material m;
+    m.type = 0; m.baseColor[0] = m.baseColor[1] = m.baseColor[2] = .9f; m.metallic = 0.f; m.roughness = 1.f; m.ior = 1.5f;
+    m.baseColorMapId = m.metallicMapId = m.roughnessMapId = m.normalMapId = -1;
+    return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_build_transformation_matrix(const float* translation, const float* rotation, const float* scl, float* out16) {
+    if (!translation || !rotation || !scl || !out16) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_build_transformation_matrix: null argument");
+    const M4 m = build_transformation_matrix(ld3(translation), ld3(rotation), ld3(scl));
+    std::memcpy(out16, &m, sizeof m);
+    return 0;
+}
+
+int rs_bake_instance(const float* translation, const float* rotation, const float* scl, int n, const float* vertsIn, const float* normalsIn,
+                     float* vertsOut, float* normalsOut) {
+    if (!translation || !rotation || !scl || n < 0 || (n > 0 && (!vertsIn || !normalsIn || !vertsOut || !normalsOut)))
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_bake_instance: bad argument");
+    bake(build_transformation_matrix(ld3(translation), ld3(rotation), ld3(scl)), n, vertsIn, normalsIn, vertsOut, normalsOut);
+    return 0;
+}
+
+int rs_scene_file_free(rs_scene_file* s) { delete s; return 0; }
+
+int rs_scene_file_load(const char* path, rs_scene_file** out) {
+    if (!path || !out) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_file_load: null argument");
+    *out = nullptr;
+    Lines fp;
+    if (!fp.open(path)) return rs_fail(RS_ERR_INVALID_ARGUMENT, (std::string("Error reading from file ") + path).c_str());
+    std::string dir(path);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);      // file names in the scene are relative to it
+
+    rs_scene_file* s = new rs_scene_file();
+    auto bail = [&](int e) { delete s; return e; };
+    std::map<std::string, Mesh> meshPool;                              // Resource::meshDataPool
+    static const std::map<std::string, int> typeOf = { { "Lambertian", 0 }, { "MetallicWorkflow", 1 }, { "Dielectric", 2 }, { "Light", 4 } };   // :16-21
+
+    try {
+    std::string line;
+    while (fp.good()) {
+        line = fp.next();
+        if (line.empty()) continue;
+        const std::vector<std::string> tokens = tokenize(line);
+        if (tokens.empty()) continue;
+        if (tokens[0] == "Material" && tokens.size() >= 2) {                                     // loadMaterial (:371-433): exactly six lines follow
+            rs_material material = default_material();
+            for (int i = 0; i < 6; i++) {
+                line = fp.next();
+                const std::vector<std::string> t = tokenize(line);
+                if (t.size() < 2) continue;
+                if (t[0] == "Type") {
+                    auto it = typeOf.find(t[1]);
+                    material.type = it == typeOf.end() ? 0 : it->second;   // std::map::operator[] of an unknown token yields 0 = Lambertian (:386)
+                }
+                else if (t[0] == "BaseColor") {
+                    if (t.size() > 2) { if (t.size() < 4) return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, "BaseColor needs three numbers")); for (int k = 0; k < 3; k++) material.baseColor[k] = std::stof(t[1 + k]); }
+                    else if (t[1] == "Procedural") material.baseColorMapId = -2;
+                    else if (int e = add_texture(s, dir, t[1], true, &material.baseColorMapId)) return bail(e);
+                }
+                else if (t[0] == "Metallic") {
+                    if (std::isdigit((unsigned char)t[1][t[1].length() - 1])) material.metallic = std::stof(t[1]);
+                    else if (int e = add_texture(s, dir, t[1], true, &material.metallicMapId)) return bail(e);
+                }
+                else if (t[0] == "Roughness") {
+                    if (std::isdigit((unsigned char)t[1][t[1].length() - 1])) material.roughness = std::stof(t[1]);
+                    else if (int e = add_texture(s, dir, t[1], true, &material.roughnessMapId)) return bail(e);
+                }
+                else if (t[0] == "Ior") material.ior = std::stof(t[1]);
+                else if (t[0] == "NormalMap") {
+                    if (t[1] != "Null") if (int e = add_texture(s, dir, t[1], true, &material.normalMapId)) return bail(e);
+                }
+            }
+            s->materialMap[tokens[1]] = (int)s->materials.size();
+            s->materials.push_back(material);
+        }
+        else if (tokens[0] == "Object" && tokens.size() >= 2) {                                    // loadModel (:222-283)
+            line = fp.next();
+            const std::string filename = line;
+            auto pool = meshPool.find(filename);
+            if (pool == meshPool.end()) {
+                if (filename.find(".obj") == std::string::npos) return bail(rs_fail(RS_ERR_UNSUPPORTED, ("only OBJ meshes are read here: " + filename).c_str()));
+                Mesh mesh;
+                const int e = load_obj(resolve(dir, filename), mesh);
+                if (e > 0) return bail(e);
+                if (e < 0) {                                          // "[Fail to load, skipped]" (:234-240)
+                    while (!line.empty() && fp.good()) line = fp.next();
+                    s->skipped.push_back(filename);
+                    continue;
+                }
+                pool = meshPool.emplace(filename, std::move(mesh)).first;
+            }
+            int materialId = 0;
+            line = fp.next();
+            if (!line.empty() && fp.good()) {
+                const std::vector<std::string> t = tokenize(line);
+                if (t.size() < 2) return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, "Object: expected `Material <name>`"));
+                if (t[1] == "Null") { materialId = (int)s->materials.size(); s->materials.push_back(default_material()); }
+                else {
+                    auto it = s->materialMap.find(t[1]);
+                    if (it == s->materialMap.end()) return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, ("Material " + t[1] + " doesn't exist").c_str()));
+                    materialId = it->second;
+                }
+            }
+            f3 translation = splat(0.f), rotation = splat(0.f), scl = splat(0.f);                   // glm::vec3() members of ModelInstance (Q13)
+            line = fp.next();
+            while (!line.empty() && fp.good()) {
+                const std::vector<std::string> t = tokenize(line);
+                if (t.size() >= 4) {
+                    const f3 v = mk3(std::stof(t[1]), std::stof(t[2]), std::stof(t[3]));
+                    if (t[0] == "Translate") translation = v;
+                    else if (t[0] == "Rotate") rotation = v;
+                    else if (t[0] == "Scale") scl = v;
+                }
+                line = fp.next();
+            }
+            // buildDevData (:161-176): transformed corners appended in instance order, one material id per triangle
+            const Mesh& mesh = pool->second;
+            const int n = (int)(mesh.v.size() / 3);
+            const size_t at = s->vertices.size();
+            s->vertices.resize(at + mesh.v.size()); s->normals.resize(at + mesh.n.size());
+            bake(build_transformation_matrix(translation, rotation, scl), n, mesh.v.data(), mesh.n.data(), s->vertices.data() + at, s->normals.data() + at);
+            s->texcoords.insert(s->texcoords.end(), mesh.t.begin(), mesh.t.end());
+            s->materialIds.insert(s->materialIds.end(), (size_t)(n / 3), materialId);
+        }
+        else if (tokens[0] == "Camera") {                                                        // loadCamera (:285-354)
+            float fovy = 0.f;
+            rs_camera& cam = s->camera;
+            for (int i = 0; i < 8; i++) {
+                line = fp.next();
+                const std::vector<std::string> t = tokenize(line);
+                if (t.size() < 2) continue;
+                if (t[0] == "Resolution" && t.size() >= 3) { cam.resolution[0] = std::stoi(t[1]); cam.resolution[1] = std::stoi(t[2]); }
+                else if (t[0] == "FovY") fovy = std::stof(t[1]);
+                else if (t[0] == "LensRadius") cam.lensRadius = std::stof(t[1]);
+                else if (t[0] == "FocalDist") cam.focalDist = std::stof(t[1]);
+                else if (t[0] == "Sample") s->iterations = std::stoi(t[1]);
+                else if (t[0] == "Depth") s->traceDepth = std::stoi(t[1]);
+                else if (t[0] == "File") s->imageName = t[1];
+            }
+            line = fp.next();
+            while (!line.empty() && fp.good()) {
+                const std::vector<std::string> t = tokenize(line);
+                if (t.size() >= 4) {
+                    float* dst = t[0] == "Eye" ? cam.position : t[0] == "Rotation" ? cam.rotation : t[0] == "Up" ? cam.up : nullptr;
+                    if (dst) for (int k = 0; k < 3; k++) dst[k] = std::stof(t[1 + k]);
+                }
+                line = fp.next();
+            }
+            if (cam.resolution[0] <= 0 || cam.resolution[1] <= 0) return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, "Camera: missing Resolution"));
+            const float yscaled = tanf(fovy * (kPi / 180));                                      // :343-348
+            const float xscaled = (yscaled * (float)cam.resolution[0]) / (float)cam.resolution[1];
+            const float fovx = (atanf(xscaled) * 180) / kPi;
+            cam.fov[0] = fovx; cam.fov[1] = fovy;
+            cam.tanFovY = tanf(radians(fovy * 0.5f));
+            cam.pixelLength[0] = cam.pixelLength[1] = 0.f;
+            if (int e = rs_camera_update(&cam)) return bail(e);
+        }
+        else if (tokens[0] == "EnvMap" && tokens.size() >= 2) {                                   // :122-128: not flipped
+            if (tokens[1] != "Null") if (int e = add_texture(s, dir, tokens[1], false, &s->envMapTexId)) return bail(e);
+        }
+    }
+    } catch (const std::exception& e) {                                // std::stof / std::stoi on malformed numbers
+        return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, (std::string("malformed number in scene file: ") + e.what()).c_str()));
+    }
+    if (s->vertices.empty()) return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, "No mesh data loaded"));      // scene.cpp:192-195
+    for (size_t i = 0; i < s->textures.size(); i++) s->textures[i].data = s->texData[i].data();
+    *out = s;
+    return 0;
+}
+
+int rs_scene_file_get(const rs_scene_file* s, rs_scene_file_view* v) {
+    if (!s || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_file_get: null argument");
+    v->numPrims = (int)(s->vertices.size() / 9);
+    v->vertices = s->vertices.data(); v->normals = s->normals.data(); v->texcoords = s->texcoords.data();
+    v->materialIds = s->materialIds.data();
+    v->numMaterials = (int)s->materials.size(); v->materials = s->materials.data();
+    v->numTextures = (int)s->textures.size(); v->textures = s->textures.data(); v->envMapTexId = s->envMapTexId;
+    v->camera = s->camera; v->iterations = s->iterations; v->traceDepth = s->traceDepth; v->imageName = s->imageName.c_str();
+    v->numSkippedObjects = (int)s->skipped.size();
+    return 0;
+}
+
+}  // extern "C"

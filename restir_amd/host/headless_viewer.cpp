@@ -1,13 +1,16 @@
 // headless_viewer.cpp -- the reference's main() / runCuda() call sequence (src/main.cpp:55-103,146-185)
 // written against restir_compat.h, with the GLFW/ImGui/PBO display replaced by a PPM dump.
 // It exists to show (and compile-check) that the reference's host code drives librestir_hip through
-// the same names.  Scene input: a binary triangle soup written by restir_amd/scenes.py (dump_scene).
+// the same names.  Scene input: a scene file in the reference's text format (Scene(filename), as main() does), or a
+// binary triangle soup written by restir_amd/scenes.py (dump_scene).
 //
+//   headless_viewer scene.txt frames reuse out.ppm                  (resolution and camera from the file)
 //   headless_viewer scene.bin width height frames reuse out.ppm
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "restir_compat.h"
@@ -28,8 +31,8 @@ static void runCuda(void* devPBO) {                       // src/main.cpp:146-18
     gBuffer.update(scene->camera);
 }
 
-int main(int argc, char** argv) {
-    if (argc < 7) { std::printf("Usage: %s scene.bin width height frames reuse out.ppm\n", argv[0]); return 1; }
+static int load_soup(int argc, char** argv, int& frames) {
+    if (argc < 7) return 1;
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 1; }
     int32_t hdr[2];                                       // numPrims, numMaterials
@@ -45,18 +48,37 @@ int main(int argc, char** argv) {
     std::fclose(f);
 
     width = std::atoi(argv[2]); height = std::atoi(argv[3]);
-    const int frames = std::atoi(argv[4]);
+    frames = std::atoi(argv[4]);
     Settings::reservoirReuse = std::atoi(argv[5]);
 
-    rsc::check(rs_init(0), "init");
     scene = new Scene();
     Camera& cam = scene->camera;
-    std::memset(&cam, 0, sizeof cam);
+    std::memset(static_cast<rs_camera*>(&cam), 0, sizeof(rs_camera));
     cam.resolution[0] = width; cam.resolution[1] = height;
     for (int i = 0; i < 3; i++) { cam.position[i] = camv[i]; cam.rotation[i] = camv[3 + i]; }
     cam.fov[1] = camv[6]; cam.focalDist = camv[7];
-
     scene->buildDevData((int)np, v.data(), n.data(), t.data(), m.data(), hdr[1], mats.data());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const size_t len = argc > 1 ? std::strlen(argv[1]) : 0;
+    const bool text = len > 4 && std::strcmp(argv[1] + len - 4, ".txt") == 0;
+    if (argc < (text ? 5 : 7)) {
+        std::printf("Usage: %s scene.txt frames reuse out.ppm\n       %s scene.bin width height frames reuse out.ppm\n", argv[0], argv[0]);
+        return 1;
+    }
+    rsc::check(rs_init(0), "init");
+    int frames = 0;
+    const char* outName = argv[text ? 4 : 6];
+    if (text) {                                           // src/main.cpp:60-83
+        scene = new Scene(std::string(argv[1]));
+        width = scene->camera.resolution[0]; height = scene->camera.resolution[1];
+        frames = std::atoi(argv[2]);
+        Settings::reservoirReuse = std::atoi(argv[3]);
+        scene->buildDevData();
+    }
+    else if (load_soup(argc, argv, frames)) return 1;
     State::scene = scene;
     if (hipMalloc((void**)&devDirectIllum, sizeof(rsc::vec3) * (size_t)width * height) != hipSuccess) return 1;
     (void)hipMemset(devDirectIllum, 0, sizeof(rsc::vec3) * (size_t)width * height);
@@ -70,7 +92,7 @@ int main(int argc, char** argv) {
 
     std::vector<unsigned char> rgba(4 * (size_t)width * height);
     (void)hipMemcpy(rgba.data(), devPBO, rgba.size(), hipMemcpyDeviceToHost);
-    FILE* o = std::fopen(argv[6], "wb");
+    FILE* o = std::fopen(outName, "wb");
     std::fprintf(o, "P6\n%d %d\n255\n", width, height);
     for (size_t i = 0; i < (size_t)width * height; i++) std::fwrite(&rgba[4 * i], 1, 3, o);
     std::fclose(o);

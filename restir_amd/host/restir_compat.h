@@ -12,14 +12,16 @@
 // Differences that remain visible to the caller:
 //   * image pointers are hipMalloc memory; the CUDA-GL PBO interop of main.cpp:176-181 is replaced by
 //     a plain device buffer (display interop is outside this path);
-//   * Scene::buildDevData() hands the baked triangle soup to rs_scene_build (BVH, light table and alias
-//     table are built by the library with the reference's exact results).
+//   * Scene(filename) + buildDevData() go through rs_scene_file_load / rs_scene_build_textured (parser, OBJ reader, instance
+//     baking, BVH, light table and alias tables are built by the library with the reference's exact results); image files
+//     named in a scene must be binary PPM, other formats are decoded by the caller and passed as arrays.
 // Errors keep the reference's convention: print and exit (checkCUDAError, src/cudaUtil.h:13-31).
 #pragma once
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <utility>
 
 #include "../../include/restir_hip.h"
@@ -68,10 +70,41 @@ using Material = rs_material;                           // src/material.h:113-26
 using DevScene = rs_scene;                              // src/scene.h:64-481
 
 // ---- src/scene.h:483-531 (only what the path needs) -----------------------------------------------
+struct RenderState {                                    // src/sceneStructs.h:128-133 (the members main.cpp reads)
+    unsigned int iterations = 0;
+    std::string imageName;
+};
+
 struct Scene {
     Camera camera{};
+    RenderState state;
     DevScene* devScene = nullptr;
-    // buildDevData (src/scene.cpp:159-215) on an already baked, de-indexed triangle soup
+    rs_scene_file* file = nullptr;                      // what Scene(filename) parsed (materials, instances, textures, camera)
+
+    Scene() = default;
+    // Scene::Scene(filename) (src/scene.cpp:96-131): materials, objects (OBJ, baked per instance), camera, environment map.
+    // Image files must be binary PPM; see include/restir_hip.h "scene files".
+    explicit Scene(const std::string& filename) {
+        rsc::check(rs_scene_file_load(filename.c_str(), &file), "Scene loading");
+        rs_scene_file_view v;
+        rsc::check(rs_scene_file_get(file, &v), "Scene loading");
+        static_cast<rs_camera&>(camera) = v.camera;
+        state.iterations = (unsigned int)v.iterations;
+        state.imageName = v.imageName;
+        Settings::traceDepth = v.traceDepth;            // loadCamera's "Depth" line (src/scene.cpp:321-323)
+    }
+    ~Scene() { rs_scene_file_free(file); }
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+
+    // buildDevData (src/scene.cpp:159-215) of the scene the constructor parsed
+    void buildDevData() {
+        rs_scene_file_view v;
+        rsc::check(rs_scene_file_get(file, &v), "Dev Scene");
+        rsc::check(rs_scene_build_textured(v.numPrims, v.vertices, v.normals, v.texcoords, v.materialIds, v.numMaterials, v.materials,
+                                           v.numTextures, v.textures, v.envMapTexId, &devScene), "Dev Scene");
+    }
+    // buildDevData on an already baked, de-indexed triangle soup
     void buildDevData(int numPrims, const float* vertices, const float* normals, const float* texcoords,
                       const int* materialIds, int numMaterials, const Material* materials) {
         rsc::check(rs_scene_build(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials, &devScene), "Dev Scene");

@@ -1,0 +1,130 @@
+"""Writers for the reference's on-disk scene format (the reader is in the library: capi.SceneFile /
+rs_scene_file_load, restir_amd/csrc/scene_file.cpp).
+
+The text format is the one Scene::Scene(filename) parses (/root/reference/src/scene.cpp:96-131 with loadMaterial
+:371-433, loadModel :222-283, loadCamera :285-354):
+
+    Material <name>                Object <name>                     Camera
+    Type <Lambertian|...>          <mesh file>.obj                   Resolution <w> <h>
+    BaseColor <r g b|file|Procedural>   Material <name|Null>         FovY <deg>
+    Metallic <x|file>              Translate <x y z>                 LensRadius <x>
+    Roughness <x|file>             Rotate <x y z>      (degrees)     FocalDist <x>
+    Ior <x>                        Scale <x y z>                     ApertureMask Null
+    NormalMap <file|Null>          <empty line>                      Sample <n>
+                                                                     Depth <n>
+    EnvMap <file|Null>                                               File <name>
+                                                                     Eye / Rotation / Up <x y z>, then an empty line
+
+so a scene written here can be rendered by the reference itself on its own hardware and compared with this port.
+Images are written as binary PPM (P6), which both stb_image (the reference) and the library's reader decode to byte / 255.
+"""
+import os
+
+import numpy as np
+
+_TYPE_NAMES = {0: "Lambertian", 1: "MetallicWorkflow", 2: "Dielectric", 4: "Light"}
+
+
+def _num(x):
+    return repr(float(np.float32(x)))       # exact decimal expansion of the float, ends in a digit
+
+
+def _vec(v):
+    return " ".join(_num(x) for x in v)
+
+
+def write_ppm(path, rgb):
+    """rgb: (h, w, 3) uint8."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    assert rgb.ndim == 3 and rgb.shape[2] == 3
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+        f.write(rgb.tobytes())
+
+
+def write_obj(path, vertices, normals, texcoords=None):
+    """De-indexed triangle soup: vertices / normals (n, 3, 3), texcoords (n, 3, 2) or None."""
+    v = np.asarray(vertices, np.float32).reshape(-1, 3)
+    n = np.asarray(normals, np.float32).reshape(-1, 3)
+    t = None if texcoords is None else np.asarray(texcoords, np.float32).reshape(-1, 2)
+    with open(path, "w") as f:
+        for p in v:
+            f.write("v " + _vec(p) + "\n")
+        for p in n:
+            f.write("vn " + _vec(p) + "\n")
+        if t is not None:
+            for p in t:
+                f.write("vt " + _vec(p) + "\n")
+        for i in range(0, len(v), 3):
+            c = [(f"{k + 1}/{k + 1}/{k + 1}" if t is not None else f"{k + 1}//{k + 1}") for k in (i, i + 1, i + 2)]
+            f.write("f " + " ".join(c) + "\n")
+
+
+def material_lines(name, m):
+    """m: dict(type=int|str, baseColor=(r, g, b)|"Procedural"|file, metallic=x|file, roughness=x|file, ior=x, normalMap=file|None)."""
+    ty = m.get("type", 0)
+    base = m.get("baseColor", (0.9, 0.9, 0.9))
+
+    def scalar(x):
+        return x if isinstance(x, str) else _num(x)
+    return [
+        f"Material {name}",
+        f"Type {ty if isinstance(ty, str) else _TYPE_NAMES[int(ty)]}",
+        "BaseColor " + (base if isinstance(base, str) else _vec(base)),
+        "Metallic " + scalar(m.get("metallic", 0.0)),
+        "Roughness " + scalar(m.get("roughness", 1.0)),
+        "Ior " + _num(m.get("ior", 1.5)),
+        "NormalMap " + (m.get("normalMap") or "Null"),
+        "",
+    ]
+
+
+def object_lines(name, mesh_file, material, translate=(0, 0, 0), rotate=(0, 0, 0), scale=(1, 1, 1)):
+    return [f"Object {name}", mesh_file, f"Material {material or 'Null'}",
+            "Translate " + _vec(translate), "Rotate " + _vec(rotate), "Scale " + _vec(scale), ""]
+
+
+def camera_lines(width, height, fov_y, position, rotation, up=(0, 1, 0), lens_radius=0.0, focal_dist=1.0,
+                 sample=1, depth=4, file="out"):
+    return ["Camera", f"Resolution {int(width)} {int(height)}", "FovY " + _num(fov_y), "LensRadius " + _num(lens_radius),
+            "FocalDist " + _num(focal_dist), "ApertureMask Null", f"Sample {int(sample)}", f"Depth {int(depth)}", f"File {file}",
+            "Eye " + _vec(position), "Rotation " + _vec(rotation), "Up " + _vec(up), ""]
+
+
+def write_scene(path, materials, objects, camera, env_map=None, newline="\n"):
+    """materials: [(name, dict)], objects: [dict(name=, file=, material=, translate=, rotate=, scale=)], camera: kwargs of
+    camera_lines, env_map: file name or None."""
+    lines = []
+    for name, m in materials:
+        lines += material_lines(name, m)
+    for o in objects:
+        lines += object_lines(o["name"], o["file"], o.get("material"), o.get("translate", (0, 0, 0)), o.get("rotate", (0, 0, 0)),
+                              o.get("scale", (1, 1, 1)))
+    lines += camera_lines(**camera)
+    lines += [f"EnvMap {env_map or 'Null'}"]
+    with open(path, "w", newline="") as f:
+        f.write(newline.join(lines) + newline)
+
+
+def export_scene_data(sd, directory, width, height, name="scene", sample=1, depth=4):
+    """Write a restir_amd.scenes.SceneData (untextured materials) as <directory>/<name>.txt + one OBJ per material, with
+    identity transforms, e.g. to render the benchmark scenes in the reference itself.  Returns the scene file path."""
+    os.makedirs(directory, exist_ok=True)
+    mats, objs = [], []
+    for i, m in enumerate(sd.materials):
+        mats.append((f"m{i}", dict(type=int(m["type"]), baseColor=tuple(m["baseColor"]), metallic=float(m["metallic"]),
+                                   roughness=float(m["roughness"]), ior=float(m["ior"]))))
+    ids = np.asarray(sd.material_ids)
+    # the reader appends instances in file order: keep triangle order by cutting the soup into runs of equal material
+    cuts = np.flatnonzero(np.diff(ids)) + 1
+    starts = np.concatenate([[0], cuts]); ends = np.concatenate([cuts, [len(ids)]])
+    for k, (a, b) in enumerate(zip(starts, ends)):
+        fn = f"{name}_{k}.obj"
+        write_obj(os.path.join(directory, fn), sd.vertices[a:b], sd.normals[a:b], sd.texcoords[a:b])
+        objs.append(dict(name=f"o{k}", file=fn, material=f"m{int(ids[a])}"))
+    ca = sd.camera_args
+    cam = dict(width=width, height=height, fov_y=ca["fov_y"], position=ca["position"], rotation=ca["rotation"],
+               focal_dist=ca.get("focal_dist", 1.0), lens_radius=ca.get("lens_radius", 0.0), sample=sample, depth=depth, file=name)
+    path = os.path.join(directory, name + ".txt")
+    write_scene(path, mats, objs, cam)
+    return path

@@ -1,0 +1,92 @@
+"""Generates tests/golden/scene_files.npz: the scene-file test case (tests/scene_file_cases.py) as file bytes, together with
+what the REFERENCE'S OWN loaders make of those files -- tinyobj::LoadObj + the flattening loop of Resource::loadOBJMesh,
+Image(filename) = stbi_loadf under both flip settings, the safeGetline / tokenizeString read loop, and
+Math::buildTransformationMatrix + the GLM baking of Scene::buildDevData -- through oracle/_ref/libref_loaders.so and
+libref_subset.so (oracle/ref_loaders.cpp, oracle/ref_subset.cpp; compiled from /root/reference in place).
+
+Run in the build container (needs /root/reference):   python tests/golden/make_scene_golden.py
+The fixture holds data only: generated inputs and the reference's outputs for them."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import binding as ob  # noqa: E402
+from tests import scene_file_cases as cases  # noqa: E402
+
+
+def ref_obj(R, path):
+    cap = 1 << 16
+    v = np.zeros((cap, 3), np.float32); n = np.zeros((cap, 3), np.float32); t = np.zeros((cap, 2), np.float32)
+    cnt = R.ref_obj_load(path.encode(), cap, v.ctypes.data, n.ctypes.data, t.ctypes.data)
+    assert 0 <= cnt <= cap, cnt
+    return v[:cnt].copy(), n[:cnt].copy(), t[:cnt].copy()
+
+
+def ref_image(R, path, flip):
+    w, h = C.c_int(), C.c_int()
+    assert R.ref_image_load(path.encode(), flip, C.byref(w), C.byref(h), None, 0) == 0
+    buf = np.zeros(w.value * h.value * 3, np.float32)
+    assert R.ref_image_load(path.encode(), flip, C.byref(w), C.byref(h), buf.ctypes.data, buf.size) == 0
+    return buf.reshape(h.value, w.value, 3)
+
+
+def ref_lines(R, path):
+    out = C.create_string_buffer(1 << 22)
+    ln = R.ref_read_lines(path.encode(), out, 1 << 22)
+    assert 0 <= ln <= (1 << 22)
+    return out.raw[:ln]
+
+
+def main():
+    R, S = ob.ref_loaders(), ob.ref_subset()
+    assert R is not None and S is not None, "build oracle/_ref first (make -C oracle)"
+    g = {}
+    with tempfile.TemporaryDirectory() as d:
+        cases.write_case(d)
+        for name in cases.CASE_FILES:
+            g["file_" + name] = np.frombuffer(open(os.path.join(d, name), "rb").read(), np.uint8)
+        for name in cases.CASE_FILES:
+            p = os.path.join(d, name)
+            if name.endswith(".obj"):
+                g["obj_v_" + name], g["obj_n_" + name], g["obj_t_" + name] = ref_obj(R, p)
+            elif name.endswith(".ppm"):
+                g["img_flip_" + name] = ref_image(R, p, 1)
+                g["img_noflip_" + name] = ref_image(R, p, 0)
+            g["lines_" + name] = np.frombuffer(ref_lines(R, p), np.uint8)
+        # line-ending variants of the scene text
+        text = open(os.path.join(d, "scene.txt"), "rb").read()
+        variants = {"crlf": text.replace(b"\n", b"\r\n"), "cr": text.replace(b"\n", b"\r"), "nofinal": text.rstrip(b"\n"),
+                    "blanks": text.replace(b"\n\n", b"\n \t\n") + b"\n\n"}
+        for key, data in variants.items():
+            p = os.path.join(d, "variant.txt")
+            open(p, "wb").write(data)
+            g["variant_" + key] = np.frombuffer(data, np.uint8)
+            g["variant_lines_" + key] = np.frombuffer(ref_lines(R, p), np.uint8)
+    # baking math
+    rng = np.random.default_rng(5)
+    k = 200
+    t = rng.uniform(-5, 5, (k, 3)).astype(np.float32)
+    r = rng.uniform(-360, 360, (k, 3)).astype(np.float32)
+    s = np.exp(rng.uniform(-3, 3, (k, 3))).astype(np.float32) * rng.choice([-1.0, 1.0], (k, 3)).astype(np.float32)
+    r[:20] = np.round(r[:20] / 90) * 90
+    t[0] = 0; r[0] = 0; s[0] = 1
+    verts = rng.uniform(-3, 3, (k, 32, 3)).astype(np.float32)
+    nrm = rng.normal(size=(k, 32, 3)).astype(np.float32)
+    mats = np.zeros((k, 16), np.float32); vo = np.zeros_like(verts); no = np.zeros_like(nrm)
+    for i in range(k):
+        S.ref_build_transformation_matrix(t[i], r[i], s[i], mats[i])
+        S.ref_bake_instance(t[i], r[i], s[i], 32, verts[i].reshape(-1), nrm[i].reshape(-1), vo[i].reshape(-1), no[i].reshape(-1))
+    g.update(bake_t=t, bake_r=r, bake_s=s, bake_verts=verts, bake_normals=nrm, bake_matrix=mats, bake_verts_out=vo, bake_normals_out=no)
+    out = os.path.join(ROOT, "tests", "golden", "scene_files.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays", os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
