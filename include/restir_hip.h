@@ -138,6 +138,11 @@ int  rs_set_stream(void* hipStream);
 /* 1 (default): every entry point synchronises and checks errors before returning, like
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);
+/* With rs_set_sync(0): GBuffer::render is enqueued on an internal second stream, ordered after everything enqueued before
+ * it, and joined into the library stream by the first call that reads the G-buffer (the temporal pass of ReSTIRDirect,
+ * the denoisers, rs_gbuffer_get_view, rs_synchronize), so that it overlaps the primary-ray and RIS kernels.  1 = on
+ * (default; the environment variable RS_SIDE_STREAM=0 turns it off), 0 = everything on the library stream. */
+int  rs_set_side_stream(int enable);
 int  rs_synchronize(void);
 
 /* ---- host scene build: replaces Scene::buildDevData (src/scene.cpp:159-215) ----------- */

@@ -95,7 +95,7 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_init", "rs_set_stream", "rs_set_sync", "rs_synchronize",
+    "rs_last_error", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
@@ -134,6 +134,7 @@ def lib():
     L.rs_init.argtypes = [ci]
     L.rs_set_stream.argtypes = [vp]
     L.rs_set_sync.argtypes = [ci]
+    L.rs_set_side_stream.argtypes = [ci]
     L.rs_build_bvh.argtypes = [ci, vp, vp, C.POINTER(vp * 6), C.POINTER(ci)]
     L.rs_build_light_table.argtypes = [ci, vp, vp, ci, vp, C.POINTER(ci), vp, vp, vp]
     L.rs_build_alias_table.argtypes = [ci, vp, vp, vp, C.POINTER(cf)]
@@ -221,6 +222,11 @@ def init(device=0):
 
 def set_sync(sync):
     check(lib().rs_set_sync(1 if sync else 0))
+
+
+def set_side_stream(enable):
+    """GBuffer::render on the library's second stream when launches are asynchronous (include/restir_hip.h)."""
+    check(lib().rs_set_side_stream(1 if enable else 0))
 
 
 def synchronize():

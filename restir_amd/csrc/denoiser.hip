@@ -243,6 +243,7 @@ int rs_eaw_create(int width, int height, int level, rs_eaw** out) {
 }
 
 int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
+    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
@@ -308,6 +309,7 @@ int rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* v) {
 // it is swapped with devAccumColor[frameIdx], so the caller's buffer becomes the filter's history and the caller
 // continues with one of the filter's buffers; as in the reference the caller must keep using the pointer it gets back.
 int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
+    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: size mismatch");
@@ -341,6 +343,7 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
 }
 
 int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {
+    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
     if (!devImage || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "modulateAlbedo: null argument");
     const int n = g->width * g->height;
     hipLaunchKernelGGL(k_modulate, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devImage, g->devAlbedo, n);

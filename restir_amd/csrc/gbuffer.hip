@@ -55,6 +55,7 @@ extern "C" {
 
 int rs_gbuffer_destroy(rs_gbuffer* g) {
     if (!g) return 0;
+    (void)rs_synchronize();                             // joins a render still running on the side stream
     rs_dev_free(g->devAlbedo); rs_dev_free(g->devMotion);
     for (int i = 0; i < 2; i++) { rs_dev_free(g->devNormal[i]); rs_dev_free(g->devPrimId[i]); rs_dev_free(g->devDepth[i]); }
     delete g;
@@ -98,12 +99,18 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
     if (y1 <= y0) return 0;
     GBufWrite w{ g->devAlbedo, g->devMotion, g->devNormal[g->frameIdx], g->devPrimId[g->frameIdx], g->devDepth[g->frameIdx] };
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
+    // Nothing in the primary-ray and RIS kernels of the frame reads the G-buffer, and both this kernel and k_primary end in a
+    // long tail of a few heavy tiles: when launches are asynchronous the render goes to the side stream and is joined by its
+    // first consumer (the temporal pass), so the two tails overlap.
+    const hipStream_t side = rs_side_fork();
+    const hipStream_t st = side ? side : rs_stream();
     if (scene->textured)
-        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(),
+        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, st,
                            scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
     else
-        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(),
+        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, st,
                            scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
+    if (side) { RS_TRY(rs_check_hip(hipGetLastError(), "renderGBuffer")); return rs_side_submitted(); }
     return rs_after_launch("renderGBuffer");
 }
 
@@ -124,6 +131,7 @@ size_t rs_gbuffer_rows_bytes(const rs_gbuffer* g, int rows) { return g ? (size_t
 
 int rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* devBuffer) {
     if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_pack: bad argument");
+    RS_TRY(rs_side_join());
     const int f = g->frameIdx ^ sel;
     const size_t n = (size_t)g->width * rows, off = (size_t)y0 * g->width;
     char* b = (char*)devBuffer;
@@ -135,6 +143,7 @@ int rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* d
 
 int rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void* devBuffer) {
     if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_unpack: bad argument");
+    RS_TRY(rs_side_join());
     const int f = g->frameIdx ^ sel;
     const size_t n = (size_t)g->width * rows, off = (size_t)y0 * g->width;
     const char* b = (const char*)devBuffer;
@@ -146,6 +155,7 @@ int rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void*
 
 int rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* v) {
     if (!g || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_get_view: null argument");
+    RS_TRY(rs_side_join());                             // the caller is about to use the planes on the library stream
     v->devAlbedo = g->devAlbedo; v->devMotion = g->devMotion;
     for (int i = 0; i < 2; i++) { v->devNormal[i] = g->devNormal[i]; v->devPrimId[i] = g->devPrimId[i]; v->devDepth[i] = g->devDepth[i]; }
     v->frameIdx = g->frameIdx; v->width = g->width; v->height = g->height;

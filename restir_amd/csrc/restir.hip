@@ -614,6 +614,7 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     else
         hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
     mark(r, 2);
+    RS_TRY(rs_side_join());                                     // first consumer of the G-buffer planes
     hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
                        r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
     mark(r, 3);
@@ -629,6 +630,7 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     if (y1 <= y0) return 0;
     const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
+    RS_TRY(rs_side_join());
     hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(kBThreads), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
                        r->cur, r->temp, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);

@@ -15,6 +15,10 @@ hipStream_t rs_stream();
 bool rs_sync_enabled();
 // after a launch: hipGetLastError (+ stream sync when sync mode is on), like checkCUDAError
 int rs_after_launch(const char* what);
+// side stream for work the next kernels do not depend on (api_common.hip): fork -> launch there -> submitted; consumers join
+hipStream_t rs_side_fork();
+int rs_side_submitted();
+int rs_side_join();
 
 #define RS_TRY(expr)                                       \
     do {                                                   \
