@@ -119,7 +119,6 @@ def main():
     scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
     cam = capi.camera_update(sd.camera(WIDTH, HEIGHT))
     backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
-    backend.restir.enable_timing(True)
     strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit)
     y0, y1 = strips.y0, strips.y1
     rows = y1 - y0
@@ -171,6 +170,7 @@ def main():
     # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
     # primary-ray and RIS kernels from the library's second stream)
     capi.set_side_stream(False)
+    backend.restir.enable_timing(True)
     spatial_ms, pass_ms = [], np.zeros(4)
     for _ in range(20):
         frame()
@@ -187,6 +187,7 @@ def main():
         torch.cuda.synchronize()
         gb_ms.append(ev[0].elapsed_time(ev[1])); pbo_ms.append(ev[2].elapsed_time(ev[3]))
     capi.set_side_stream(True)
+    backend.restir.enable_timing(False)
 
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device="cuda")
     if world > 1:

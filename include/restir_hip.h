@@ -118,7 +118,10 @@ typedef struct rs_restir  rs_restir;   /* = module statics of restir.cu      (sr
 typedef struct rs_eaw     rs_eaw;      /* = LeveledEAWFilter                 (src/denoiser.h:33-43) */
 typedef struct rs_svgf    rs_svgf;     /* = SpatioTemporalFilter             (src/denoiser.h:45-70) */
 
-/* Device pointers of a GBuffer's planes (src/gbuffer.h:41-58). */
+/* Device pointers of a GBuffer's planes (src/gbuffer.h:41-58): [frameIdx] = this frame's, [frameIdx ^ 1] = last frame's.
+ * The library keeps the planes in a ring of three sets (so that the next frame's render never overwrites what this frame's
+ * temporal pass reads): the pointers are those of the current frame and change at every rs_gbuffer_update -- fetch the
+ * view again after it. */
 typedef struct rs_gbuffer_view {
     float* devAlbedo;        /* float[3] / px */
     int*   devMotion;
@@ -138,10 +141,12 @@ int  rs_set_stream(void* hipStream);
 /* 1 (default): every entry point synchronises and checks errors before returning, like
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);
-/* With rs_set_sync(0): GBuffer::render is enqueued on an internal second stream, ordered after everything enqueued before
- * it, and joined into the library stream by the first call that reads the G-buffer (the temporal pass of ReSTIRDirect,
- * the denoisers, rs_gbuffer_get_view, rs_synchronize), so that it overlaps the primary-ray and RIS kernels.  1 = on
- * (default; the environment variable RS_SIDE_STREAM=0 turns it off), 0 = everything on the library stream. */
+/* With rs_set_sync(0), frames overlap: GBuffer::render and the primary-ray + RIS kernels of ReSTIRDirect are enqueued on two
+ * internal streams, ordered only after the work that last used their buffers (G-buffer planes in a ring of three, per-frame
+ * surface planes double-buffered), and joined into the library stream where their results are first read (the temporal
+ * pass, the denoisers, rs_gbuffer_get_view, rs_synchronize).  They then run next to the previous frame's temporal / spatial
+ * passes.  Results are identical; output buffers are valid in library-stream order as before.  1 = on (default; the
+ * environment variable RS_SIDE_STREAM=0 turns it off), 0 = everything on the library stream. */
 int  rs_set_side_stream(int enable);
 int  rs_synchronize(void);
 

@@ -500,6 +500,7 @@ def _hiprt():
     if _hip is None:
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _hip.hipFree.argtypes = [C.c_void_p]
     return _hip
@@ -523,6 +524,14 @@ def hip_memcpy_d2d(dst, src, nbytes):
     e = _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
     if e != 0:
         raise RestirHipError(f"hipMemcpy failed: {e}")
+
+
+def hip_memcpy_d2d_async(dst, src, nbytes):
+    """Device-to-device copy enqueued on the default stream (the library's stream unless rs_set_stream changed it)."""
+    _hiprt()
+    e = _hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, None)
+    if e != 0:
+        raise RestirHipError(f"hipMemcpyAsync failed: {e}")
 
 
 class ReSTIR:

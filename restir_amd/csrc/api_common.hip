@@ -11,12 +11,12 @@ std::mutex g_errMutex;
 std::string g_lastError;
 hipStream_t g_stream = nullptr;
 bool g_sync = true;
-// side stream: work that the next kernels on the library stream do not depend on (the G-buffer render next to the
-// primary-ray and RIS kernels) runs here and is joined where it is first consumed
-hipStream_t g_side = nullptr;
-hipEvent_t g_sideFork = nullptr, g_sideDone = nullptr;
-bool g_sidePending = false;
-int g_sideMode = -1;                                    // -1: not decided yet; 0 off; 1 on
+// Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 the primary-ray + RIS kernels of ReSTIRDirect.
+// Neither reads what the temporal / spatial passes of the previous frame write, so with the per-frame surface planes
+// double-buffered and the G-buffer planes in a ring of three they run next to those passes; the objects own the events
+// that order them (rs_gbuffer, rs_restir).
+hipStream_t g_aux[2] = { nullptr, nullptr };
+int g_auxMode = -1;                                     // -1: not decided yet; 0 off; 1 on
 }  // namespace
 
 int rs_fail(int code, const char* msg) {
@@ -34,33 +34,20 @@ int rs_check_hip(hipError_t e, const char* what) {
 hipStream_t rs_stream() { return g_stream; }
 bool rs_sync_enabled() { return g_sync; }
 
-// Returns the side stream, ordered after everything enqueued on the library stream so far, or nullptr when launches are
-// synchronous (rs_set_sync(1): nothing to overlap) or RS_SIDE_STREAM=0.
-hipStream_t rs_side_fork() {
-    if (g_sideMode < 0) {
+// The auxiliary stream i, or nullptr when launches are synchronous (rs_set_sync(1): nothing to overlap) or the feature is
+// off (rs_set_side_stream(0) / RS_SIDE_STREAM=0).
+hipStream_t rs_aux_stream(int i) {
+    if (g_auxMode < 0) {
         const char* e = std::getenv("RS_SIDE_STREAM");
-        g_sideMode = (e && e[0] == '0') ? 0 : 1;
+        g_auxMode = (e && e[0] == '0') ? 0 : 1;
     }
-    if (g_sync || !g_sideMode) return nullptr;
-    if (!g_side) {
-        if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; g_sideMode = 0; return nullptr; }
-        if (hipEventCreateWithFlags(&g_sideFork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g_sideDone, hipEventDisableTiming) != hipSuccess) { g_sideMode = 0; return nullptr; }
-    }
-    if (hipEventRecord(g_sideFork, g_stream) != hipSuccess || hipStreamWaitEvent(g_side, g_sideFork, 0) != hipSuccess) return nullptr;
-    return g_side;
+    if (g_sync || !g_auxMode) return nullptr;
+    if (!g_aux[i] && hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking) != hipSuccess) { g_aux[i] = nullptr; g_auxMode = 0; return nullptr; }
+    return g_aux[i];
 }
-// after the launches on the side stream
-int rs_side_submitted() {
-    RS_HIP(hipEventRecord(g_sideDone, g_side));
-    g_sidePending = true;
+int rs_aux_synchronize() {
+    for (hipStream_t st : g_aux) if (st) RS_HIP(hipStreamSynchronize(st));
     return 0;
-}
-// the library stream waits for the side stream's work; called by every consumer of what was produced there
-int rs_side_join() {
-    if (!g_sidePending) return 0;
-    g_sidePending = false;
-    return rs_check_hip(hipStreamWaitEvent(g_stream, g_sideDone, 0), "side-stream join");
 }
 
 int rs_after_launch(const char* what) {
@@ -109,19 +96,19 @@ int rs_init(int device) {
 }
 
 int rs_set_stream(void* hipStream) {
-    RS_TRY(rs_side_join());                             // pending side work is ordered into the stream being left
+    if ((hipStream_t)hipStream != g_stream) RS_TRY(rs_synchronize());   // events recorded on the old stream order the auxiliary ones
     g_stream = (hipStream_t)hipStream;
     return 0;
 }
 int rs_set_sync(int sync) { g_sync = sync != 0; return 0; }
 int rs_set_side_stream(int enable) {
-    RS_TRY(rs_side_join());
-    g_sideMode = enable ? 1 : 0;
+    g_auxMode = enable ? 1 : 0;                         // work already enqueued on the auxiliary streams is still joined by its consumers
     return 0;
 }
 int rs_synchronize(void) {
-    RS_TRY(rs_side_join());
-    return rs_check_hip(hipStreamSynchronize(g_stream), "rs_synchronize");
+    RS_TRY(rs_aux_synchronize());
+    RS_TRY(rs_check_hip(hipStreamSynchronize(g_stream), "rs_synchronize"));
+    return rs_aux_synchronize();                        // (an auxiliary launch may have been waiting for the library stream)
 }
 
 }  // extern "C"

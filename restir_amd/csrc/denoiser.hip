@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
 
 int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer* g, int level) {
     dim3 grid((f->width + 31) / 32, (f->height + 7) / 8);
-    hipLaunchKernelGGL(k_wavelet, grid, dim3(256), 0, rs_stream(), out, in, g->devPrimId[g->frameIdx], g->devNormal[g->frameIdx],
+    hipLaunchKernelGGL(k_wavelet, grid, dim3(256), 0, rs_stream(), out, in, g->primId[g->cur()], g->normal[g->cur()],
                        f->devPos, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin, level);
     return rs_after_launch("EAW Filter");
 }
@@ -243,13 +243,13 @@ int rs_eaw_create(int width, int height, int level, rs_eaw** out) {
 }
 
 int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
-    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
+    RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
     const int n = f->width * f->height;
     hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
-                       g->devDepth[g->frameIdx], g->devPrimId[g->frameIdx], f->devPos);
+                       g->depth[g->cur()], g->primId[g->cur()], f->devPos);
     RS_TRY(rs_after_launch("EAW positions"));
     // LeveledEAWFilter::filter (denoiser.cu:463-477): level 0 into out, then four ping-pongs with the
     // internal buffer; the caller's pointer and the internal one are swapped after each
@@ -309,7 +309,7 @@ int rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* v) {
 // it is swapped with devAccumColor[frameIdx], so the caller's buffer becomes the filter's history and the caller
 // continues with one of the filter's buffers; as in the reference the caller must keep using the pointer it gets back.
 int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
-    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
+    RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: size mismatch");
@@ -318,7 +318,7 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
     const dim3 grid2((W + 31) / 32, (H + 7) / 8);
     const GBufView gv = gbuf_view(g);
     hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
-                       g->devDepth[g->frameIdx], g->devPrimId[g->frameIdx], f->devPos);
+                       g->depth[g->cur()], g->primId[g->cur()], f->devPos);
     // temporalAccumulate (:506-519), estimateVariance (:521-527)
     hipLaunchKernelGGL(k_svgf_temporal, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), f->devAccumColor[fi], f->devAccumColor[fi ^ 1],
                        f->devAccumMoment[fi], f->devAccumMoment[fi ^ 1], devColorIn, gv, f->firstTime ? 1 : 0);
@@ -343,10 +343,10 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
 }
 
 int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {
-    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
+    RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!devImage || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "modulateAlbedo: null argument");
     const int n = g->width * g->height;
-    hipLaunchKernelGGL(k_modulate, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devImage, g->devAlbedo, n);
+    hipLaunchKernelGGL(k_modulate, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devImage, g->albedo[g->latest()], n);
     return rs_after_launch("modulate");
 }
 

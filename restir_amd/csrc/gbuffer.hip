@@ -51,13 +51,24 @@ __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams ca
     }
 }
 
+// the library stream waits for a render still running on the auxiliary stream
+int rs_gbuffer_join(const rs_gbuffer* g) {
+    if (!g || !g->pending) return 0;
+    g->pending = false;
+    return rs_check_hip(hipStreamWaitEvent(rs_stream(), g->doneEv, 0), "G-buffer join");
+}
+
 extern "C" {
 
 int rs_gbuffer_destroy(rs_gbuffer* g) {
     if (!g) return 0;
-    (void)rs_synchronize();                             // joins a render still running on the side stream
-    rs_dev_free(g->devAlbedo); rs_dev_free(g->devMotion);
-    for (int i = 0; i < 2; i++) { rs_dev_free(g->devNormal[i]); rs_dev_free(g->devPrimId[i]); rs_dev_free(g->devDepth[i]); }
+    (void)rs_synchronize();                             // also a render still running on the auxiliary stream
+    for (int i = 0; i < rs_gbuffer::kSets; i++) {
+        rs_dev_free(g->albedo[i]); rs_dev_free(g->motion[i]); rs_dev_free(g->normal[i]); rs_dev_free(g->primId[i]); rs_dev_free(g->depth[i]);
+        if (g->useEv[i]) (void)hipEventDestroy(g->useEv[i]);
+    }
+    if (g->forkEv) (void)hipEventDestroy(g->forkEv);
+    if (g->doneEv) (void)hipEventDestroy(g->doneEv);
     delete g;
     return 0;
 }
@@ -69,22 +80,23 @@ int rs_gbuffer_create(int width, int height, rs_gbuffer** out) {
     g->width = width; g->height = height;
     const size_t n = (size_t)width * height;
     int e = 0;
-    if (!e) e = rs_dev_alloc(&g->devAlbedo, n * 3);
-    if (!e) e = rs_dev_alloc(&g->devMotion, n);
-    for (int i = 0; i < 2 && !e; i++) {
-        if (!e) e = rs_dev_alloc(&g->devNormal[i], n * 3);
-        if (!e) e = rs_dev_alloc(&g->devPrimId[i], n);
-        if (!e) e = rs_dev_alloc(&g->devDepth[i], n);
-    }
     // The reference leaves the planes uninitialised (cudaMalloc only).  They are zeroed here so that
     // first-frame reads of the "last" planes are deterministic; no reference-visible value changes.
-    if (!e) e = rs_check_hip(hipMemset(g->devAlbedo, 0, n * 12), "memset");
-    if (!e) e = rs_check_hip(hipMemset(g->devMotion, 0, n * 4), "memset");
-    for (int i = 0; i < 2 && !e; i++) {
-        if (!e) e = rs_check_hip(hipMemset(g->devNormal[i], 0, n * 12), "memset");
-        if (!e) e = rs_check_hip(hipMemset(g->devPrimId[i], 0, n * 4), "memset");
-        if (!e) e = rs_check_hip(hipMemset(g->devDepth[i], 0, n * 4), "memset");
+    for (int i = 0; i < rs_gbuffer::kSets && !e; i++) {
+        if (!e) e = rs_dev_alloc(&g->albedo[i], n * 3);
+        if (!e) e = rs_dev_alloc(&g->motion[i], n);
+        if (!e) e = rs_dev_alloc(&g->normal[i], n * 3);
+        if (!e) e = rs_dev_alloc(&g->primId[i], n);
+        if (!e) e = rs_dev_alloc(&g->depth[i], n);
+        if (!e) e = rs_check_hip(hipMemset(g->albedo[i], 0, n * 12), "memset");
+        if (!e) e = rs_check_hip(hipMemset(g->motion[i], 0, n * 4), "memset");
+        if (!e) e = rs_check_hip(hipMemset(g->normal[i], 0, n * 12), "memset");
+        if (!e) e = rs_check_hip(hipMemset(g->primId[i], 0, n * 4), "memset");
+        if (!e) e = rs_check_hip(hipMemset(g->depth[i], 0, n * 4), "memset");
+        if (!e) e = rs_check_hip(hipEventCreateWithFlags(&g->useEv[i], hipEventDisableTiming), "hipEventCreate");
     }
+    if (!e) e = rs_check_hip(hipEventCreateWithFlags(&g->forkEv, hipEventDisableTiming), "hipEventCreate");
+    if (!e) e = rs_check_hip(hipEventCreateWithFlags(&g->doneEv, hipEventDisableTiming), "hipEventCreate");
     if (e) { rs_gbuffer_destroy(g); return e; }
     *out = g;
     return 0;
@@ -97,20 +109,36 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
     if (y0 < 0) y0 = 0;
     if (y1 > g->height) y1 = g->height;
     if (y1 <= y0) return 0;
-    GBufWrite w{ g->devAlbedo, g->devMotion, g->devNormal[g->frameIdx], g->devPrimId[g->frameIdx], g->devDepth[g->frameIdx] };
+    const int c = g->cur();
+    GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
-    // Nothing in the primary-ray and RIS kernels of the frame reads the G-buffer, and both this kernel and k_primary end in a
-    // long tail of a few heavy tiles: when launches are asynchronous the render goes to the side stream and is joined by its
-    // first consumer (the temporal pass), so the two tails overlap.
-    const hipStream_t side = rs_side_fork();
-    const hipStream_t st = side ? side : rs_stream();
+    // Nothing in the primary-ray and RIS kernels of a frame reads the G-buffer, and the set written here is not the one the
+    // previous frame's passes read: in asynchronous mode the render goes to an auxiliary stream, ordered after the last
+    // readers of its set (or, for a second render without an update in between, after everything enqueued so far), and is
+    // joined by its first consumer.  Its long tail of a few heavy tiles then overlaps other kernels' tails.
+    const hipStream_t aux = rs_aux_stream(0);
+    if (aux) {
+        if (g->renderedSinceUpdate) {
+            RS_HIP(hipEventRecord(g->forkEv, rs_stream()));
+            RS_HIP(hipStreamWaitEvent(aux, g->forkEv, 0));
+        }
+        else if (g->useOf[c] >= 0) RS_HIP(hipStreamWaitEvent(aux, g->useEv[g->useOf[c]], 0));
+    }
+    else RS_TRY(rs_gbuffer_join(g));                    // an earlier render of this frame may still be on the auxiliary stream
+    const hipStream_t st = aux ? aux : rs_stream();
     if (scene->textured)
         hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, st,
                            scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
     else
         hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, st,
                            scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
-    if (side) { RS_TRY(rs_check_hip(hipGetLastError(), "renderGBuffer")); return rs_side_submitted(); }
+    g->renderedSinceUpdate = true;
+    if (aux) {
+        RS_TRY(rs_check_hip(hipGetLastError(), "renderGBuffer"));
+        RS_HIP(hipEventRecord(g->doneEv, aux));
+        g->pending = true;
+        return 0;
+    }
     return rs_after_launch("renderGBuffer");
 }
 
@@ -121,7 +149,19 @@ int rs_gbuffer_render(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam
 int rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam) {
     if (!g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_update: null argument");
     g->lastCamera = *cam;
+    // the frame that read sets cur (as current) and prev (as last) has been enqueued on the library stream up to here
+    const int c = g->cur(), l = g->prev();
+    if (!rs_sync_enabled()) {
+        RS_TRY(rs_gbuffer_join(g));                     // a render nobody consumed is ordered before the event too
+        const int k = g->updates % rs_gbuffer::kSets;
+        RS_HIP(hipEventRecord(g->useEv[k], rs_stream()));
+        g->useOf[c] = g->useOf[l] = k;
+    }
+    else g->useOf[c] = g->useOf[l] = -1;                // synchronous mode: those readers have finished
+    g->updates++;
+    g->ring = (g->ring + 1) % rs_gbuffer::kSets;
     g->frameIdx ^= 1;
+    g->renderedSinceUpdate = false;
     return 0;
 }
 
@@ -131,33 +171,36 @@ size_t rs_gbuffer_rows_bytes(const rs_gbuffer* g, int rows) { return g ? (size_t
 
 int rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* devBuffer) {
     if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_pack: bad argument");
-    RS_TRY(rs_side_join());
-    const int f = g->frameIdx ^ sel;
+    RS_TRY(rs_gbuffer_join(g));
+    const int f = sel ? g->prev() : g->cur();
     const size_t n = (size_t)g->width * rows, off = (size_t)y0 * g->width;
     char* b = (char*)devBuffer;
-    RS_HIP(hipMemcpyAsync(b, g->devPrimId[f] + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 4, g->devNormal[f] + off * 3, n * 12, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(b + n * 16, g->devDepth[f] + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b, g->primId[f] + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 4, g->normal[f] + off * 3, n * 12, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(b + n * 16, g->depth[f] + off, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
     return rs_after_launch("rs_gbuffer_rows_pack");
 }
 
 int rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void* devBuffer) {
     if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_unpack: bad argument");
-    RS_TRY(rs_side_join());
-    const int f = g->frameIdx ^ sel;
+    RS_TRY(rs_gbuffer_join(g));
+    const int f = sel ? g->prev() : g->cur();
     const size_t n = (size_t)g->width * rows, off = (size_t)y0 * g->width;
     const char* b = (const char*)devBuffer;
-    RS_HIP(hipMemcpyAsync(g->devPrimId[f] + off, b, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(g->devNormal[f] + off * 3, b + n * 4, n * 12, hipMemcpyDeviceToDevice, rs_stream()));
-    RS_HIP(hipMemcpyAsync(g->devDepth[f] + off, b + n * 16, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(g->primId[f] + off, b, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(g->normal[f] + off * 3, b + n * 4, n * 12, hipMemcpyDeviceToDevice, rs_stream()));
+    RS_HIP(hipMemcpyAsync(g->depth[f] + off, b + n * 16, n * 4, hipMemcpyDeviceToDevice, rs_stream()));
     return rs_after_launch("rs_gbuffer_rows_unpack");
 }
 
 int rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* v) {
     if (!g || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_get_view: null argument");
-    RS_TRY(rs_side_join());                             // the caller is about to use the planes on the library stream
-    v->devAlbedo = g->devAlbedo; v->devMotion = g->devMotion;
-    for (int i = 0; i < 2; i++) { v->devNormal[i] = g->devNormal[i]; v->devPrimId[i] = g->devPrimId[i]; v->devDepth[i] = g->devDepth[i]; }
+    RS_TRY(rs_gbuffer_join(g));                         // the caller is about to use the planes on the library stream
+    const int c = g->cur(), l = g->prev(), f = g->frameIdx;
+    v->devAlbedo = g->albedo[g->latest()]; v->devMotion = g->motion[g->latest()];
+    v->devNormal[f] = g->normal[c]; v->devNormal[f ^ 1] = g->normal[l];
+    v->devPrimId[f] = g->primId[c]; v->devPrimId[f ^ 1] = g->primId[l];
+    v->devDepth[f] = g->depth[c]; v->devDepth[f ^ 1] = g->depth[l];
     v->frameIdx = g->frameIdx; v->width = g->width; v->height = g->height;
     return 0;
 }

@@ -316,7 +316,7 @@ int rs_path_trace_indirect(const rs_scene* scene, const rs_camera* cam, float* d
 
 int rs_restir_indirect(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, float* devIndirectIllum,
                        int iter, int looper, int reuse, int maxDepth, unsigned long long* rays) {
-    RS_TRY(rs_side_join());                             // a G-buffer render may still be on the side stream
+    RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!r || !scene || !cam || !g || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRIndirect: null argument");
     if (cam->resolution[0] != r->width || cam->resolution[1] != r->height || g->width != r->width || g->height != r->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRIndirect: size mismatch");

@@ -513,10 +513,11 @@ void free_planes(ResvPlanes& p) { rs_dev_free(p.li); rs_dev_free(p.wi); rs_dev_f
 
 ResvPlanes* pick(rs_restir* r, int which) { return which == 0 ? &r->cur : (which == 1 ? &r->last : nullptr); }
 
-SurfPlanes surf_of(rs_restir* r) {
+SurfPlanes surf_of(rs_restir* r) {                       // the set of the frame in flight
+    const rs_restir::Surf& f = r->surf[r->surfSet];
     SurfPlanes sp;
-    sp.posMat = r->surfPosKind; sp.norm = r->surfNorm; sp.wo = r->surfWo; sp.rngMat = r->rngMat;
-    sp.candLi = r->candLi; sp.candWi = r->candWi;
+    sp.posMat = f.posKind; sp.norm = f.norm; sp.wo = f.wo; sp.rngMat = f.rngMat;
+    sp.candLi = f.candLi; sp.candWi = f.candWi;
     return sp;
 }
 
@@ -535,12 +536,18 @@ extern "C" {
 
 int rs_restir_free(rs_restir* r) {
     if (!r) return 0;
+    (void)rs_synchronize();                                     // also kernels still running on the auxiliary stream
     free_planes(r->cur); free_planes(r->last);
     rs_dev_free(r->temp.li); rs_dev_free(r->temp.wi); rs_dev_free(r->temp.tap);
-    rs_dev_free(r->surfPosKind); rs_dev_free(r->surfNorm); rs_dev_free(r->surfWo); rs_dev_free(r->rngMat);
-    rs_dev_free(r->candLi); rs_dev_free(r->candWi); rs_dev_free(r->dRayCount);
+    for (auto& f : r->surf) {
+        rs_dev_free(f.posKind); rs_dev_free(f.norm); rs_dev_free(f.wo); rs_dev_free(f.rngMat); rs_dev_free(f.candLi); rs_dev_free(f.candWi);
+    }
+    rs_dev_free(r->dRayCount);
     rs_dev_free(r->indResv[0]); rs_dev_free(r->indResv[1]);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
+    if (r->auxFork) (void)hipEventDestroy(r->auxFork);
+    if (r->auxDone) (void)hipEventDestroy(r->auxDone);
     delete r;
     return 0;
 }
@@ -560,14 +567,19 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     if (!e) e = rs_check_hip(hipMemset(r->temp.li, 0, n * 16), "memset");
     if (!e) e = rs_check_hip(hipMemset(r->temp.wi, 0, n * 16), "memset");
     if (!e) e = rs_check_hip(hipMemset(r->temp.tap, 0, n * 16), "memset");
-    if (!e) e = rs_dev_alloc(&r->surfPosKind, n);
-    if (!e) e = rs_dev_alloc(&r->surfNorm, n);
-    if (!e) e = rs_dev_alloc(&r->surfWo, n);
-    if (!e) e = rs_dev_alloc(&r->rngMat, n);
-    if (!e) e = rs_dev_alloc(&r->candLi, n);
-    if (!e) e = rs_dev_alloc(&r->candWi, n);
+    for (auto& f : r->surf) {
+        if (!e) e = rs_dev_alloc(&f.posKind, n);
+        if (!e) e = rs_dev_alloc(&f.norm, n);
+        if (!e) e = rs_dev_alloc(&f.wo, n);
+        if (!e) e = rs_dev_alloc(&f.rngMat, n);
+        if (!e) e = rs_dev_alloc(&f.candLi, n);
+        if (!e) e = rs_dev_alloc(&f.candWi, n);
+        if (!e) e = rs_check_hip(hipMemset(f.rngMat, 0, n * 8), "memset");
+    }
+    for (auto& ev : r->surfFree) if (!e) e = rs_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxFork, hipEventDisableTiming), "hipEventCreate");
+    if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxDone, hipEventDisableTiming), "hipEventCreate");
     if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots * kRaySub * kRayStride);
-    if (!e) e = rs_check_hip(hipMemset(r->rngMat, 0, n * 8), "memset");
     if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * (size_t)kRaySlots * kRaySub * kRayStride), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (e) { rs_restir_free(r); return e; }
@@ -594,27 +606,49 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     if (y1 > r->height) y1 = r->height;
     r->raySlot = (r->raySlot + 1) % kRaySlots;                  // one counter slot per frame (ring)
     unsigned long long* rayCounter = r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride;
-    RS_HIP(hipMemsetAsync(rayCounter, 0, 8 * kRaySub * kRayStride, rs_stream()));
-    if (y1 <= y0) return 0;
+    // The primary-ray and RIS kernels read nothing the previous frame's temporal / spatial passes write and fill this
+    // frame's own set of surface planes: in asynchronous mode they go to an auxiliary stream, ordered after the frame
+    // that last used the set (or, for a second call within one frame, after everything enqueued so far), and the library
+    // stream joins them before the temporal pass.  Their heavy-tile tails then overlap the other frame's passes.
+    const hipStream_t aux = r->timing ? nullptr : rs_aux_stream(1);
+    const hipStream_t st = aux ? aux : rs_stream();
+    if (aux) {
+        if (r->phaseACalls > 0) {
+            RS_HIP(hipEventRecord(r->auxFork, rs_stream()));
+            RS_HIP(hipStreamWaitEvent(aux, r->auxFork, 0));
+        }
+        else if (r->surfFreeValid[r->surfSet]) RS_HIP(hipStreamWaitEvent(aux, r->surfFree[r->surfSet], 0));
+    }
+    r->phaseACalls++;
+    RS_HIP(hipMemsetAsync(rayCounter, 0, 8 * kRaySub * kRayStride, st));
+    if (y1 <= y0) {
+        if (aux) { RS_HIP(hipEventRecord(r->auxDone, aux)); RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0)); }
+        return 0;
+    }
     const int W = r->width;
     const int tilesX = (W + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
     const SurfPlanes sp = surf_of(r);
     const CamParams cp = rs_make_cam_params(cam);
     mark(r, 0);
     if (scene->textured)
-        hipLaunchKernelGGL(k_primary<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+        hipLaunchKernelGGL(k_primary<true>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     else
-        hipLaunchKernelGGL(k_primary<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+        hipLaunchKernelGGL(k_primary<false>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     mark(r, 1);
     const int npx = (y1 - y0) * W;
     if (scene->envMapTexId >= 0)       // the environment map is one more light (scene.h:400-403)
-        hipLaunchKernelGGL(k_ris<true>, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+        hipLaunchKernelGGL(k_ris<true>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
     else if (scene->numLights > 0 && scene->numLights <= kRisLdsLights)
-        hipLaunchKernelGGL(k_ris_lds, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+        hipLaunchKernelGGL(k_ris_lds, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), 0, st, scene->dev, sp, W, y0, y1);
     else
-        hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1);
+        hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
     mark(r, 2);
-    RS_TRY(rs_side_join());                                     // first consumer of the G-buffer planes
+    if (aux) {
+        RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS)"));
+        RS_HIP(hipEventRecord(r->auxDone, aux));
+        RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
+    }
+    RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
                        r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
     mark(r, 3);
@@ -630,7 +664,7 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     if (y1 <= y0) return 0;
     const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
-    RS_TRY(rs_side_join());
+    RS_TRY(rs_gbuffer_join(g));
     hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(kBThreads), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
                        r->cur, r->temp, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);
@@ -641,6 +675,11 @@ int rs_restir_end_frame(rs_restir* r) {
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_end_frame: null");
     ResvPlanes t = r->cur; r->cur = r->last; r->last = t;       // std::swap(devDirectReservoir, devLastDirectReservoir)
     r->firstFrame = false;
+    // every reader of this frame's surface planes has been enqueued: the set is free for the frame after the next one
+    if (!rs_sync_enabled()) { RS_HIP(hipEventRecord(r->surfFree[r->surfSet], rs_stream())); r->surfFreeValid[r->surfSet] = true; }
+    else r->surfFreeValid[r->surfSet] = false;
+    r->surfSet ^= 1;
+    r->phaseACalls = 0;
     return 0;
 }
 

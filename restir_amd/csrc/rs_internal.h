@@ -15,10 +15,9 @@ hipStream_t rs_stream();
 bool rs_sync_enabled();
 // after a launch: hipGetLastError (+ stream sync when sync mode is on), like checkCUDAError
 int rs_after_launch(const char* what);
-// side stream for work the next kernels do not depend on (api_common.hip): fork -> launch there -> submitted; consumers join
-hipStream_t rs_side_fork();
-int rs_side_submitted();
-int rs_side_join();
+// auxiliary streams of the asynchronous mode (api_common.hip): 0 = GBuffer::render, 1 = primary rays + RIS; nullptr = not in use
+hipStream_t rs_aux_stream(int i);
+int rs_aux_synchronize();
 
 #define RS_TRY(expr)                                       \
     do {                                                   \
@@ -74,16 +73,36 @@ struct rs_scene {
 };
 
 // ---- G-buffer (src/gbuffer.h:41-58) ------------------------------------------------------------
+// The reference keeps two sets of the id / normal / depth planes and toggles frameIdx.  Here all planes live in a ring of
+// three sets: the set of the frame being rendered, of the previous frame ("last" planes) and a free one, so that the next
+// frame's render (auxiliary stream) never writes what this frame's temporal pass still reads.  frameIdx is still toggled
+// and reported by rs_gbuffer_get_view, whose devNormal[frameIdx] / [frameIdx ^ 1] are the current / last sets.
 struct rs_gbuffer {
-    float* devAlbedo = nullptr;
-    int* devMotion = nullptr;
-    float* devNormal[2] = { nullptr, nullptr };
-    int* devPrimId[2] = { nullptr, nullptr };
-    float* devDepth[2] = { nullptr, nullptr };
+    static constexpr int kSets = 3;
+    float* albedo[kSets] = { nullptr, nullptr, nullptr };
+    int* motion[kSets] = { nullptr, nullptr, nullptr };
+    float* normal[kSets] = { nullptr, nullptr, nullptr };
+    int* primId[kSets] = { nullptr, nullptr, nullptr };
+    float* depth[kSets] = { nullptr, nullptr, nullptr };
+    int ring = 0;                // set of the current frame; the previous frame's is (ring + 2) % 3
     int frameIdx = 0;
     rs_camera lastCamera{};      // uninitialised in the reference until the first update (Q14); zero here
     int width = 0, height = 0;
+    // ordering of a render on the auxiliary stream (asynchronous mode)
+    hipEvent_t forkEv = nullptr;             // "everything enqueued on the library stream so far"
+    hipEvent_t doneEv = nullptr;             // the render
+    hipEvent_t useEv[kSets] = { nullptr, nullptr, nullptr };   // recorded by update(): the frame that ended there has been enqueued
+    int useOf[kSets] = { -1, -1, -1 };       // per set: which useEv covers its last readers (-1: none outstanding)
+    int updates = 0;
+    bool renderedSinceUpdate = false;
+    mutable bool pending = false;            // a render on the auxiliary stream has not been joined yet
+    int cur() const { return ring; }
+    int prev() const { return (ring + kSets - 1) % kSets; }
+    // albedo / motion are single planes in the reference: they show the most recent render, also after update()
+    int latest() const { return (renderedSinceUpdate || updates == 0) ? cur() : prev(); }
 };
+// the library stream waits for a render that is still on the auxiliary stream; every reader of the planes calls it first
+int rs_gbuffer_join(const rs_gbuffer* g);
 
 // device view of the planes the kernels read
 struct GBufView {
@@ -96,10 +115,11 @@ struct GBufView {
 };
 static inline GBufView gbuf_view(const rs_gbuffer* g) {
     GBufView v;
-    v.albedo = g->devAlbedo; v.motion = g->devMotion;
-    v.normal = g->devNormal[g->frameIdx]; v.lastNormal = g->devNormal[g->frameIdx ^ 1];
-    v.primId = g->devPrimId[g->frameIdx]; v.lastPrimId = g->devPrimId[g->frameIdx ^ 1];
-    v.depth = g->devDepth[g->frameIdx]; v.lastDepth = g->devDepth[g->frameIdx ^ 1];
+    const int c = g->cur(), l = g->prev();
+    v.albedo = g->albedo[g->latest()]; v.motion = g->motion[g->latest()];
+    v.normal = g->normal[c]; v.lastNormal = g->normal[l];
+    v.primId = g->primId[c]; v.lastPrimId = g->primId[l];
+    v.depth = g->depth[c]; v.lastDepth = g->depth[l];
     v.width = g->width; v.height = g->height;
     return v;
 }
@@ -139,13 +159,21 @@ struct rs_restir {
     rs_indirect_reservoir* indResv[2] = { nullptr, nullptr };   // devIndTemporalReservoir / devIndLastTemporalReservoir (gi.hip), allocated on first use
     bool firstFrame = true;
     // per-pixel state carried between the passes of one frame (implementation bytes, not in the
-    // reference: its single fused kernel keeps these in registers)
-    float4* surfPosKind = nullptr;   // hit position xyz, w = bit pattern of (matId | kind<<24)
-    float4* surfNorm = nullptr;      // shading normal xyz (flipped to wo side)
-    float4* surfWo = nullptr;        // wo xyz (read only for non-Lambertian materials)
-    uint2*  rngMat = nullptr;        // { RNG state, matId | kind<<24 }
-    float4* candLi = nullptr;        // RIS winner: Li xyz, w = dist
-    float4* candWi = nullptr;        // RIS winner: wi xyz, w = weight (sum of candidate weights)
+    // reference: its single fused kernel keeps these in registers).  Two sets, alternating per frame: the primary-ray
+    // and RIS kernels of frame f + 1 (auxiliary stream) fill one while the temporal / spatial passes of frame f read the other.
+    struct Surf {
+        float4* posKind = nullptr;   // hit position xyz, w = bit pattern of (matId | kind<<24)
+        float4* norm = nullptr;      // shading normal xyz (flipped to wo side)
+        float4* wo = nullptr;        // wo xyz (read only for non-Lambertian materials)
+        uint2*  rngMat = nullptr;    // { RNG state, matId | kind<<24 }
+        float4* candLi = nullptr;    // RIS winner: Li xyz, w = dist
+        float4* candWi = nullptr;    // RIS winner: wi xyz, w = weight (sum of candidate weights)
+    } surf[2];
+    int surfSet = 0;
+    hipEvent_t surfFree[2] = { nullptr, nullptr };   // recorded by end_frame: the frame that used the set has been enqueued
+    bool surfFreeValid[2] = { false, false };
+    hipEvent_t auxFork = nullptr, auxDone = nullptr;
+    int phaseACalls = 0;             // since the last end_frame
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
     int raySlot = 0;
     // timing

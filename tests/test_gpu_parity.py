@@ -525,12 +525,12 @@ def test_eaw_filter(hip):
     W, H = 160, 96
     o = OracleRenderer(sd, W, H)
     h = HipRenderer(hip, sd, W, H)
-    a = o.frame(3); h.frame(3)
-    # the G-buffer frame index was flipped by update(); filter against the planes just rendered
-    o.gbuf.c.frameIdx ^= 1
+    # runCuda order: G-buffer, shading, (denoise here), gBuffer.update
+    o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+    o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, 0, 3)
+    h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, 0, 3)
+    a = o.image
     ref = ob.eaw_filter(o.gbuf, o.cam, a)
-    o.gbuf.c.frameIdx ^= 1
-    hip.check(hip.lib().rs_gbuffer_update(h.gbuf.handle, C.byref(h.cam)))      # flip back
     f = hip.EAWFilter(W, H, 5)
     out = torch.zeros_like(h.image)
     p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
@@ -637,6 +637,63 @@ def test_strip_tiling_equals_full_frame(hip):
         hip.synchronize()
         got = np.concatenate([ranks[0].image.cpu().numpy()[:bounds[0][1] * W], ranks[1].image.cpu().numpy()[bounds[1][0] * W:]])
         assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
+
+
+def test_overlapped_frames_equal_synchronous_frames(hip):
+    """Asynchronous mode (rs_set_sync(0)) lets frames overlap: GBuffer::render and the primary-ray + RIS kernels of frame f + 1
+    run on auxiliary streams next to the temporal / spatial passes of frame f (G-buffer planes in a ring of three, surface
+    planes double-buffered, events for every true dependency).  Twelve frames of an orbiting camera enqueued without any host
+    synchronisation, with the EAW filter and the tone map reading each frame's planes, must equal the synchronous run bit
+    for bit -- images, filtered images, final reservoirs and the G-buffer."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.2")
+    W, H, frames = 640, 360, 12
+    scene = hip_scene(hip, sd)
+
+    def run(overlapped):
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        f = hip.EAWFilter(W, H, 5)
+        out = torch.zeros_like(h.image)
+        images, filtered, pbos = [], [], []
+        hip.set_sync(not overlapped)
+        try:
+            for frame in range(frames):
+                h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.5))
+                h.gbuf.render(h.scene, h.cam)
+                if frame % 5 == 3:                                       # a second render without an update in between
+                    h.gbuf.render(h.scene, h.cam, 0, H // 2)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                h.looper += 1
+                images.append(h.image.clone())                           # enqueued on the library (= torch's current) stream
+                p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+                t = torch.empty_like(h.image)
+                hip.hip_memcpy_d2d_async(t.data_ptr(), p, t.numel() * 4)
+                filtered.append(t)
+                pbo = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")
+                hip.copy_image_to_pbo(pbo.data_ptr(), h.image.data_ptr(), W, H, 2, 1.0)
+                pbos.append(pbo)
+                h.gbuf.update(h.cam)
+            hip.synchronize()
+            torch.cuda.synchronize()
+        finally:
+            hip.set_sync(True)
+        res = dict(images=[t.cpu().numpy() for t in images], filtered=[t.cpu().numpy() for t in filtered],
+                   pbos=[t.cpu().numpy() for t in pbos], resv=h.restir.download(1), gbuf=h.gbuf.download())
+        f.destroy()
+        return res
+
+    a, b = run(False), run(True)
+    for k in ("images", "filtered", "pbos"):
+        for frame in range(frames):
+            assert bits_equal(a[k][frame], b[k][frame]), (k, frame)
+    assert a["resv"].tobytes() == b["resv"].tobytes()
+    for k in ("albedo", "motion"):
+        assert bits_equal(a["gbuf"][k], b["gbuf"][k]), k
+    for k in ("normal", "prim_id", "depth"):
+        for i in range(2):
+            assert bits_equal(a["gbuf"][k][i], b["gbuf"][k][i]), (k, i)
+    assert not bits_equal(a["images"][0], a["images"][-1])
 
 
 def test_phase_b_in_row_bands_equals_one_call(hip):
