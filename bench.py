@@ -112,14 +112,22 @@ def main():
 
     from restir_amd import capi, scenes
     from restir_amd.scenes import orbit_position
-    from restir_amd.tiling import HipBackend, StripRenderer
+    from restir_amd.tiling import HipBackend, StripRenderer, calibrate_bounds
     capi.init(device)
 
     sd = scenes.sponza_class(seed=1, scale=1.0)
     scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
     cam = capi.camera_update(sd.camera(WIDTH, HEIGHT))
     backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
-    strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit)
+    capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
+    # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
+    # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights
+    bounds = None
+    if world > 1 and os.environ.get("BENCH_EVEN_STRIPS", "0") != "1":
+        bounds = calibrate_bounds(backend, world, rank, HEIGHT, dist, torch.cuda.synchronize, reuse=REUSE)
+        torch.cuda.synchronize()
+        backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)          # fresh reservoirs and G-buffer for the measured run
+    strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit, bounds=bounds)
     y0, y1 = strips.y0, strips.y1
     rows = y1 - y0
     # RGBA8 strip of this rank; with N > 1 two sets of buffers, so that the gather of frame f (asynchronous, on RCCL's
@@ -130,7 +138,6 @@ def main():
     frame_no = [0]
 
     base_pos = sd.camera_args["position"]
-    capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
 
     def frame():
         if args.orbit:
@@ -217,7 +224,8 @@ def main():
             "config": {"workload": "BASELINE config 3: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 1920x1080, "
                                    "32 RIS candidates, spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update",
                        "camera": "orbit" if args.orbit else "static",
-                       "tiling": f"{world} row strips, 5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0" if world > 1 else "none",
+                       "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in strips.bounds) + " rows (cost-balanced by measurement), "
+                                  "5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0") if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade") if world == 1 else None,

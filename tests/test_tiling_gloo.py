@@ -25,7 +25,7 @@ def _free_port():
 BALANCED = {3: [(0, 8), (8, 45), (45, 64)]}     # uneven (cost-balanced style) strips: still exact
 
 
-def _worker(rank, world, port, moving, outdir, balanced=False):
+def _worker(rank, world, port, moving, outdir, balanced=False, calibrated=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +36,13 @@ def _worker(rank, world, port, moving, outdir, balanced=False):
     sd = get_scene("sponza:0.02")
     cam = ob.camera_update(sd.camera(W, H))
     backend = OracleBackend(oracle_scene(sd), cam, W, H)
-    r = StripRenderer(backend, world, rank, H, dist=dist, share_history=moving, bounds=BALANCED[world] if balanced else None)
+    bounds = BALANCED[world] if balanced else None
+    if calibrated:                                  # what bench.py does for N > 1: measure, all-gather, rebalance; then fresh buffers
+        from restir_amd.tiling import calibrate_bounds
+        bounds = calibrate_bounds(backend, world, rank, H, dist, lambda: None, rounds=2, frames=1)
+        backend = OracleBackend(backend.scene, cam, W, H)
+        np.save(os.path.join(outdir, f"bounds_{rank}.npy"), np.array(bounds))
+    r = StripRenderer(backend, world, rank, H, dist=dist, share_history=moving, bounds=bounds)
     for frame in range(FRAMES):
         if moving:
             p = orbit_position(sd.camera_args["position"], frame, radius=0.6)
@@ -75,6 +81,17 @@ def test_strips_equal_full_frame(tmp_path, world, moving):
 def test_uneven_strips_equal_full_frame(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(3, port, True, str(tmp_path), True), nprocs=3, join=True)
+    got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(3)])
+    assert np.array_equal(got.view(np.uint32), _reference(True).view(np.uint32))
+
+
+def test_calibrated_strips_equal_full_frame(tmp_path):
+    """Strip heights chosen by measurement (timing, all-gather, rebalance -- identical on every rank); the frames
+    rendered afterwards with fresh buffers equal the full-frame render."""
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, True, str(tmp_path), False, True), nprocs=3, join=True)
+    b = [np.load(tmp_path / f"bounds_{r}.npy") for r in range(3)]
+    assert all(np.array_equal(b[0], x) for x in b) and b[0][0][0] == 0 and b[0][-1][1] == H
     got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(3)])
     assert np.array_equal(got.view(np.uint32), _reference(True).view(np.uint32))
 
