@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/summarize_profile.py PROF_DIR OUT_PREFIX -- condense the output of tools/profile.sh:
-  OUT_PREFIX_kernel_stats.csv    per-kernel calls / total / average / min / max (ns) from the kernel trace
+  OUT_PREFIX_kernel_stats.csv    per-kernel calls / total / average / min / max (ns) from the kernel trace (one stream)
+  OUT_PREFIX_kernel_stats_overlapped.csv   the same with frames overlapped on the auxiliary streams
   OUT_PREFIX_hbm_counters.json   per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch, as reported) and HBM bytes per
                                  launch with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE x 2)
 """
@@ -13,9 +14,9 @@ def short(name):
     return m.group(1) if m else name.split("(")[0][-48:]
 
 
-def kernel_stats(root):
+def kernel_stats(root, sub="trace"):
     rows = defaultdict(list)
-    for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -39,6 +40,13 @@ def main():
         fh.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
         for k, v in sorted(ks.items(), key=lambda kv: -sum(kv[1])):
             fh.write("%s,%d,%d,%.1f,%d,%d\n" % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
+    ko = kernel_stats(root, "trace_overlap")
+    if ko:
+        with open(out + "_kernel_stats_overlapped.csv", "w") as fh:
+            fh.write("# the same command with frames overlapped on the auxiliary streams (the timed region's mode): kernels share the CUs\n")
+            fh.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
+            for k, v in sorted(ko.items(), key=lambda kv: -sum(kv[1])):
+                fh.write("%s,%d,%d,%.1f,%d,%d\n" % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
     fetch, write = counter(root, "fetch", "FETCH_SIZE"), counter(root, "write", "WRITE_SIZE")
     res = {"units": "FETCH_SIZE / WRITE_SIZE in KB per launch as reported by rocprofv3 (separate --pmc passes); "
                     "hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 reports half of wide coalesced reads) + WRITE_SIZE*1024",
