@@ -7,7 +7,8 @@ Follows, function by function:
     Scene::loadCamera               src/scene.cpp:285-354
     Resource::loadOBJMesh           src/scene.cpp:27-61 over tinyobjloader 2.0 (external/include/tiny_obj_loader.h:
                                     tryParseDouble 866-996, quad split 1429-1524)
-    Image::Image(filename)          src/image.cpp:14-31 (stbi_loadf of an 8-bit image with ldr_to_hdr gamma 1 = value / 255)
+    Image::Image(filename)          src/image.cpp:14-31 (stbi_loadf: an 8-bit image with ldr_to_hdr gamma 1 = value / 255; Radiance
+                                    HDR = mantissa * 2^(e - 136))
     instance baking of buildDevData src/scene.cpp:161-176 (through liboracle's orc_bake_instance)
     safeGetline / tokenizeString    src/utilities.cpp:57-95
 
@@ -217,6 +218,60 @@ def load_ppm(path, flip):
     return (px.astype(np.float32) / np.float32(255)).astype(np.float32)
 
 
+def load_hdr(path, flip):
+    """Radiance .hdr (32-bit_rle_rgbe, -Y h +X w) -> (h, w, 3) float32 = mantissa * 2^(e - 136), 0 where e == 0 (stb_image's
+    stbi__hdr_load + stbi__hdr_convert, external/include/stb_image.h:6736-6862); rows reversed when `flip`."""
+    raw = open(path, "rb").read()
+    at = 0
+
+    def line():
+        nonlocal at
+        end = raw.find(b"\n", at)
+        end = len(raw) if end < 0 else end
+        l = raw[at:end]
+        at = min(end + 1, len(raw))
+        return l
+    assert line() in (b"#?RADIANCE", b"#?RGBE"), "not HDR"
+    ok = False
+    while True:
+        l = line()
+        if l == b"":
+            break
+        ok |= l == b"FORMAT=32-bit_rle_rgbe"
+    assert ok, "unsupported HDR format"
+    f = line().split()
+    assert f[0] == b"-Y" and f[2] == b"+X"
+    h, w = int(f[1]), int(f[3])
+    px = np.zeros((h, w, 4), np.uint8)
+    if w < 8 or w >= 32768 or not (raw[at] == 2 and raw[at + 1] == 2 and not raw[at + 2] & 0x80):
+        px[:] = np.frombuffer(raw, np.uint8, w * h * 4, at).reshape(h, w, 4)
+    else:
+        for y in range(h):
+            assert raw[at] == 2 and raw[at + 1] == 2 and ((raw[at + 2] << 8) | raw[at + 3]) == w
+            at += 4
+            for k in range(4):
+                x = 0
+                while x < w:
+                    count = raw[at]; at += 1
+                    if count > 128:
+                        px[y, x:x + count - 128, k] = raw[at]; at += 1
+                        x += count - 128
+                    else:
+                        px[y, x:x + count, k] = np.frombuffer(raw, np.uint8, count, at); at += count
+                        x += count
+    if flip:
+        px = px[::-1]
+    e = px[..., 3].astype(np.int32)
+    scale = np.where(e != 0, np.ldexp(np.float32(1), e - 136), np.float32(0)).astype(np.float32)
+    return (px[..., :3].astype(np.float32) * scale[..., None]).astype(np.float32)
+
+
+def load_image(path, flip):
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return load_hdr(path, flip) if magic == b"#?" else load_ppm(path, flip)
+
+
 _TYPES = {"Lambertian": 0, "MetallicWorkflow": 1, "Dielectric": 2, "Light": 4}
 
 
@@ -258,7 +313,7 @@ def load_scene(path):
     def add_texture(name, flip):
         if name not in texture_ids:
             texture_ids[name] = len(s.textures)
-            s.textures.append(load_ppm(resolve(name), flip))
+            s.textures.append(load_image(resolve(name), flip))
         return texture_ids[name]
 
     while fp.good():

@@ -6,9 +6,10 @@
 //   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
 //   instance baking of buildDevData   src/scene.cpp:161-176
 //   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
-// What it does not do: decode PNG / JPG / HDR (stb_image in the reference).  Texture and environment-map files must be
-// binary PPM (P6, 8 bit): stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1) (src/scene.cpp:97), rows
-// flipped for textures (stbi_set_flip_vertically_on_load(true), :98) and not for the environment map (:124-126).
+// What it does not do: decode PNG / JPG (stb_image in the reference).  Texture and environment-map files must be binary PPM
+// (P6, 8 bit: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR (.hdr,
+// RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
+// :98) and not for the environment map (:124-126).
 // glTF (Resource::loadGLTFMesh) is not read either.
 #include <cmath>
 #include <cstdio>
@@ -274,7 +275,7 @@ int load_obj(const std::string& path, Mesh& m) {
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
-    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (only binary PPM P6 / 8 bit is decoded here; decode other formats in the caller)").c_str()); };
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (only binary PPM P6 / 8 bit and Radiance HDR are decoded here; decode other formats in the caller)").c_str()); };
     auto token = [&](std::string& out) {
         out.clear();
         int c = std::fgetc(f);
@@ -302,6 +303,91 @@ int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, i
         for (int i = 0; i < w * 3; i++) data[((size_t)y * w) * 3 + i] = (float)raw[((size_t)sy * w) * 3 + i] / 255.f;
     }
     return 0;
+}
+
+// Radiance picture (.hdr, "32-bit_rle_rgbe", -Y h +X w) -> linear float RGB: mantissa * 2^(e - 136), 0 when e == 0 -- the
+// values stbi_loadf returns for such a file (HDR data passes through without the ldr-to-hdr scale).  Scan lines are either all
+// flat RGBE quadruples or all run-length coded per channel (marker 2, 2, width as 16 bits; widths 8..32767).
+int load_hdr(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    std::string raw;
+    {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+        char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) raw.append(buf, got);
+        std::fclose(f);
+    }
+    auto fail = [&](const char* why) { return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path).c_str()); };
+    size_t at = 0;
+    auto header_line = [&]() {
+        std::string l;
+        while (at < raw.size() && raw[at] != '\n') l += raw[at++];
+        if (at < raw.size()) at++;
+        return l;
+    };
+    const std::string magic = header_line();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") return fail("not a Radiance HDR picture");
+    bool rgbe = false;
+    for (;;) {
+        if (at >= raw.size()) return fail("truncated HDR header");
+        const std::string l = header_line();
+        if (l.empty()) break;
+        if (l == "FORMAT=32-bit_rle_rgbe") rgbe = true;
+    }
+    if (!rgbe) return fail("unsupported HDR pixel format (need 32-bit_rle_rgbe)");
+    const std::string res = header_line();
+    if (std::sscanf(res.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) return fail("unsupported HDR orientation (need -Y h +X w)");
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(raw.data());
+    const size_t n = raw.size();
+    std::vector<unsigned char> px((size_t)w * h * 4);
+    const bool coded = w >= 8 && w < 32768 && at + 4 <= n && p[at] == 2 && p[at + 1] == 2 && !(p[at + 2] & 0x80);
+    if (!coded) {
+        if (n - at < px.size()) return fail("truncated HDR pixel data");
+        std::memcpy(px.data(), p + at, px.size());
+    }
+    else for (int y = 0; y < h; y++) {
+        if (at + 4 > n || p[at] != 2 || p[at + 1] != 2 || ((p[at + 2] << 8) | p[at + 3]) != w) return fail("corrupt HDR scan line");
+        at += 4;
+        for (int k = 0; k < 4; k++) {
+            int x = 0;
+            while (x < w) {
+                if (at >= n) return fail("truncated HDR pixel data");
+                int count = p[at++];
+                if (count > 128) {                                    // a run of one value
+                    count -= 128;
+                    if (count > w - x || at >= n) return fail("corrupt HDR run");
+                    const unsigned char v = p[at++];
+                    for (int z = 0; z < count; z++) px[((size_t)y * w + x++) * 4 + k] = v;
+                }
+                else {                                                // literal bytes
+                    if (count > w - x || at + count > n) return fail("corrupt HDR run");
+                    for (int z = 0; z < count; z++) px[((size_t)y * w + x++) * 4 + k] = p[at++];
+                }
+            }
+        }
+    }
+    data.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) {
+        const int sy = flipRows ? h - 1 - y : y;
+        for (int x = 0; x < w; x++) {
+            const unsigned char* q = &px[((size_t)sy * w + x) * 4];
+            const float scale = q[3] ? std::ldexp(1.f, (int)q[3] - 136) : 0.f;
+            for (int c = 0; c < 3; c++) data[((size_t)y * w + x) * 3 + c] = q[3] ? (float)q[c] * scale : 0.f;
+        }
+    }
+    return 0;
+}
+
+// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR
+int load_image(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+    unsigned char m[2] = { 0, 0 };
+    const size_t got = std::fread(m, 1, 2, f);
+    std::fclose(f);
+    if (got == 2 && m[0] == '#' && m[1] == '?') return load_hdr(path, flipRows, data, w, h);
+    return load_ppm(path, flipRows, data, w, h);
 }
 
 }  // namespace
@@ -334,7 +420,7 @@ int add_texture(rs_scene_file* s, const std::string& dir, const std::string& nam
     auto it = s->textureIds.find(name);
     if (it != s->textureIds.end()) { *id = it->second; return 0; }
     std::vector<float> data; int w = 0, h = 0;
-    RS_TRY(load_ppm(resolve(dir, name), flip, data, w, h));
+    RS_TRY(load_image(resolve(dir, name), flip, data, w, h));
     s->texData.push_back(std::move(data));
     *id = (int)s->texData.size() - 1;
     s->textureIds[name] = *id;

@@ -16,7 +16,8 @@ The text format is the one Scene::Scene(filename) parses (/root/reference/src/sc
                                                                      Eye / Rotation / Up <x y z>, then an empty line
 
 so a scene written here can be rendered by the reference itself on its own hardware and compared with this port.
-Images are written as binary PPM (P6), which both stb_image (the reference) and the library's reader decode to byte / 255.
+Images are written as binary PPM (P6, decoded to byte / 255) or Radiance HDR (.hdr, RGBE), which both stb_image (the reference)
+and the library's reader decode to the same floats.
 """
 import os
 
@@ -40,6 +41,50 @@ def write_ppm(path, rgb):
     with open(path, "wb") as f:
         f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
         f.write(rgb.tobytes())
+
+
+def float_to_rgbe(rgb):
+    """(h, w, 3) float -> (h, w, 4) uint8 Radiance RGBE (shared exponent of the largest component)."""
+    rgb = np.maximum(np.asarray(rgb, np.float64), 0.0)
+    m = rgb.max(axis=2)
+    e = np.zeros_like(m, dtype=np.int64)
+    nz = m > 1e-32
+    e[nz] = np.floor(np.log2(m[nz])).astype(np.int64) + 1             # m = f * 2^e, f in [0.5, 1)
+    scale = np.where(nz, 256.0 / np.exp2(e.astype(np.float64)), 0.0)
+    out = np.zeros(rgb.shape[:2] + (4,), np.uint8)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(nz, e + 128, 0).astype(np.uint8)
+    return out
+
+
+def write_hdr(path, rgb, rle=True):
+    """Radiance .hdr (32-bit_rle_rgbe, -Y h +X w) from a float (h, w, 3) image; run-length coded scan lines when `rle`
+    (needs 8 <= w < 32768), flat RGBE quadruples otherwise."""
+    px = float_to_rgbe(rgb)
+    h, w = px.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\n# written by restir_amd.scene_io\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        if not rle or w < 8 or w >= 32768:
+            f.write(px.tobytes())
+            return
+        for y in range(h):
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for k in range(4):
+                row = px[y, :, k]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, int(row[x])]))
+                        x += run
+                    else:
+                        lit = x
+                        while lit < w and lit - x < 128 and not (lit + 2 < w and row[lit] == row[lit + 1] == row[lit + 2]):
+                            lit += 1
+                        f.write(bytes([lit - x]) + row[x:lit].tobytes())
+                        x = lit
 
 
 def write_obj(path, vertices, normals, texcoords=None):

@@ -78,6 +78,15 @@ def write_case(directory, newline="\n", seed=11):
     env[3:5, 8:10] = 255                                            # a bright patch above the open front
     env = (env.astype(np.int32) + rng.integers(0, 4, env.shape)).clip(0, 255).astype(np.uint8)
     scene_io.write_ppm(os.path.join(directory, "env.ppm"), env)
+    # the environment map the scene uses: HDR, with a sun far above 1.0 (run-length coded scan lines); a second picture in the
+    # flat layout and a narrow one (flat by width) for the decoder
+    sky = (0.3 + 0.5 * np.linspace(1.0, 0.1, 16))[:, None, None] * np.array([0.6, 0.8, 1.0]) + np.zeros((16, 32, 3))
+    sky[3:5, 8:10] = (90.0, 80.0, 60.0)
+    sky[10:, :] *= 0.25
+    sky += 0.01 * rng.uniform(size=sky.shape) * (np.arange(32)[None, :, None] % 4 == 0)
+    scene_io.write_hdr(os.path.join(directory, "env.hdr"), sky)
+    scene_io.write_hdr(os.path.join(directory, "flat.hdr"), sky * 3.7e-5, rle=False)
+    scene_io.write_hdr(os.path.join(directory, "narrow.hdr"), rng.uniform(0, 5e4, (9, 5, 3)))
 
     sd = scenes.cornell_box()
     # triangles 0..9 = the five walls, 10..33 = the two boxes (replaced by instances of cube.obj), 34.. = the light
@@ -111,12 +120,12 @@ def write_case(directory, newline="\n", seed=11):
             dict(name="lamp", file="light.obj", material="lamp")]
     cam = dict(width=96, height=64, fov_y=27.0, position=(0, 1, 3.5), rotation=(-90, 0, 0), sample=7, depth=3, file="case")
     path = os.path.join(directory, "scene.txt")
-    scene_io.write_scene(path, mats, objs, cam, env_map="env.ppm", newline=newline)
+    scene_io.write_scene(path, mats, objs, cam, env_map="env.hdr", newline=newline)
     return path
 
 
 CASE_FILES = ("scene.txt", "floor.obj", "walls.obj", "light.obj", "cube.obj", "numbers.obj",
-              "base.ppm", "metal.ppm", "rough.ppm", "nrm.ppm", "env.ppm")
+              "base.ppm", "metal.ppm", "rough.ppm", "nrm.ppm", "env.ppm", "env.hdr", "flat.hdr", "narrow.hdr")
 
 
 def parsed_equal(a, b):

@@ -63,10 +63,11 @@ def test_oracle_obj_reader_matches_tinyobj(g, case_dir):
 
 def test_oracle_image_decoder_matches_stb_image(g, case_dir):
     for name in cases.CASE_FILES:
-        if name.endswith(".ppm"):
-            assert bits_equal(sf.load_ppm(os.path.join(case_dir, name), True), g["img_flip_" + name]), name
-            assert bits_equal(sf.load_ppm(os.path.join(case_dir, name), False), g["img_noflip_" + name]), name
+        if name.endswith(".ppm") or name.endswith(".hdr"):
+            assert bits_equal(sf.load_image(os.path.join(case_dir, name), True), g["img_flip_" + name]), name
+            assert bits_equal(sf.load_image(os.path.join(case_dir, name), False), g["img_noflip_" + name]), name
             assert not np.array_equal(g["img_flip_" + name], g["img_noflip_" + name])
+    assert g["img_noflip_env.hdr"].max() > 50 and g["img_noflip_flat.hdr"].max() < 0.01      # HDR range, not byte / 255
 
 
 def test_oracle_line_reader_matches_safe_getline(g, case_dir, tmp_path):
@@ -134,6 +135,41 @@ def test_obj_number_syntax_fuzz_against_tinyobj(tmp_path):
 
 
 @needs_ref
+def test_hdr_decoder_fuzz_against_stb_image(tmp_path):
+    """Random Radiance pictures -- widths on both sides of the run-length limits, long runs, zero exponents, flat and coded --
+    decoded by the oracle restatement and by the product equal stbi_loadf's floats under both flip settings."""
+    from restir_amd import scene_io
+    rng = np.random.default_rng(31)
+    cam = "Camera\nResolution 8 8\nFovY 20\nLensRadius 0\nFocalDist 1\nApertureMask Null\nSample 1\nDepth 1\nFile x\nEye 0 0 3\nRotation -90 0 0\nUp 0 1 0\n\n"
+    obj = tmp_path / "t.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    for i, (h, w, rle) in enumerate([(3, 7, True), (4, 8, True), (5, 33, True), (2, 300, True), (6, 40, False), (1, 129, True)]):
+        img = rng.uniform(0, 1, (h, w, 3)) * 10.0 ** rng.integers(-6, 6, (h, w, 1))
+        img[:, w // 3: w // 3 + w // 2] = img[:, w // 3: w // 3 + 1]            # long runs
+        img[0, :2] = 0.0                                                       # zero exponent
+        p = str(tmp_path / f"r{i}.hdr")
+        scene_io.write_hdr(p, img, rle=rle)
+        for flip in (0, 1):
+            ww, hh = C.c_int(), C.c_int()
+            buf = np.zeros(h * w * 3, np.float32)
+            assert RL.ref_image_load(p.encode(), flip, C.byref(ww), C.byref(hh), buf.ctypes.data, buf.size) == 0
+            assert (hh.value, ww.value) == (h, w)
+            ref = buf.reshape(h, w, 3)
+            assert bits_equal(sf.load_hdr(p, bool(flip)), ref), (i, flip)
+            # the product: as a texture (flipped) or as the environment map (not flipped) of a one-triangle scene
+            scene = tmp_path / "s.txt"
+            if flip:
+                scene.write_text(f"Material m\nType Lambertian\nBaseColor {p}\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n"
+                                 f"Object o\n{obj}\nMaterial m\nScale 1 1 1\n\n" + cam)
+            else:
+                scene.write_text(f"Object o\n{obj}\nMaterial Null\nScale 1 1 1\n\n" + cam + f"EnvMap {p}\n")
+            a = capi.SceneFile(str(scene))
+            assert len(a.textures) == 1 and bits_equal(a.textures[0], ref), (i, flip)
+        dec = sf.load_hdr(p, False)                                            # RGBE keeps 8 bits of a pixel's largest component
+        assert (np.abs(dec - img).max(axis=2) <= img.max(axis=2) / 128 + 1e-30).all()
+
+
+@needs_ref
 def test_baking_fuzz_against_glm():
     rng = np.random.default_rng(8)
     for i in range(400):
@@ -157,6 +193,7 @@ def test_product_scene_file_matches_oracle(case_dir):
     assert cases.parsed_equal(a, b) == []
     assert a.num_skipped_objects == 1 and a.iterations == 7 and a.trace_depth == 3 and a.image_name == "case"
     assert a.vertices.shape[0] == 2 + 8 + 5 * 12 + 2 and a.env_map_tex == 4 and len(a.textures) == 5
+    assert a.textures[4].max() > 50                          # the Radiance HDR environment map keeps its range
     # instances of one mesh file share the pool entry; "Material Null" appended a default material after the seven named ones
     assert len(a.materials) == 8 and a.material_ids[10 + 24] == 7
     assert a.materials[5]["type"] == 0                      # the unknown type token
