@@ -136,6 +136,17 @@ public:
         return true;
     }
     bool good() const { return !exhausted_; }
+    size_t size() const { return text_.size(); }
+    // the same line as next(), as a range inside the file buffer (no copy)
+    void next_span(const char*& b, const char*& e) {
+        b = e = text_.data() + at_;
+        if (exhausted_) return;
+        size_t end = at_;
+        while (end < text_.size() && text_[end] != '\n' && text_[end] != '\r') end++;
+        e = text_.data() + end;
+        if (end == text_.size()) { if (b == e) exhausted_ = true; at_ = end; }
+        else at_ = end + ((text_[end] == '\r' && end + 1 < text_.size() && text_[end + 1] == '\n') ? 2 : 1);
+    }
     const std::string& next() {
         line_.clear();
         if (exhausted_) return line_;                                  // reads on a failed stream return nothing
@@ -172,9 +183,9 @@ struct Mesh { std::vector<float> v, n, t; };                          // de-inde
 // "tryParseDouble"): digits are accumulated in double -- integer part by *10 + d, fraction digit k by d * 10^-k, a decimal
 // exponent e as ldexp(m * 5^e, e) -- and the result is narrowed to float.  It is not strtof: for long decimals the two can
 // differ in the last float bit, so the same accumulation is done here.  Unparsable text reads as 0.
-float obj_real(const std::string& tok) {
-    const char* c = tok.c_str();
-    const char* end = c + tok.size();
+float obj_real(const char* c, const char* end) {
+    // 10^-k exactly as std::pow(10.0, -k) returns it (the reader calls it per digit; a table of the same values is faster)
+    static const std::vector<double> tenTo = [] { std::vector<double> t(64); for (int k = 0; k < 64; k++) t[k] = std::pow(10.0, -k); return t; }();
     if (c == end) return 0.f;
     double mant = 0.0;
     int expo = 0, got = 0;
@@ -192,7 +203,7 @@ float obj_real(const std::string& tok) {
         static const double lut[] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
         c++;
         int k = 1;
-        while (digit(c)) { mant += (int)(*c - '0') * (k < 8 ? lut[k] : std::pow(10.0, -k)); k++; c++; }
+        while (digit(c)) { mant += (int)(*c - '0') * (k < 8 ? lut[k] : k < 64 ? tenTo[k] : std::pow(10.0, -k)); k++; c++; }
     }
     else if (c != end && *c != 'e' && *c != 'E') c = end;            // trailing text after the integer part: the number so far
     if (c != end && (*c == 'e' || *c == 'E')) {
@@ -218,27 +229,42 @@ int load_obj(const std::string& path, Mesh& m) {
     if (!in.open(path)) return -1;
     std::vector<float> pv, pn, pt;
     struct Corner { int v, t, n; };
-    std::vector<Corner> flat;
+    std::vector<Corner> flat, cs;
+    pv.reserve(in.size() / 24); pn.reserve(in.size() / 24);
+    const auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\v' || c == '\f' || c == '\r' || c == '\n'; };
     while (in.good()) {
-        const std::vector<std::string> tok = tokenize(in.next());
-        if (tok.empty()) continue;
-        auto real = [&](size_t k) { return k < tok.size() ? obj_real(tok[k]) : 0.f; };
-        if (tok[0] == "v") for (size_t k = 1; k <= 3; k++) pv.push_back(real(k));
-        else if (tok[0] == "vn") for (size_t k = 1; k <= 3; k++) pn.push_back(real(k));
-        else if (tok[0] == "vt") for (size_t k = 1; k <= 2; k++) pt.push_back(real(k));
-        else if (tok[0] == "f") {
-            std::vector<Corner> cs;
-            for (size_t k = 1; k < tok.size(); k++) {
+        const char *p, *e;
+        in.next_span(p, e);
+        // the next whitespace-separated token of the line as [tb, te); false at the end of the line
+        const char *tb, *te;
+        const auto token = [&]() {
+            while (p != e && blank(*p)) p++;
+            tb = p;
+            while (p != e && !blank(*p)) p++;
+            te = p;
+            return tb != te;
+        };
+        if (!token()) continue;
+        const size_t klen = (size_t)(te - tb);
+        const auto reals = [&](std::vector<float>& dst, int count) {
+            for (int k = 0; k < count; k++) dst.push_back(token() ? obj_real(tb, te) : 0.f);
+        };
+        if (klen == 1 && tb[0] == 'v') reals(pv, 3);
+        else if (klen == 2 && tb[0] == 'v' && tb[1] == 'n') reals(pn, 3);
+        else if (klen == 2 && tb[0] == 'v' && tb[1] == 't') reals(pt, 2);
+        else if (klen == 1 && tb[0] == 'f') {
+            cs.clear();
+            while (token()) {
                 int raw[3] = { 0, 0, 0 };
                 bool have[3] = { false, false, false };
-                int field = 0; std::string cur;
-                const std::string str = tok[k] + "/";
-                for (char ch : str) {
-                    if (ch == '/') {
-                        if (!cur.empty() && field < 3) { raw[field] = std::atoi(cur.c_str()); have[field] = true; }
-                        cur.clear(); field++;
-                    }
-                    else cur += ch;
+                int field = 0;
+                const char* q = tb;
+                while (q != te && field < 3) {                         // v, v/t, v//n, v/t/n
+                    const char* fb = q;
+                    while (q != te && *q != '/') q++;
+                    if (q != fb) { raw[field] = std::atoi(std::string(fb, q).c_str()); have[field] = true; }
+                    field++;
+                    if (q != te) q++;
                 }
                 auto fix = [](bool present, int idx, size_t count) { return !present ? -1 : idx > 0 ? idx - 1 : idx < 0 ? (int)count + idx : -2; };
                 Corner c{ fix(have[0], raw[0], pv.size() / 3), fix(have[1], raw[1], pt.size() / 2), fix(have[2], raw[2], pn.size() / 3) };
@@ -263,10 +289,12 @@ int load_obj(const std::string& path, Mesh& m) {
         }
     }
     const bool hasTexcoord = !pt.empty();                              // scene.cpp:39,46-49
-    for (const Corner& c : flat) {
+    m.v.resize(flat.size() * 3); m.n.resize(flat.size() * 3); m.t.resize(flat.size() * 2);
+    for (size_t i = 0; i < flat.size(); i++) {
+        const Corner& c = flat[i];
         if (hasTexcoord && c.t < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("OBJ face corner without a texcoord in a file that has vt lines: " + path).c_str());
-        for (int d = 0; d < 3; d++) { m.v.push_back(pv[(size_t)c.v * 3 + d]); m.n.push_back(pn[(size_t)c.n * 3 + d]); }
-        for (int d = 0; d < 2; d++) m.t.push_back(hasTexcoord ? pt[(size_t)c.t * 2 + d] : 0.f);
+        for (int d = 0; d < 3; d++) { m.v[i * 3 + d] = pv[(size_t)c.v * 3 + d]; m.n[i * 3 + d] = pn[(size_t)c.n * 3 + d]; }
+        for (int d = 0; d < 2; d++) m.t[i * 2 + d] = hasTexcoord ? pt[(size_t)c.t * 2 + d] : 0.f;
     }
     return 0;
 }
