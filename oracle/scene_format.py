@@ -266,10 +266,87 @@ def load_hdr(path, flip):
     return (px[..., :3].astype(np.float32) * scale[..., None]).astype(np.float32)
 
 
+def load_png(path, flip):
+    """PNG -> (h, w, 3) float32 as stbi_loadf(.., 3) returns it: 8-bit samples (high byte of 16-bit ones, 1 / 2 / 4-bit grey scaled
+    to 0..255), palette expanded, grey replicated, alpha dropped, byte / 255 (stb_image.h: stbi__do_png, stbi__convert_format,
+    stbi__convert_16_to_8, stbi__ldr_to_hdr with gamma 1).  zlib does the inflate here."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, palette = 8, b"", None
+    while at + 12 <= len(raw):
+        n, tag = struct.unpack(">I4s", raw[at:at + 8])
+        body = raw[at + 8:at + 8 + n]
+        if tag == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+        elif tag == b"PLTE":
+            palette = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif tag == b"IDAT":
+            idat += body
+        elif tag == b"IEND":
+            break
+        at += 12 + n
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+    px = zlib.decompress(idat)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    passes = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)) if interlace else ((0, 0, 1, 1),)
+    pos = 0
+    for x0, y0, dx, dy in passes:
+        pw, ph = (w - x0 + dx - 1) // dx, (h - y0 + dy - 1) // dy
+        if pw <= 0 or ph <= 0:
+            continue
+        nb = (pw * bits + 7) // 8
+        prev = bytearray(nb)
+        for y in range(ph):
+            ft = px[pos]
+            cur = bytearray(px[pos + 1:pos + 1 + nb])
+            pos += 1 + nb
+            for i in range(nb):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 1:
+                    pred = a
+                elif ft == 2:
+                    pred = b
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                elif ft == 4:
+                    pp = a + b - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    pred = 0
+                cur[i] = (cur[i] + pred) & 255
+            prev = cur
+            row = np.frombuffer(bytes(cur), np.uint8)
+            if depth == 8:
+                s = row[:pw * ch].reshape(pw, ch)
+            elif depth == 16:
+                s = row[:pw * ch * 2].reshape(pw, ch, 2)[:, :, 0]
+            else:
+                bitsarr = np.unpackbits(row)[:pw * depth].reshape(pw, depth)
+                s = (bitsarr * (1 << np.arange(depth - 1, -1, -1))).sum(axis=1).astype(np.uint8).reshape(pw, 1)
+            if ctype == 3:
+                out = palette[s[:, 0]]
+            elif ch <= 2:
+                g = (s[:, 0].astype(np.uint16) * ({1: 255, 2: 85, 4: 17}.get(depth, 1) if depth < 8 else 1)).astype(np.uint8)
+                out = np.stack([g, g, g], axis=1)
+            else:
+                out = s[:, :3]
+            rgb[y0 + y * dy, x0::dx][:pw] = out
+    if flip:
+        rgb = rgb[::-1]
+    return (rgb.astype(np.float32) / np.float32(255)).astype(np.float32)
+
+
 def load_image(path, flip):
     with open(path, "rb") as f:
         magic = f.read(2)
-    return load_hdr(path, flip) if magic == b"#?" else load_ppm(path, flip)
+    return load_hdr(path, flip) if magic == b"#?" else load_png(path, flip) if magic == b"\x89P" else load_ppm(path, flip)
 
 
 _TYPES = {"Lambertian": 0, "MetallicWorkflow": 1, "Dielectric": 2, "Light": 4}

@@ -6,13 +6,14 @@
 //   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
 //   instance baking of buildDevData   src/scene.cpp:161-176
 //   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
-// What it does not do: decode PNG / JPG (stb_image in the reference).  Texture and environment-map files must be binary PPM
-// (P6, 8 bit: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR (.hdr,
-// RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
+// What it does not do: decode JPG / TGA / BMP ... (stb_image in the reference).  Texture and environment-map files must be PNG or
+// binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
+// (.hdr, RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
 // :98) and not for the environment map (:124-126).
 // glTF (Resource::loadGLTFMesh) is not read either.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -303,7 +304,7 @@ int load_obj(const std::string& path, Mesh& m) {
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
-    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (only binary PPM P6 / 8 bit and Radiance HDR are decoded here; decode other formats in the caller)").c_str()); };
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR and PNG are decoded here; decode other formats in the caller)").c_str()); };
     auto token = [&](std::string& out) {
         out.clear();
         int c = std::fgetc(f);
@@ -407,7 +408,238 @@ int load_hdr(const std::string& path, bool flipRows, std::vector<float>& data, i
     return 0;
 }
 
-// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR
+// ---- PNG ------------------------------------------------------------------------------------------------------------
+// What stbi_loadf(file, .., 3) returns for a PNG (src/image.cpp:17): the 8-bit image -- 16-bit samples keep their high byte,
+// 1 / 2 / 4-bit grey is scaled to 0..255, palette entries are expanded, grey is replicated to RGB, alpha and tRNS are dropped
+// -- as byte / 255 (ldr-to-hdr gamma 1).  gAMA and other ancillary chunks are ignored and checksums are not verified, as there.
+// Decoder: zlib stream of the concatenated IDAT chunks (stored / fixed / dynamic Huffman blocks), the five scan-line filters,
+// Adam7 interlacing.
+
+// LSB-first bit reader over the deflate stream
+struct BitReader {
+    const unsigned char* p; size_t n, at = 0; unsigned acc = 0; int have = 0; bool bad = false;
+    int bits(int count) {
+        while (have < count) { if (at >= n) { bad = true; return 0; } acc |= (unsigned)p[at++] << have; have += 8; }
+        const int v = (int)(acc & ((1u << count) - 1u));
+        acc >>= count; have -= count;
+        return v;
+    }
+};
+// canonical Huffman code: per length, how many codes and (in order) their symbols
+struct Huffman {
+    unsigned short count[16], symbol[288];
+    bool build(const unsigned char* lengths, int n) {
+        std::memset(count, 0, sizeof count);
+        for (int i = 0; i < n; i++) count[lengths[i]]++;
+        int left = 1;
+        for (int len = 1; len < 16; len++) { left = (left << 1) - count[len]; if (left < 0) return false; }
+        unsigned short offs[16]; offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = (unsigned short)(offs[len] + count[len]);
+        for (int i = 0; i < n; i++) if (lengths[i]) symbol[offs[lengths[i]]++] = (unsigned short)i;
+        return true;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len < 16; len++) {
+            code |= br.bits(1);
+            if (br.bad) return -1;
+            const int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        return -1;
+    }
+};
+
+bool inflate_zlib(const std::vector<unsigned char>& in, std::vector<unsigned char>& out, size_t expected) {
+    if (in.size() < 2 || (in[0] & 15) != 8 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 32)) return false;
+    BitReader br{ in.data() + 2, in.size() - 2 };
+    static const unsigned short lenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+    static const unsigned char lenExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+    static const unsigned short distBase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+    static const unsigned char distExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+    out.clear(); out.reserve(expected);
+    for (;;) {
+        const int last = br.bits(1), type = br.bits(2);
+        if (br.bad) return false;
+        if (type == 0) {                                              // stored
+            br.acc = 0; br.have = 0;
+            if (br.at + 4 > br.n) return false;
+            const unsigned len = br.p[br.at] | (br.p[br.at + 1] << 8), nlen = br.p[br.at + 2] | (br.p[br.at + 3] << 8);
+            br.at += 4;
+            if ((len ^ 0xffffu) != nlen || br.at + len > br.n) return false;
+            out.insert(out.end(), br.p + br.at, br.p + br.at + len);
+            br.at += len;
+        }
+        else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            unsigned char lengths[320];
+            if (type == 1) {
+                for (int i = 0; i < 288; i++) lengths[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                lit.build(lengths, 288);
+                for (int i = 0; i < 30; i++) lengths[i] = 5;
+                dist.build(lengths, 30);
+            }
+            else {
+                const int nlen = br.bits(5) + 257, ndist = br.bits(5) + 1, ncode = br.bits(4) + 4;
+                if (br.bad || nlen > 286 || ndist > 30) return false;
+                static const unsigned char order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+                unsigned char cl[19] = { 0 };
+                for (int i = 0; i < ncode; i++) cl[order[i]] = (unsigned char)br.bits(3);
+                Huffman lencode;
+                if (!lencode.build(cl, 19)) return false;
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    const int sym = lencode.decode(br);
+                    if (sym < 0) return false;
+                    if (sym < 16) lengths[idx++] = (unsigned char)sym;
+                    else {
+                        int prev = 0, rep;
+                        if (sym == 16) { if (idx == 0) return false; prev = lengths[idx - 1]; rep = 3 + br.bits(2); }
+                        else if (sym == 17) rep = 3 + br.bits(3);
+                        else rep = 11 + br.bits(7);
+                        if (br.bad || idx + rep > nlen + ndist) return false;
+                        while (rep--) lengths[idx++] = (unsigned char)prev;
+                    }
+                }
+                if (!lit.build(lengths, nlen) || !dist.build(lengths + nlen, ndist)) return false;
+            }
+            for (;;) {
+                const int sym = lit.decode(br);
+                if (sym < 0) return false;
+                if (sym < 256) out.push_back((unsigned char)sym);
+                else if (sym == 256) break;
+                else {
+                    if (sym > 285) return false;
+                    const int len = lenBase[sym - 257] + br.bits(lenExtra[sym - 257]);
+                    const int ds = dist.decode(br);
+                    if (ds < 0 || ds > 29) return false;
+                    const size_t d = (size_t)distBase[ds] + (size_t)br.bits(distExtra[ds]);
+                    if (br.bad || d > out.size()) return false;
+                    const size_t from = out.size() - d;
+                    for (int i = 0; i < len; i++) out.push_back(out[from + i]);
+                }
+            }
+        }
+        else return false;
+        if (last) return true;
+    }
+}
+
+int load_png(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    std::vector<unsigned char> raw;
+    {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+        unsigned char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + got);
+        std::fclose(f);
+    }
+    auto fail = [&](const char* why) { return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path).c_str()); };
+    static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
+    if (raw.size() < 8 || std::memcmp(raw.data(), sig, 8) != 0) return fail("not a PNG");
+    auto be32 = [&](size_t at) { return ((unsigned)raw[at] << 24) | ((unsigned)raw[at + 1] << 16) | ((unsigned)raw[at + 2] << 8) | raw[at + 3]; };
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, palette;
+    bool header = false, ended = false;
+    for (size_t at = 8; at + 12 <= raw.size() && !ended;) {
+        const size_t len = be32(at);
+        const char* tag = reinterpret_cast<const char*>(&raw[at + 4]);
+        const size_t body = at + 8;
+        if (body + len + 4 > raw.size()) return fail("truncated PNG chunk");
+        if (!std::memcmp(tag, "IHDR", 4)) {
+            if (len != 13) return fail("bad PNG header");
+            w = (int)be32(body); h = (int)be32(body + 4);
+            depth = raw[body + 8]; ctype = raw[body + 9]; interlace = raw[body + 12];
+            if (raw[body + 10] || raw[body + 11] || interlace > 1 || w <= 0 || h <= 0) return fail("bad PNG header");
+            header = true;
+        }
+        else if (!std::memcmp(tag, "PLTE", 4)) palette.assign(raw.begin() + body, raw.begin() + body + len);
+        else if (!std::memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), raw.begin() + body, raw.begin() + body + len);
+        else if (!std::memcmp(tag, "IEND", 4)) ended = true;
+        else if (!std::memcmp(tag, "CgBI", 4)) return fail("CgBI PNG variants are not decoded");
+        at = body + len + 4;
+    }
+    if (!header) return fail("PNG without a header");
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depthOk = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                       : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+    if (!channels || !depthOk) return fail("unsupported PNG colour type / bit depth");
+    if (ctype == 3 && palette.size() < 3) return fail("palette PNG without a palette");
+    const int bitsPerPixel = channels * depth, bpp = (bitsPerPixel + 7) / 8;
+    // passes: the whole image, or the seven Adam7 sub-images
+    struct Pass { int x0, y0, dx, dy; };
+    static const Pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    static const Pass whole = { 0, 0, 1, 1 };
+    const int numPasses = interlace ? 7 : 1;
+    size_t expected = 0;
+    for (int pi = 0; pi < numPasses; pi++) {
+        const Pass& ps = interlace ? adam7[pi] : whole;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw > 0 && ph > 0) expected += (size_t)ph * (1 + ((size_t)pw * bitsPerPixel + 7) / 8);
+    }
+    std::vector<unsigned char> px;
+    if (!inflate_zlib(idat, px, expected) || px.size() < expected) return fail("corrupt PNG data stream");
+    std::vector<unsigned char> rgb((size_t)w * h * 3);
+    const int greyScale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;
+    size_t at = 0;
+    std::vector<unsigned char> prevRow, curRow;
+    for (int pi = 0; pi < numPasses; pi++) {
+        const Pass& ps = interlace ? adam7[pi] : whole;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t rowBytes = ((size_t)pw * bitsPerPixel + 7) / 8;
+        prevRow.assign(rowBytes, 0);
+        for (int y = 0; y < ph; y++) {
+            const int filter = px[at++];
+            curRow.assign(px.begin() + at, px.begin() + at + rowBytes);
+            at += rowBytes;
+            if (filter > 4) return fail("bad PNG filter");
+            for (size_t i = 0; i < rowBytes; i++) {
+                const int a = i >= (size_t)bpp ? curRow[i - bpp] : 0, b = prevRow[i], c = i >= (size_t)bpp ? prevRow[i - bpp] : 0;
+                int pred = 0;
+                if (filter == 1) pred = a;
+                else if (filter == 2) pred = b;
+                else if (filter == 3) pred = (a + b) >> 1;
+                else if (filter == 4) {
+                    const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                }
+                curRow[i] = (unsigned char)(curRow[i] + pred);
+            }
+            const int oy = ps.y0 + y * ps.dy;
+            for (int x = 0; x < pw; x++) {
+                unsigned char sample[4] = { 0, 0, 0, 0 };
+                for (int ch = 0; ch < channels; ch++) {
+                    if (depth == 8) sample[ch] = curRow[(size_t)x * channels + ch];
+                    else if (depth == 16) sample[ch] = curRow[((size_t)x * channels + ch) * 2];       // the high byte
+                    else {
+                        const size_t bit = (size_t)x * depth;
+                        sample[ch] = (unsigned char)((curRow[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1));
+                    }
+                }
+                unsigned char* o = &rgb[((size_t)oy * w + ps.x0 + (size_t)x * ps.dx) * 3];
+                if (ctype == 3) {
+                    const size_t e = (size_t)sample[0] * 3;
+                    if (e + 3 > palette.size()) return fail("PNG palette index out of range");
+                    o[0] = palette[e]; o[1] = palette[e + 1]; o[2] = palette[e + 2];
+                }
+                else if (channels <= 2) { const unsigned char g = (unsigned char)(sample[0] * (depth < 8 ? greyScale : 1)); o[0] = o[1] = o[2] = g; }
+                else { o[0] = sample[0]; o[1] = sample[1]; o[2] = sample[2]; }
+            }
+            prevRow.swap(curRow);
+        }
+    }
+    data.resize(rgb.size());
+    for (int y = 0; y < h; y++) {
+        const int sy = flipRows ? h - 1 - y : y;
+        for (int i = 0; i < w * 3; i++) data[((size_t)y * w) * 3 + i] = (float)rgb[((size_t)sy * w) * 3 + i] / 255.f;
+    }
+    return 0;
+}
+
+// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR, 0x89 "PNG" = PNG
 int load_image(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
@@ -415,6 +647,7 @@ int load_image(const std::string& path, bool flipRows, std::vector<float>& data,
     const size_t got = std::fread(m, 1, 2, f);
     std::fclose(f);
     if (got == 2 && m[0] == '#' && m[1] == '?') return load_hdr(path, flipRows, data, w, h);
+    if (got == 2 && m[0] == 0x89 && m[1] == 'P') return load_png(path, flipRows, data, w, h);
     return load_ppm(path, flipRows, data, w, h);
 }
 

@@ -16,8 +16,8 @@ The text format is the one Scene::Scene(filename) parses (/root/reference/src/sc
                                                                      Eye / Rotation / Up <x y z>, then an empty line
 
 so a scene written here can be rendered by the reference itself on its own hardware and compared with this port.
-Images are written as binary PPM (P6, decoded to byte / 255) or Radiance HDR (.hdr, RGBE), which both stb_image (the reference)
-and the library's reader decode to the same floats.
+Images are written as binary PPM (P6, decoded to byte / 255), PNG or Radiance HDR (.hdr, RGBE), which both stb_image (the
+reference) and the library's reader decode to the same floats.
 """
 import os
 
@@ -41,6 +41,90 @@ def write_ppm(path, rgb):
     with open(path, "wb") as f:
         f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
         f.write(rgb.tobytes())
+
+
+def write_png(path, samples, color_type, depth=8, palette=None, interlace=False, filters=None, level=6, idat_split=0):
+    """A PNG from raw samples: samples (h, w) or (h, w, channels) integers below 2**depth (palette indices for colour type
+    3, with palette = (n, 3) uint8).  color_type 0 grey, 2 RGB, 3 palette, 4 grey + alpha, 6 RGBA.  filters: a scan-line filter
+    type 0..4, or a callable(row_index) -> type (default: cycles through all five); interlace: Adam7; idat_split: bytes per
+    IDAT chunk (0 = one chunk).  For tests of the decoders: every legal colour type / depth combination can be written."""
+    import struct
+    import zlib
+    a = np.asarray(samples)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, ch = a.shape
+    assert ch == {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+
+    def pack_rows(sub):                              # (ph, pw, ch) -> list of byte rows
+        rows = []
+        for r in sub:
+            flat = r.reshape(-1).astype(np.uint32)
+            if depth == 8:
+                rows.append(flat.astype(np.uint8).tobytes())
+            elif depth == 16:
+                rows.append(flat.astype(">u2").tobytes())
+            else:
+                nb = (len(flat) * depth + 7) // 8
+                out = np.zeros(nb, np.uint8)
+                for i, v in enumerate(flat):
+                    bit = i * depth
+                    out[bit >> 3] |= (int(v) & ((1 << depth) - 1)) << (8 - depth - (bit & 7))
+                rows.append(out.tobytes())
+        return rows
+
+    def filt(rows, row0):
+        out = bytearray()
+        prev = bytes(len(rows[0])) if rows else b""
+        for y, cur in enumerate(rows):
+            ft = filters(row0 + y) if callable(filters) else (row0 + y) % 5 if filters is None else int(filters)
+            line = bytearray(len(cur))
+            for i in range(len(cur)):
+                aa = cur[i - bpp] if i >= bpp else 0
+                bb = prev[i]
+                cc = prev[i - bpp] if i >= bpp else 0
+                if ft == 0:
+                    pred = 0
+                elif ft == 1:
+                    pred = aa
+                elif ft == 2:
+                    pred = bb
+                elif ft == 3:
+                    pred = (aa + bb) >> 1
+                else:
+                    pp = aa + bb - cc
+                    pa, pb, pc = abs(pp - aa), abs(pp - bb), abs(pp - cc)
+                    pred = aa if (pa <= pb and pa <= pc) else (bb if pb <= pc else cc)
+                line[i] = (cur[i] - pred) & 255
+            out.append(ft)
+            out += line
+            prev = cur
+        return bytes(out)
+
+    stream = b""
+    if interlace:
+        for n, (x0, y0, dx, dy) in enumerate(((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))):
+            sub = a[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                stream += filt(pack_rows(sub), n)
+    else:
+        stream = filt(pack_rows(a), 0)
+    z = zlib.compress(stream, level)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0)))
+        f.write(chunk(b"gAMA", struct.pack(">I", 45455)))            # ancillary chunks are skipped by the readers
+        if palette is not None:
+            f.write(chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes()))
+        step = idat_split or len(z)
+        for i in range(0, len(z), step):
+            f.write(chunk(b"IDAT", z[i:i + step]))
+        f.write(chunk(b"IEND", b""))
 
 
 def float_to_rgbe(rgb):

@@ -55,7 +55,7 @@ def main():
             p = os.path.join(d, name)
             if name.endswith(".obj"):
                 g["obj_v_" + name], g["obj_n_" + name], g["obj_t_" + name] = ref_obj(R, p)
-            elif name.endswith(".ppm") or name.endswith(".hdr"):
+            elif name.endswith((".ppm", ".hdr", ".png")):
                 g["img_flip_" + name] = ref_image(R, p, 1)
                 g["img_noflip_" + name] = ref_image(R, p, 0)
             g["lines_" + name] = np.frombuffer(ref_lines(R, p), np.uint8)

@@ -1,4 +1,4 @@
-"""A small scene in the reference's on-disk format (scene text + OBJ meshes + PPM images), used by the scene-file tests.
+"""A small scene in the reference's on-disk format (scene text + OBJ meshes + PPM / PNG / HDR images), used by the scene-file tests.
 
 Everything is generated here (restir_amd.scene_io writers + hand-written OBJ text that exercises quads, negative and
 mixed index styles, groups and the number syntax); nothing comes from the reference."""
@@ -74,6 +74,13 @@ def write_case(directory, newline="\n", seed=11):
             img[..., 2] = 255
             img[..., :2] = 128 + rng.integers(-40, 41, (h, w, 2))
         scene_io.write_ppm(os.path.join(directory, name), img)
+    # PNG textures: the metallic map as an interlaced 8-bit grey picture, the roughness map as a 4-bit palette picture, and an
+    # RGBA / 16-bit pair for the decoder only
+    scene_io.write_png(os.path.join(directory, "metal.png"), rng.integers(0, 256, (8, 8)), 0, 8, interlace=True)
+    pal = rng.integers(30, 230, (16, 3), dtype=np.uint8)
+    scene_io.write_png(os.path.join(directory, "rough.png"), rng.integers(0, 16, (4, 8)), 3, 4, palette=pal)
+    scene_io.write_png(os.path.join(directory, "rgba.png"), rng.integers(0, 256, (9, 13, 4)), 6, 8, idat_split=64)
+    scene_io.write_png(os.path.join(directory, "rgb16.png"), rng.integers(0, 65536, (5, 7, 3)), 2, 16, interlace=True)
     env = (40 + 60 * np.linspace(1.0, 0.2, 16)[:, None, None] * np.array([0.6, 0.8, 1.0])).astype(np.uint8) + np.zeros((16, 32, 3), np.uint8)
     env[3:5, 8:10] = 255                                            # a bright patch above the open front
     env = (env.astype(np.int32) + rng.integers(0, 4, env.shape)).clip(0, 255).astype(np.uint8)
@@ -104,7 +111,7 @@ def write_case(directory, newline="\n", seed=11):
 
     mats = [("white", dict(type=0, baseColor="base.ppm")),
             ("red", dict(type=0, baseColor="Procedural")),
-            ("metal", dict(type=1, baseColor=(0.9, 0.8, 0.5), metallic="metal.ppm", roughness="rough.ppm", normalMap="nrm.ppm")),
+            ("metal", dict(type=1, baseColor=(0.9, 0.8, 0.5), metallic="metal.png", roughness="rough.png", normalMap="nrm.ppm")),
             ("satin", dict(type="MetallicWorkflow", baseColor=(0.3, 0.5, 0.8), metallic=0.25, roughness=0.35)),
             ("glass", dict(type=2, baseColor=(0.95, 0.95, 0.95), ior=1.45)),
             ("odd", dict(type="NoSuchType", baseColor=(0.2, 0.7, 0.3))),           # unknown type token -> Lambertian
@@ -125,7 +132,8 @@ def write_case(directory, newline="\n", seed=11):
 
 
 CASE_FILES = ("scene.txt", "floor.obj", "walls.obj", "light.obj", "cube.obj", "numbers.obj",
-              "base.ppm", "metal.ppm", "rough.ppm", "nrm.ppm", "env.ppm", "env.hdr", "flat.hdr", "narrow.hdr")
+              "base.ppm", "metal.ppm", "rough.ppm", "nrm.ppm", "env.ppm", "env.hdr", "flat.hdr", "narrow.hdr",
+              "metal.png", "rough.png", "rgba.png", "rgb16.png")
 
 
 def parsed_equal(a, b):

@@ -63,10 +63,11 @@ def test_oracle_obj_reader_matches_tinyobj(g, case_dir):
 
 def test_oracle_image_decoder_matches_stb_image(g, case_dir):
     for name in cases.CASE_FILES:
-        if name.endswith(".ppm") or name.endswith(".hdr"):
+        if name.endswith((".ppm", ".hdr", ".png")):
             assert bits_equal(sf.load_image(os.path.join(case_dir, name), True), g["img_flip_" + name]), name
             assert bits_equal(sf.load_image(os.path.join(case_dir, name), False), g["img_noflip_" + name]), name
             assert not np.array_equal(g["img_flip_" + name], g["img_noflip_" + name])
+    assert g["img_noflip_rgba.png"].shape == (9, 13, 3) and g["img_noflip_rgb16.png"].shape == (5, 7, 3)
     assert g["img_noflip_env.hdr"].max() > 50 and g["img_noflip_flat.hdr"].max() < 0.01      # HDR range, not byte / 255
 
 
@@ -170,6 +171,48 @@ def test_hdr_decoder_fuzz_against_stb_image(tmp_path):
 
 
 @needs_ref
+def test_png_decoder_against_stb_image(tmp_path):
+    """Every legal PNG colour type / bit depth, plain and Adam7-interlaced, all five scan-line filters, stored / fixed / dynamic
+    deflate blocks and split IDAT chunks: the oracle restatement and the product's own inflate + unfilter equal stbi_loadf's
+    floats under both flip settings."""
+    from restir_amd import scene_io
+    rng = np.random.default_rng(4)
+    obj = tmp_path / "t.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    cam = "Camera\nResolution 8 8\nFovY 20\nLensRadius 0\nFocalDist 1\nApertureMask Null\nSample 1\nDepth 1\nFile x\nEye 0 0 3\nRotation -90 0 0\nUp 0 1 0\n\n"
+    combos = [(ct, dp, il) for ct, depths in ((0, (1, 2, 4, 8, 16)), (2, (8, 16)), (3, (1, 2, 4, 8)), (4, (8, 16)), (6, (8, 16)))
+              for dp in depths for il in (False, True)]
+    combos += [(2, 8, False)] * 3                                             # larger pictures: long matches, many blocks
+    for i, (ct, dp, il) in enumerate(combos):
+        big = i >= len(combos) - 3
+        h, w = (int(rng.integers(60, 90)), int(rng.integers(100, 140))) if big else (int(rng.integers(1, 20)), int(rng.integers(1, 40)))
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ct]
+        pal = rng.integers(0, 256, (min(256, 1 << dp), 3), dtype=np.uint8) if ct == 3 else None
+        smp = rng.integers(0, 1 << dp, (h, w, ch))
+        if i % 3 == 0 or big:
+            smp[:, w // 2:] = smp[:, w // 2: w // 2 + 1]                      # runs: back-references in the deflate stream
+        if big:
+            smp[h // 2:] = smp[: h - h // 2]
+        p = str(tmp_path / f"c{i}.png")
+        scene_io.write_png(p, smp, ct, dp, palette=pal, interlace=il, level=(0, 1, 9)[i % 3] if not big else 9,
+                           idat_split=37 if i % 2 else 0, filters=None if i % 4 else int(rng.integers(0, 5)))
+        for flip in (0, 1):
+            ww, hh = C.c_int(), C.c_int()
+            buf = np.zeros(h * w * 3, np.float32)
+            assert RL.ref_image_load(p.encode(), flip, C.byref(ww), C.byref(hh), buf.ctypes.data, buf.size) == 0
+            ref = buf.reshape(h, w, 3)
+            assert bits_equal(sf.load_png(p, bool(flip)), ref), (ct, dp, il, flip)
+            scene = tmp_path / "s.txt"
+            if flip:
+                scene.write_text(f"Material m\nType Lambertian\nBaseColor {p}\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n"
+                                 f"Object o\n{obj}\nMaterial m\nScale 1 1 1\n\n" + cam)
+            else:
+                scene.write_text(f"Object o\n{obj}\nMaterial Null\nScale 1 1 1\n\n" + cam + f"EnvMap {p}\n")
+            a = capi.SceneFile(str(scene))
+            assert len(a.textures) == 1 and bits_equal(a.textures[0], ref), (ct, dp, il, flip)
+
+
+@needs_ref
 def test_baking_fuzz_against_glm():
     rng = np.random.default_rng(8)
     for i in range(400):
@@ -251,8 +294,11 @@ def test_product_scene_file_errors(case_dir, tmp_path):
     with pytest.raises(capi.RestirHipError, match="without a valid normal"):
         load("Object o\n" + str(tmp_path / "nonormal.obj") + "\nMaterial Null\nScale 1 1 1\n\n" + cam)
     (tmp_path / "tex.png").write_bytes(b"\x89PNG\r\n\x1a\n....")
-    with pytest.raises(capi.RestirHipError, match="only binary PPM"):
+    with pytest.raises(capi.RestirHipError, match="PNG"):
         load("Material m\nType Lambertian\nBaseColor " + str(tmp_path / "tex.png") + "\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n" + cam)
+    (tmp_path / "tex.jpg").write_bytes(b"\xff\xd8\xff\xe0....")
+    with pytest.raises(capi.RestirHipError, match="are decoded here"):
+        load("Material m\nType Lambertian\nBaseColor " + str(tmp_path / "tex.jpg") + "\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n" + cam)
     with pytest.raises(capi.RestirHipError, match="only OBJ"):
         load("Object o\nmesh.gltf\nMaterial Null\n\n" + cam)
     with pytest.raises(capi.RestirHipError, match="malformed number"):
