@@ -8,7 +8,7 @@ import torch
 from restir_amd import capi, scenes
 from restir_amd.tiling import HipBackend, StripRenderer, rebalance_bounds, strip_bounds
 
-W, H = 1920, 1080
+W, H = int(os.environ.get("RS_W", 1920)), int(os.environ.get("RS_H", 1080))
 capi.init(0)
 sd = scenes.sponza_class(seed=1, scale=1.0)
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
