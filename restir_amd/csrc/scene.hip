@@ -91,6 +91,7 @@ int build_occlusion_side(rs_scene* s) {
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
+    (void)rs_synchronize();                             // asynchronous mode: kernels on the library / auxiliary streams may still read the scene
     rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
