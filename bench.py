@@ -19,6 +19,7 @@ One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its
                 HIP-event duration (events recorded on the stream the kernel is launched on),
                 against the 8 TB/s HBM3E peak; `traffic` is filled from profiles/ PMC runs when known
+  cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a
                 bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -79,6 +80,34 @@ def cpu_baseline(sd, frames):
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "ms_per_frame": dt / frames * 1e3,
             "sample": f"{frames} frames of the same workload (1920x1080 spatiotemporal, Sponza-class 262144 tris), OpenMP over rows"}
+
+
+def cpu_reference_loop(sd, threads):
+    """The baseline north_star names: a host-side loop over the reference's own intersections.h / bvh.h -- DevScene::intersect's
+    traversal around the reference's compiled AABB::intersect / intersectTriangle on the reference builder's tree
+    (oracle/_ref/libref_subset.so, prebuilt in the build container; oracle/ref_subset.cpp).  Closest hits of the benchmark view's
+    camera rays (one jittered ray per pixel of the 1920x1080 frame), repeated for about five seconds.  None when the library
+    is not there."""
+    import ctypes as C
+    import numpy as np
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import binding as ob
+    R = ob.ref_subset()
+    if R is None:
+        return None
+    w, h = WIDTH, HEIGHT
+    cam = ob.camera_update(sd.camera(w, h))
+    rng = np.random.default_rng(1)
+    ys, xs = np.mgrid[0:h, 0:w]
+    xy = np.stack([xs.reshape(-1), ys.reshape(-1)], 1).astype(np.int32)
+    r4 = rng.uniform(0, 1, (len(xy), 4)).astype(np.float32)
+    rays = np.zeros((len(xy), 6), np.float32)
+    ob.lib().orc_camera_sample(C.byref(cam), len(xy), xy.reshape(-1), r4.reshape(-1), rays.reshape(-1))
+    prim, _, seconds = ob.ref_closest_hit_loop(R, sd.vertices, rays, min_seconds=5.0)
+    return {"value": len(xy) / seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "reference",
+            "hit_fraction": float((prim >= 0).mean()),
+            "sample": f"closest hit of the {len(xy)} camera rays of the benchmark view, repeated for 5 s, through the reference's compiled "
+                      "AABB::intersect / intersectTriangle on the reference builder's MTBVH, OpenMP over rays"}
 
 
 def main():
@@ -235,6 +264,9 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(sd, args.cpu_frames)
+            ref_loop = cpu_reference_loop(sd, out["cpu_baseline"]["cores"])
+            if ref_loop is not None:
+                out["cpu_reference_loop"] = ref_loop
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -570,9 +570,35 @@ def ref_subset():
     R.ref_to_plane.argtypes = [C.c_int, f32p, f32p]
     R.ref_local_to_world.argtypes = [C.c_int, f32p, f32p, f32p]
     R.ref_bvh_build.restype = C.c_int
+    R.ref_closest_hit_loop.argtypes = [C.c_int, f32p, C.POINTER(C.c_void_p * 6), f32p, C.c_int, f32p, i32p, f32p]
     R.ref_build_transformation_matrix.argtypes = [f32p, f32p, f32p, f32p]
     R.ref_bake_instance.argtypes = [f32p, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p]
     return R
+
+
+def ref_closest_hit_loop(R, vertices, rays, min_seconds=0.0):
+    """Closest hits of `rays` (n, 6) in the triangle soup `vertices` through the reference's own builder and intersection code
+    (oracle/ref_subset.cpp ref_bvh_build + ref_closest_hit_loop).  The traced loop is repeated until `min_seconds` have passed.
+    Returns (prim ids, distances, seconds per pass over the rays)."""
+    import time
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1)
+    n_prims = v.size // 9
+    size = 2 * n_prims - 1
+    boxes = np.zeros(size * 6, np.float32)
+    nodes = [np.zeros(size * 3, np.int32) for _ in range(6)]
+    ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in nodes])
+    bvh_size = R.ref_bvh_build(n_prims, v, boxes, C.byref(ptrs))
+    r = np.ascontiguousarray(rays, np.float32).reshape(-1)
+    n = r.size // 6
+    prim = np.zeros(n, np.int32); dist = np.zeros(n, np.float32)
+    R.ref_closest_hit_loop(bvh_size, boxes, C.byref(ptrs), v, min(n, 4096), r, prim, dist)      # untimed: thread start-up
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        R.ref_closest_hit_loop(bvh_size, boxes, C.byref(ptrs), v, n, r, prim, dist)
+        passes += 1
+        if time.perf_counter() - t0 >= min_seconds:
+            break
+    return prim, dist, (time.perf_counter() - t0) / passes
 
 
 def ref_loaders():

@@ -140,6 +140,47 @@ int ref_bvh_build(int numPrims, const float* vertices, float* boxesOut, int* nod
     return size;
 }
 
+// A host-side closest-hit loop over the reference's own intersections.h / bvh.h: the traversal is the loop of
+// DevScene::intersect (scene.h:245-284; scene.h itself needs Thrust, so the dozen lines are restated here) and every
+// geometric test in it is the reference's compiled code -- AABB::intersect (bvh.h:85-157), intersectTriangle
+// (intersections.h:17-54) -- on the tree of the reference's BVHBuilder (ref_bvh_build).  bench.py times it on the host cores
+// as the "reference loop" CPU baseline; tests check it against the oracle.  nodes[k]: MTBVHNode arrays of the six orders.
+void ref_closest_hit_loop(int bvhSize, const float* boxes, const int* const nodes[6], const float* vertices,
+                          int n, const float* rays, int* primOut, float* distOut) {
+    const AABB* bb = reinterpret_cast<const AABB*>(boxes);
+    const glm::vec3* verts = reinterpret_cast<const glm::vec3*>(vertices);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < n; i++) {
+        const Ray ray = ldRay(rays + 6 * (size_t)i);
+        const glm::vec3 dir = -ray.direction, absDir = glm::abs(dir);         // getMTBVHId(-ray.direction), scene.h:101-119
+        int id;
+        if (absDir.x > absDir.y) id = absDir.x > absDir.z ? (dir.x > 0 ? 0 : 1) : (dir.z > 0 ? 4 : 5);
+        else id = absDir.y > absDir.z ? (dir.y > 0 ? 2 : 3) : (dir.z > 0 ? 4 : 5);
+        const MTBVHNode* nd = reinterpret_cast<const MTBVHNode*>(nodes[id]);
+        float closestDist = FLT_MAX;
+        int closestPrimId = NullPrimitive;
+        int node = 0;
+        while (node != bvhSize) {
+            AABB bound = bb[nd[node].boundingBoxId];
+            float boundDist;
+            const bool boundHit = bound.intersect(ray, boundDist);
+            if (boundHit && boundDist < closestDist) {
+                const int primId = nd[node].primitiveId;
+                if (primId != NullPrimitive) {
+                    float dist;
+                    glm::vec2 bary;
+                    const bool hit = intersectTriangle(ray, verts[primId * 3 + 0], verts[primId * 3 + 1], verts[primId * 3 + 2], bary, dist);
+                    if (hit && dist < closestDist) { closestDist = dist; closestPrimId = primId; }
+                }
+                node++;
+            }
+            else node = nd[node].nextNodeIfMiss;
+        }
+        primOut[i] = closestPrimId;
+        distOut[i] = closestDist;
+    }
+}
+
 // material.h:230-256.  Fields the reference leaves unwritten for an Invalid sample are reported as 0.
 void ref_material_sample(int n, const Material* mats, const float* nrm, const float* wo, const float* r3,
                          float* dir, float* bsdf, float* pdf, uint32_t* type) {

@@ -142,3 +142,27 @@ def test_material_sample_and_pdf():
     assert np.array_equal(a[3], b[3])
     assert bits_equal(a[0], b[0]) and bits_equal(a[1], b[1]) and bits_equal(a[2], b[2])
     assert bits_equal(ob.material_pdf(mats, nrm, wo, wi), ob.material_pdf(mats, nrm, wo, wi, R.ref_material_pdf))
+
+
+@needs_ref
+def test_closest_hit_loop_over_reference_intersections():
+    """bench.py's "reference loop" CPU baseline -- DevScene::intersect's traversal around the reference's compiled
+    AABB::intersect / intersectTriangle on the reference builder's tree -- returns the oracle's hits (primitive ids; the oracle
+    reports position, not distance, so distances are compared through it)."""
+    from tests.common import get_scene, oracle_scene
+    sd = get_scene("sponza:0.05")
+    W, H = 160, 90
+    cam = ob.camera_update(sd.camera(W, H))
+    rng = np.random.default_rng(2)
+    ys, xs = np.mgrid[0:H, 0:W]
+    xy = np.stack([xs.reshape(-1), ys.reshape(-1)], 1).astype(np.int32)
+    r4 = rng.uniform(0, 1, (len(xy), 4)).astype(np.float32)
+    rays = np.zeros((len(xy), 6), np.float32)
+    ob.lib().orc_camera_sample(C.byref(cam), len(xy), xy.reshape(-1), r4.reshape(-1), rays.reshape(-1))
+    prim, dist, seconds = ob.ref_closest_hit_loop(R, sd.vertices, rays)
+    oprim, _, opos, _, _ = oracle_scene(sd).intersect(rays)
+    assert np.array_equal(prim, oprim)
+    hit = prim >= 0
+    assert hit.mean() > 0.5 and seconds > 0
+    d = np.linalg.norm(opos[hit] - rays[hit, :3], axis=1)
+    assert np.allclose(d, dist[hit], rtol=1e-4, atol=1e-4)
