@@ -90,6 +90,13 @@ class StripRenderer:
         self.max_rows = max(b[1] - b[0] for b in self.bounds)
         self.looper = 0
 
+    def _host_visible(self):
+        """RCCL orders its transfers after the work already enqueued on the current stream.  gloo -- the stand-in used to rehearse
+        the multi-process path on a one-GPU box -- reads device buffers from the host without any stream ordering: wait for the
+        packing copies first when launches are asynchronous."""
+        if self.dist is not None and self.dist.get_backend() == "gloo" and hasattr(self.b, "torch") and self.b.torch.cuda.is_available():
+            self.b.torch.cuda.synchronize()
+
     def start_halo_exchange(self):
         """Pack the strip's border rows and post the sends / receives; returns what finish_halo_exchange needs."""
         d = self.dist
@@ -104,6 +111,8 @@ class StripRenderer:
             recv = self.b.empty(send.numel())
             ops += [d.P2POp(d.isend, send, self.down), d.P2POp(d.irecv, recv, self.down)]
             recvs.append((self.y1, recv))
+        if ops:
+            self._host_visible()
         works = d.batch_isend_irecv(ops) if ops else []
         return works, recvs, ops                 # ops keeps the send buffers alive until the wait
 
@@ -141,6 +150,7 @@ class StripRenderer:
         send = self.b.empty(nmax)
         send[: mine.numel()] = mine
         out = [self.b.empty(nmax) for _ in range(self.world)]
+        self._host_visible()
         d.all_gather(out, send)
         for r, (a, bnd) in enumerate(self.bounds):
             if r != self.rank:

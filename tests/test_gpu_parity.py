@@ -720,7 +720,7 @@ def test_phase_b_in_row_bands_equals_one_call(hip):
 def test_multi_process_strips_on_one_gpu():
     """The real multi-process path (one process per rank, StripRenderer + HipBackend + torch.distributed point-to-point
     and all-gather) with two ranks sharing this GPU and gloo standing in for RCCL: tools/rehearse_strips.py compares
-    the gathered strips with a full-frame render, static and orbiting camera."""
+    the gathered strips with a full-frame render, static and orbiting camera, synchronous launches and overlapped frames."""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -728,7 +728,7 @@ def test_multi_process_strips_on_one_gpu():
                         "--master-port", str(port), os.path.join(root, "tools", "rehearse_strips.py")],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("strips == full frame: True") == 2, r.stdout[-2000:]
+    assert r.stdout.count("strips == full frame: True") == 4, r.stdout[-2000:]
 
 
 def test_config4_4k_eight_strips_equal_full_frame(hip):

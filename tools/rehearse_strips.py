@@ -23,7 +23,9 @@ capi.init(0)
 sd = scenes.sponza_class(seed=1, scale=0.1)
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
 ok = True
-for moving in (False, True):
+for moving, overlapped in ((False, False), (True, False), (False, True), (True, True)):
+    # overlapped: asynchronous launches (rs_set_sync(0)) -- frames overlap on the auxiliary streams, as in bench.py
+    capi.set_sync(not overlapped)
     cam = capi.camera_update(sd.camera(W, H))
     strips = StripRenderer(HipBackend(capi, scene, cam, W, H), world, rank, H, dist=dist, share_history=moving)
     full = StripRenderer(HipBackend(capi, scene, cam, W, H), 1, 0, H) if rank == 0 else None
@@ -36,6 +38,8 @@ for moving in (False, True):
         strips.frame(3, 0)
         if full is not None:
             full.frame(3, 0)
+    torch.cuda.synchronize()
+    capi.set_sync(True)
     mine = strips.b.image[strips.y0 * W:strips.y1 * W].contiguous()
     pad = torch.zeros((strips.max_rows * W, 3), dtype=torch.float32, device="cuda"); pad[:mine.shape[0]] = mine
     out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
@@ -44,7 +48,8 @@ for moving in (False, True):
         got = torch.cat([out[r][:(b[1] - b[0]) * W] for r, b in enumerate(strips.bounds)]).cpu().numpy()
         ref = full.b.image.cpu().numpy()
         same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-        print("world %d, %s camera: strips == full frame: %s" % (world, "orbiting" if moving else "static", same), flush=True)
+        print("world %d, %s camera, %s launches: strips == full frame: %s" %
+              (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", same), flush=True)
         ok = ok and same
 dist.barrier()
 dist.destroy_process_group()
