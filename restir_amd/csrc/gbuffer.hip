@@ -97,6 +97,9 @@ int rs_gbuffer_create(int width, int height, rs_gbuffer** out) {
     }
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&g->forkEv, hipEventDisableTiming), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&g->doneEv, hipEventDisableTiming), "hipEventCreate");
+    // the clears above are enqueued on the default stream, which the auxiliary streams are not ordered after: finish them
+    // before the first render can be launched there
+    if (!e) e = rs_check_hip(hipDeviceSynchronize(), "rs_gbuffer_create");
     if (e) { rs_gbuffer_destroy(g); return e; }
     *out = g;
     return 0;

@@ -582,6 +582,9 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots * kRaySub * kRayStride);
     if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * (size_t)kRaySlots * kRaySub * kRayStride), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
+    // the clears above are enqueued on the default stream, which the auxiliary streams are not ordered after: finish them
+    // before the first primary-ray kernel can be launched there
+    if (!e) e = rs_check_hip(hipDeviceSynchronize(), "rs_restir_init");
     if (e) { rs_restir_free(r); return e; }
     *out = r;
     return 0;
