@@ -233,6 +233,20 @@ def main():
     else:
         total_rays = float(local_rays)
 
+    # HBM bandwidth as this box delivers it to a plain device-to-device copy (report the roofline fraction "of spec"
+    # and "of measured copy"): 1 GiB read + 1 GiB written per copy, best of 10
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").fill_(1.0)
+        dst = torch.empty_like(src)
+        best = 1e9
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        copy_gbs = 2.0 * src.numel() * 4 / (best * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         spatial_us = float(np.median(spatial_ms)) * 1e3
         algo_bytes = ALGO_BYTES_PER_PIXEL * WIDTH * rows
@@ -259,6 +273,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade") if world == 1 else None,
                          "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us,
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }
