@@ -328,6 +328,11 @@ int  rs_eaw_destroy(rs_eaw* f);
 /* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
  * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
 int  rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);
+/* Row-strip form for framebuffer tiling: positions of rows [y0, y1) (EAWaveletFilter's cam.getPosition per tap, computed once),
+ * then one wavelet level (src/denoiser.cu:64-134) on rows [y0, y1).  Level l reads rows up to 2 << l outside the strip from
+ * devColorIn, the G-buffer and the positions; the caller exchanges those colour rows between the levels and owns the buffers. */
+int  rs_eaw_positions_rows(rs_eaw* f, const rs_gbuffer* g, const rs_camera* cam, int y0, int y1);
+int  rs_eaw_level_rows(rs_eaw* f, float* devColorOut, const float* devColorIn, const rs_gbuffer* g, int level, int y0, int y1);
 /* ---- SVGF (src/denoiser.h:45-70) ---------------------------------------------------------- */
 /* SpatioTemporalFilter::create / destroy (src/denoiser.cu:479-504); wavelet sigmas 4 / 128 / 1 as in the reference */
 int  rs_svgf_create(int width, int height, int level, rs_svgf** f);

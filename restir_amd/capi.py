@@ -105,7 +105,7 @@ EXPORTS = [
     "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
-    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_modulate_albedo",
+    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
@@ -200,6 +200,8 @@ def lib():
     L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
     L.rs_eaw_destroy.argtypes = [vp]
     L.rs_eaw_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
+    L.rs_eaw_positions_rows.argtypes = [vp, vp, C.POINTER(Camera), ci, ci]
+    L.rs_eaw_level_rows.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.rs_modulate_albedo.argtypes = [vp, vp]
     L.rs_add_image.argtypes = [vp, vp, ci, ci]
     L.rs_add_image3.argtypes = [vp, vp, vp, ci, ci]
@@ -637,6 +639,12 @@ class EAWFilter:
         p = C.c_void_p(out_ptr)
         check(lib().rs_eaw_filter(self.handle, C.byref(p), in_ptr, gbuf.handle, C.byref(cam)))
         return p.value
+
+    def positions_rows(self, gbuf, cam, y0, y1):
+        check(lib().rs_eaw_positions_rows(self.handle, gbuf.handle, C.byref(cam), y0, y1))
+
+    def level_rows(self, out_ptr, in_ptr, gbuf, level, y0, y1):
+        check(lib().rs_eaw_level_rows(self.handle, out_ptr, in_ptr, gbuf.handle, level, y0, y1))
 
     def destroy(self):
         if self.handle:

@@ -25,9 +25,9 @@ __constant__ float kGaussian5x5[5][5] = {        // src/denoiser.cu:18-24
 };
 
 __global__ void __launch_bounds__(256) k_positions(CamParams cam, const float* __restrict__ depth, const int* __restrict__ primId,
-                                                   float* __restrict__ pos) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cam.width * cam.height) return;
+                                                   float* __restrict__ pos, int first, int last) {
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= last) return;
     const int x = i % cam.width, y = i / cam.width;
     f3 p = splat(0.f);
     if (primId[i] > kNullPrim) p = camera_get_position(cam, x, y, depth[i]);
@@ -40,10 +40,10 @@ template <int MUL>
 __global__ void __launch_bounds__(256) k_wavelet(float* __restrict__ colorOut, const float* __restrict__ colorIn,
                                                  const int* __restrict__ primId, const float* __restrict__ normal,
                                                  const float* __restrict__ pos, int W, int H,
-                                                 float sigDepth, float sigNormal, float sigLumin, int level) {
+                                                 float sigDepth, float sigNormal, float sigLumin, int level, int y0, int y1) {
     const float rLumin = 1.f / sigLumin, rNormal = 1.f / sigNormal, rDepth = 1.f / sigDepth;
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= y1) return;
     const int step = 1 << level;
     const int idxP = y * W + x;
     const int idP = primId[idxP];
@@ -222,12 +222,12 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
     varOut[idxP] = sumW2 < 1.1920928955078125e-7f ? varIn[idxP] : sumVar / sumW2;
 }
 
-int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer* g, int level) {
-    dim3 grid((f->width + 31) / 32, (f->height + 7) / 8);
+int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer* g, int level, int y0, int y1) {
+    dim3 grid((f->width + 31) / 32, (y1 - y0 + 7) / 8);
     const auto pow2 = [](float v) { int e; return v > 0.f && std::isfinite(v) && std::frexp(v, &e) == 0.5f && 1.f / v > 0.f && std::isfinite(1.f / v) && std::isnormal(1.f / v); };
     const int mul = (pow2(f->sigLumin) ? 1 : 0) | (pow2(f->sigNormal) ? 2 : 0) | (pow2(f->sigDepth) ? 4 : 0);
 #define RS_WAVELET(M) hipLaunchKernelGGL(k_wavelet<M>, grid, dim3(256), 0, rs_stream(), out, in, g->primId[g->cur()], g->normal[g->cur()], \
-                                         f->devPos, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin, level)
+                                         f->devPos, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin, level, y0, y1)
     switch (mul) {
         case 0: RS_WAVELET(0); break; case 1: RS_WAVELET(1); break; case 2: RS_WAVELET(2); break; case 3: RS_WAVELET(3); break;
         case 4: RS_WAVELET(4); break; case 5: RS_WAVELET(5); break; case 6: RS_WAVELET(6); break; default: RS_WAVELET(7); break;
@@ -266,17 +266,45 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
     const int n = f->width * f->height;
     hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
-                       g->depth[g->cur()], g->primId[g->cur()], f->devPos);
+                       g->depth[g->cur()], g->primId[g->cur()], f->devPos, 0, n);
     RS_TRY(rs_after_launch("EAW positions"));
     // LeveledEAWFilter::filter (denoiser.cu:463-477): level 0 into out, then four ping-pongs with the
     // internal buffer; the caller's pointer and the internal one are swapped after each
-    RS_TRY(wavelet_level(f, *devColorOut, devColorIn, g, 0));
+    RS_TRY(wavelet_level(f, *devColorOut, devColorIn, g, 0, 0, f->height));
     for (int level = 1; level <= 4; level++) {
-        RS_TRY(wavelet_level(f, f->devTempImg, *devColorOut, g, level));
+        RS_TRY(wavelet_level(f, f->devTempImg, *devColorOut, g, level, 0, f->height));
         float* t = *devColorOut; *devColorOut = f->devTempImg; f->devTempImg = t;
     }
     return 0;
 }
+
+// Row-strip form of the filter for framebuffer tiling (the levels of rs_eaw_filter one by one, on rows [y0, y1)): a level reads
+// its input, the G-buffer ids / normals and the positions up to 2 << level rows outside the strip, so between the levels the
+// caller exchanges those rows of the colour buffer with the neighbouring strips (restir_amd/tiling.py).
+int rs_eaw_positions_rows(rs_eaw* f, const rs_gbuffer* g, const rs_camera* cam, int y0, int y1) {
+    RS_TRY(rs_gbuffer_join(g));
+    if (!f || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW positions: null argument");
+    if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
+    if (y0 < 0) y0 = 0;
+    if (y1 > f->height) y1 = f->height;
+    if (y1 <= y0) return 0;
+    const int first = y0 * f->width, last = y1 * f->width;
+    hipLaunchKernelGGL(k_positions, dim3((last - first + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
+                       g->depth[g->cur()], g->primId[g->cur()], f->devPos, first, last);
+    return rs_after_launch("EAW positions");
+}
+
+int rs_eaw_level_rows(rs_eaw* f, float* devColorOut, const float* devColorIn, const rs_gbuffer* g, int level, int y0, int y1) {
+    RS_TRY(rs_gbuffer_join(g));
+    if (!f || !devColorOut || !devColorIn || !g || level < 0 || level > 30) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW level: bad argument");
+    if (g->width != f->width || g->height != f->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
+    if (y0 < 0) y0 = 0;
+    if (y1 > f->height) y1 = f->height;
+    if (y1 <= y0) return 0;
+    return wavelet_level(f, devColorOut, devColorIn, g, level, y0, y1);
+}
+
 
 // ---- SpatioTemporalFilter (src/denoiser.cu:479-568) -----------------------------------------------------------
 int rs_svgf_destroy(rs_svgf* f) {
@@ -335,7 +363,7 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
     const dim3 grid2((W + 31) / 32, (H + 7) / 8);
     const GBufView gv = gbuf_view(g);
     hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
-                       g->depth[g->cur()], g->primId[g->cur()], f->devPos);
+                       g->depth[g->cur()], g->primId[g->cur()], f->devPos, 0, n);
     // temporalAccumulate (:506-519), estimateVariance (:521-527)
     hipLaunchKernelGGL(k_svgf_temporal, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), f->devAccumColor[fi], f->devAccumColor[fi ^ 1],
                        f->devAccumMoment[fi], f->devAccumMoment[fi ^ 1], devColorIn, gv, f->firstTime ? 1 : 0);

@@ -141,6 +141,45 @@ class StripRenderer:
         if self.y1 > bot_start:
             b.phase_b(iteration, reuse, bot_start, self.y1)
 
+    # ---- LeveledEAWFilter on strips (BASELINE config 5) ----------------------------------------------------------------
+    def _exchange_rows(self, rows, get, put):
+        """Send this strip's first / last `rows` rows to the strip above / below and receive theirs into the rows just outside
+        the strip.  get(y, rows) -> contiguous tensor, put(y, rows, tensor)."""
+        d = self.dist
+        ops, recvs = [], []
+        for peer, send_y, recv_y in ((self.up, self.y0, self.y0 - rows), (self.down, self.y1 - rows, self.y1)):
+            if peer is None:
+                continue
+            send = get(send_y, rows)
+            recv = self.b.torch.empty_like(send)
+            ops += [d.P2POp(d.isend, send, peer), d.P2POp(d.irecv, recv, peer)]
+            recvs.append((recv_y, recv))
+        if ops:
+            self._host_visible()
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        for y, buf in recvs:
+            put(y, rows, buf)
+
+    def eaw_filter(self):
+        """LeveledEAWFilter::filter (src/denoiser.cu:453-477) on this strip's rows of the radiance image: five a-trous levels
+        whose taps reach 2 << level rows beyond the strip.  The G-buffer rows the taps look at (32 at most) come from the
+        neighbouring strips once, and before each level the strips swap the 2 << level border rows of that level's input --
+        the same values a full-frame filter reads there, so the result equals the full-frame filter's rows bit for bit.
+        Returns the backend's result buffer (rows [y0, y1) valid)."""
+        b = self.b
+        reach = 2 << 4
+        if self.world > 1:
+            if min(y1 - y0 for y0, y1 in self.bounds) < reach:
+                raise ValueError("EAW on strips needs strips of at least %d rows" % reach)
+            self._exchange_rows(reach, b.gbuffer_rows_get, b.gbuffer_rows_put)
+        b.eaw_positions(max(0, self.y0 - reach), min(self.height, self.y1 + reach))
+        for level in range(5):
+            if self.world > 1:
+                self._exchange_rows(2 << level, lambda y, n: b.eaw_rows_get(level, y, n), lambda y, n, t: b.eaw_rows_put(level, y, n, t))
+            b.eaw_level(level, self.y0, self.y1)
+        return b.eaw_result()
+
     def exchange_history(self):
         """All-gather of the rows this frame produced that the next frame's temporal merge may read."""
         d = self.dist
@@ -156,7 +195,9 @@ class StripRenderer:
             if r != self.rank:
                 self.b.history_unpack(a, bnd - a, out[r][: self.b.history_bytes(bnd - a)])
 
-    def frame(self, reuse, iteration=0):
+    def frame(self, reuse, iteration=0, denoise=False):
+        """One runCuda frame; denoise=True also runs LeveledEAWFilter on the strip before GBuffer::update (the reference's
+        order, src/main.cpp:146-185) and leaves its result in self.filtered."""
         b = self.b
         if self.world == 1:
             b.gbuffer_render(0, self.height)
@@ -169,6 +210,8 @@ class StripRenderer:
                 self.phase_b_overlapped(iteration, reuse)
             else:
                 b.phase_b(iteration, reuse, self.y0, self.y1)
+        if denoise:
+            self.filtered = self.eaw_filter()
         b.end_frame()
         if self.share_history and (reuse & 1):
             self.exchange_history()
@@ -240,6 +283,41 @@ class HipBackend:
         buf = self.empty(self.restir.halo_bytes(rows))
         self.restir.halo_pack(y0, rows, buf.data_ptr())
         return buf
+
+    # LeveledEAWFilter on strips: level l reads input l (the radiance image for l = 0, else the output of level l - 1) and
+    # writes one of two full-frame buffers, alternating, so that the result of the five levels ends in buffer 0
+    def _eaw_init(self):
+        if getattr(self, "eaw", None) is None:
+            self.eaw = self.capi.EAWFilter(self.W, self.H, 5)
+            self.eaw_buf = [self.torch.zeros_like(self.image), self.torch.zeros_like(self.image)]
+
+    def _eaw_input(self, level):
+        self._eaw_init()
+        return self.image if level == 0 else self.eaw_buf[(level - 1) % 2]
+
+    def gbuffer_rows_get(self, y, rows):
+        buf = self.empty(self.gbuf.rows_bytes(rows))
+        self.gbuf.rows_pack(0, y, rows, buf.data_ptr())
+        return buf
+
+    def gbuffer_rows_put(self, y, rows, buf):
+        self.gbuf.rows_unpack(0, y, rows, buf.contiguous().data_ptr())
+
+    def eaw_rows_get(self, level, y, rows):
+        return self._eaw_input(level)[y * self.W:(y + rows) * self.W]          # rows of a row-major image are contiguous
+
+    def eaw_rows_put(self, level, y, rows, buf):
+        self._eaw_input(level)[y * self.W:(y + rows) * self.W].copy_(buf)
+
+    def eaw_positions(self, y0, y1):
+        self._eaw_init()
+        self.eaw.positions_rows(self.gbuf, self.cam, y0, y1)
+
+    def eaw_level(self, level, y0, y1):
+        self.eaw.level_rows(self.eaw_buf[level % 2].data_ptr(), self._eaw_input(level).data_ptr(), self.gbuf, level, y0, y1)
+
+    def eaw_result(self):
+        return self.eaw_buf[0]
 
     def halo_unpack(self, y0, rows, buf):
         self.restir.halo_unpack(y0, rows, buf.data_ptr())

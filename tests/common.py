@@ -157,6 +157,44 @@ class OracleBackend:
     def halo_unpack(self, y0, rows, buf):
         self._rows(self.restir.temp, y0, rows)[:] = buf.numpy().view(RESERVOIR_DTYPE)
 
+    # LeveledEAWFilter on strips (the interface of HipBackend): two full-frame buffers, the oracle's level on the whole frame
+    # (rows outside the strip and its exchanged border hold stale values and are never looked at)
+    def _eaw_input(self, level):
+        if not hasattr(self, "eaw_buf"):
+            self.eaw_buf = [np.zeros_like(self.image), np.zeros_like(self.image)]
+        return self.image if level == 0 else self.eaw_buf[(level - 1) % 2]
+
+    def gbuffer_rows_get(self, y, rows):
+        cur = self.gbuf.frame_idx
+        parts = [self._rows(self.gbuf.prim_id[cur], y, rows).view(np.uint8).reshape(-1),
+                 self._rows(self.gbuf.normal[cur], y, rows).reshape(-1).view(np.uint8),
+                 self._rows(self.gbuf.depth[cur], y, rows).view(np.uint8).reshape(-1)]
+        return self.torch.from_numpy(np.concatenate(parts))
+
+    def gbuffer_rows_put(self, y, rows, buf):
+        cur = self.gbuf.frame_idx
+        n = rows * self.W
+        b = buf.numpy()
+        self._rows(self.gbuf.prim_id[cur], y, rows)[:] = b[:n * 4].view(np.int32)
+        self._rows(self.gbuf.normal[cur], y, rows)[:] = b[n * 4:n * 16].view(np.float32).reshape(n, 3)
+        self._rows(self.gbuf.depth[cur], y, rows)[:] = b[n * 16:n * 20].view(np.float32)
+
+    def eaw_rows_get(self, level, y, rows):
+        return self.torch.from_numpy(self._rows(self._eaw_input(level), y, rows).copy())
+
+    def eaw_rows_put(self, level, y, rows, buf):
+        self._rows(self._eaw_input(level), y, rows)[:] = buf.numpy()
+
+    def eaw_positions(self, y0, y1):
+        pass                                             # the oracle reconstructs positions per tap from the depth plane
+
+    def eaw_level(self, level, y0, y1):
+        src = self._eaw_input(level)
+        ob.lib().orc_eaw_level(C.byref(self.gbuf.c), C.byref(self.cam), src.reshape(-1), self.eaw_buf[level % 2].reshape(-1), 1.0, 0.2, 64.0, level)
+
+    def eaw_result(self):
+        return self.eaw_buf[0]
+
     def history_bytes(self, rows):
         return rows * self.W * (36 + 20)
 

@@ -543,6 +543,33 @@ def test_eaw_filter(hip):
     assert np.abs(ref - a).max() > 1e-3               # the filter did something
 
 
+def test_eaw_row_strip_form_equals_filter(hip):
+    """rs_eaw_positions_rows + rs_eaw_level_rows (the form the strip tiling drives, restir_amd/tiling.py eaw_filter) over the
+    whole frame, in bands, give the image of rs_eaw_filter bit for bit."""
+    import torch
+    from restir_amd.tiling import HipBackend, StripRenderer
+    sd = get_scene("sponza:0.03")
+    W, H = 160, 96
+    scene = hip_scene(hip, sd)
+    cam = hip.camera_update(sd.camera(W, H))
+    b = HipBackend(hip, scene, cam, W, H)
+    s = StripRenderer(b, 1, 0, H)
+    b.gbuffer_render(0, H); b.phase_a(0, 3, 0, H); b.phase_b(0, 3, 0, H)
+    f = hip.EAWFilter(W, H, 5)
+    out = torch.zeros_like(b.image)
+    p = f.filter(out.data_ptr(), b.image.data_ptr(), b.gbuf, cam)
+    ref = torch.empty_like(b.image); hip.hip_memcpy_d2d(ref.data_ptr(), p, ref.numel() * 4)
+    got = s.eaw_filter().clone()
+    assert bits_equal(ref.cpu().numpy(), got.cpu().numpy())
+    # the same levels in three row bands
+    b.eaw_positions(0, H)
+    for level in range(5):
+        for y0, y1 in ((40, 77), (0, 40), (77, H)):
+            b.eaw_level(level, y0, y1)
+    assert bits_equal(ref.cpu().numpy(), b.eaw_result().cpu().numpy())
+    f.destroy()
+
+
 def test_svgf_filter(hip):
     """SpatioTemporalFilter (denoiser.cu:136-216,250-371,479-568) on an orbiting camera: temporal accumulation through
     devMotion, spatial then (from the fifth frame on) temporal variance, five variance-guided a-trous levels, and
@@ -720,7 +747,8 @@ def test_phase_b_in_row_bands_equals_one_call(hip):
 def test_multi_process_strips_on_one_gpu():
     """The real multi-process path (one process per rank, StripRenderer + HipBackend + torch.distributed point-to-point
     and all-gather) with two ranks sharing this GPU and gloo standing in for RCCL: tools/rehearse_strips.py compares
-    the gathered strips with a full-frame render, static and orbiting camera, synchronous launches and overlapped frames."""
+    the gathered strips with a full-frame render, static and orbiting camera, synchronous launches and overlapped frames,
+    radiance and the EAW-filtered image (BASELINE config 5's denoiser on strips)."""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -728,7 +756,7 @@ def test_multi_process_strips_on_one_gpu():
                         "--master-port", str(port), os.path.join(root, "tools", "rehearse_strips.py")],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("strips == full frame: True") == 4, r.stdout[-2000:]
+    assert r.stdout.count("strips == full frame: True") == 6, r.stdout[-2000:]
 
 
 def test_config4_4k_eight_strips_equal_full_frame(hip):

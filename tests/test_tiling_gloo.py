@@ -25,7 +25,7 @@ def _free_port():
 BALANCED = {3: [(0, 8), (8, 45), (45, 64)]}     # uneven (cost-balanced style) strips: still exact
 
 
-def _worker(rank, world, port, moving, outdir, balanced=False, calibrated=False):
+def _worker(rank, world, port, moving, outdir, balanced=False, calibrated=False, denoise=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,8 +49,10 @@ def _worker(rank, world, port, moving, outdir, balanced=False, calibrated=False)
             for i in range(3):
                 cam.position[i] = float(p[i])
             ob.camera_update(cam)
-        r.frame(3)
+        r.frame(3, denoise=denoise)
     np.save(os.path.join(outdir, f"strip_{rank}.npy"), backend.image[r.y0 * W:r.y1 * W])
+    if denoise:
+        np.save(os.path.join(outdir, f"filtered_{rank}.npy"), r.filtered[r.y0 * W:r.y1 * W])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,6 +96,28 @@ def test_calibrated_strips_equal_full_frame(tmp_path):
     assert all(np.array_equal(b[0], x) for x in b) and b[0][0][0] == 0 and b[0][-1][1] == H
     got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(3)])
     assert np.array_equal(got.view(np.uint32), _reference(True).view(np.uint32))
+
+
+def test_eaw_on_strips_equals_full_frame_filter(tmp_path):
+    """BASELINE config 5's denoiser on a tiled framebuffer: five a-trous levels per strip with the 2 << level border rows of each
+    level's input (and 32 G-buffer rows once) exchanged between neighbours reproduce the full-frame LeveledEAWFilter."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, True, str(tmp_path), False, False, True), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / f"filtered_{r}.npy") for r in range(2)])
+    from oracle import binding as ob
+    from restir_amd.scenes import orbit_position
+    from tests.common import OracleRenderer, get_scene
+    sd = get_scene("sponza:0.02")
+    o = OracleRenderer(sd, W, H)
+    for frame in range(FRAMES):
+        o.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.6))
+        o.gbuf.render(o.scene, o.cam)
+        o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, o.looper, 3)
+        o.looper += 1
+        ref = ob.eaw_filter(o.gbuf, o.cam, o.image).copy()          # denoise before GBuffer::update, as runCuda does
+        o.gbuf.update(o.cam)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.abs(ref - o.image).max() > 1e-3
 
 
 def test_rebalance_bounds():

@@ -23,7 +23,8 @@ capi.init(0)
 sd = scenes.sponza_class(seed=1, scale=0.1)
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
 ok = True
-for moving, overlapped in ((False, False), (True, False), (False, True), (True, True)):
+for moving, overlapped, denoise in ((False, False, False), (True, False, False), (False, True, False), (True, True, False), (True, False, True), (True, True, True)):
+    # denoise: LeveledEAWFilter on the strips (border rows of every level exchanged), compared with the full-frame filter
     # overlapped: asynchronous launches (rs_set_sync(0)) -- frames overlap on the auxiliary streams, as in bench.py
     capi.set_sync(not overlapped)
     cam = capi.camera_update(sd.camera(W, H))
@@ -35,21 +36,22 @@ for moving, overlapped in ((False, False), (True, False), (False, True), (True, 
             for i in range(3):
                 cam.position[i] = float(p[i])
             capi.camera_update(cam)
-        strips.frame(3, 0)
+        strips.frame(3, 0, denoise=denoise)
         if full is not None:
-            full.frame(3, 0)
+            full.frame(3, 0, denoise=denoise)
     torch.cuda.synchronize()
     capi.set_sync(True)
-    mine = strips.b.image[strips.y0 * W:strips.y1 * W].contiguous()
+    src = strips.filtered if denoise else strips.b.image
+    mine = src[strips.y0 * W:strips.y1 * W].contiguous()
     pad = torch.zeros((strips.max_rows * W, 3), dtype=torch.float32, device="cuda"); pad[:mine.shape[0]] = mine
     out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
     dist.gather(pad, out, dst=0)
     if rank == 0:
         got = torch.cat([out[r][:(b[1] - b[0]) * W] for r, b in enumerate(strips.bounds)]).cpu().numpy()
-        ref = full.b.image.cpu().numpy()
+        ref = (full.filtered if denoise else full.b.image).cpu().numpy()
         same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-        print("world %d, %s camera, %s launches: strips == full frame: %s" %
-              (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", same), flush=True)
+        print("world %d, %s camera, %s launches%s: strips == full frame: %s" %
+              (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", ", EAW filter" if denoise else "", same), flush=True)
         ok = ok and same
 dist.barrier()
 dist.destroy_process_group()
