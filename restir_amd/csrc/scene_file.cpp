@@ -6,11 +6,12 @@
 //   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
 //   instance baking of buildDevData   src/scene.cpp:161-176
 //   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
-// What it does not do: decode JPG / TGA / BMP ... (stb_image in the reference).  Texture and environment-map files must be PNG or
-// binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
+// What it does not do: decode progressive JPEG / TGA / BMP ... (stb_image in the reference).  Texture and environment-map files must be
+// PNG, baseline JPEG or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
 // (.hdr, RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
 // :98) and not for the environment map (:124-126).
 // glTF (Resource::loadGLTFMesh) is not read either.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -304,7 +305,7 @@ int load_obj(const std::string& path, Mesh& m) {
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
-    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR and PNG are decoded here; decode other formats in the caller)").c_str()); };
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG and baseline JPEG are decoded here; decode other formats in the caller)").c_str()); };
     auto token = [&](std::string& out) {
         out.clear();
         int c = std::fgetc(f);
@@ -639,7 +640,350 @@ int load_png(const std::string& path, bool flipRows, std::vector<float>& data, i
     return 0;
 }
 
-// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR, 0x89 "PNG" = PNG
+// ---- JPEG (baseline / extended sequential, Huffman, 8 bit) -------------------------------------------------------------------
+// What stbi_loadf(file, .., 3) returns for such a file: entropy decoding and dequantisation as the standard defines them, the
+// integer inverse DCT stb_image uses (jidctint's "slow" form with its rounding: columns keep two extra bits, rows add 65536 +
+// (128 << 17) before >> 17), its chroma up-sampling (nearest for 1x, (3 near + far + 2) >> 2 for 2x in one direction, the
+// (3 (3 a + b) + (3 c + d) + 8) >> 4 tent for 2x2, replication otherwise) and its fixed-point YCbCr -> RGB
+// (external/include/stb_image.h:2267-2340, 3226-3460, 3636-3790); grey files are replicated to RGB, "RGB"-tagged and Adobe
+// transform-0 files are taken as RGB; then byte / 255.  Progressive (SOF2), arithmetic-coded, 12-bit and four-component
+// (CMYK / YCCK) files are not decoded.
+struct JpegHuff { unsigned char bits[17]; unsigned char vals[256]; int mincode[18], maxcode[18], valptr[18]; bool present = false; };
+
+void jpeg_build(JpegHuff& h) {
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; len++) {
+        h.valptr[len] = k;
+        h.mincode[len] = code;
+        code += h.bits[len];
+        k += h.bits[len];
+        h.maxcode[len] = h.bits[len] ? code - 1 : -1;
+        code <<= 1;
+    }
+    h.present = true;
+}
+
+struct JpegBits {
+    const unsigned char* p; size_t n, at; unsigned acc = 0; int have = 0; int marker = -1;
+    int bit() {
+        if (!have) {
+            unsigned b = 0;
+            if (marker < 0 && at < n) {
+                b = p[at++];
+                if (b == 0xff) {
+                    unsigned m = at < n ? p[at] : 0;
+                    while (m == 0xff && at + 1 < n) m = p[++at];          // fill bytes
+                    if (m == 0) at++;                                     // stuffed zero: a data byte 0xff
+                    else { marker = (int)m; at++; b = 0; }                // a marker ends the data: zeros from here on
+                }
+            }
+            acc = b; have = 8;
+        }
+        have--;
+        return (int)((acc >> have) & 1u);
+    }
+    int receive(int count) { int v = 0; for (int i = 0; i < count; i++) v = (v << 1) | bit(); return v; }
+    int extend(int count) {                                               // the signed value of `count` magnitude bits
+        if (!count) return 0;
+        const int v = receive(count);
+        return v < (1 << (count - 1)) ? v - (1 << count) + 1 : v;
+    }
+    int decode(const JpegHuff& h) {
+        int code = 0;
+        for (int len = 1; len <= 16; len++) {
+            code = (code << 1) | bit();
+            if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len]) return h.vals[h.valptr[len] + code - h.mincode[len]];
+        }
+        return -1;
+    }
+    void reset() { acc = 0; have = 0; marker = -1; }
+};
+
+inline unsigned char jpeg_clamp(int x) { return (unsigned char)(x < 0 ? 0 : x > 255 ? 255 : x); }
+
+// one pass of the inverse DCT over s0..s7 (constants scaled by 4096)
+#define RS_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                          \
+    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                 \
+    p2 = s2; p3 = s6; p1 = (p2 + p3) * 2217; t2 = p1 + p3 * -7567; t3 = p1 + p2 * 3135;                    \
+    p2 = s0; p3 = s4; t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                         \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                                 \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                                     \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2; p5 = (p3 + p4) * 4816;                          \
+    t0 = t0 * 1223; t1 = t1 * 8410; t2 = t2 * 12586; t3 = t3 * 6149;                                        \
+    p1 = p5 + p1 * -3685; p2 = p5 + p2 * -10497; p3 = p3 * -8034; p4 = p4 * -1597;                          \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+
+void jpeg_idct(unsigned char* out, int stride, const short d[64]) {
+    int val[64];
+    for (int i = 0; i < 8; i++) {
+        const short* c = d + i;
+        int* v = val + i;
+        if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
+            const int dc = c[0] * 4;
+            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+        }
+        else {
+            RS_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+    }
+    for (int i = 0; i < 8; i++) {
+        const int* v = val + i * 8;
+        unsigned char* o = out + (size_t)i * stride;
+        RS_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+        o[0] = jpeg_clamp((x0 + t3) >> 17); o[7] = jpeg_clamp((x0 - t3) >> 17); o[1] = jpeg_clamp((x1 + t2) >> 17); o[6] = jpeg_clamp((x1 - t2) >> 17);
+        o[2] = jpeg_clamp((x2 + t1) >> 17); o[5] = jpeg_clamp((x2 - t1) >> 17); o[3] = jpeg_clamp((x3 + t0) >> 17); o[4] = jpeg_clamp((x3 - t0) >> 17);
+    }
+}
+#undef RS_IDCT_1D
+
+int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    std::vector<unsigned char> raw;
+    {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+        unsigned char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + got);
+        std::fclose(f);
+    }
+    auto fail = [&](const char* why) { return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path).c_str()); };
+    static const unsigned char zigzag[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+    struct Comp { int id, h, v, tq, td = 0, ta = 0, x, y, w2, h2, pred = 0; std::vector<unsigned char> px; };
+    Comp comp[3];
+    int ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, restart = 0, adobe = -1, rgbTags = 0;
+    bool jfif = false, frame = false, done = false;
+    unsigned short quant[4][64] = {};
+    JpegHuff dc[4], ac[4];
+    const size_t n = raw.size();
+    if (n < 4 || raw[0] != 0xff || raw[1] != 0xd8) return fail("not a JPEG");
+    size_t at = 2;
+    int pendingMarker = -1;
+    while (!done) {
+        int m = pendingMarker;
+        pendingMarker = -1;
+        if (m < 0) {
+            while (at < n && raw[at] != 0xff) at++;                       // (stb skips stray bytes between segments)
+            while (at < n && raw[at] == 0xff) at++;
+            if (at >= n) return fail("truncated JPEG");
+            m = raw[at++];
+        }
+        if (m == 0xd9) break;                                              // EOI
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;              // markers without a segment
+        if (at + 2 > n) return fail("truncated JPEG");
+        const size_t len = ((size_t)raw[at] << 8) | raw[at + 1];
+        if (len < 2 || at + len > n) return fail("corrupt JPEG segment");
+        const unsigned char* q = &raw[at + 2];
+        const size_t body = len - 2;
+        at += len;
+        if (m == 0xc2) return fail("progressive JPEG files are not decoded here");
+        if (m == 0xc0 || m == 0xc1) {                                      // SOF0 / SOF1
+            if (body < 6 || q[0] != 8) return fail("only 8-bit JPEG files are decoded");
+            h = (q[1] << 8) | q[2]; w = (q[3] << 8) | q[4]; ncomp = q[5];
+            if (w <= 0 || h <= 0) return fail("bad JPEG size");
+            if (ncomp != 1 && ncomp != 3) return fail("only grey and three-component JPEG files are decoded");
+            if (body < 6 + 3 * (size_t)ncomp) return fail("corrupt JPEG frame header");
+            static const unsigned char tags[3] = { 'R', 'G', 'B' };
+            for (int i = 0; i < ncomp; i++) {
+                Comp& c = comp[i];
+                c.id = q[6 + 3 * i]; c.h = q[7 + 3 * i] >> 4; c.v = q[7 + 3 * i] & 15; c.tq = q[8 + 3 * i];
+                if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return fail("corrupt JPEG frame header");
+                if (ncomp == 3 && c.id == tags[i]) rgbTags++;
+                hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v);
+            }
+            for (int i = 0; i < ncomp; i++) if (hmax % comp[i].h || vmax % comp[i].v) return fail("unsupported JPEG sampling factors");
+            mcux = (w + hmax * 8 - 1) / (hmax * 8); mcuy = (h + vmax * 8 - 1) / (vmax * 8);
+            for (int i = 0; i < ncomp; i++) {
+                Comp& c = comp[i];
+                c.x = (w * c.h + hmax - 1) / hmax; c.y = (h * c.v + vmax - 1) / vmax;
+                c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8;
+                c.px.assign((size_t)c.w2 * c.h2, 0);
+            }
+            frame = true;
+        }
+        else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc && m != 0xc4)) return fail("unsupported JPEG coding process");
+        else if (m == 0xc4) {                                              // DHT
+            size_t o = 0;
+            while (o + 17 <= body) {
+                const int tc = q[o] >> 4, th = q[o] & 15;
+                if (tc > 1 || th > 3) return fail("corrupt JPEG Huffman table");
+                JpegHuff& t = tc ? ac[th] : dc[th];
+                int total = 0;
+                t.bits[0] = 0;
+                for (int i = 1; i <= 16; i++) { t.bits[i] = q[o + i]; total += t.bits[i]; }
+                if (total > 256 || o + 17 + total > body) return fail("corrupt JPEG Huffman table");
+                std::memcpy(t.vals, q + o + 17, (size_t)total);
+                jpeg_build(t);
+                o += 17 + (size_t)total;
+            }
+        }
+        else if (m == 0xdb) {                                              // DQT
+            size_t o = 0;
+            while (o < body) {
+                const int pq = q[o] >> 4, tq = q[o] & 15;
+                if (pq > 1 || tq > 3 || o + 1 + (pq ? 128 : 64) > body) return fail("corrupt JPEG quantisation table");
+                for (int i = 0; i < 64; i++) quant[tq][zigzag[i]] = pq ? (unsigned short)((q[o + 1 + 2 * i] << 8) | q[o + 2 + 2 * i]) : q[o + 1 + i];
+                o += 1 + (pq ? 128 : 64);
+            }
+        }
+        else if (m == 0xdd) { if (body < 2) return fail("corrupt JPEG restart interval"); restart = (q[0] << 8) | q[1]; }
+        else if (m == 0xe0) { if (body >= 5 && !std::memcmp(q, "JFIF\0", 5)) jfif = true; }
+        else if (m == 0xee) { if (body >= 12 && !std::memcmp(q, "Adobe\0", 6)) adobe = q[11]; }
+        else if (m == 0xda) {                                              // SOS + entropy-coded data
+            if (!frame) return fail("JPEG scan before the frame header");
+            const int ns = body ? q[0] : 0;
+            if (ns < 1 || ns > ncomp || body < 1 + 2 * (size_t)ns + 3) return fail("corrupt JPEG scan header");
+            int order[3];
+            for (int i = 0; i < ns; i++) {
+                int which = -1;
+                for (int k = 0; k < ncomp; k++) if (comp[k].id == q[1 + 2 * i]) which = k;
+                if (which < 0) return fail("corrupt JPEG scan header");
+                comp[which].td = q[2 + 2 * i] >> 4; comp[which].ta = q[2 + 2 * i] & 15;
+                if (comp[which].td > 3 || comp[which].ta > 3 || !dc[comp[which].td].present || !ac[comp[which].ta].present) return fail("JPEG scan without its Huffman tables");
+                order[i] = which;
+            }
+            JpegBits br{ raw.data(), n, at };
+            for (int k = 0; k < ncomp; k++) comp[k].pred = 0;
+            int todo = restart ? restart : 0x7fffffff;
+            auto block = [&](Comp& c, int bx, int by) {
+                short coef[64] = { 0 };
+                const unsigned short* dq = quant[c.tq];
+                const int t = br.decode(dc[c.td]);
+                if (t < 0 || t > 15) return false;
+                c.pred += br.extend(t);
+                coef[0] = (short)(c.pred * dq[0]);
+                for (int k = 1; k < 64;) {
+                    const int rs = br.decode(ac[c.ta]);
+                    if (rs < 0) return false;
+                    const int sz = rs & 15, run = rs >> 4;
+                    if (sz == 0) { if (rs != 0xf0) break; k += 16; }
+                    else {
+                        k += run;
+                        if (k > 63) return false;
+                        const int zz = zigzag[k++];
+                        coef[zz] = (short)(br.extend(sz) * dq[zz]);
+                    }
+                }
+                jpeg_idct(&c.px[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, coef);
+                return true;
+            };
+            auto restart_point = [&]() {
+                if (--todo > 0) return true;
+                // a restart marker ends the interval: drop the padding bits, expect RSTn, start over
+                br.have = 0;
+                if (br.marker < 0) {
+                    while (br.at + 1 < n && !(raw[br.at] == 0xff && raw[br.at + 1] != 0 && raw[br.at + 1] != 0xff)) br.at++;
+                    if (br.at + 1 < n) { br.marker = raw[br.at + 1]; br.at += 2; }
+                }
+                if (br.marker < 0xd0 || br.marker > 0xd7) return false;    // some other marker: the scan is over
+                br.reset();
+                for (int k = 0; k < ncomp; k++) comp[k].pred = 0;
+                todo = restart ? restart : 0x7fffffff;
+                return true;
+            };
+            bool ok = true, more = true;
+            if (ns == 1) {                                                 // one component: its blocks in raster order
+                Comp& c = comp[order[0]];
+                const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+                for (int by = 0; by < bh && ok && more; by++)
+                    for (int bx = 0; bx < bw && ok && more; bx++) { ok = block(c, bx, by); if (ok) more = restart_point(); }
+            }
+            else {
+                for (int my = 0; my < mcuy && ok && more; my++)
+                    for (int mx = 0; mx < mcux && ok && more; mx++) {
+                        for (int i = 0; i < ns && ok; i++) {
+                            Comp& c = comp[order[i]];
+                            for (int y = 0; y < c.v && ok; y++)
+                                for (int x = 0; x < c.h && ok; x++) ok = block(c, mx * c.h + x, my * c.v + y);
+                        }
+                        if (ok) more = restart_point();
+                    }
+            }
+            if (!ok) return fail("corrupt JPEG entropy-coded data");
+            at = br.at;
+            pendingMarker = br.marker;
+            if (pendingMarker >= 0xd0 && pendingMarker <= 0xd7) pendingMarker = -1;
+        }
+        // every other segment (APPn, COM, ...) is skipped
+    }
+    if (!frame) return fail("JPEG without a frame header");
+    // up-sample row by row and convert
+    const bool isRgb = ncomp == 3 && (rgbTags == 3 || (adobe == 0 && !jfif));
+    std::vector<unsigned char> rgb((size_t)w * h * 3), line[3];
+    struct Up { int hs, vs, ystep, ypos, wl; const unsigned char* l0; const unsigned char* l1; } up[3];
+    for (int k = 0; k < ncomp; k++) {
+        up[k].hs = hmax / comp[k].h; up[k].vs = vmax / comp[k].v; up[k].ystep = up[k].vs >> 1; up[k].ypos = 0;
+        up[k].wl = (w + up[k].hs - 1) / up[k].hs; up[k].l0 = up[k].l1 = comp[k].px.data();
+        line[k].assign((size_t)w + 8, 0);
+    }
+    for (int j = 0; j < h; j++) {
+        const unsigned char* src[3] = { nullptr, nullptr, nullptr };
+        for (int k = 0; k < ncomp; k++) {
+            Up& u = up[k];
+            const bool bot = u.ystep >= (u.vs >> 1);
+            const unsigned char* nr = bot ? u.l1 : u.l0;
+            const unsigned char* fr = bot ? u.l0 : u.l1;
+            unsigned char* o = line[k].data();
+            const int wl = u.wl;
+            if (u.hs == 1 && u.vs == 1) src[k] = nr;
+            else if (u.hs == 1 && u.vs == 2) { for (int i = 0; i < wl; i++) o[i] = (unsigned char)((3 * nr[i] + fr[i] + 2) >> 2); src[k] = o; }
+            else if (u.hs == 2 && u.vs == 1) {
+                if (wl == 1) o[0] = o[1] = nr[0];
+                else {
+                    o[0] = nr[0]; o[1] = (unsigned char)((nr[0] * 3 + nr[1] + 2) >> 2);
+                    int i = 1;
+                    for (; i < wl - 1; i++) { const int t = 3 * nr[i] + 2; o[i * 2] = (unsigned char)((t + nr[i - 1]) >> 2); o[i * 2 + 1] = (unsigned char)((t + nr[i + 1]) >> 2); }
+                    o[i * 2] = (unsigned char)((nr[wl - 2] * 3 + nr[wl - 1] + 2) >> 2); o[i * 2 + 1] = nr[wl - 1];
+                }
+                src[k] = o;
+            }
+            else if (u.hs == 2 && u.vs == 2) {
+                if (wl == 1) o[0] = o[1] = (unsigned char)((3 * nr[0] + fr[0] + 2) >> 2);
+                else {
+                    int t1 = 3 * nr[0] + fr[0];
+                    o[0] = (unsigned char)((t1 + 2) >> 2);
+                    for (int i = 1; i < wl; i++) {
+                        const int t0 = t1;
+                        t1 = 3 * nr[i] + fr[i];
+                        o[i * 2 - 1] = (unsigned char)((3 * t0 + t1 + 8) >> 4);
+                        o[i * 2] = (unsigned char)((3 * t1 + t0 + 8) >> 4);
+                    }
+                    o[wl * 2 - 1] = (unsigned char)((t1 + 2) >> 2);
+                }
+                src[k] = o;
+            }
+            else { for (int i = 0; i < wl; i++) for (int r = 0; r < u.hs; r++) if (i * u.hs + r < w + 8) o[i * u.hs + r] = nr[i]; src[k] = o; }
+            if (++u.ystep >= u.vs) {
+                u.ystep = 0;
+                u.l0 = u.l1;
+                if (++u.ypos < comp[k].y) u.l1 += comp[k].w2;
+            }
+        }
+        unsigned char* o = &rgb[(size_t)j * w * 3];
+        if (ncomp == 1) for (int i = 0; i < w; i++) o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = src[0][i];
+        else if (isRgb) for (int i = 0; i < w; i++) { o[3 * i] = src[0][i]; o[3 * i + 1] = src[1][i]; o[3 * i + 2] = src[2][i]; }
+        else for (int i = 0; i < w; i++) {                                 // fixed point: constants (int)(x * 4096 + 0.5) << 8
+            const int yf = (src[0][i] << 20) + (1 << 19), cb = src[1][i] - 128, cr = src[2][i] - 128;
+            int r = yf + cr * (5743 << 8);
+            int g = yf + cr * -(2925 << 8) + ((cb * -(1410 << 8)) & (int)0xffff0000);
+            int b = yf + cb * (7258 << 8);
+            r >>= 20; g >>= 20; b >>= 20;
+            o[3 * i] = jpeg_clamp(r); o[3 * i + 1] = jpeg_clamp(g); o[3 * i + 2] = jpeg_clamp(b);
+        }
+    }
+    data.resize(rgb.size());
+    for (int y = 0; y < h; y++) {
+        const int sy = flipRows ? h - 1 - y : y;
+        for (int i = 0; i < w * 3; i++) data[((size_t)y * w) * 3 + i] = (float)rgb[((size_t)sy * w) * 3 + i] / 255.f;
+    }
+    return 0;
+}
+
+// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR, 0x89 "PNG" = PNG, 0xff 0xd8 = JPEG
 int load_image(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
@@ -648,6 +992,7 @@ int load_image(const std::string& path, bool flipRows, std::vector<float>& data,
     std::fclose(f);
     if (got == 2 && m[0] == '#' && m[1] == '?') return load_hdr(path, flipRows, data, w, h);
     if (got == 2 && m[0] == 0x89 && m[1] == 'P') return load_png(path, flipRows, data, w, h);
+    if (got == 2 && m[0] == 0xff && m[1] == 0xd8) return load_jpeg(path, flipRows, data, w, h);
     return load_ppm(path, flipRows, data, w, h);
 }
 

@@ -68,6 +68,23 @@ def main():
             open(p, "wb").write(data)
             g["variant_" + key] = np.frombuffer(data, np.uint8)
             g["variant_lines_" + key] = np.frombuffer(ref_lines(R, p), np.uint8)
+    # JPEG pictures (written with Pillow: a generation-time dependency only) and what the reference's stb_image makes of them.
+    # The product's decoder is pinned against these directly; the oracle has no JPEG restatement.
+    from PIL import Image
+    rng = np.random.default_rng(12)
+    yy, xx = np.mgrid[0:37, 0:53]
+    pic = np.stack([128 + 100 * np.sin(xx / 7.0 + yy / 11.0), 128 + 100 * np.cos(xx / 5.0), 128 + 90 * np.sin(yy / 3.0)], axis=2) + rng.normal(0, 25, (37, 53, 3))
+    pic = np.clip(pic, 0, 255).astype(np.uint8)
+    variants = {"444": dict(subsampling=0, quality=92), "422": dict(subsampling=1, quality=75), "420": dict(subsampling=2, quality=60, optimize=True),
+                "411": dict(subsampling="4:1:1", quality=70), "restart": dict(subsampling=2, quality=85, restart_marker_blocks=3),
+                "grey": dict(quality=80), "rgb": dict(subsampling=0, quality=90, keep_rgb=True)}
+    with tempfile.TemporaryDirectory() as d:
+        for key, opt in variants.items():
+            p = os.path.join(d, key + ".jpg")
+            (Image.fromarray(pic[..., 1]) if key == "grey" else Image.fromarray(pic)).save(p, "JPEG", **opt)
+            g["jpeg_file_" + key] = np.frombuffer(open(p, "rb").read(), np.uint8)
+            g["jpeg_flip_" + key] = ref_image(R, p, 1)
+            g["jpeg_noflip_" + key] = ref_image(R, p, 0)
     # baking math
     rng = np.random.default_rng(5)
     k = 200
