@@ -6,8 +6,8 @@
 //   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
 //   instance baking of buildDevData   src/scene.cpp:161-176
 //   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
-// What it does not do: decode progressive JPEG / TGA / BMP ... (stb_image in the reference).  Texture and environment-map files must be
-// PNG, baseline JPEG or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
+// What it does not do: decode TGA / BMP / GIF / PSD ... (stb_image in the reference).  Texture and environment-map files must be
+// PNG, JPEG or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
 // (.hdr, RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
 // :98) and not for the environment map (:124-126).
 // glTF (Resource::loadGLTFMesh) is not read either.
@@ -305,7 +305,7 @@ int load_obj(const std::string& path, Mesh& m) {
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
-    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG and baseline JPEG are decoded here; decode other formats in the caller)").c_str()); };
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG and JPEG are decoded here; decode other formats in the caller)").c_str()); };
     auto token = [&](std::string& out) {
         out.clear();
         int c = std::fgetc(f);
@@ -640,14 +640,15 @@ int load_png(const std::string& path, bool flipRows, std::vector<float>& data, i
     return 0;
 }
 
-// ---- JPEG (baseline / extended sequential, Huffman, 8 bit) -------------------------------------------------------------------
+// ---- JPEG (baseline / extended sequential / progressive, Huffman, 8 bit) -------------------------------------------------------------------
 // What stbi_loadf(file, .., 3) returns for such a file: entropy decoding and dequantisation as the standard defines them, the
 // integer inverse DCT stb_image uses (jidctint's "slow" form with its rounding: columns keep two extra bits, rows add 65536 +
 // (128 << 17) before >> 17), its chroma up-sampling (nearest for 1x, (3 near + far + 2) >> 2 for 2x in one direction, the
 // (3 (3 a + b) + (3 c + d) + 8) >> 4 tent for 2x2, replication otherwise) and its fixed-point YCbCr -> RGB
 // (external/include/stb_image.h:2267-2340, 3226-3460, 3636-3790); grey files are replicated to RGB, "RGB"-tagged and Adobe
-// transform-0 files are taken as RGB; then byte / 255.  Progressive (SOF2), arithmetic-coded, 12-bit and four-component
-// (CMYK / YCCK) files are not decoded.
+// transform-0 files are taken as RGB; then byte / 255.  Progressive files accumulate their coefficients over the scans (spectral
+// selection and successive approximation, ITU T.81 annex G) and are transformed at the end.  Arithmetic-coded, 12-bit and
+// four-component (CMYK / YCCK) files are not decoded.
 struct JpegHuff { unsigned char bits[17]; unsigned char vals[256]; int mincode[18], maxcode[18], valptr[18]; bool present = false; };
 
 void jpeg_build(JpegHuff& h) {
@@ -753,10 +754,10 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
     auto fail = [&](const char* why) { return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path).c_str()); };
     static const unsigned char zigzag[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                               35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
-    struct Comp { int id, h, v, tq, td = 0, ta = 0, x, y, w2, h2, pred = 0; std::vector<unsigned char> px; };
+    struct Comp { int id, h, v, tq, td = 0, ta = 0, x, y, w2, h2, pred = 0; std::vector<unsigned char> px; std::vector<short> coef; };
     Comp comp[3];
     int ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, restart = 0, adobe = -1, rgbTags = 0;
-    bool jfif = false, frame = false, done = false;
+    bool jfif = false, frame = false, done = false, progressive = false;
     unsigned short quant[4][64] = {};
     JpegHuff dc[4], ac[4];
     const size_t n = raw.size();
@@ -780,8 +781,8 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
         const unsigned char* q = &raw[at + 2];
         const size_t body = len - 2;
         at += len;
-        if (m == 0xc2) return fail("progressive JPEG files are not decoded here");
-        if (m == 0xc0 || m == 0xc1) {                                      // SOF0 / SOF1
+        if (m == 0xc0 || m == 0xc1 || m == 0xc2) {                         // SOF0 / SOF1 / SOF2 (progressive)
+            progressive = m == 0xc2;
             if (body < 6 || q[0] != 8) return fail("only 8-bit JPEG files are decoded");
             h = (q[1] << 8) | q[2]; w = (q[3] << 8) | q[4]; ncomp = q[5];
             if (w <= 0 || h <= 0) return fail("bad JPEG size");
@@ -802,6 +803,7 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
                 c.x = (w * c.h + hmax - 1) / hmax; c.y = (h * c.v + vmax - 1) / vmax;
                 c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8;
                 c.px.assign((size_t)c.w2 * c.h2, 0);
+                if (progressive) c.coef.assign((size_t)c.w2 * c.h2, 0);      // 64 coefficients per 8x8 block, kept across the scans
             }
             frame = true;
         }
@@ -837,19 +839,93 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
             if (!frame) return fail("JPEG scan before the frame header");
             const int ns = body ? q[0] : 0;
             if (ns < 1 || ns > ncomp || body < 1 + 2 * (size_t)ns + 3) return fail("corrupt JPEG scan header");
+            const int specStart = q[1 + 2 * ns], specEnd = q[2 + 2 * ns], succHigh = q[3 + 2 * ns] >> 4, succLow = q[3 + 2 * ns] & 15;
+            if (progressive) {
+                if (specStart > 63 || specEnd > 63 || specStart > specEnd || succHigh > 13 || succLow > 13) return fail("corrupt JPEG scan header");
+                if ((specStart == 0) != (specEnd == 0) || (specStart && ns != 1)) return fail("corrupt JPEG scan header");
+            }
+            else if (specStart != 0 || succHigh != 0 || succLow != 0) return fail("corrupt JPEG scan header");
+            const bool dcScan = !progressive || specStart == 0, acScan = !progressive || specStart != 0;
             int order[3];
             for (int i = 0; i < ns; i++) {
                 int which = -1;
                 for (int k = 0; k < ncomp; k++) if (comp[k].id == q[1 + 2 * i]) which = k;
                 if (which < 0) return fail("corrupt JPEG scan header");
                 comp[which].td = q[2 + 2 * i] >> 4; comp[which].ta = q[2 + 2 * i] & 15;
-                if (comp[which].td > 3 || comp[which].ta > 3 || !dc[comp[which].td].present || !ac[comp[which].ta].present) return fail("JPEG scan without its Huffman tables");
+                if (comp[which].td > 3 || comp[which].ta > 3) return fail("corrupt JPEG scan header");
+                if ((dcScan && !(progressive && succHigh) && !dc[comp[which].td].present) || (acScan && !ac[comp[which].ta].present)) return fail("JPEG scan without its Huffman tables");
                 order[i] = which;
             }
             JpegBits br{ raw.data(), n, at };
             for (int k = 0; k < ncomp; k++) comp[k].pred = 0;
             int todo = restart ? restart : 0x7fffffff;
+            int eobRun = 0;
+            bool bad = false;
             auto block = [&](Comp& c, int bx, int by) {
+                if (progressive) {                                          // ITU T.81 annex G: this scan's share of the block's coefficients
+                    short* d = &c.coef[((size_t)by * (c.w2 >> 3) + bx) * 64];
+                    if (dcScan) {
+                        if (succHigh == 0) {
+                            std::memset(d, 0, 64 * sizeof(short));
+                            const int t = br.decode(dc[c.td]);
+                            if (t < 0 || t > 15) return false;
+                            c.pred += br.extend(t);
+                            d[0] = (short)(c.pred << succLow);
+                        }
+                        else if (br.bit()) d[0] += (short)(1 << succLow);
+                        return true;
+                    }
+                    if (succHigh == 0) {
+                        if (eobRun) { eobRun--; return true; }
+                        int k = specStart;
+                        do {
+                            const int rs = br.decode(ac[c.ta]);
+                            if (rs < 0) return false;
+                            const int sz = rs & 15, run = rs >> 4;
+                            if (sz == 0) {
+                                if (run < 15) { eobRun = (1 << run); if (run) eobRun += br.receive(run); eobRun--; break; }
+                                k += 16;
+                            }
+                            else {
+                                k += run;
+                                if (k > 63) return false;
+                                d[zigzag[k++]] = (short)(br.extend(sz) << succLow);
+                            }
+                        } while (k <= specEnd);
+                        return true;
+                    }
+                    const short bit = (short)(1 << succLow);                  // refinement of coefficients that are already non-zero
+                    auto refine = [&](short* p) {
+                        if (br.bit() && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+                    };
+                    if (eobRun) {
+                        eobRun--;
+                        for (int k = specStart; k <= specEnd; k++) { short* p = &d[zigzag[k]]; if (*p != 0) refine(p); }
+                        return true;
+                    }
+                    int k = specStart;
+                    do {
+                        const int rs = br.decode(ac[c.ta]);
+                        if (rs < 0) return false;
+                        int sz = rs & 15, run = rs >> 4;
+                        if (sz == 0) {
+                            if (run < 15) { eobRun = (1 << run) - 1; if (run) eobRun += br.receive(run); run = 64; }
+                        }
+                        else {
+                            if (sz != 1) return false;
+                            sz = br.bit() ? bit : -bit;
+                        }
+                        while (k <= specEnd) {
+                            short* p = &d[zigzag[k++]];
+                            if (*p != 0) refine(p);
+                            else {
+                                if (run == 0) { *p = (short)sz; break; }
+                                run--;
+                            }
+                        }
+                    } while (k <= specEnd);
+                    return true;
+                }
                 short coef[64] = { 0 };
                 const unsigned short* dq = quant[c.tq];
                 const int t = br.decode(dc[c.td]);
@@ -882,6 +958,7 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
                 if (br.marker < 0xd0 || br.marker > 0xd7) return false;    // some other marker: the scan is over
                 br.reset();
                 for (int k = 0; k < ncomp; k++) comp[k].pred = 0;
+                eobRun = 0;
                 todo = restart ? restart : 0x7fffffff;
                 return true;
             };
@@ -903,6 +980,7 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
                         if (ok) more = restart_point();
                     }
             }
+            (void)bad;
             if (!ok) return fail("corrupt JPEG entropy-coded data");
             at = br.at;
             pendingMarker = br.marker;
@@ -911,6 +989,17 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
         // every other segment (APPn, COM, ...) is skipped
     }
     if (!frame) return fail("JPEG without a frame header");
+    if (progressive)                                                       // all scans are in: dequantise and transform every block
+        for (int k = 0; k < ncomp; k++) {
+            Comp& c = comp[k];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    short* d = &c.coef[((size_t)by * (c.w2 >> 3) + bx) * 64];
+                    for (int i = 0; i < 64; i++) d[i] = (short)(d[i] * quant[c.tq][i]);
+                    jpeg_idct(&c.px[(size_t)by * 8 * c.w2 + (size_t)bx * 8], c.w2, d);
+                }
+        }
     // up-sample row by row and convert
     const bool isRgb = ncomp == 3 && (rgbTags == 3 || (adobe == 0 && !jfif));
     std::vector<unsigned char> rgb((size_t)w * h * 3), line[3];

@@ -77,11 +77,13 @@ def main():
     pic = np.clip(pic, 0, 255).astype(np.uint8)
     variants = {"444": dict(subsampling=0, quality=92), "422": dict(subsampling=1, quality=75), "420": dict(subsampling=2, quality=60, optimize=True),
                 "411": dict(subsampling="4:1:1", quality=70), "restart": dict(subsampling=2, quality=85, restart_marker_blocks=3),
-                "grey": dict(quality=80), "rgb": dict(subsampling=0, quality=90, keep_rgb=True)}
+                "grey": dict(quality=80), "rgb": dict(subsampling=0, quality=90, keep_rgb=True),
+                "prog420": dict(subsampling=2, quality=65, progressive=True), "prog444": dict(subsampling=0, quality=90, progressive=True, optimize=True),
+                "proggrey": dict(quality=70, progressive=True), "progrestart": dict(subsampling=1, quality=80, progressive=True, restart_marker_blocks=2)}
     with tempfile.TemporaryDirectory() as d:
         for key, opt in variants.items():
             p = os.path.join(d, key + ".jpg")
-            (Image.fromarray(pic[..., 1]) if key == "grey" else Image.fromarray(pic)).save(p, "JPEG", **opt)
+            (Image.fromarray(pic[..., 1]) if key.endswith("grey") else Image.fromarray(pic)).save(p, "JPEG", **opt)
             g["jpeg_file_" + key] = np.frombuffer(open(p, "rb").read(), np.uint8)
             g["jpeg_flip_" + key] = ref_image(R, p, 1)
             g["jpeg_noflip_" + key] = ref_image(R, p, 0)

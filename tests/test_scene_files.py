@@ -286,11 +286,11 @@ def _decode_through_scene(tmp_path, image_path, flipped):
 
 
 def test_product_jpeg_decoder_matches_stb_image_fixture(g, tmp_path):
-    """Baseline JPEG files (4:4:4, 4:2:2, 4:2:0 with optimised tables, 4:1:1, restart markers, grey, RGB-tagged): the library's
-    decoder -- Huffman decoding, stb_image's integer IDCT, chroma up-sampling and fixed-point YCbCr conversion -- returns
-    stbi_loadf's floats bit for bit.  Progressive files are refused."""
+    """Baseline and progressive JPEG files (4:4:4, 4:2:2, 4:2:0 with optimised tables, 4:1:1, restart markers, grey, RGB-tagged):
+    the library's decoder -- Huffman decoding, spectral selection / successive approximation, stb_image's integer IDCT, chroma
+    up-sampling and fixed-point YCbCr conversion -- returns stbi_loadf's floats bit for bit.  Arithmetic coding is refused."""
     keys = [k[len("jpeg_file_"):] for k in g.files if k.startswith("jpeg_file_")]
-    assert len(keys) >= 7
+    assert len(keys) >= 11
     for key in keys:
         p = tmp_path / (key + ".jpg")
         p.write_bytes(g["jpeg_file_" + key].tobytes())
@@ -298,10 +298,10 @@ def test_product_jpeg_decoder_matches_stb_image_fixture(g, tmp_path):
         assert bits_equal(_decode_through_scene(tmp_path, p, False), g["jpeg_noflip_" + key]), key
     raw = bytearray(g["jpeg_file_444"].tobytes())
     i = raw.find(b"\xff\xc0")
-    raw[i + 1] = 0xc2                                       # claim to be progressive
-    p = tmp_path / "prog.jpg"
+    raw[i + 1] = 0xc9                                       # claim to be arithmetic-coded
+    p = tmp_path / "arith.jpg"
     p.write_bytes(bytes(raw))
-    with pytest.raises(capi.RestirHipError, match="progressive"):
+    with pytest.raises(capi.RestirHipError, match="unsupported JPEG coding process"):
         _decode_through_scene(tmp_path, p, True)
 
 
@@ -310,7 +310,7 @@ def test_jpeg_decoder_fuzz_against_stb_image(tmp_path):
     Image = pytest.importorskip("PIL.Image")
     rng = np.random.default_rng(9)
     n = 0
-    for i in range(60):
+    for i in range(90):
         h, w = int(rng.integers(1, 80)), int(rng.integers(1, 100))
         yy, xx = np.mgrid[0:h, 0:w]
         pic = np.stack([128 + 100 * np.sin(xx / 7.0 + yy / 11.0), 128 + 100 * np.cos(xx / 5.0), 128 + 90 * np.sin(yy / 3.0)], axis=2)
@@ -323,6 +323,8 @@ def test_jpeg_decoder_fuzz_against_stb_image(tmp_path):
                 opt["keep_rgb"] = True; opt["subsampling"] = 0
         if i % 3 == 0:
             opt["optimize"] = True
+        if i % 5 in (1, 2):
+            opt["progressive"] = True
         if i % 4 == 1:
             opt["restart_marker_blocks"] = int(rng.integers(1, 9))
         if i % 11 == 5:
@@ -335,7 +337,7 @@ def test_jpeg_decoder_fuzz_against_stb_image(tmp_path):
             assert RL.ref_image_load(p.encode(), flip, C.byref(ww), C.byref(hh), buf.ctypes.data, buf.size) == 0
             assert bits_equal(_decode_through_scene(tmp_path, p, bool(flip)), buf.reshape(h, w, 3)), (i, opt, flip)
             n += 1
-    assert n == 120
+    assert n == 180
 
 
 def test_product_baking_matches_glm_fixture(g):
