@@ -6,12 +6,13 @@
 //   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
 //   instance baking of buildDevData   src/scene.cpp:161-176
 //   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
-// What it does not do: decode TGA / BMP / GIF / PSD ... (stb_image in the reference).  Texture and environment-map files must be
-// PNG, JPEG or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
+// What it does not do: decode BMP / GIF / PSD ... (stb_image in the reference).  Texture and environment-map files must be
+// PNG, JPEG, TGA or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
 // (.hdr, RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
 // :98) and not for the environment map (:124-126).
 // glTF (Resource::loadGLTFMesh) is not read either.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -305,7 +306,7 @@ int load_obj(const std::string& path, Mesh& m) {
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
-    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG and JPEG are decoded here; decode other formats in the caller)").c_str()); };
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG, JPEG and TGA are decoded here; decode other formats in the caller)").c_str()); };
     auto token = [&](std::string& out) {
         out.clear();
         int c = std::fgetc(f);
@@ -1072,6 +1073,106 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
     return 0;
 }
 
+// ---- TGA ------------------------------------------------------------------------------------------------------------
+// Truevision TGA as stb_image reads it (external/include/stb_image.h:5520-5720): image types 1 / 2 / 3 (colour-mapped, true
+// colour, grey) and their run-length coded forms 9 / 10 / 11; 8, 15 / 16 (5-5-5, scaled v * 255 / 31), 24 and 32 bits; colour
+// maps of those depths; rows bottom-up unless bit 5 of the descriptor says top-down; BGR order in the file.  To RGB as for the
+// other formats (grey replicated, alpha dropped), byte / 255.  The format has no signature: files are taken as TGA by name.
+int load_tga(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    std::vector<unsigned char> raw;
+    {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+        unsigned char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + got);
+        std::fclose(f);
+    }
+    auto fail = [&](const char* why) { return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path).c_str()); };
+    if (raw.size() < 18) return fail("truncated TGA header");
+    const int idLen = raw[0], indexed = raw[1];
+    int type = raw[2];
+    const int palStart = raw[3] | (raw[4] << 8), palLen = raw[5] | (raw[6] << 8), palBits = raw[7];
+    w = raw[12] | (raw[13] << 8); h = raw[14] | (raw[15] << 8);
+    const int bpp = raw[16], bottomUp = 1 - ((raw[17] >> 5) & 1);
+    const bool rle = type >= 8;
+    if (rle) type -= 8;
+    if (type < 1 || type > 3 || w <= 0 || h <= 0 || (indexed != 0) != (type == 1)) return fail("unsupported TGA image type");
+    auto channels = [](int bits, bool grey, bool& rgb16) {
+        rgb16 = false;
+        switch (bits) {
+        case 8: return 1;
+        case 16: if (grey) return 2;  // grey + alpha
+                 // fall through
+        case 15: rgb16 = true; return 3;
+        case 24: return 3;
+        case 32: return 4;
+        default: return 0;
+        }
+    };
+    bool rgb16 = false;
+    const int comp = indexed ? channels(palBits, false, rgb16) : channels(bpp, type == 3, rgb16);
+    if (!comp || (indexed && bpp != 8 && bpp != 16)) return fail("unsupported TGA pixel format");
+    size_t at = 18 + (size_t)idLen;
+    auto need = [&](size_t count) { return at + count <= raw.size(); };
+    auto rgb555 = [&](unsigned char* o) {
+        const unsigned px = raw[at] | (raw[at + 1] << 8);
+        at += 2;
+        o[0] = (unsigned char)((((px >> 10) & 31) * 255) / 31); o[1] = (unsigned char)((((px >> 5) & 31) * 255) / 31); o[2] = (unsigned char)(((px & 31) * 255) / 31);
+    };
+    std::vector<unsigned char> palette;
+    if (indexed) {
+        at += (size_t)palStart;                                            // (stb skips this many bytes before the colour map)
+        palette.resize((size_t)palLen * comp);
+        if (rgb16) { if (!need((size_t)palLen * 2)) return fail("truncated TGA colour map"); for (int i = 0; i < palLen; i++) rgb555(&palette[(size_t)i * 3]); }
+        else { if (!need(palette.size())) return fail("truncated TGA colour map"); std::memcpy(palette.data(), &raw[at], palette.size()); at += palette.size(); }
+    }
+    std::vector<unsigned char> px((size_t)w * h * comp);
+    unsigned char cur[4] = { 0, 0, 0, 0 };
+    int count = 0;
+    bool repeating = false, read = true;
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        if (rle) {
+            if (count == 0) {
+                if (!need(1)) return fail("truncated TGA pixel data");
+                const int cmd = raw[at++];
+                count = 1 + (cmd & 127); repeating = (cmd >> 7) != 0; read = true;
+            }
+            else if (!repeating) read = true;
+        }
+        else read = true;
+        if (read) {
+            if (indexed) {
+                if (!need(bpp == 8 ? 1 : 2)) return fail("truncated TGA pixel data");
+                int idx = bpp == 8 ? raw[at] : (raw[at] | (raw[at + 1] << 8));
+                at += bpp == 8 ? 1 : 2;
+                if (idx >= palLen) idx = 0;
+                for (int j = 0; j < comp; j++) cur[j] = palLen ? palette[(size_t)idx * comp + j] : 0;
+            }
+            else if (rgb16) { if (!need(2)) return fail("truncated TGA pixel data"); rgb555(cur); }
+            else { if (!need((size_t)comp)) return fail("truncated TGA pixel data"); for (int j = 0; j < comp; j++) cur[j] = raw[at++]; }
+            read = false;
+        }
+        for (int j = 0; j < comp; j++) px[i * comp + j] = cur[j];
+        count--;
+    }
+    data.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) {
+        int sy = bottomUp ? h - 1 - y : y;                                 // file order -> top-down ...
+        if (flipRows) sy = bottomUp ? y : h - 1 - y;                       // ... and the loader's vertical flip on top of it
+        for (int x = 0; x < w; x++) {
+            const unsigned char* q = &px[((size_t)sy * w + x) * comp];
+            unsigned char r, g, b;
+            if (comp <= 2) r = g = b = q[0];
+            else if (rgb16) { r = q[0]; g = q[1]; b = q[2]; }
+            else { r = q[2]; g = q[1]; b = q[0]; }
+            float* o = &data[((size_t)y * w + x) * 3];
+            o[0] = (float)r / 255.f; o[1] = (float)g / 255.f; o[2] = (float)b / 255.f;
+        }
+    }
+    return 0;
+}
+
 // by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR, 0x89 "PNG" = PNG, 0xff 0xd8 = JPEG
 int load_image(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
@@ -1082,6 +1183,11 @@ int load_image(const std::string& path, bool flipRows, std::vector<float>& data,
     if (got == 2 && m[0] == '#' && m[1] == '?') return load_hdr(path, flipRows, data, w, h);
     if (got == 2 && m[0] == 0x89 && m[1] == 'P') return load_png(path, flipRows, data, w, h);
     if (got == 2 && m[0] == 0xff && m[1] == 0xd8) return load_jpeg(path, flipRows, data, w, h);
+    if (path.size() >= 4) {
+        std::string ext = path.substr(path.size() - 4);
+        for (char& c : ext) c = (char)std::tolower((unsigned char)c);
+        if (ext == ".tga") return load_tga(path, flipRows, data, w, h);
+    }
     return load_ppm(path, flipRows, data, w, h);
 }
 

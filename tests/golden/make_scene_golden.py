@@ -87,6 +87,33 @@ def main():
             g["jpeg_file_" + key] = np.frombuffer(open(p, "rb").read(), np.uint8)
             g["jpeg_flip_" + key] = ref_image(R, p, 1)
             g["jpeg_noflip_" + key] = ref_image(R, p, 0)
+    # TGA pictures: Pillow writes the 8 / 24 / 32-bit kinds (plain and run-length coded, both row orders, colour-mapped); the
+    # 16-bit 5-5-5 kinds (true colour and a 15-bit colour map) are assembled by hand
+    import struct
+    rng = np.random.default_rng(13)
+    with tempfile.TemporaryDirectory() as d:
+        def add(key, p):
+            g["tga_file_" + key] = np.frombuffer(open(p, "rb").read(), np.uint8)
+            g["tga_flip_" + key] = ref_image(R, p, 1)
+            g["tga_noflip_" + key] = ref_image(R, p, 0)
+        a = rng.integers(0, 256, (11, 19, 4), dtype=np.uint8)
+        a[:, 9:] = a[:, 9:10]
+        for key, im, opt in (("rgb", Image.fromarray(a[..., :3]), dict(orientation=-1)), ("rgba_rle", Image.fromarray(a), dict(compression="tga_rle", orientation=1)),
+                             ("grey_rle", Image.fromarray(a[..., 0]), dict(compression="tga_rle", orientation=-1)), ("la", Image.fromarray(a[..., :2], "LA"), dict(orientation=1))):
+            p = os.path.join(d, key + ".tga")
+            im.save(p, "TGA", **opt)
+            add(key, p)
+        im = Image.fromarray(a[..., 0], "P"); im.putpalette(rng.integers(0, 256, 768, dtype=np.uint8).tobytes())
+        p = os.path.join(d, "pal.tga"); im.save(p, "TGA", compression="tga_rle", orientation=-1); add("pal_rle", p)
+        px16 = rng.integers(0, 65536, (7, 13), dtype=np.uint16)
+        p = os.path.join(d, "rgb16.tga")
+        open(p, "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 13, 7, 16, 0x20) + px16.astype("<u2").tobytes())
+        add("rgb16", p)
+        idx = rng.integers(0, 40, (5, 9), dtype=np.uint8)
+        pal = rng.integers(0, 32768, 32, dtype=np.uint16)              # indices 32..39 fall outside the map: entry 0, as stb_image does
+        p = os.path.join(d, "pal15.tga")
+        open(p, "wb").write(struct.pack("<BBBHHBHHHHBB", 3, 1, 1, 0, 32, 15, 0, 0, 9, 5, 8, 0) + b"id!" + pal.astype("<u2").tobytes() + idx.tobytes())
+        add("pal15", p)
     # baking math
     rng = np.random.default_rng(5)
     k = 200

@@ -305,6 +305,18 @@ def test_product_jpeg_decoder_matches_stb_image_fixture(g, tmp_path):
         _decode_through_scene(tmp_path, p, True)
 
 
+def test_product_tga_decoder_matches_stb_image_fixture(g, tmp_path):
+    """TGA files -- true colour 24 / 32 / 16 bit (5-5-5), grey, grey + alpha, colour-mapped (24-bit and 15-bit maps, indices past
+    the map), plain and run-length coded, bottom-up and top-down -- decode to stbi_loadf's floats under both flip settings."""
+    keys = [k[len("tga_file_"):] for k in g.files if k.startswith("tga_file_")]
+    assert len(keys) >= 7
+    for key in keys:
+        p = tmp_path / (key + ".TGA")                        # recognised by name, any case
+        p.write_bytes(g["tga_file_" + key].tobytes())
+        assert bits_equal(_decode_through_scene(tmp_path, p, True), g["tga_flip_" + key]), key
+        assert bits_equal(_decode_through_scene(tmp_path, p, False), g["tga_noflip_" + key]), key
+
+
 @needs_ref
 def test_jpeg_decoder_fuzz_against_stb_image(tmp_path):
     Image = pytest.importorskip("PIL.Image")
