@@ -142,6 +142,66 @@ def obj_real(tok):
         return np.float32(val)
 
 
+def _ear_clip(cs, pv):
+    """tinyobjloader's triangulation of a polygon with five or more corners (tiny_obj_loader.h:1536-1800), float32 throughout."""
+    f = np.float32
+    n0 = len(cs)
+    P = [np.asarray(pv[c[0]], np.float32) for c in cs]
+    ax0, ax1 = 1, 2
+    with np.errstate(all="ignore"):
+        for k in range(n0):
+            a, b, c = P[k], P[(k + 1) % n0], P[(k + 2) % n0]
+            e0, e1 = b - a, c - b
+            cx = abs(f(f(e0[1] * e1[2]) - f(e0[2] * e1[1]))); cy = abs(f(f(e0[2] * e1[0]) - f(e0[0] * e1[2]))); cz = abs(f(f(e0[0] * e1[1]) - f(e0[1] * e1[0])))
+            eps = f(1.1920928955078125e-7)
+            if cx > eps or cy > eps or cz > eps:
+                if not (cx > cy and cx > cz):
+                    ax0 = 0
+                    if cz > cx and cz > cy:
+                        ax1 = 1
+                break
+        rest = list(range(n0))
+        out = []
+        guess, budget, previous = 0, n0, n0
+        while len(rest) > 3 and budget > 0:
+            n = len(rest)
+            if guess >= n:
+                guess -= n
+            if previous != n:
+                previous, budget = n, n
+            else:
+                budget -= 1
+            ear = [rest[(guess + k) % n] for k in range(3)]
+            vx = [P[e][ax0] for e in ear]; vy = [P[e][ax1] for e in ear]
+            e0x, e0y, e1x, e1y = f(vx[1] - vx[0]), f(vy[1] - vy[0]), f(vx[2] - vx[1]), f(vy[2] - vy[1])
+            cross = f(f(e0x * e1y) - f(e0y * e1x))
+            area = f(f(f(vx[0] * vy[1]) - f(vy[0] * vx[1])) * f(0.5))
+            if f(cross * area) < 0:
+                guess += 1
+                continue
+            overlap = False
+            for other in range(3, n):
+                o = rest[(guess + other) % n]
+                tx, ty = P[o][ax0], P[o][ax1]
+                inside = False
+                j = 2
+                for i in range(3):
+                    if (vy[i] > ty) != (vy[j] > ty) and tx < f(f(f(f(vx[j] - vx[i]) * f(ty - vy[i])) / f(vy[j] - vy[i])) + vx[i]):
+                        inside = not inside
+                    j = i
+                if inside:
+                    overlap = True
+                    break
+            if overlap:
+                guess += 1
+                continue
+            out += ear
+            del rest[(guess + 1) % n]
+        if len(rest) == 3:
+            out += rest
+    return [cs[i] for i in out]
+
+
 def load_obj(path):
     """(vertices, normals, texcoords) de-indexed as Resource::loadOBJMesh leaves them: (n, 3), (n, 3), (n, 2) float32; None when the
     file cannot be opened."""
@@ -184,7 +244,7 @@ def load_obj(path):
                 order = (0, 1, 2, 0, 2, 3) if sqr02 < sqr13 else (0, 1, 3, 1, 2, 3)
                 flat += [cs[q] for q in order]
             else:
-                raise ValueError(f"{path}: polygon with more than four corners")
+                flat += _ear_clip(cs, pv)
     has_tc = len(pt) > 0
     v = np.array([pv[c[0]] for c in flat], np.float32).reshape(-1, 3)
     n = np.array([pn[c[2]] for c in flat], np.float32).reshape(-1, 3)

@@ -224,8 +224,7 @@ float obj_real(const char* c, const char* end) {
 
 // The subset of Wavefront OBJ the reference gets through tinyobj::LoadObj (triangulate = true): v / vn / vt / f with 1-based and
 // negative indices; a quad is split along its shorter diagonal (tiny_obj_loader.h:1429-1524); other statements (o, g, s, usemtl,
-// mtllib, comments) do not change the flattened corner order.  Polygons with more than four corners (ear clipping there) are not
-// accepted.  Every corner needs a normal (the reference indexes attrib.normals unconditionally, scene.cpp:44).
+// mtllib, comments) do not change the flattened corner order; polygons with more corners are ear-clipped as there.  Every corner needs a normal (the reference indexes attrib.normals unconditionally, scene.cpp:44).
 // returns 0, an error, or -1 when the file cannot be opened (the caller skips the object, as scene.cpp:234-240 does)
 int load_obj(const std::string& path, Mesh& m) {
     Lines in;
@@ -288,7 +287,55 @@ int load_obj(const std::string& path, Mesh& m) {
                 if (sqr02 < sqr13) for (int q : { 0, 1, 2, 0, 2, 3 }) flat.push_back(cs[q]);
                 else for (int q : { 0, 1, 3, 1, 2, 3 }) flat.push_back(cs[q]);
             }
-            else return rs_fail(RS_ERR_UNSUPPORTED, ("polygon with more than four corners in " + path + ": triangulate the mesh first").c_str());
+            else {
+                // five corners and more: tinyobjloader's ear clipping (tiny_obj_loader.h:1536-1800) in the plane of the two axes
+                // picked from the first corner that is not degenerate; the same float expressions, so the same ears in the same
+                // order (and, like there, a polygon it cannot finish within its iteration budget yields fewer triangles)
+                const size_t np0 = cs.size();
+                int ax0 = 1, ax1 = 2;
+                for (size_t k = 0; k < np0; k++) {
+                    const float* a = &pv[(size_t)cs[k].v * 3]; const float* b = &pv[(size_t)cs[(k + 1) % np0].v * 3]; const float* c = &pv[(size_t)cs[(k + 2) % np0].v * 3];
+                    const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2];
+                    const float e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+                    const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+                    const float eps = 1.1920928955078125e-7f;
+                    if (cx > eps || cy > eps || cz > eps) {
+                        if (!(cx > cy && cx > cz)) { ax0 = 0; if (cz > cx && cz > cy) ax1 = 1; }
+                        break;
+                    }
+                }
+                std::vector<Corner> rest(cs);
+                size_t guess = 0, budget = np0, previous = np0;
+                while (rest.size() > 3 && budget > 0) {
+                    const size_t np = rest.size();
+                    if (guess >= np) guess -= np;
+                    if (previous != np) { previous = np; budget = np; }
+                    else budget--;
+                    Corner ear[3];
+                    float vx[3], vy[3];
+                    for (int k = 0; k < 3; k++) {
+                        ear[k] = rest[(guess + k) % np];
+                        vx[k] = pv[(size_t)ear[k].v * 3 + ax0]; vy[k] = pv[(size_t)ear[k].v * 3 + ax1];
+                    }
+                    const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+                    const float cross = e0x * e1y - e0y * e1x;
+                    const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+                    if (cross * area < 0.f) { guess += 1; continue; }      // "an internal angle"
+                    bool overlap = false;
+                    for (size_t other = 3; other < np && !overlap; other++) {
+                        const Corner& o = rest[(guess + other) % np];
+                        const float tx = pv[(size_t)o.v * 3 + ax0], ty = pv[(size_t)o.v * 3 + ax1];
+                        bool inside = false;                               // point in the candidate triangle (crossing number)
+                        for (int i = 0, j = 2; i < 3; j = i++)
+                            if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) inside = !inside;
+                        overlap = inside;
+                    }
+                    if (overlap) { guess += 1; continue; }
+                    flat.push_back(ear[0]); flat.push_back(ear[1]); flat.push_back(ear[2]);
+                    rest.erase(rest.begin() + (long)((guess + 1) % np));
+                }
+                if (rest.size() == 3) flat.insert(flat.end(), rest.begin(), rest.end());
+            }
         }
     }
     const bool hasTexcoord = !pt.empty();                              // scene.cpp:39,46-49

@@ -60,6 +60,35 @@ f 3//1 7//2 8//2
 """
 
 
+# polygons with more than four corners: tinyobjloader's ear clipping (convex, concave, tilted, with a repeated corner)
+POLY_OBJ = """vn 0 0 1
+vn 0.6 0 0.8
+v 0 0 0
+v 2 0 0
+v 2.5 1 0
+v 1 2 0
+v -0.5 1 0
+f 1//1 2//1 3//1 4//1 5//1
+v 0 0 1
+v 1 0.2 1
+v 2 0 1
+v 1.6 1 1
+v 2 2 1
+v 1 1.7 1
+v 0 2 1
+v 0.4 1 1
+f 6//1 7//1 8//1 9//1 10//1 11//1 12//1 13//1
+v 0 0 2
+v 1 0 2.75
+v 1 0 2.75
+v 2 1 3.5
+v 1 2 2.75
+v 0 1 2
+f 14//2 15//2 16//2 17//2 18//2 19//2
+f -6//2 -4//2 -3//2 -2//2 -1//2
+"""
+
+
 def _noise_image(rng, h, w):
     return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
 
@@ -108,6 +137,8 @@ def write_case(directory, newline="\n", seed=11):
         f.write(CUBE_OBJ)
     with open(os.path.join(directory, "numbers.obj"), "w") as f:
         f.write(NUMBERS_OBJ)
+    with open(os.path.join(directory, "poly.obj"), "w") as f:
+        f.write(POLY_OBJ)
 
     mats = [("white", dict(type=0, baseColor="base.ppm")),
             ("red", dict(type=0, baseColor="Procedural")),
@@ -131,7 +162,7 @@ def write_case(directory, newline="\n", seed=11):
     return path
 
 
-CASE_FILES = ("scene.txt", "floor.obj", "walls.obj", "light.obj", "cube.obj", "numbers.obj",
+CASE_FILES = ("scene.txt", "floor.obj", "walls.obj", "light.obj", "cube.obj", "numbers.obj", "poly.obj",
               "base.ppm", "metal.ppm", "rough.ppm", "nrm.ppm", "env.ppm", "env.hdr", "flat.hdr", "narrow.hdr",
               "metal.png", "rough.png", "rgba.png", "rgb16.png")
 
