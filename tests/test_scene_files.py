@@ -306,6 +306,92 @@ def test_product_obj_reader_matches_tinyobj_fixture(g, case_dir, tmp_path, name)
     assert a.env_map_tex == -1 and len(a.textures) == 0 and len(a.materials) == 1
 
 
+_ONE_TRIANGLE = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n"
+_CAMERA = "Camera\nResolution 8 8\nFovY 20\nLensRadius 0\nFocalDist 1\nApertureMask Null\nSample 1\nDepth 1\nFile x\nEye 0 0 3\nRotation -90 0 0\nUp 0 1 0\n\n"
+
+
+def _decode_through_scene(tmp_path, image_path, flipped):
+    """The library's picture decoder, reached the way a scene reaches it: as a texture (rows flipped) or as the environment map."""
+    obj = tmp_path / "one.obj"
+    obj.write_text(_ONE_TRIANGLE)
+    scene = tmp_path / "one.txt"
+    if flipped:
+        scene.write_text(f"Material m\nType Lambertian\nBaseColor {image_path}\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n"
+                         f"Object o\n{obj}\nMaterial m\nScale 1 1 1\n\n" + _CAMERA)
+    else:
+        scene.write_text(f"Object o\n{obj}\nMaterial Null\nScale 1 1 1\n\n" + _CAMERA + f"EnvMap {image_path}\n")
+    a = capi.SceneFile(str(scene))
+    assert len(a.textures) == 1
+    return a.textures[0]
+
+
+def test_product_jpeg_decoder_matches_stb_image_fixture(g, tmp_path):
+    """Baseline and progressive JPEG files (4:4:4, 4:2:2, 4:2:0 with optimised tables, 4:1:1, restart markers, grey, RGB-tagged):
+    the library's decoder -- Huffman decoding, spectral selection / successive approximation, stb_image's integer IDCT, chroma
+    up-sampling and fixed-point YCbCr conversion -- returns stbi_loadf's floats bit for bit.  Arithmetic coding is refused."""
+    keys = [k[len("jpeg_file_"):] for k in g.files if k.startswith("jpeg_file_")]
+    assert len(keys) >= 11
+    for key in keys:
+        p = tmp_path / (key + ".jpg")
+        p.write_bytes(g["jpeg_file_" + key].tobytes())
+        assert bits_equal(_decode_through_scene(tmp_path, p, True), g["jpeg_flip_" + key]), key
+        assert bits_equal(_decode_through_scene(tmp_path, p, False), g["jpeg_noflip_" + key]), key
+    raw = bytearray(g["jpeg_file_444"].tobytes())
+    i = raw.find(b"\xff\xc0")
+    raw[i + 1] = 0xc9                                       # claim to be arithmetic-coded
+    p = tmp_path / "arith.jpg"
+    p.write_bytes(bytes(raw))
+    with pytest.raises(capi.RestirHipError, match="unsupported JPEG coding process"):
+        _decode_through_scene(tmp_path, p, True)
+
+
+def test_product_tga_decoder_matches_stb_image_fixture(g, tmp_path):
+    """TGA files -- true colour 24 / 32 / 16 bit (5-5-5), grey, grey + alpha, colour-mapped (24-bit and 15-bit maps, indices past
+    the map), plain and run-length coded, bottom-up and top-down -- decode to stbi_loadf's floats under both flip settings."""
+    keys = [k[len("tga_file_"):] for k in g.files if k.startswith("tga_file_")]
+    assert len(keys) >= 7
+    for key in keys:
+        p = tmp_path / (key + ".TGA")                        # recognised by name, any case
+        p.write_bytes(g["tga_file_" + key].tobytes())
+        assert bits_equal(_decode_through_scene(tmp_path, p, True), g["tga_flip_" + key]), key
+        assert bits_equal(_decode_through_scene(tmp_path, p, False), g["tga_noflip_" + key]), key
+
+
+@needs_ref
+def test_jpeg_decoder_fuzz_against_stb_image(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(9)
+    n = 0
+    for i in range(90):
+        h, w = int(rng.integers(1, 80)), int(rng.integers(1, 100))
+        yy, xx = np.mgrid[0:h, 0:w]
+        pic = np.stack([128 + 100 * np.sin(xx / 7.0 + yy / 11.0), 128 + 100 * np.cos(xx / 5.0), 128 + 90 * np.sin(yy / 3.0)], axis=2)
+        pic = np.clip(pic + rng.normal(0, float(rng.choice([0, 10, 60])), pic.shape), 0, 255).astype(np.uint8)
+        opt = dict(quality=int(rng.integers(1, 101)))
+        grey = i % 7 == 3
+        if not grey:
+            opt["subsampling"] = [0, 1, 2, "4:1:1"][int(rng.integers(0, 4))]
+            if i % 9 == 4:
+                opt["keep_rgb"] = True; opt["subsampling"] = 0
+        if i % 3 == 0:
+            opt["optimize"] = True
+        if i % 5 in (1, 2):
+            opt["progressive"] = True
+        if i % 4 == 1:
+            opt["restart_marker_blocks"] = int(rng.integers(1, 9))
+        if i % 11 == 5:
+            opt["restart_marker_rows"] = 1
+        p = str(tmp_path / f"f{i}.jpg")
+        (Image.fromarray(pic[..., 0]) if grey else Image.fromarray(pic)).save(p, "JPEG", **opt)
+        for flip in (0, 1):
+            ww, hh = C.c_int(), C.c_int()
+            buf = np.zeros(h * w * 3, np.float32)
+            assert RL.ref_image_load(p.encode(), flip, C.byref(ww), C.byref(hh), buf.ctypes.data, buf.size) == 0
+            assert bits_equal(_decode_through_scene(tmp_path, p, bool(flip)), buf.reshape(h, w, 3)), (i, opt, flip)
+            n += 1
+    assert n == 180
+
+
 def test_product_baking_matches_glm_fixture(g):
     for i in range(len(g["bake_t"])):
         t, r, s = g["bake_t"][i], g["bake_r"][i], g["bake_s"][i]
