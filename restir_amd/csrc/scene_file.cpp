@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -519,6 +520,7 @@ bool inflate_zlib(const std::vector<unsigned char>& in, std::vector<unsigned cha
             if ((len ^ 0xffffu) != nlen || br.at + len > br.n) return false;
             out.insert(out.end(), br.p + br.at, br.p + br.at + len);
             br.at += len;
+            if (out.size() > expected) return false;                  // more data than the picture has: not a valid stream
         }
         else if (type == 1 || type == 2) {
             Huffman lit, dist;
@@ -556,7 +558,7 @@ bool inflate_zlib(const std::vector<unsigned char>& in, std::vector<unsigned cha
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0) return false;
-                if (sym < 256) out.push_back((unsigned char)sym);
+                if (sym < 256) { if (out.size() >= expected) return false; out.push_back((unsigned char)sym); }
                 else if (sym == 256) break;
                 else {
                     if (sym > 285) return false;
@@ -566,6 +568,7 @@ bool inflate_zlib(const std::vector<unsigned char>& in, std::vector<unsigned cha
                     const size_t d = (size_t)distBase[ds] + (size_t)br.bits(distExtra[ds]);
                     if (br.bad || d > out.size()) return false;
                     const size_t from = out.size() - d;
+                    if (out.size() + (size_t)len > expected) return false;
                     for (int i = 0; i < len; i++) out.push_back(out[from + i]);
                 }
             }
@@ -918,7 +921,7 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
                             const int t = br.decode(dc[c.td]);
                             if (t < 0 || t > 15) return false;
                             c.pred += br.extend(t);
-                            d[0] = (short)(c.pred << succLow);
+                            d[0] = (short)(c.pred * (1 << succLow));
                         }
                         else if (br.bit()) d[0] += (short)(1 << succLow);
                         return true;
@@ -937,7 +940,7 @@ int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, 
                             else {
                                 k += run;
                                 if (k > 63) return false;
-                                d[zigzag[k++]] = (short)(br.extend(sz) << succLow);
+                                d[zigzag[k++]] = (short)(br.extend(sz) * (1 << succLow));
                             }
                         } while (k <= specEnd);
                         return true;
@@ -1442,6 +1445,8 @@ int rs_scene_file_load(const char* path, rs_scene_file** out) {
             if (tokens[1] != "Null") if (int e = add_texture(s, dir, tokens[1], false, &s->envMapTexId)) return bail(e);
         }
     }
+    } catch (const std::bad_alloc&) {
+        return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, "out of memory while reading the scene (a picture or mesh of absurd size?)"));
     } catch (const std::exception& e) {                                // std::stof / std::stoi on malformed numbers
         return bail(rs_fail(RS_ERR_INVALID_ARGUMENT, (std::string("malformed number in scene file: ") + e.what()).c_str()));
     }
