@@ -185,7 +185,7 @@ int  rs_camera_update(rs_camera* cam);
  * Scene::Scene(filename) (src/scene.cpp:96-131) with loadMaterial (:371-433), loadModel (:222-283), loadCamera
  * (:285-354), Resource::loadOBJMesh (:27-61) and the instance baking of buildDevData (:161-176): parses the
  * reference's text scene format and returns the flat arrays rs_scene_build_textured takes.  Image files named in
- * the scene must be PNG, JPEG (Huffman-coded, 8 bit), TGA, binary PPM (P6, 8 bit) or Radiance HDR (.hdr, RGBE) -- the other stb_image
+ * the scene must be PNG, JPEG (Huffman-coded, 8 bit), TGA, BMP, binary PPM (P6, 8 bit) or Radiance HDR (.hdr, RGBE) -- the other stb_image
  * formats stay with the caller, who can build the arrays directly; glTF meshes are not read.  Pointers in the view stay valid until
  * rs_scene_file_free. */
 typedef struct rs_scene_file rs_scene_file;

@@ -6,8 +6,8 @@
 //   Resource::loadOBJMesh         src/scene.cpp:27-61       (tinyobj there; a reader of the same subset here)
 //   instance baking of buildDevData   src/scene.cpp:161-176
 //   Math::buildTransformationMatrix   src/mathUtil.cpp:13-20 + glm translate / rotate / scale / inverse
-// What it does not do: decode BMP / GIF / PSD ... (stb_image in the reference).  Texture and environment-map files must be
-// PNG, JPEG, TGA or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
+// What it does not do: decode GIF / PSD / PIC (stb_image in the reference).  Texture and environment-map files must be
+// PNG, JPEG, TGA, BMP or binary PPM (8-bit values: stbi_loadf's LDR path is value / 255 with stbi_ldr_to_hdr_gamma(1), src/scene.cpp:97) or Radiance HDR
 // (.hdr, RGBE, flat or run-length coded: mantissa * 2^(e - 136)); rows flipped for textures (stbi_set_flip_vertically_on_load(true),
 // :98) and not for the environment map (:124-126).
 // glTF (Resource::loadGLTFMesh) is not read either.
@@ -354,7 +354,7 @@ int load_obj(const std::string& path, Mesh& m) {
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
-    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG, JPEG and TGA are decoded here; decode other formats in the caller)").c_str()); };
+    auto fail = [&](const char* why) { std::fclose(f); return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path + " (binary PPM P6 / 8 bit, Radiance HDR, PNG, JPEG, BMP and TGA are decoded here; decode other formats in the caller)").c_str()); };
     auto token = [&](std::string& out) {
         out.clear();
         int c = std::fgetc(f);
@@ -1223,7 +1223,157 @@ int load_tga(const std::string& path, bool flipRows, std::vector<float>& data, i
     return 0;
 }
 
-// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR, 0x89 "PNG" = PNG, 0xff 0xd8 = JPEG
+// ---- BMP ------------------------------------------------------------------------------------------------------------
+// Windows / OS2 bitmaps as the reference's stb_image v2.21 reads them (external/include/stb_image.h:5122-5400): header sizes 12,
+// 40, 56, 108 and 124; 1 / 4 / 8-bit palette pictures, 16-bit (5-5-5 or bit fields), 24-bit and 32-bit (bit fields or 8-8-8-8);
+// no run-length coding; bottom-up unless the height is negative.  Channels of other widths than 8 bits are expanded by bit
+// replication as there.  Its reading position is followed literally -- bytes past the end of the file read as zero, and the
+// pixel offset is applied relative to where the header parser stopped, which for a 40-byte header followed by three mask words
+// skips twelve bytes of pixel data, as that version does.
+int load_bmp(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
+    std::vector<unsigned char> raw;
+    {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
+        unsigned char buf[1 << 16];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + got);
+        std::fclose(f);
+    }
+    auto fail = [&](const char* why) { return rs_fail(RS_ERR_UNSUPPORTED, (std::string(why) + ": " + path).c_str()); };
+    size_t at = 0;
+    auto get8 = [&]() -> unsigned { return at < raw.size() ? raw[at++] : 0u; };
+    auto get16 = [&]() -> unsigned { const unsigned a = get8(); return a | (get8() << 8); };
+    auto get32 = [&]() -> unsigned { const unsigned a = get16(); return a | (get16() << 16); };
+    auto skip = [&](long long count) { if (count < 0) at = raw.size(); else at = (size_t)std::min<unsigned long long>(raw.size(), at + (unsigned long long)count); };
+    if (get8() != 'B' || get8() != 'M') return fail("not a BMP");
+    get32(); get16(); get16();
+    const long long offset = (int)get32();
+    const int hsz = (int)get32();
+    unsigned mr = 0, mg = 0, mb = 0, ma = 0;
+    if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) return fail("unknown BMP header");
+    int height;
+    if (hsz == 12) { w = (int)get16(); height = (int)get16(); }
+    else { w = (int)get32(); height = (int)get32(); }
+    if (get16() != 1) return fail("bad BMP");
+    const int bpp = (int)get16();
+    if (hsz != 12) {
+        const int compress = (int)get32();
+        if (compress == 1 || compress == 2) return fail("run-length coded BMP files are not decoded");
+        get32(); get32(); get32(); get32(); get32();
+        if (hsz == 40 || hsz == 56) {
+            if (hsz == 56) { get32(); get32(); get32(); get32(); }
+            if (bpp == 16 || bpp == 32) {
+                if (compress == 0) {
+                    if (bpp == 32) { mr = 0xffu << 16; mg = 0xffu << 8; mb = 0xffu; ma = 0xffu << 24; }
+                    else { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+                }
+                else if (compress == 3) {
+                    mr = get32(); mg = get32(); mb = get32();
+                    if (mr == mg && mg == mb) return fail("bad BMP masks");
+                }
+                else return fail("bad BMP compression");
+            }
+        }
+        else {
+            mr = get32(); mg = get32(); mb = get32(); ma = get32();
+            get32();
+            for (int i = 0; i < 12; i++) get32();
+            if (hsz == 124) { get32(); get32(); get32(); get32(); }
+        }
+    }
+    const bool bottomUp = height > 0;
+    h = std::abs(height);
+    if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) return fail("bad BMP size");
+    int psize = 0;
+    if (hsz == 12) { if (bpp < 24) psize = (int)((offset - 14 - 24) / 3); }
+    else if (bpp < 16) psize = (int)((offset - 14 - hsz) >> 2);
+    std::vector<unsigned char> rgb((size_t)w * h * 3);
+    size_t z = 0;
+    if (bpp < 16) {
+        if (psize <= 0 || psize > 256) return fail("corrupt BMP palette");
+        unsigned char pal[256][3];
+        for (int i = 0; i < psize; i++) { pal[i][2] = (unsigned char)get8(); pal[i][1] = (unsigned char)get8(); pal[i][0] = (unsigned char)get8(); if (hsz != 12) get8(); }
+        for (int i = psize; i < 256; i++) pal[i][0] = pal[i][1] = pal[i][2] = 0;       // (uninitialised there)
+        skip(offset - 14 - hsz - (long long)psize * (hsz == 12 ? 3 : 4));
+        int width;
+        if (bpp == 1) width = (w + 7) >> 3;
+        else if (bpp == 4) width = (w + 1) >> 1;
+        else if (bpp == 8) width = w;
+        else return fail("bad BMP bit depth");
+        const int pad = (-width) & 3;
+        for (int j = 0; j < h; j++) {
+            if (bpp == 1) {
+                int bit = 7;
+                unsigned v = get8();
+                for (int i = 0; i < w; i++) {
+                    const int c = (int)((v >> bit) & 1u);
+                    rgb[z++] = pal[c][0]; rgb[z++] = pal[c][1]; rgb[z++] = pal[c][2];
+                    if (i + 1 == w) break;
+                    if (--bit < 0) { bit = 7; v = get8(); }
+                }
+            }
+            else for (int i = 0; i < w; i += 2) {
+                unsigned v = get8(), v2 = 0;
+                if (bpp == 4) { v2 = v & 15u; v >>= 4; }
+                rgb[z++] = pal[v][0]; rgb[z++] = pal[v][1]; rgb[z++] = pal[v][2];
+                if (i + 1 == w) break;
+                v = bpp == 8 ? get8() : v2;
+                rgb[z++] = pal[v][0]; rgb[z++] = pal[v][1]; rgb[z++] = pal[v][2];
+            }
+            skip(pad);
+        }
+    }
+    else {
+        skip(offset - 14 - hsz);
+        const int width = bpp == 24 ? 3 * w : bpp == 16 ? 2 * w : 0;
+        const int pad = (-width) & 3;
+        int easy = 0;
+        if (bpp == 24) easy = 1;
+        else if (bpp == 32 && mb == 0xffu && mg == 0xff00u && mr == 0x00ff0000u && ma == 0xff000000u) easy = 2;
+        else if (bpp != 16 && bpp != 32) return fail("bad BMP bit depth");
+        auto high_bit = [](unsigned v) { int n = -1; while (v) { n++; v >>= 1; } return n; };
+        auto bit_count = [](unsigned v) { int n = 0; while (v) { n += (int)(v & 1u); v >>= 1; } return n; };
+        int rshift = 0, gshift = 0, bshift = 0, rcount = 0, gcount = 0, bcount = 0;
+        if (!easy) {
+            if (!mr || !mg || !mb) return fail("bad BMP masks");
+            rshift = high_bit(mr) - 7; rcount = bit_count(mr);
+            gshift = high_bit(mg) - 7; gcount = bit_count(mg);
+            bshift = high_bit(mb) - 7; bcount = bit_count(mb);
+            if (rcount > 8 || gcount > 8 || bcount > 8) return fail("bad BMP masks");
+        }
+        auto channel = [](unsigned v, int shift, int bits) {               // an n-bit field made 8 bits wide by bit replication
+            static const unsigned mul[9] = { 0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01 };
+            static const unsigned shr[9] = { 0, 0, 0, 1, 0, 2, 4, 6, 0 };
+            if (shift < 0) v <<= -shift; else v >>= shift;
+            v >>= (8 - bits);
+            return (unsigned char)((v * mul[bits]) >> shr[bits]);
+        };
+        for (int j = 0; j < h; j++) {
+            for (int i = 0; i < w; i++) {
+                if (easy) {
+                    rgb[z + 2] = (unsigned char)get8(); rgb[z + 1] = (unsigned char)get8(); rgb[z] = (unsigned char)get8();
+                    z += 3;
+                    if (easy == 2) get8();
+                }
+                else {
+                    const unsigned v = bpp == 16 ? get16() : get32();
+                    rgb[z++] = channel(v & mr, rshift, rcount); rgb[z++] = channel(v & mg, gshift, gcount); rgb[z++] = channel(v & mb, bshift, bcount);
+                }
+            }
+            skip(pad);
+        }
+    }
+    data.resize(rgb.size());
+    for (int y = 0; y < h; y++) {
+        int sy = bottomUp ? h - 1 - y : y;
+        if (flipRows) sy = bottomUp ? y : h - 1 - y;
+        for (int i = 0; i < w * 3; i++) data[((size_t)y * w) * 3 + i] = (float)rgb[((size_t)sy * w) * 3 + i] / 255.f;
+    }
+    return 0;
+}
+
+// by content, not by file name: "P6" = binary PPM, "#?" = Radiance HDR, 0x89 "PNG" = PNG, 0xff 0xd8 = JPEG, "BM" = BMP; TGA by its file name
 int load_image(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
@@ -1233,6 +1383,7 @@ int load_image(const std::string& path, bool flipRows, std::vector<float>& data,
     if (got == 2 && m[0] == '#' && m[1] == '?') return load_hdr(path, flipRows, data, w, h);
     if (got == 2 && m[0] == 0x89 && m[1] == 'P') return load_png(path, flipRows, data, w, h);
     if (got == 2 && m[0] == 0xff && m[1] == 0xd8) return load_jpeg(path, flipRows, data, w, h);
+    if (got == 2 && m[0] == 'B' && m[1] == 'M') return load_bmp(path, flipRows, data, w, h);
     if (path.size() >= 4) {
         std::string ext = path.substr(path.size() - 4);
         for (char& c : ext) c = (char)std::tolower((unsigned char)c);

@@ -14,7 +14,7 @@
 //     a plain device buffer (display interop is outside this path);
 //   * Scene(filename) + buildDevData() go through rs_scene_file_load / rs_scene_build_textured (parser, OBJ reader, instance
 //     baking, BVH, light table and alias tables are built by the library with the reference's exact results); image files
-//     named in a scene must be PNG, JPEG, TGA, binary PPM or Radiance HDR, other formats are decoded by the caller and passed as arrays.
+//     named in a scene must be PNG, JPEG, TGA, BMP, binary PPM or Radiance HDR, other formats are decoded by the caller and passed as arrays.
 // Errors keep the reference's convention: print and exit (checkCUDAError, src/cudaUtil.h:13-31).
 #pragma once
 
@@ -83,7 +83,7 @@ struct Scene {
 
     Scene() = default;
     // Scene::Scene(filename) (src/scene.cpp:96-131): materials, objects (OBJ, baked per instance), camera, environment map.
-    // Image files must be PNG, JPEG, TGA, binary PPM or Radiance HDR; see include/restir_hip.h "scene files".
+    // Image files must be PNG, JPEG, TGA, BMP, binary PPM or Radiance HDR; see include/restir_hip.h "scene files".
     explicit Scene(const std::string& filename) {
         rsc::check(rs_scene_file_load(filename.c_str(), &file), "Scene loading");
         rs_scene_file_view v;

@@ -114,6 +114,55 @@ def main():
         p = os.path.join(d, "pal15.tga")
         open(p, "wb").write(struct.pack("<BBBHHBHHHHBB", 3, 1, 1, 0, 32, 15, 0, 0, 9, 5, 8, 0) + b"id!" + pal.astype("<u2").tobytes() + idx.tobytes())
         add("pal15", p)
+    # BMP pictures: Pillow writes the palette / 24-bit / 32-bit kinds; 16-bit and bit-field pictures, the V4 / V5 / OS-2 headers and a
+    # top-down file are assembled by hand
+    rng = np.random.default_rng(14)
+    with tempfile.TemporaryDirectory() as d:
+        def add_bmp(key, p):
+            g["bmp_file_" + key] = np.frombuffer(open(p, "rb").read(), np.uint8)
+            g["bmp_flip_" + key] = ref_image(R, p, 1)
+            g["bmp_noflip_" + key] = ref_image(R, p, 0)
+        a = rng.integers(0, 256, (9, 14, 4), dtype=np.uint8)
+        pal = rng.integers(0, 256, 768, dtype=np.uint8).tobytes()
+        for key, im, opt in (("mono", Image.fromarray(a[..., 0] > 127), {}), ("grey", Image.fromarray(a[..., 0]), {}), ("rgb", Image.fromarray(a[..., :3]), {}),
+                             ("rgba", Image.fromarray(a), {}), ("pal8", Image.fromarray(a[..., 0], "P"), {}), ("pal4", Image.fromarray(a[..., 0] % 16, "P"), dict(bits=4))):
+            if key.startswith("pal"):
+                im.putpalette(pal)
+            p = os.path.join(d, key + ".bmp")
+            im.save(p, "BMP", **opt)
+            add_bmp(key, p)
+
+        def bmp(hsz, w, h, bpp, compress, pixels, masks=b"", v4masks=None, palette=b""):
+            if hsz == 12:
+                hdr = struct.pack("<IHHHH", 12, w, h & 0xffff, 1, bpp)
+            else:
+                hdr = struct.pack("<IiiHHIIiiII", hsz, w, h, 1, bpp, compress, 0, 2835, 2835, 0, 0)
+                if hsz == 56:
+                    hdr += struct.pack("<IIII", 0, 0, 0, 0)
+                if hsz in (108, 124):
+                    hdr += struct.pack("<IIII", *v4masks) + struct.pack("<I", 0x73524742) + bytes(48)
+                    if hsz == 124:
+                        hdr += bytes(16)
+            off = 14 + len(hdr) + len(masks) + len(palette)
+            return b"BM" + struct.pack("<IHHI", off + len(pixels), 0, 0, off) + hdr + masks + palette + pixels
+
+        def rows(a, nbytes, w):
+            pad = (-(w * nbytes)) & 3
+            return b"".join(a[j].tobytes() + bytes(pad) for j in range(a.shape[0]))
+        h, w = 6, 7
+        px16 = rng.integers(0, 65536, (h, w), dtype=np.uint16).astype("<u2")
+        px32 = rng.integers(0, 2 ** 32, (h, w), dtype=np.uint32).astype("<u4")
+        hand = {"rgb555": bmp(40, w, h, 16, 0, rows(px16, 2, w)),
+                "rgb565_bitfields40": bmp(40, w, h, 16, 3, rows(px16, 2, w), masks=struct.pack("<III", 0xf800, 0x07e0, 0x001f)),     # stb_image 2.21 skips 12 pixel bytes here
+                "v4_masks_topdown": bmp(108, w, -h, 32, 3, rows(px32, 4, w), v4masks=(0x00fc0000, 0x0000f800, 0x0000007e, 0x07000000)),
+                "v5_8888": bmp(124, w, h, 32, 3, rows(px32, 4, w), v4masks=(0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000)),
+                "x8888": bmp(40, w, h, 32, 0, rows(px32, 4, w)),
+                "os2_pal": bmp(12, w, h, 8, 0, rows(rng.integers(0, 12, (h, w), dtype=np.uint8), 1, w), palette=rng.integers(0, 256, 48, dtype=np.uint8).tobytes()),
+                "v3_56": bmp(56, w, h, 16, 3, rows(px16, 2, w), masks=struct.pack("<III", 0x7c00, 0x03e0, 0x001f))}
+        for key, data in hand.items():
+            p = os.path.join(d, key + ".bmp")
+            open(p, "wb").write(data)
+            add_bmp(key, p)
     # baking math
     rng = np.random.default_rng(5)
     k = 200

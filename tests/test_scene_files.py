@@ -357,6 +357,19 @@ def test_product_tga_decoder_matches_stb_image_fixture(g, tmp_path):
         assert bits_equal(_decode_through_scene(tmp_path, p, False), g["tga_noflip_" + key]), key
 
 
+def test_product_bmp_decoder_matches_stb_image_fixture(g, tmp_path):
+    """BMP files -- 1 / 4 / 8-bit palette, 16-bit 5-5-5 and bit fields, 24-bit, 32-bit with and without masks, header sizes 12 / 40 /
+    56 / 108 / 124, bottom-up and top-down -- decode to the floats of the reference's stb_image 2.21, its handling of a 40-byte
+    header followed by bit-field masks included."""
+    keys = [k[len("bmp_file_"):] for k in g.files if k.startswith("bmp_file_")]
+    assert len(keys) >= 13
+    for key in keys:
+        p = tmp_path / (key + ".bmp")
+        p.write_bytes(g["bmp_file_" + key].tobytes())
+        assert bits_equal(_decode_through_scene(tmp_path, p, True), g["bmp_flip_" + key]), key
+        assert bits_equal(_decode_through_scene(tmp_path, p, False), g["bmp_noflip_" + key]), key
+
+
 @needs_ref
 def test_jpeg_decoder_fuzz_against_stb_image(tmp_path):
     Image = pytest.importorskip("PIL.Image")
@@ -423,8 +436,11 @@ def test_product_scene_file_errors(case_dir, tmp_path):
     with pytest.raises(capi.RestirHipError, match="JPEG"):
         load("Material m\nType Lambertian\nBaseColor " + str(tmp_path / "tex.jpg") + "\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n" + cam)
     (tmp_path / "tex.bmp").write_bytes(b"BM" + bytes(60))
-    with pytest.raises(capi.RestirHipError, match="are decoded here"):
+    with pytest.raises(capi.RestirHipError, match="BMP"):
         load("Material m\nType Lambertian\nBaseColor " + str(tmp_path / "tex.bmp") + "\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n" + cam)
+    (tmp_path / "tex.gif").write_bytes(b"GIF89a" + bytes(60))
+    with pytest.raises(capi.RestirHipError, match="are decoded here"):
+        load("Material m\nType Lambertian\nBaseColor " + str(tmp_path / "tex.gif") + "\nMetallic 0\nRoughness 1\nIor 1.5\nNormalMap Null\n\n" + cam)
     with pytest.raises(capi.RestirHipError, match="only OBJ"):
         load("Object o\nmesh.gltf\nMaterial Null\n\n" + cam)
     with pytest.raises(capi.RestirHipError, match="malformed number"):

@@ -21,6 +21,7 @@ pics = {}
 for k in g.files:
     if k.startswith('jpeg_file_'): pics[k[10:] + '.jpg'] = g[k].tobytes()
     if k.startswith('tga_file_'): pics[k[9:] + '.tga'] = g[k].tobytes()
+    if k.startswith('bmp_file_'): pics[k[9:] + '.bmp'] = g[k].tobytes()
 for name in cases.CASE_FILES:
     if name.endswith(('.png', '.hdr', '.ppm')): pics[name] = g['file_' + name].tobytes()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
