@@ -350,7 +350,7 @@ int load_obj(const std::string& path, Mesh& m) {
     return 0;
 }
 
-// binary PPM (P6, maxval 255) -> linear float RGB, value / 255
+// binary PPM / PGM (P6 / P5, 8 bit) -> linear float RGB, value / 255
 int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, ("cannot open image " + path).c_str());
@@ -367,19 +367,21 @@ int load_ppm(const std::string& path, bool flipRows, std::vector<float>& data, i
         return !out.empty();
     };
     std::string t;
-    if (!token(t) || t != "P6") return fail("not a binary PPM");
+    if (!token(t) || (t != "P6" && t != "P5")) return fail("not a binary PPM / PGM");
+    const int comp = t == "P6" ? 3 : 1;                                  // P5: grey, replicated to RGB
     int maxv = 0;
     if (!token(t)) return fail("truncated header"); w = std::atoi(t.c_str());
     if (!token(t)) return fail("truncated header"); h = std::atoi(t.c_str());
     if (!token(t)) return fail("truncated header"); maxv = std::atoi(t.c_str());
-    if (w <= 0 || h <= 0 || maxv != 255) return fail("unsupported PPM header");
-    std::vector<unsigned char> raw((size_t)w * h * 3);
+    if (w <= 0 || h <= 0 || maxv <= 0 || maxv > 255) return fail("unsupported PPM header");      // the bytes are taken as they are (no rescaling by maxval, as in stb_image)
+    std::vector<unsigned char> raw((size_t)w * h * comp);
     if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) return fail("truncated pixel data");
     std::fclose(f);
-    data.resize(raw.size());
+    data.resize((size_t)w * h * 3);
     for (int y = 0; y < h; y++) {
         const int sy = flipRows ? h - 1 - y : y;
-        for (int i = 0; i < w * 3; i++) data[((size_t)y * w) * 3 + i] = (float)raw[((size_t)sy * w) * 3 + i] / 255.f;
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++) data[((size_t)y * w + x) * 3 + c] = (float)raw[((size_t)sy * w + x) * comp + (comp == 3 ? c : 0)] / 255.f;
     }
     return 0;
 }

@@ -163,6 +163,15 @@ def main():
             p = os.path.join(d, key + ".bmp")
             open(p, "wb").write(data)
             add_bmp(key, p)
+    # binary PGM (P5) and a PPM with a maxval below 255 (stb_image takes the bytes as they are)
+    rng = np.random.default_rng(15)
+    with tempfile.TemporaryDirectory() as d:
+        for key, magic, comp, maxv in (("pgm", b"P5", 1, 255), ("ppm_max100", b"P6", 3, 100)):
+            p = os.path.join(d, key + ".pnm")
+            open(p, "wb").write(magic + b"\n# comment\n%d %d\n%d\n" % (9, 5, maxv) + rng.integers(0, maxv + 1, (5, 9, comp), dtype=np.uint8).tobytes())
+            g["pnm_file_" + key] = np.frombuffer(open(p, "rb").read(), np.uint8)
+            g["pnm_flip_" + key] = ref_image(R, p, 1)
+            g["pnm_noflip_" + key] = ref_image(R, p, 0)
     # baking math
     rng = np.random.default_rng(5)
     k = 200

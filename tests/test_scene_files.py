@@ -368,6 +368,11 @@ def test_product_bmp_decoder_matches_stb_image_fixture(g, tmp_path):
         p.write_bytes(g["bmp_file_" + key].tobytes())
         assert bits_equal(_decode_through_scene(tmp_path, p, True), g["bmp_flip_" + key]), key
         assert bits_equal(_decode_through_scene(tmp_path, p, False), g["bmp_noflip_" + key]), key
+    for key in ("pgm", "ppm_max100"):                        # binary PGM, and a PPM whose maxval is not 255
+        p = tmp_path / (key + ".pnm")
+        p.write_bytes(g["pnm_file_" + key].tobytes())
+        assert bits_equal(_decode_through_scene(tmp_path, p, True), g["pnm_flip_" + key]), key
+        assert bits_equal(_decode_through_scene(tmp_path, p, False), g["pnm_noflip_" + key]), key
 
 
 @needs_ref
