@@ -227,8 +227,9 @@ def set_sync(sync):
 
 
 def set_side_stream(enable):
-    """GBuffer::render on the library's second stream when launches are asynchronous (include/restir_hip.h)."""
-    check(lib().rs_set_side_stream(1 if enable else 0))
+    """Overlapped frames when launches are asynchronous (include/restir_hip.h): False / 0 off, True / 1 on, 2 = on with the
+    G-buffer render deferred into ReSTIRDirect's primary-ray launch."""
+    check(lib().rs_set_side_stream(int(enable)))
 
 
 def synchronize():

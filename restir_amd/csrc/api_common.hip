@@ -17,6 +17,7 @@ bool g_sync = true;
 // that order them (rs_gbuffer, rs_restir).
 hipStream_t g_aux[2] = { nullptr, nullptr };
 int g_auxMode = -1;                                     // -1: not decided yet; 0 off; 1 on
+int g_fuseMode = -1;                                    // deferred G-buffer render walked with the primary rays: -1 from the environment
 }  // namespace
 
 int rs_fail(int code, const char* msg) {
@@ -45,6 +46,15 @@ hipStream_t rs_aux_stream(int i) {
     if (!g_aux[i] && hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking) != hipSuccess) { g_aux[i] = nullptr; g_auxMode = 0; return nullptr; }
     return g_aux[i];
 }
+// RS_FUSE_GBUFFER=1: in asynchronous mode GBuffer::render is deferred and launched by ReSTIRDirect together with its primary rays
+// (the two rays of a pixel in one packet walk).  Off by default: it saves 10 % of the walk work, 4 % of a Sponza-class 1080p
+// frame, but the slowest tile of the launch takes almost twice as long, which costs 28 % on the Bistro-class scene whose
+// closest-hit kernels are tails of a few long tiles; choosing per scene needs a measurement at run time.
+bool rs_fuse_enabled() {
+    if (g_fuseMode < 0) { const char* e = std::getenv("RS_FUSE_GBUFFER"); g_fuseMode = (e && e[0] == '1') ? 1 : 0; }
+    return g_fuseMode >= 1;
+}
+bool rs_fuse_any_size() { return g_fuseMode == 2; }
 int rs_aux_synchronize() {
     for (hipStream_t st : g_aux) if (st) RS_HIP(hipStreamSynchronize(st));
     return 0;
@@ -103,6 +113,7 @@ int rs_set_stream(void* hipStream) {
 int rs_set_sync(int sync) { g_sync = sync != 0; return 0; }
 int rs_set_side_stream(int enable) {
     g_auxMode = enable ? 1 : 0;                         // work already enqueued on the auxiliary streams is still joined by its consumers
+    g_fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : 0;      // 3: also for launches too small to gain (tests)
     return 0;
 }
 int rs_synchronize(void) {

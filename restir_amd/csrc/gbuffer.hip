@@ -9,10 +9,6 @@
 
 using namespace rs;
 
-struct GBufWrite {
-    float* albedo; int* motion; float* normal; int* primId; float* depth;
-};
-
 // TEX: the scene has texture maps or an environment map (getTexturedMaterialAndSurface, gbuffer.cu:38,59-62)
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
@@ -28,32 +24,55 @@ __global__ void __launch_bounds__(256) k_render_gbuffer(DevScene s, CamParams ca
     Ray ray = camera_center_ray(cam, x, y);
     Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
     if (!inside) return;
-
-    if (h.primId != kNullPrim) {
-        int matId = h.matId;
-        f3 norm = h.norm;
-        const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
-        if (m.type == 4) matId = kNullPrim - 1;          // lights -> -2 (gbuffer.cu:30-31; the map lookup cannot change the type)
-        st3(g.albedo + (size_t)idx * 3, m.baseColor);
-        st3(g.normal + (size_t)idx * 3, norm);
-        g.primId[idx] = matId;
-        g.depth[idx] = length(ray.o - h.pos);            // glm::distance(pos, origin) = length(origin - pos)
-        int lx, ly;
-        camera_raster_coord(lastCam, h.pos, lx, ly);
-        g.motion[idx] = (lx >= 0 && lx < cam.width && ly >= 0 && ly < cam.height) ? ly * cam.width + lx : -1;
-    }
-    else {
-        st3(g.albedo + (size_t)idx * 3, (TEX && s.envTex >= 0) ? env_radiance(s, ray.d) : splat(0.f));
-        st3(g.normal + (size_t)idx * 3, splat(0.f));
-        g.primId[idx] = kNullPrim;
-        g.depth[idx] = 1.f;
-        g.motion[idx] = 0;
-    }
+    gbuffer_store<TEX>(s, cam, lastCam, g, idx, ray, h);
 }
 
-// the library stream waits for a render still running on the auxiliary stream
+namespace {
+
+void launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, const rs_camera* lastCam, int y0, int y1, hipStream_t st) {
+    const int c = g->cur();
+    GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
+    const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
+    if (scene->textured)
+        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, st,
+                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX);
+    else
+        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, st,
+                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX);
+}
+
+// launches a deferred render on the auxiliary stream
+int flush_deferred(const rs_gbuffer* g) {
+    if (!g->deferred.valid) return 0;
+    g->deferred.valid = false;
+    hipStream_t aux = rs_aux_stream(0);
+    if (aux) RS_TRY(rs_gbuffer_order_before_render(g, aux));
+    else aux = rs_stream();                                 // (the mode was switched in between: plain launch on the library stream)
+    launch_render(g, g->deferred.scene, &g->deferred.cam, &g->deferred.lastCam, g->deferred.y0, g->deferred.y1, aux);
+    RS_TRY(rs_check_hip(hipGetLastError(), "renderGBuffer"));
+    if (aux != rs_stream()) { RS_HIP(hipEventRecord(g->doneEv, aux)); g->pending = true; }
+    return 0;
+}
+
+}  // namespace
+
+// Nothing that runs before the temporal pass of a frame reads the G-buffer, and the set written is not the one the previous
+// frame's passes read: the render is ordered after the last readers of its set (or, for a second render without an update in
+// between, after everything enqueued so far on the library stream).
+int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream) {
+    if (g->deferred.rerender) {
+        RS_HIP(hipEventRecord(g->forkEv, rs_stream()));
+        RS_HIP(hipStreamWaitEvent(stream, g->forkEv, 0));
+    }
+    else if (g->useOf[g->cur()] >= 0) RS_HIP(hipStreamWaitEvent(stream, g->useEv[g->useOf[g->cur()]], 0));
+    return 0;
+}
+
+// the library stream waits for a render still running on an auxiliary stream; a deferred render is launched first
 int rs_gbuffer_join(const rs_gbuffer* g) {
-    if (!g || !g->pending) return 0;
+    if (!g) return 0;
+    RS_TRY(flush_deferred(g));
+    if (!g->pending) return 0;
     g->pending = false;
     return rs_check_hip(hipStreamWaitEvent(rs_stream(), g->doneEv, 0), "G-buffer join");
 }
@@ -112,36 +131,21 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
     if (y0 < 0) y0 = 0;
     if (y1 > g->height) y1 = g->height;
     if (y1 <= y0) return 0;
-    const int c = g->cur();
-    GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
-    const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
-    // Nothing in the primary-ray and RIS kernels of a frame reads the G-buffer, and the set written here is not the one the
-    // previous frame's passes read: in asynchronous mode the render goes to an auxiliary stream, ordered after the last
-    // readers of its set (or, for a second render without an update in between, after everything enqueued so far), and is
-    // joined by its first consumer.  Its long tail of a few heavy tiles then overlaps other kernels' tails.
+    // Asynchronous mode: the render is only recorded here.  ReSTIRDirect launches it together with its primary rays (the two rays
+    // of a pixel in one packet walk); any other reader of the planes launches it on the auxiliary stream first, where it is
+    // ordered after the last readers of the set it writes and overlaps the other frame's passes (rs_gbuffer_join).
     const hipStream_t aux = rs_aux_stream(0);
     if (aux) {
-        if (g->renderedSinceUpdate) {
-            RS_HIP(hipEventRecord(g->forkEv, rs_stream()));
-            RS_HIP(hipStreamWaitEvent(aux, g->forkEv, 0));
-        }
-        else if (g->useOf[c] >= 0) RS_HIP(hipStreamWaitEvent(aux, g->useEv[g->useOf[c]], 0));
-    }
-    else RS_TRY(rs_gbuffer_join(g));                    // an earlier render of this frame may still be on the auxiliary stream
-    const hipStream_t st = aux ? aux : rs_stream();
-    if (scene->textured)
-        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, st,
-                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
-    else
-        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, st,
-                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(&g->lastCamera), w, y0, y1, tilesX);
-    g->renderedSinceUpdate = true;
-    if (aux) {
-        RS_TRY(rs_check_hip(hipGetLastError(), "renderGBuffer"));
-        RS_HIP(hipEventRecord(g->doneEv, aux));
-        g->pending = true;
+        RS_TRY(flush_deferred(g));                          // an earlier render of this frame goes first
+        g->deferred.valid = true; g->deferred.rerender = g->renderedSinceUpdate;
+        g->deferred.scene = scene; g->deferred.cam = *cam; g->deferred.lastCam = g->lastCamera; g->deferred.y0 = y0; g->deferred.y1 = y1;
+        g->renderedSinceUpdate = true;
+        if (!rs_fuse_enabled()) RS_TRY(flush_deferred(g));
         return 0;
     }
+    RS_TRY(rs_gbuffer_join(g));                             // an earlier render of this frame may still be on the auxiliary stream
+    launch_render(g, scene, cam, &g->lastCamera, y0, y1, rs_stream());
+    g->renderedSinceUpdate = true;
     return rs_after_launch("renderGBuffer");
 }
 
@@ -151,11 +155,11 @@ int rs_gbuffer_render(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam
 
 int rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam) {
     if (!g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_update: null argument");
+    RS_TRY(rs_gbuffer_join(g));                         // a render nobody consumed (possibly still deferred) belongs to the frame that ends here
     g->lastCamera = *cam;
     // the frame that read sets cur (as current) and prev (as last) has been enqueued on the library stream up to here
     const int c = g->cur(), l = g->prev();
     if (!rs_sync_enabled()) {
-        RS_TRY(rs_gbuffer_join(g));                     // a render nobody consumed is ordered before the event too
         const int k = g->updates % rs_gbuffer::kSets;
         RS_HIP(hipEventRecord(g->useEv[k], rs_stream()));
         g->useOf[c] = g->useOf[l] = k;

@@ -57,6 +57,40 @@ __device__ __forceinline__ void pixel_of_lane(int tilesX, int y0, int& x, int& y
 }
 
 // ---- phase A.1: primary hit ---------------------------------------------------------------------
+// what ReSTIRDirectKernel keeps of its primary hit (restir.cu:127-153) for the later passes; returns whether the pixel is shaded
+template <bool TEX>
+__device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes& sp, int index, const Ray& ray, const Hit& h, const Rng& rng) {
+    int shaded = 0;
+    int kind = kKindMiss, matId = 0, type = 0;
+    f3 norm = splat(0.f), wo = splat(0.f), p = h.pos;
+    float metallic = 0.f, roughness = 0.f;
+    if (h.primId != kNullPrim) {
+        matId = h.matId;
+        norm = h.norm;
+        const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, matId);    // restir.cu:140 (baseColor is then forced to 1)
+        type = m.type; metallic = m.metallic; roughness = m.roughness;
+        if (type == 4) {
+            kind = kKindLight;
+            norm = splat(0.f);
+        }
+        else {
+            kind = kKindShaded;
+            wo = -ray.d;
+            if (type != 2 && dot(norm, wo) < 0.f) norm = -norm;     // restir.cu:150-153
+            shaded = 1;
+        }
+    }
+    else if (TEX && s.envTex >= 0) {
+        p = env_radiance(s, ray.d);                                 // restir.cu:134-136: the pixel's radiance
+    }
+    const int mk = matId | (kind << 24) | (type << 26);
+    sp.posMat[index] = make_float4(p.x, p.y, p.z, __int_as_float(mk));
+    sp.norm[index] = make_float4(norm.x, norm.y, norm.z, metallic);
+    if (type == 1) sp.wo[index] = make_float4(wo.x, wo.y, wo.z, roughness);     // only the metallic BSDF reads wo (k_ris, k_spatial_shade)
+    sp.rngMat[index] = make_uint2(rng.x, (unsigned)mk);
+    return shaded;
+}
+
 template <bool TEX>
 __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
@@ -69,38 +103,38 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
     f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
     Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
-    if (inside) {
-
-        int kind = kKindMiss, matId = 0, type = 0;
-        f3 norm = splat(0.f), wo = splat(0.f), p = h.pos;
-        float metallic = 0.f, roughness = 0.f;
-        if (h.primId != kNullPrim) {
-            matId = h.matId;
-            norm = h.norm;
-            const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, matId);    // restir.cu:140 (baseColor is then forced to 1)
-            type = m.type; metallic = m.metallic; roughness = m.roughness;
-            if (type == 4) {
-                kind = kKindLight;
-                norm = splat(0.f);
-            }
-            else {
-                kind = kKindShaded;
-                wo = -ray.d;
-                if (type != 2 && dot(norm, wo) < 0.f) norm = -norm;     // restir.cu:150-153
-                shaded = 1;
-            }
-        }
-        else if (TEX && s.envTex >= 0) {
-            p = env_radiance(s, ray.d);                                 // restir.cu:134-136: the pixel's radiance
-        }
-        const int mk = matId | (kind << 24) | (type << 26);
-        sp.posMat[index] = make_float4(p.x, p.y, p.z, __int_as_float(mk));
-        sp.norm[index] = make_float4(norm.x, norm.y, norm.z, metallic);
-        if (type == 1) sp.wo[index] = make_float4(wo.x, wo.y, wo.z, roughness);     // only the metallic BSDF reads wo (k_ris, k_spatial_shade)
-        sp.rngMat[index] = make_uint2(rng.x, (unsigned)mk);
-    }
+    if (inside) shaded = primary_store<TEX>(s, sp, index, ray, h, rng);
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
+        if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
+    }
+}
+
+// GBuffer::render and the primary rays of ReSTIRDirect in one launch (asynchronous mode, when the render of this frame is
+// still pending -- rs_gbuffer_render_rows defers it): per 8x8 tile the pixel-centre ray and the jittered ray are walked together
+// (walk_two_packet), then each is stored as k_render_gbuffer / k_primary store it.  Tiles are laid out from the G-buffer rows
+// [gy0, gy1); the shading ray is active on rows [y0, y1).
+constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
+
+template <bool TEX>
+__global__ void __launch_bounds__(256) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+                                                         int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
+    int x, y;
+    pixel_of_lane(tilesX, gy0, x, y);
+    const bool insideG = x < cam.width && y < gy1;
+    const bool insideP = x < cam.width && y >= y0 && y < y1;
+    const int index = y * cam.width + x;
+    Rng rng = seeded_rng(looper, index, 0);
+    const f4 r = rng.uniform4();
+    const Ray rayG = camera_center_ray(cam, x, y), rayP = camera_sample(cam, x, y, r.x, r.y);
+    WalkResult wg, wp;
+    walk_two_packet(s, rayG, rayP, insideG, insideP, wg, wp);
+    if (insideG) gbuffer_store<TEX>(s, cam, lastCam, g, index, rayG, hit_of_walk(s, wg));
+    int shaded = 0;
+    if (insideP) shaded = primary_store<TEX>(s, sp, index, rayP, hit_of_walk(s, wp), rng);
+    const unsigned long long ballotIn = __ballot(insideP), ballotSh = __ballot(shaded);
     if ((threadIdx.x & 63) == 0) {
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
         if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
@@ -633,7 +667,30 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     const SurfPlanes sp = surf_of(r);
     const CamParams cp = rs_make_cam_params(cam);
     mark(r, 0);
-    if (scene->textured)
+    // a render of this frame that rs_gbuffer_render_rows deferred (asynchronous mode) is launched here, together with the primary
+    // rays: same scene and camera, rows that contain the rows shaded here
+    // ... and a launch large enough to be bound by throughput: in a fused tile one wave walks both rays, which saves 10 % of the
+    // work but makes the slowest tile of the launch take almost twice as long -- on a full 1080p frame (32 400 waves over 8 192
+    // wave slots) the frame gains 4 %, on a half frame and below the long tiles set the launch time and it loses 8-20 %
+    // (tools/strip_balance.py with and without RS_FUSE_GBUFFER=0)
+    const rs_gbuffer::Deferred& d = g->deferred;
+    const bool fuse = aux && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
+                      (rs_fuse_any_size() || (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves);
+    if (fuse) {
+        RS_TRY(rs_gbuffer_order_before_render(g, aux));
+        g->deferred.valid = false;
+        const int c = g->cur();
+        const GBufWrite gw{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
+        const int gTilesY = (d.y1 - d.y0 + 7) / 8;
+        const CamParams lp = rs_make_cam_params(&d.lastCam);
+        if (scene->textured)
+            hipLaunchKernelGGL(k_gbuffer_primary<true>, dim3(tilesX * gTilesY), dim3(256), 0, st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
+        else
+            hipLaunchKernelGGL(k_gbuffer_primary<false>, dim3(tilesX * gTilesY), dim3(256), 0, st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
+        RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
+        g->pending = true;
+    }
+    else if (scene->textured)
         hipLaunchKernelGGL(k_primary<true>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     else
         hipLaunchKernelGGL(k_primary<false>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);

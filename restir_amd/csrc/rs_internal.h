@@ -96,13 +96,28 @@ struct rs_gbuffer {
     int updates = 0;
     bool renderedSinceUpdate = false;
     mutable bool pending = false;            // a render on the auxiliary stream has not been joined yet
+    // asynchronous mode: a render that has been requested but not launched yet.  ReSTIRDirect launches it together with its
+    // primary rays (one packet walk for the two rays of a pixel, restir.hip k_gbuffer_primary); any other reader of the planes
+    // launches it by itself first (rs_gbuffer_join).
+    struct Deferred {
+        bool valid = false, rerender = false;
+        const rs_scene* scene = nullptr;
+        rs_camera cam{}, lastCam{};
+        int y0 = 0, y1 = 0;
+    };
+    mutable Deferred deferred;
     int cur() const { return ring; }
     int prev() const { return (ring + kSets - 1) % kSets; }
     // albedo / motion are single planes in the reference: they show the most recent render, also after update()
     int latest() const { return (renderedSinceUpdate || updates == 0) ? cur() : prev(); }
 };
-// the library stream waits for a render that is still on the auxiliary stream; every reader of the planes calls it first
+// the library stream waits for a render that is still on the auxiliary stream (and a deferred one is launched first); every
+// reader of the planes calls it first
 int rs_gbuffer_join(const rs_gbuffer* g);
+// orders `stream` after the last readers of the set a (deferred) render is about to write
+int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream);
+bool rs_fuse_enabled();
+bool rs_fuse_any_size();
 
 // device view of the planes the kernels read
 struct GBufView {
@@ -123,6 +138,40 @@ static inline GBufView gbuf_view(const rs_gbuffer* g) {
     v.width = g->width; v.height = g->height;
     return v;
 }
+
+#if defined(__HIPCC__)
+// what renderGBuffer writes for one pixel (src/gbuffer.cu:21-72); shared by k_render_gbuffer and the kernel that walks the
+// G-buffer ray together with the shading ray (restir.hip)
+struct GBufWrite {
+    float* albedo; int* motion; float* normal; int* primId; float* depth;
+};
+
+template <bool TEX>
+__device__ __forceinline__ void gbuffer_store(const rs::DevScene& s, const rs::CamParams& cam, const rs::CamParams& lastCam, const GBufWrite& g,
+                                              int idx, const rs::Ray& ray, const rs::Hit& h) {
+    using namespace rs;
+    if (h.primId != kNullPrim) {
+        int matId = h.matId;
+        f3 norm = h.norm;
+        const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+        if (m.type == 4) matId = kNullPrim - 1;          // lights -> -2 (gbuffer.cu:30-31; the map lookup cannot change the type)
+        st3(g.albedo + (size_t)idx * 3, m.baseColor);
+        st3(g.normal + (size_t)idx * 3, norm);
+        g.primId[idx] = matId;
+        g.depth[idx] = length(ray.o - h.pos);            // glm::distance(pos, origin) = length(origin - pos)
+        int lx, ly;
+        camera_raster_coord(lastCam, h.pos, lx, ly);
+        g.motion[idx] = (lx >= 0 && lx < cam.width && ly >= 0 && ly < cam.height) ? ly * cam.width + lx : -1;
+    }
+    else {
+        st3(g.albedo + (size_t)idx * 3, (TEX && s.envTex >= 0) ? env_radiance(s, ray.d) : splat(0.f));
+        st3(g.normal + (size_t)idx * 3, splat(0.f));
+        g.primId[idx] = kNullPrim;
+        g.depth[idx] = 1.f;
+        g.motion[idx] = 0;
+    }
+}
+#endif
 
 // ---- reservoirs ----------------------------------------------------------------------------------
 // One Reservoir<DirectLiSample> (36 B AoS in the reference, src/restir.h:114-116) is stored as four

@@ -766,6 +766,90 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     return h;
 }
 
+// ---- two coherent rays per lane in one packet walk ------------------------------------------------------------------------
+// The G-buffer ray (pixel centre) and the shading ray (jittered inside the pixel) of an 8x8 tile visit nearly the same nodes.
+// Walked together, every node record is fetched once and the loop control and the next-node reduction are shared; each ray
+// keeps its own walk state and makes exactly the visits of DevScene::intersect, so both results are those of separate walks
+// (tools/probe_fused_walk.py: -10.6 % against two packet walks).  Must be called by all 64 lanes.
+template <bool GENERAL>
+__device__ __forceinline__ void packet_walk_order2(const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra, const RayBoxCtx& ca,
+                                                   const Ray& rb, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
+    const BvhNode* __restrict__ nodes = s.nodesAll + (size_t)order * (size_t)s.bvhSize;
+    const unsigned end = (unsigned)s.bvhSize;
+    unsigned nextA = mineA ? 0u : end, nextB = mineB ? 0u : end;
+    unsigned c = 0;
+    const float4* np0 = reinterpret_cast<const float4*>(nodes);
+    float4 lo = np0[0], hi = np0[1];
+    while (c != end) {
+        const float4* nq = reinterpret_cast<const float4*>(nodes + c + 1);
+        const float4 plo = nq[0], phi = nq[1];
+        const int prim = __float_as_int(lo.w);
+        const unsigned nxt = (unsigned)__float_as_int(hi.w);
+        const bool partA = nextA == c, partB = nextB == c;
+        float ta, tb;
+        bool ha, hb;
+        if (GENERAL) { ha = box_hit_general(ca.o, ca.dinv, lo, hi, ta); hb = box_hit_general(cb.o, cb.dinv, lo, hi, tb); }
+        else { ha = box_hit(ca, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), ta); hb = box_hit(cb, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), tb); }
+        const bool inA = partA & ha & (ta < wa.closest), inB = partB & hb & (tb < wb.closest);
+        if (prim != kNullPrim) {
+            if (__any(inA | inB)) {
+                const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);
+                const float4 a = tp[0], b = tp[1], e = tp[2];
+                float bx, by, dist;
+                if (inA) { if (tri_hit(ra.o, ra.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wa.closest) { wa.closest = dist; wa.bx = bx; wa.by = by; wa.prim = prim; } }
+                if (inB) { if (tri_hit(rb.o, rb.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wb.closest) { wb.closest = dist; wb.bx = bx; wb.by = by; wb.prim = prim; } }
+            }
+        }
+        nextA = partA ? (inA ? c + 1u : nxt) : nextA;
+        nextB = partB ? (inB ? c + 1u : nxt) : nextB;
+        const unsigned want = min(nextA, nextB);
+        if (__any(want == c + 1u)) { c = c + 1u; lo = plo; hi = phi; }
+        else {
+            c = wave_min_u32(want);
+            const float4* np = reinterpret_cast<const float4*>(nodes + c);
+            lo = np[0]; hi = np[1];
+        }
+    }
+}
+
+__device__ __forceinline__ void walk_two_packet(const DevScene& s, const Ray& ra, const Ray& rb, bool activeA, bool activeB, WalkResult& wa, WalkResult& wb) {
+    wa.closest = wb.closest = 3.402823466e+38f; wa.prim = wb.prim = kNullPrim; wa.bx = wa.by = wb.bx = wb.by = 0.f; wa.any = wb.any = false;
+    RayBoxCtx ca = make_box_ctx(ra), cb = make_box_ctx(rb);
+    ca.cull = cb.cull = s.axisCull;
+    const bool special = (activeA && (ca.mode != 0 || ca.zx || ca.zy || ca.zz || !(ra.d.x == ra.d.x))) || (activeB && (cb.mode != 0 || cb.zx || cb.zy || cb.zz || !(rb.d.x == rb.d.x)));
+    const bool anySpecial = __any(special);
+    const int oa = mtbvh_order(-ra.d), ob = mtbvh_order(-rb.d);
+    unsigned long long todoA = __ballot(activeA), todoB = __ballot(activeB);
+    while (todoA | todoB) {
+        int k;
+        if (todoA) k = __builtin_amdgcn_readlane(oa, __ffsll((long long)todoA) - 1);
+        else k = __builtin_amdgcn_readlane(ob, __ffsll((long long)todoB) - 1);
+        const bool mineA = activeA && oa == k && ((todoA >> __lane_id()) & 1ull), mineB = activeB && ob == k && ((todoB >> __lane_id()) & 1ull);
+        todoA &= ~__ballot(mineA); todoB &= ~__ballot(mineB);
+        if (anySpecial) packet_walk_order2<false>(s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
+        else packet_walk_order2<true>(s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
+    }
+}
+
+// a Hit from a WalkResult (getIntersecGeomInfo, scene.h:135-151), as trace_closest_packet returns it
+__device__ __forceinline__ Hit hit_of_walk(const DevScene& s, const WalkResult& w) {
+    Hit h;
+    h.primId = w.prim;
+    h.matId = 0;
+    h.pos = splat(0.f);
+    h.norm = splat(0.f);
+    h.bx = w.bx; h.by = w.by;
+    if (w.prim != kNullPrim) {
+        const float* v = s.vertices + (size_t)w.prim * 9;
+        const float* n = s.normals + (size_t)w.prim * 9;
+        const float wgt = 1.f - w.bx - w.by;
+        h.pos = ld3(v + 3) * w.bx + ld3(v + 6) * w.by + ld3(v) * wgt;
+        h.norm = normalize(ld3(n + 3) * w.bx + ld3(n + 6) * w.by + ld3(n) * wgt);
+        h.matId = s.materialIds[w.prim];
+    }
+    return h;
+}
+
 // closest hit for a whole wave of INCOHERENT rays (bounce rays): per-lane walks of the reference's tree with the
 // pair-cooperative node fetch; every lane of the wave must call it, `active` false where there is no ray
 __device__ inline Hit trace_closest_wave(const DevScene& s, const Ray& ray, bool active) {

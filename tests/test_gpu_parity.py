@@ -666,7 +666,8 @@ def test_strip_tiling_equals_full_frame(hip):
         assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
 
 
-def test_overlapped_frames_equal_synchronous_frames(hip):
+@pytest.mark.parametrize("fused", [False, True])
+def test_overlapped_frames_equal_synchronous_frames(hip, fused):
     """Asynchronous mode (rs_set_sync(0)) lets frames overlap: GBuffer::render and the primary-ray + RIS kernels of frame f + 1
     run on auxiliary streams next to the temporal / spatial passes of frame f (G-buffer planes in a ring of three, surface
     planes double-buffered, events for every true dependency).  Twelve frames of an orbiting camera enqueued without any host
@@ -684,6 +685,7 @@ def test_overlapped_frames_equal_synchronous_frames(hip):
         out = torch.zeros_like(h.image)
         images, filtered, pbos = [], [], []
         hip.set_sync(not overlapped)
+        hip.set_side_stream(3 if fused else 1)                   # 3: GBuffer::render deferred into the primary-ray launch (one walk for both rays), any size
         try:
             for frame in range(frames):
                 h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.5))
@@ -705,6 +707,7 @@ def test_overlapped_frames_equal_synchronous_frames(hip):
             torch.cuda.synchronize()
         finally:
             hip.set_sync(True)
+            hip.set_side_stream(1)
         res = dict(images=[t.cpu().numpy() for t in images], filtered=[t.cpu().numpy() for t in filtered],
                    pbos=[t.cpu().numpy() for t in pbos], resv=h.restir.download(1), gbuf=h.gbuf.download())
         f.destroy()
