@@ -205,7 +205,7 @@ def main():
     # per-pass times of a few extra (untimed) frames, HIP events on the library's stream; the G-buffer render is kept on
     # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
     # primary-ray and RIS kernels from the library's second stream)
-    capi.set_side_stream(False)
+    capi.set_side_stream(0)
     backend.restir.enable_timing(True)
     spatial_ms, pass_ms = [], np.zeros(4)
     for _ in range(20):
@@ -222,7 +222,7 @@ def main():
         ev[2].record(); capi.copy_image_to_pbo(pbos[0].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0); ev[3].record()
         torch.cuda.synchronize()
         gb_ms.append(ev[0].elapsed_time(ev[1])); pbo_ms.append(ev[2].elapsed_time(ev[3]))
-    capi.set_side_stream(True)
+    capi.set_side_stream(4)
     backend.restir.enable_timing(False)
 
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device="cuda")

@@ -145,11 +145,15 @@ int  rs_set_sync(int sync);
  * internal streams, ordered only after the work that last used their buffers (G-buffer planes in a ring of three, per-frame
  * surface planes double-buffered), and joined into the library stream where their results are first read (the temporal
  * pass, the denoisers, rs_gbuffer_get_view, rs_synchronize).  They then run next to the previous frame's temporal / spatial
- * passes.  Results are identical; output buffers are valid in library-stream order as before.  1 = on (default; the
- * environment variable RS_SIDE_STREAM=0 turns it off), 0 = everything on the library stream, 2 = on, and GBuffer::render is
- * deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal
- * (default for RS_FUSE_GBUFFER=1; 4 % faster on a full Sponza-class frame, slower where a few long tiles set the launch time:
- * DESIGN.md; launches below three rounds of the chip's wave slots stay separate), 3 = like 2 for launches of any size. */
+ * passes.  Results are identical; output buffers are valid in library-stream order as before.  GBuffer::render can in addition
+ * be deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal:
+ * 4 % faster on a full Sponza-class frame, slower where a few long tiles set the launch time, so by default
+ * every rs_restir measures the frame period both ways once per scene (frames 4..19) and keeps the faster.
+ *   0 = everything on the library stream (also RS_SIDE_STREAM=0)
+ *   1 = overlapped frames, the render always its own launch (also RS_FUSE_GBUFFER=0)
+ *   2 = overlapped frames, the render always deferred for launches of at least three rounds of the chip's wave slots (RS_FUSE_GBUFFER=1)
+ *   3 = like 2 for launches of any size
+ *   4 = overlapped frames, measured choice (the default) */
 int  rs_set_side_stream(int enable);
 int  rs_synchronize(void);
 

@@ -227,8 +227,8 @@ def set_sync(sync):
 
 
 def set_side_stream(enable):
-    """Overlapped frames when launches are asynchronous (include/restir_hip.h): False / 0 off, True / 1 on, 2 = on with the
-    G-buffer render deferred into ReSTIRDirect's primary-ray launch."""
+    """Overlapped frames when launches are asynchronous (include/restir_hip.h): 0 off, 1 on with GBuffer::render as its own launch,
+    2 / 3 on with the render deferred into ReSTIRDirect's primary-ray launch (3: at any size), 4 on with that choice measured."""
     check(lib().rs_set_side_stream(int(enable)))
 
 

@@ -46,15 +46,20 @@ hipStream_t rs_aux_stream(int i) {
     if (!g_aux[i] && hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking) != hipSuccess) { g_aux[i] = nullptr; g_auxMode = 0; return nullptr; }
     return g_aux[i];
 }
-// RS_FUSE_GBUFFER=1: in asynchronous mode GBuffer::render is deferred and launched by ReSTIRDirect together with its primary rays
-// (the two rays of a pixel in one packet walk).  Off by default: it saves 10 % of the walk work, 4 % of a Sponza-class 1080p
-// frame, but the slowest tile of the launch takes almost twice as long, which costs 28 % on the Bistro-class scene whose
-// closest-hit kernels are tails of a few long tiles; choosing per scene needs a measurement at run time.
-bool rs_fuse_enabled() {
-    if (g_fuseMode < 0) { const char* e = std::getenv("RS_FUSE_GBUFFER"); g_fuseMode = (e && e[0] == '1') ? 1 : 0; }
-    return g_fuseMode >= 1;
+// In asynchronous mode GBuffer::render can be deferred and launched by ReSTIRDirect together with its primary rays (the two rays
+// of a pixel in one packet walk).  That saves 10 % of the walk work, 4 % of a Sponza-class 1080p frame, but the slowest tile of
+// the launch takes almost twice as long, which costs 28 % on the Bistro-class scene whose closest-hit kernels are tails of a
+// few long tiles: by default every rs_restir measures the frame period both ways once and keeps the
+// faster (restir.hip).  RS_FUSE_GBUFFER=0 / 1 force it off / on.
+// 0 never, 1 always (launches of at least three rounds of wave slots), 2 always (any size), 3 decided per rs_restir by measuring
+int rs_fuse_mode() {
+    if (g_fuseMode < 0) {
+        const char* e = std::getenv("RS_FUSE_GBUFFER");
+        g_fuseMode = !e ? 3 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : 3;
+    }
+    return g_fuseMode;
 }
-bool rs_fuse_any_size() { return g_fuseMode == 2; }
+bool rs_fuse_enabled() { return rs_fuse_mode() != 0; }
 int rs_aux_synchronize() {
     for (hipStream_t st : g_aux) if (st) RS_HIP(hipStreamSynchronize(st));
     return 0;
@@ -113,7 +118,7 @@ int rs_set_stream(void* hipStream) {
 int rs_set_sync(int sync) { g_sync = sync != 0; return 0; }
 int rs_set_side_stream(int enable) {
     g_auxMode = enable ? 1 : 0;                         // work already enqueued on the auxiliary streams is still joined by its consumers
-    g_fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : 0;      // 3: also for launches too small to gain (tests)
+    g_fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : enable == 4 ? 3 : 0;      // 2 always, 3 always and at any size (tests), 4 measured
     return 0;
 }
 int rs_synchronize(void) {

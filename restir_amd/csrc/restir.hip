@@ -580,6 +580,7 @@ int rs_restir_free(rs_restir* r) {
     rs_dev_free(r->indResv[0]); rs_dev_free(r->indResv[1]);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
+    for (auto& e : r->tuneEv) if (e) (void)hipEventDestroy(e);
     if (r->auxFork) (void)hipEventDestroy(r->auxFork);
     if (r->auxDone) (void)hipEventDestroy(r->auxDone);
     delete r;
@@ -611,6 +612,7 @@ int rs_restir_init(int width, int height, rs_restir** out) {
         if (!e) e = rs_check_hip(hipMemset(f.rngMat, 0, n * 8), "memset");
     }
     for (auto& ev : r->surfFree) if (!e) e = rs_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    for (auto& ev : r->tuneEv) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxFork, hipEventDisableTiming), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxDone, hipEventDisableTiming), "hipEventCreate");
     if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots * kRaySub * kRayStride);
@@ -674,8 +676,14 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     // wave slots) the frame gains 4 %, on a half frame and below the long tiles set the launch time and it loses 8-20 %
     // (tools/strip_balance.py with and without RS_FUSE_GBUFFER=0)
     const rs_gbuffer::Deferred& d = g->deferred;
-    const bool fuse = aux && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
-                      (rs_fuse_any_size() || (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves);
+    const int fuseMode = rs_fuse_mode();
+    bool fuse = aux && fuseMode != 0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
+                (fuseMode == 2 || (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves);
+    if (fuse && fuseMode == 3) {                                  // measured choice (end_frame advances the measurement)
+        if (r->tuneScene != scene) { r->tuneScene = scene; r->tuneFrame = 0; r->tuneChoice = -1; }
+        r->tuneCounted = true;
+        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= 12 && r->tuneFrame < 20);
+    }
     if (fuse) {
         RS_TRY(rs_gbuffer_order_before_render(g, aux));
         g->deferred.valid = false;
@@ -740,6 +748,21 @@ int rs_restir_end_frame(rs_restir* r) {
     else r->surfFreeValid[r->surfSet] = false;
     r->surfSet ^= 1;
     r->phaseACalls = 0;
+    // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames 4, 12 and 20 begin; once the last
+    // one has passed (polled, never waited for) the shorter of the two 8-frame spans decides, with 3 % in favour of two launches
+    if (r->tuneCounted && r->tuneChoice < 0) {
+        const int f = ++r->tuneFrame;
+        if (f == 4 || f == 12 || f == 20) RS_HIP(hipEventRecord(r->tuneEv[f == 4 ? 0 : f == 12 ? 1 : 2], rs_stream()));
+        const hipError_t ready = f >= 20 ? hipEventQuery(r->tuneEv[2]) : hipErrorNotReady;
+        if (f >= 20 && ready != hipSuccess) (void)hipGetLastError();      // "not ready" must not look like a launch error later
+        if (ready == hipSuccess) {
+            float separate = 0.f, fused = 0.f;
+            if (hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess && hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
+                r->tuneChoice = fused < 0.97f * separate ? 1 : 0;
+            else r->tuneChoice = 0;
+        }
+    }
+    r->tuneCounted = false;
     return 0;
 }
 

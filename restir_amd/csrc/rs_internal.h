@@ -117,7 +117,7 @@ int rs_gbuffer_join(const rs_gbuffer* g);
 // orders `stream` after the last readers of the set a (deferred) render is about to write
 int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream);
 bool rs_fuse_enabled();
-bool rs_fuse_any_size();
+int rs_fuse_mode();     // 0 never, 1 always (large launches), 2 always, 3 measured per rs_restir
 
 // device view of the planes the kernels read
 struct GBufView {
@@ -223,6 +223,13 @@ struct rs_restir {
     bool surfFreeValid[2] = { false, false };
     hipEvent_t auxFork = nullptr, auxDone = nullptr;
     int phaseACalls = 0;             // since the last end_frame
+    // one traversal for the G-buffer ray and the shading ray of a pixel, or two?  Measured once per scene (rs_fuse_mode() == 3):
+    // frames 4..11 with two launches, 12..19 with one, timed by events on the library stream at the frame ends
+    const rs_scene* tuneScene = nullptr;
+    int tuneFrame = 0;               // frames with a fusable launch since tuning began
+    int tuneChoice = -1;             // -1 measuring, 0 separate, 1 fused
+    bool tuneCounted = false;        // this frame had a launch the choice applies to
+    hipEvent_t tuneEv[3] = { nullptr, nullptr, nullptr };
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
     int raySlot = 0;
     // timing

@@ -707,7 +707,7 @@ def test_overlapped_frames_equal_synchronous_frames(hip, fused):
             torch.cuda.synchronize()
         finally:
             hip.set_sync(True)
-            hip.set_side_stream(1)
+            hip.set_side_stream(4)
         res = dict(images=[t.cpu().numpy() for t in images], filtered=[t.cpu().numpy() for t in filtered],
                    pbos=[t.cpu().numpy() for t in pbos], resv=h.restir.download(1), gbuf=h.gbuf.download())
         f.destroy()
@@ -724,6 +724,39 @@ def test_overlapped_frames_equal_synchronous_frames(hip, fused):
         for i in range(2):
             assert bits_equal(a["gbuf"][k][i], b["gbuf"][k][i]), (k, i)
     assert not bits_equal(a["images"][0], a["images"][-1])
+
+
+def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
+    """Default asynchronous mode: ReSTIRDirect measures once per scene whether walking the G-buffer ray with the shading ray is
+    faster (frames 12..19 run fused, 4..11 and all others until the decision separately).  Whatever it picks, a full-size run of
+    28 frames equals the synchronous run bit for bit."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.1")
+    W, H, frames = 1920, 1080, 28
+    scene = hip_scene(hip, sd)
+
+    def run(overlapped):
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        keep = []
+        hip.set_sync(not overlapped)
+        hip.set_side_stream(4)
+        try:
+            for frame in range(frames):
+                h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.3))
+                h.gbuf.render(h.scene, h.cam)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                h.looper += 1
+                if frame in (3, 11, 13, 19, 27):
+                    keep.append(h.image.clone())
+                h.gbuf.update(h.cam)
+            hip.synchronize(); torch.cuda.synchronize()
+        finally:
+            hip.set_sync(True)
+        return [t.cpu().numpy() for t in keep] + [h.restir.download(1).view(np.uint8), h.gbuf.download()["depth"][0]]
+
+    for a, b in zip(run(False), run(True)):
+        assert bits_equal(a, b)
 
 
 def test_phase_b_in_row_bands_equals_one_call(hip):

@@ -14,16 +14,16 @@ cam = capi.camera_update(sd.camera(W,H))
 b = HipBackend(capi, scene, cam, W, H)
 eaw = capi.EAWFilter(W,H,5); out = torch.zeros_like(b.image)
 capi.set_sync(False)
-for f in range(5):
+for f in range(40):                      # warm-up, and past the frames in which ReSTIRDirect measures its launch choice
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); b.end_frame()
 torch.cuda.synchronize()
 t=time.time()
-for f in range(5,25):
+for f in range(40,60):
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); p = eaw.filter(out.data_ptr(), b.image.data_ptr(), b.gbuf, cam); b.end_frame()
 torch.cuda.synchronize(); dt=(time.time()-t)/20
 # per-pass times: one kernel at a time (timing on keeps the primary-ray + RIS kernels on the library stream)
-b.restir.enable_timing(True); capi.set_side_stream(False)
-for f in range(25,30):
+b.restir.enable_timing(True); capi.set_side_stream(0)
+for f in range(60,65):
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); b.end_frame()
 torch.cuda.synchronize()
 print("config 5 on one GPU: %.2f ms/frame incl. EAW (frames overlapped); pass ms on one stream %s; finite %s" % (dt*1e3, b.restir.pass_times(), bool(torch.isfinite(b.image).all())))

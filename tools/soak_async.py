@@ -57,7 +57,7 @@ def run(cfg, overlapped):
         capi.synchronize(); torch.cuda.synchronize()
     finally:
         capi.set_sync(True)
-        capi.set_side_stream(1)
+        capi.set_side_stream(4)
     res = [t.cpu().numpy() for t in imgs] + [b.restir.download(1).view(np.uint8)]
     if eaw is not None: eaw.destroy()
     return res
@@ -68,7 +68,7 @@ last = time.time()
 while time.time() < t_end:
     H = int(rng.integers(16, 400)); W = int(rng.integers(16, 640))
     frames = int(rng.integers(2, 9))
-    cfg = dict(streams=int(rng.choice([1, 3])), scene=str(rng.choice(["cornell", "textured", "sponza", "sponza_big"])), size=(W, H), frames=frames, reuse=int(rng.integers(0, 4)),
+    cfg = dict(streams=int(rng.choice([1, 3, 4])), scene=str(rng.choice(["cornell", "textured", "sponza", "sponza_big"])), size=(W, H), frames=frames, reuse=int(rng.integers(0, 4)),
                orbit=bool(rng.integers(0, 2)), eaw=bool(rng.integers(0, 3) == 0), bands=int(rng.integers(8, H - 1)) if H > 24 and rng.integers(0, 3) == 0 else 0,
                extra_render=set(rng.integers(0, frames, 1).tolist()) if rng.integers(0, 3) == 0 else set(), pt=set(rng.integers(0, frames, 1).tolist()) if rng.integers(0, 4) == 0 else set())
     a, o = run(cfg, False), run(cfg, True)

@@ -14,7 +14,7 @@ cam = capi.camera_update(sd.camera(W, H))
 b = HipBackend(capi, scene, cam, W, H)
 b.restir.enable_timing(True)
 capi.set_sync(False)
-capi.set_side_stream(False)          # per-pass times: one kernel at a time on the library stream
+capi.set_side_stream(0)          # per-pass times: one kernel at a time on the library stream
 args = [int(a) for a in sys.argv[1:]]
 for y0, y1 in zip(args[::2], args[1::2]):
     acc = [0.0] * 5
