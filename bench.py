@@ -267,6 +267,8 @@ def main():
             "config": {"workload": "BASELINE config 3: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 1920x1080, "
                                    "32 RIS candidates, spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update",
                        "camera": "orbit" if args.orbit else "static",
+                       "launches": "asynchronous (rs_set_sync(0)): consecutive frames overlap on the library's auxiliary streams; GBuffer::render is walked "
+                                   "together with the primary rays when the library measures that to be faster (frames 4-19 of the run measure)",
                        "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in strips.bounds) + " rows (cost-balanced by measurement), "
                                   "5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0") if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
