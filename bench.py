@@ -279,6 +279,7 @@ def main():
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }
+        out["config"]["launch_choice"] = {-1: "not decided within this run", 0: "two launches", 1: "one fused launch"}[backend.restir.launch_choice()]
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(sd, args.cpu_frames)
             ref_loop = cpu_reference_loop(sd, out["cpu_baseline"]["cores"])

@@ -270,6 +270,9 @@ int  rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam
 int  rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                        float* devDirectIllum, int iter, int reuse, int y0, int y1);
 int  rs_restir_end_frame(rs_restir* r);
+/* What the measurement of rs_set_side_stream's mode 4 decided for this object and its current scene: -1 still measuring (or
+ * nothing to choose), 0 GBuffer::render and the primary rays as two launches, 1 as one. */
+int  rs_restir_launch_choice(const rs_restir* r, int* choice);
 #define RS_SPATIAL_HALO_ROWS 5           /* taps reach y-4..y+5 (src/restir.cu:49-56) */
 /* bytes needed for `rows` rows of published reservoirs */
 size_t rs_restir_halo_bytes(const rs_restir* r, int rows);

@@ -100,7 +100,7 @@ EXPORTS = [
     "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
-    "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_halo_bytes", "rs_restir_halo_pack",
+    "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
     "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
@@ -165,6 +165,7 @@ def lib():
     L.rs_restir_phase_a.argtypes = [vp, vp, C.POINTER(Camera), vp, ci, ci, ci, ci]
     L.rs_restir_phase_b.argtypes = [vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci, ci]
     L.rs_restir_end_frame.argtypes = [vp]
+    L.rs_restir_launch_choice.argtypes = [vp, C.POINTER(ci)]
     L.rs_restir_halo_bytes.argtypes = [vp, ci]
     L.rs_restir_halo_bytes.restype = C.c_size_t
     L.rs_restir_halo_pack.argtypes = [vp, ci, ci, vp]
@@ -570,6 +571,12 @@ class ReSTIR:
 
     def end_frame(self):
         check(lib().rs_restir_end_frame(self.handle))
+
+    def launch_choice(self):
+        """-1 still measuring / nothing to choose, 0 two launches, 1 GBuffer::render walked together with the primary rays."""
+        c = C.c_int(-1)
+        check(lib().rs_restir_launch_choice(self.handle, C.byref(c)))
+        return c.value
 
     def halo_bytes(self, rows):
         return int(lib().rs_restir_halo_bytes(self.handle, rows))

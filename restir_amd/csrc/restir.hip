@@ -739,6 +739,13 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     return rs_after_launch("ReSTIR Direct (phase B)");
 }
 
+// -1 still measuring (or nothing to choose: synchronous launches, small launches, a forced mode), 0 two launches, 1 one fused launch
+int rs_restir_launch_choice(const rs_restir* r, int* choice) {
+    if (!r || !choice) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_launch_choice: null argument");
+    *choice = r->tuneChoice;
+    return 0;
+}
+
 int rs_restir_end_frame(rs_restir* r) {
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_end_frame: null");
     ResvPlanes t = r->cur; r->cur = r->last; r->last = t;       // std::swap(devDirectReservoir, devLastDirectReservoir)
@@ -749,11 +756,13 @@ int rs_restir_end_frame(rs_restir* r) {
     r->surfSet ^= 1;
     r->phaseACalls = 0;
     // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames 4, 12 and 20 begin; once the last
-    // one has passed (polled, never waited for) the shorter of the two 8-frame spans decides, with 3 % in favour of two launches
+    // one has passed the shorter of the two 8-frame spans decides, with 3 % in favour of two launches
     if (r->tuneCounted && r->tuneChoice < 0) {
         const int f = ++r->tuneFrame;
         if (f == 4 || f == 12 || f == 20) RS_HIP(hipEventRecord(r->tuneEv[f == 4 ? 0 : f == 12 ? 1 : 2], rs_stream()));
-        const hipError_t ready = f >= 20 ? hipEventQuery(r->tuneEv[2]) : hipErrorNotReady;
+        // The host can run many frames ahead of the GPU.  The stamp is polled for a while; after eight more frames the host waits
+        // for it once (the GPU has those frames queued and stays busy), so that the choice is made by frame 28 at the latest.
+        hipError_t ready = f >= 28 ? hipEventSynchronize(r->tuneEv[2]) : f >= 20 ? hipEventQuery(r->tuneEv[2]) : hipErrorNotReady;
         if (f >= 20 && ready != hipSuccess) (void)hipGetLastError();      // "not ready" must not look like a launch error later
         if (ready == hipSuccess) {
             float separate = 0.f, fused = 0.f;

@@ -729,11 +729,11 @@ def test_overlapped_frames_equal_synchronous_frames(hip, fused):
 def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     """Default asynchronous mode: ReSTIRDirect measures once per scene whether walking the G-buffer ray with the shading ray is
     faster (frames 12..19 run fused, 4..11 and all others until the decision separately).  Whatever it picks, a full-size run of
-    28 frames equals the synchronous run bit for bit."""
+    30 frames equals the synchronous run bit for bit."""
     import torch
     from restir_amd.scenes import orbit_position
     sd = get_scene("sponza:0.1")
-    W, H, frames = 1920, 1080, 28
+    W, H, frames = 1920, 1080, 30
     scene = hip_scene(hip, sd)
 
     def run(overlapped):
@@ -747,16 +747,19 @@ def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
                 h.gbuf.render(h.scene, h.cam)
                 h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
                 h.looper += 1
-                if frame in (3, 11, 13, 19, 27):
+                if frame in (3, 11, 13, 19, 27, 29):
                     keep.append(h.image.clone())
                 h.gbuf.update(h.cam)
             hip.synchronize(); torch.cuda.synchronize()
         finally:
             hip.set_sync(True)
+        choices.append(h.restir.launch_choice())
         return [t.cpu().numpy() for t in keep] + [h.restir.download(1).view(np.uint8), h.gbuf.download()["depth"][0]]
 
+    choices = []
     for a, b in zip(run(False), run(True)):
         assert bits_equal(a, b)
+    assert choices[0] == -1 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided by frame 28
 
 
 def test_phase_b_in_row_bands_equals_one_call(hip):
