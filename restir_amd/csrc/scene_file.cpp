@@ -755,44 +755,55 @@ struct JpegBits {
 
 inline unsigned char jpeg_clamp(int x) { return (unsigned char)(x < 0 ? 0 : x > 255 ? 255 : x); }
 
-// one pass of the inverse DCT over s0..s7 (constants scaled by 4096)
-#define RS_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                          \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                 \
-    p2 = s2; p3 = s6; p1 = (p2 + p3) * 2217; t2 = p1 + p3 * -7567; t3 = p1 + p2 * 3135;                    \
-    p2 = s0; p3 = s4; t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                         \
-    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                                 \
-    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                                     \
-    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2; p5 = (p3 + p4) * 4816;                          \
-    t0 = t0 * 1223; t1 = t1 * 8410; t2 = t2 * 12586; t3 = t3 * 6149;                                        \
-    p1 = p5 + p1 * -3685; p2 = p5 + p2 * -10497; p3 = p3 * -8034; p4 = p4 * -1597;                          \
-    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+// One 8-point pass of the Loeffler-Ligtenberg-Moschytz inverse DCT in 12-bit fixed point (the "slow integer" form of the IJG
+// code that stb_image follows; multipliers are round(c * 4096)).  The pass is returned as its even half (four sums / differences of
+// the even-indexed inputs) and its odd half (the four rotated odd-indexed inputs); output k is even[k] + odd[3 - k] for k < 4 and
+// even[7 - k] - odd[k - 4] above.  The integer expressions and their order are the decoder's, so the pixels are.
+struct IdctPass { int even[4], odd[4]; };
+
+inline IdctPass idct_pass(int c0, int c1, int c2, int c3, int c4, int c5, int c6, int c7) {
+    IdctPass r;
+    const int rot = (c2 + c6) * 2217;                                      // 0.5411961
+    const int lowEven = rot + c6 * -7567, highEven = rot + c2 * 3135;      // -1.847759065, 0.765366865
+    const int sum = (c0 + c4) * 4096, diff = (c0 - c4) * 4096;
+    r.even[0] = sum + highEven; r.even[3] = sum - highEven; r.even[1] = diff + lowEven; r.even[2] = diff - lowEven;
+    int o7 = c7, o5 = c5, o3 = c3, o1 = c1;
+    const int s73 = o7 + o3, s51 = o5 + o1, s71 = o7 + o1, s53 = o5 + o3;
+    const int all = (s73 + s51) * 4816;                                    // 1.175875602
+    o7 *= 1223; o5 *= 8410; o3 *= 12586; o1 *= 6149;                       // 0.298631336, 2.053119869, 3.072711026, 1.501321110
+    const int t71 = all + s71 * -3685, t53 = all + s53 * -10497;           // -0.899976223, -2.562915447
+    const int t73 = s73 * -8034, t51 = s51 * -1597;                        // -1.961570560, -0.390180644
+    r.odd[3] = o1 + (t71 + t51); r.odd[2] = o3 + (t53 + t73); r.odd[1] = o5 + (t53 + t51); r.odd[0] = o7 + (t71 + t73);
+    return r;
+}
 
 void jpeg_idct(unsigned char* out, int stride, const short d[64]) {
-    int val[64];
-    for (int i = 0; i < 8; i++) {
-        const short* c = d + i;
-        int* v = val + i;
+    int mid[64];                                                           // after the column pass, two fraction bits kept
+    for (int col = 0; col < 8; col++) {
+        const short* c = d + col;
+        int* m = mid + col;
         if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-            const int dc = c[0] * 4;
-            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+            const int flat = c[0] * 4;                                     // only the DC term: the column is constant
+            for (int k = 0; k < 8; k++) m[8 * k] = flat;
+            continue;
         }
-        else {
-            RS_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
-            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        const IdctPass p = idct_pass(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
+        for (int k = 0; k < 4; k++) {
+            m[8 * k] = (p.even[k] + 512 + p.odd[3 - k]) >> 10;
+            m[8 * (7 - k)] = (p.even[k] + 512 - p.odd[3 - k]) >> 10;
         }
     }
-    for (int i = 0; i < 8; i++) {
-        const int* v = val + i * 8;
-        unsigned char* o = out + (size_t)i * stride;
-        RS_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
-        o[0] = jpeg_clamp((x0 + t3) >> 17); o[7] = jpeg_clamp((x0 - t3) >> 17); o[1] = jpeg_clamp((x1 + t2) >> 17); o[6] = jpeg_clamp((x1 - t2) >> 17);
-        o[2] = jpeg_clamp((x2 + t1) >> 17); o[5] = jpeg_clamp((x2 - t1) >> 17); o[3] = jpeg_clamp((x3 + t0) >> 17); o[4] = jpeg_clamp((x3 - t0) >> 17);
+    for (int row = 0; row < 8; row++) {
+        const int* m = mid + row * 8;
+        unsigned char* o = out + (size_t)row * stride;
+        const IdctPass p = idct_pass(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+        const int bias = 65536 + (128 << 17);                              // rounding of the 17 fraction bits + the level shift of 128
+        for (int k = 0; k < 4; k++) {
+            o[k] = jpeg_clamp((p.even[k] + bias + p.odd[3 - k]) >> 17);
+            o[7 - k] = jpeg_clamp((p.even[k] + bias - p.odd[3 - k]) >> 17);
+        }
     }
 }
-#undef RS_IDCT_1D
 
 int load_jpeg(const std::string& path, bool flipRows, std::vector<float>& data, int& w, int& h) {
     std::vector<unsigned char> raw;
