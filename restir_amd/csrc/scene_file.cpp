@@ -76,30 +76,33 @@ M4 build_transformation_matrix(f3 translation, f3 rotation, f3 scl) {  // mathUt
     const M4 scaleMat = scale(identity(), scl);
     return mul(mul(translationMat, rotationMat), scaleMat);
 }
-M4 inverse(const M4& mm) {                                            // type_mat4x4.inl:37-92
-#define M(c_, r_) mm.c[c_][r_]
-    const float Coef00 = M(2,2) * M(3,3) - M(3,2) * M(2,3), Coef02 = M(1,2) * M(3,3) - M(3,2) * M(1,3), Coef03 = M(1,2) * M(2,3) - M(2,2) * M(1,3);
-    const float Coef04 = M(2,1) * M(3,3) - M(3,1) * M(2,3), Coef06 = M(1,1) * M(3,3) - M(3,1) * M(1,3), Coef07 = M(1,1) * M(2,3) - M(2,1) * M(1,3);
-    const float Coef08 = M(2,1) * M(3,2) - M(3,1) * M(2,2), Coef10 = M(1,1) * M(3,2) - M(3,1) * M(1,2), Coef11 = M(1,1) * M(2,2) - M(2,1) * M(1,2);
-    const float Coef12 = M(2,0) * M(3,3) - M(3,0) * M(2,3), Coef14 = M(1,0) * M(3,3) - M(3,0) * M(1,3), Coef15 = M(1,0) * M(2,3) - M(2,0) * M(1,3);
-    const float Coef16 = M(2,0) * M(3,2) - M(3,0) * M(2,2), Coef18 = M(1,0) * M(3,2) - M(3,0) * M(1,2), Coef19 = M(1,0) * M(2,2) - M(2,0) * M(1,2);
-    const float Coef20 = M(2,0) * M(3,1) - M(3,0) * M(2,1), Coef22 = M(1,0) * M(3,1) - M(3,0) * M(1,1), Coef23 = M(1,0) * M(2,1) - M(2,0) * M(1,1);
-    const float Fac0[4] = { Coef00, Coef00, Coef02, Coef03 }, Fac1[4] = { Coef04, Coef04, Coef06, Coef07 }, Fac2[4] = { Coef08, Coef08, Coef10, Coef11 };
-    const float Fac3[4] = { Coef12, Coef12, Coef14, Coef15 }, Fac4[4] = { Coef16, Coef16, Coef18, Coef19 }, Fac5[4] = { Coef20, Coef20, Coef22, Coef23 };
-    const float Vec0[4] = { M(1,0), M(0,0), M(0,0), M(0,0) }, Vec1[4] = { M(1,1), M(0,1), M(0,1), M(0,1) };
-    const float Vec2[4] = { M(1,2), M(0,2), M(0,2), M(0,2) }, Vec3[4] = { M(1,3), M(0,3), M(0,3), M(0,3) };
-    const float SignA[4] = { +1, -1, +1, -1 }, SignB[4] = { -1, +1, -1, +1 };
+// glm::inverse of a 4x4 (type_mat4x4.inl:37-92) as the cofactor expansion it is: the eighteen 2x2 minors built from two rows and
+// two of the columns 1..3, combined per output column with the entries of the remaining rows, alternating signs, divided by the
+// expansion of the determinant along the first column's row -- with GLM's grouping of every sum, so the floats are GLM's.
+M4 inverse(const M4& m) {
+    static const int rowPair[6][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 }, { 0, 3 }, { 0, 2 }, { 0, 1 } };
+    static const int colPair[3][2] = { { 2, 3 }, { 1, 3 }, { 1, 2 } };
+    float minor[6][3];
+    for (int g = 0; g < 6; g++)
+        for (int k = 0; k < 3; k++) {
+            const int ca = colPair[k][0], cb = colPair[k][1], ra = rowPair[g][0], rb = rowPair[g][1];
+            minor[g][k] = m.c[ca][ra] * m.c[cb][rb] - m.c[cb][ra] * m.c[ca][rb];
+        }
+    // per lane k of the four-wide vectors GLM works with: the minor of group g (lanes 0 and 1 share the first) and row r of the
+    // column that is left (column 1 for lane 0, column 0 otherwise)
+    auto fac = [&](int g, int k) { return minor[g][k < 2 ? 0 : k - 1]; };
+    auto vec = [&](int r, int k) { return m.c[k == 0 ? 1 : 0][r]; };
     M4 inv;
     for (int k = 0; k < 4; k++) {
-        inv.c[0][k] = ((Vec1[k] * Fac0[k] - Vec2[k] * Fac1[k]) + Vec3[k] * Fac2[k]) * SignA[k];
-        inv.c[1][k] = ((Vec0[k] * Fac0[k] - Vec2[k] * Fac3[k]) + Vec3[k] * Fac4[k]) * SignB[k];
-        inv.c[2][k] = ((Vec0[k] * Fac1[k] - Vec1[k] * Fac3[k]) + Vec3[k] * Fac5[k]) * SignA[k];
-        inv.c[3][k] = ((Vec0[k] * Fac2[k] - Vec1[k] * Fac4[k]) + Vec2[k] * Fac5[k]) * SignB[k];
+        const float plus = (k & 1) ? -1.f : 1.f, minus = -plus;
+        inv.c[0][k] = ((vec(1, k) * fac(0, k) - vec(2, k) * fac(1, k)) + vec(3, k) * fac(2, k)) * plus;
+        inv.c[1][k] = ((vec(0, k) * fac(0, k) - vec(2, k) * fac(3, k)) + vec(3, k) * fac(4, k)) * minus;
+        inv.c[2][k] = ((vec(0, k) * fac(1, k) - vec(1, k) * fac(3, k)) + vec(3, k) * fac(5, k)) * plus;
+        inv.c[3][k] = ((vec(0, k) * fac(2, k) - vec(1, k) * fac(4, k)) + vec(2, k) * fac(5, k)) * minus;
     }
-    const float d0 = M(0,0) * inv.c[0][0], d1 = M(0,1) * inv.c[1][0], d2 = M(0,2) * inv.c[2][0], d3 = M(0,3) * inv.c[3][0];
-    const float ood = 1.f / ((d0 + d1) + (d2 + d3));
-    for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) inv.c[j][k] = inv.c[j][k] * ood;
-#undef M
+    const float det = (m.c[0][0] * inv.c[0][0] + m.c[0][1] * inv.c[1][0]) + (m.c[0][2] * inv.c[2][0] + m.c[0][3] * inv.c[3][0]);
+    const float oneOverDet = 1.f / det;
+    for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) inv.c[j][k] = inv.c[j][k] * oneOverDet;
     return inv;
 }
 
