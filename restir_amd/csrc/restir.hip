@@ -118,8 +118,11 @@ __global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, Surf
 // [gy0, gy1); the shading ray is active on rows [y0, y1).
 constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
 
+#ifndef RS_FUSED_BLOCKS
+#define RS_FUSED_BLOCKS 8
+#endif
 template <bool TEX>
-__global__ void __launch_bounds__(256) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+__global__ void __launch_bounds__(256, RS_FUSED_BLOCKS) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
                                                          int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
     int x, y;
     pixel_of_lane(tilesX, gy0, x, y);
