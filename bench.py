@@ -103,7 +103,15 @@ def cpu_reference_loop(sd, threads):
     r4 = rng.uniform(0, 1, (len(xy), 4)).astype(np.float32)
     rays = np.zeros((len(xy), 6), np.float32)
     ob.lib().orc_camera_sample(C.byref(cam), len(xy), xy.reshape(-1), r4.reshape(-1), rays.reshape(-1))
-    prim, _, seconds = ob.ref_closest_hit_loop(R, sd.vertices, rays, min_seconds=5.0)
+    # the reference's BVHBuilder prints its progress on stdout (src/bvh.cpp:15): send it to stderr, stdout carries one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        prim, _, seconds = ob.ref_closest_hit_loop(R, sd.vertices, rays, min_seconds=5.0)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     return {"value": len(xy) / seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "reference",
             "hit_fraction": float((prim >= 0).mean()),
             "sample": f"closest hit of the {len(xy)} camera rays of the benchmark view, repeated for 5 s, through the reference's compiled "

@@ -151,8 +151,14 @@ __device__ inline void ind_store(rs_indirect_reservoir* p, const IndResv& r) {
 }
 __device__ inline bool ind_invalid(float W) { return is_nan_or_inf(W) || W < 0.f; }
 
+// 7 blocks per CU = 7 waves per SIMD caps the kernel at 72 VGPRs (it wants 110-140; ~200 B of scratch per lane, outside the
+// walk): measured on the bench scene at depth 4, pathTrace 12.98 -> 10.6 ms, pathTraceIndirect 12.20 -> 10.0 ms,
+// ReSTIRIndirect 15.26 -> 10.3 ms; 5 blocks 11.5 / 10.8 / 11.0 ms, 6 blocks 11.0 / 10.3 / 10.6 ms, 8 blocks (64 VGPRs) 12.3 / 12.5 / 14.1 ms
+#ifndef RS_PATH_BLOCKS
+#define RS_PATH_BLOCKS 7
+#endif
 template <int MODE, bool TEX>
-__global__ void __launch_bounds__(256) k_path(DevScene s, CamParams cam, float* __restrict__ directIllum, float* __restrict__ indirectIllum,
+__global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamParams cam, float* __restrict__ directIllum, float* __restrict__ indirectIllum,
                                               rs_indirect_reservoir* __restrict__ resvOut, const rs_indirect_reservoir* __restrict__ resvIn,
                                               GBufView g, int looper, int iter, int maxDepth, int first, int reuse, int tilesX,
                                               unsigned long long* rayCount) {

@@ -92,7 +92,7 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
 }
 
 template <bool TEX>
-__global__ void __launch_bounds__(256) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+__global__ void __launch_bounds__(256, 8) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/bench_gi.py -- 1080p timings of the multi-bounce kernels (gi.hip) on the bench scene: pathTrace (singleKernelPT),
+"""tools/bench_gi.py -- 1080p timings of the multi-bounce kernels (gi.hip) on the bench scene: pathTraceDirect (PTDirectKernel), pathTrace (singleKernelPT),
 pathTraceIndirect and ReSTIRIndirect at Settings::traceDepth = 4; Mrays/s = BVH walks (closest-hit + shadow) per second."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +26,7 @@ def run(name, fn, frames=10):
     print("%-18s %.2f ms / frame, %.2f M walks / frame -> %.0f Mrays/s" % (name, dt * 1e3, rays / frames / 1e6, rays / frames / dt / 1e6))
 
 
+run("pathTraceDirect", lambda f: capi.path_trace_direct(scene, cam, d.data_ptr(), 0, f))
 run("pathTrace", lambda f: capi.path_trace(scene, cam, d.data_ptr(), i.data_ptr(), 0, f, DEPTH))
 run("pathTraceIndirect", lambda f: capi.path_trace_indirect(scene, cam, i.data_ptr(), 0, f, DEPTH))
 run("ReSTIRIndirect", lambda f: restir.indirect(scene, cam, gbuf, i.data_ptr(), 0, f, 1, DEPTH))
