@@ -176,6 +176,11 @@ __global__ void __launch_bounds__(256) k_svgf_filter_variance(float* __restrict_
 
 // waveletFilter, SVGF form (:139-216): colour and variance filtered together, luminance weight scaled by the
 // 3x3-filtered variance.  Positions come from the per-call plane (see the header comment).
+// NSQ >= 0: sigNormal is 2^NSQ (the reference's default is 128 = 2^7), and pow(c, sigNormal) is NSQ squarings instead of powf's
+// ~100 VALU instructions -- a third of the tap.  Every squaring rounds once, so the power is within 2^(NSQ-1) ulp of the exact
+// one (3.8e-6 relative for 128; CUDA's powf is specified to 4 ulp), well inside the filter's stated tolerance (tests: rtol 3e-5).
+// NSQ < 0: powf.  DMUL: sigDepth is a power of two, x / sigDepth == x * (1 / sigDepth) exactly (default 1).
+template <int NSQ, bool DMUL>
 __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorOut, const float* __restrict__ colorIn,
                                                       float* __restrict__ varOut, const float* __restrict__ varIn,
                                                       const float* __restrict__ varFiltered,
@@ -184,6 +189,7 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
                                                       float sigDepth, float sigNormal, float sigLumin, int level) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= W || y >= H) return;
+    const float rDepth = 1.f / sigDepth;
     const int step = 1 << level;
     const int idxP = y * W + x;
     const int idP = primId[idxP];
@@ -206,8 +212,14 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
             const f3 normQ = ld3(normal + (size_t)idxQ * 3);
             const f3 colorQ = ld3(colorIn + (size_t)idxQ * 3);
             const f3 dp = posP - ld3(pos + (size_t)idxQ * 3);
-            const float wPos = expf(-dot(dp, dp) / sigDepth) + 1e-4f;
-            const float wNorm = powf(sat_dot(normP, normQ), sigNormal) + 1e-4f;
+            const float wPos = expf(DMUL ? -dot(dp, dp) * rDepth : -dot(dp, dp) / sigDepth) + 1e-4f;
+            float pn = sat_dot(normP, normQ);
+            if (NSQ >= 0) {
+#pragma unroll
+                for (int k = 0; k < NSQ; k++) pn = pn * pn;
+            }
+            else pn = powf(pn, sigNormal);
+            const float wNorm = pn + 1e-4f;
             const float denom = sigLumin * sqrtf(gmax(varFiltered[idxQ], 0.f)) + 1e-4f;
             const float wColor = expf(-gabs(lumP - luminance(colorQ)) / denom) + 1e-4f;
             const float w = wColor * wNorm * wPos * kGaussian5x5[i + 2][j + 2];
@@ -371,10 +383,17 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
     hipLaunchKernelGGL(k_svgf_variance, grid2, dim3(256), 0, rs_stream(), f->devVariance, f->devAccumMoment[fi], W, H);
     RS_TRY(rs_after_launch("SpatioTemporalFilter::temporalAccumulate"));
 
+    int de = 0;
+    const bool depthPow2 = f->sigDepth > 0.f && std::isfinite(f->sigDepth) && std::frexp(f->sigDepth, &de) == 0.5f && std::isnormal(1.f / f->sigDepth);
     auto level = [&](float* out, const float* in, int lv) {
         hipLaunchKernelGGL(k_svgf_filter_variance, grid2, dim3(256), 0, rs_stream(), f->devFilteredVariance, f->devVariance, W, H);
-        hipLaunchKernelGGL(k_svgf_wavelet, grid2, dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, f->devFilteredVariance,
-                           gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, lv);
+#define RS_SVGF_WAVELET(N, D) hipLaunchKernelGGL((k_svgf_wavelet<N, D>), grid2, dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
+                                                f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, lv)
+        if (f->sigNormal == 128.f) { if (depthPow2) RS_SVGF_WAVELET(7, true); else RS_SVGF_WAVELET(7, false); }
+        else if (f->sigNormal == 64.f) { if (depthPow2) RS_SVGF_WAVELET(6, true); else RS_SVGF_WAVELET(6, false); }
+        else if (f->sigNormal == 32.f) { if (depthPow2) RS_SVGF_WAVELET(5, true); else RS_SVGF_WAVELET(5, false); }
+        else { if (depthPow2) RS_SVGF_WAVELET(-1, true); else RS_SVGF_WAVELET(-1, false); }
+#undef RS_SVGF_WAVELET
         float* t = f->devTempVariance; f->devTempVariance = f->devVariance; f->devVariance = t;      // std::swap(devTempVariance, devVariance)
     };
     level(*devColorOut, f->devAccumColor[fi], 0);
