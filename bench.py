@@ -22,6 +22,7 @@ One JSON line is printed by rank 0; besides the contract's fields it carries
   cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a
                 bounded sample of the same workload (rank 0, N = 1 only)
+  cpu_config1   BASELINE config 1 (Cornell 256x256, 1 spp PTDirect) as a host loop on the same cores
 """
 import argparse
 import json
@@ -82,6 +83,31 @@ def cpu_baseline(sd, frames):
             "sample": f"{frames} frames of the same workload (1920x1080 spatiotemporal, Sponza-class 262144 tris), OpenMP over rows"}
 
 
+def cpu_config1(threads, seconds=3.0):
+    """BASELINE config 1: Cornell box, 256x256, 1 spp raw path trace without ReSTIR (PTDirect semantics, looper 0, 1, ...)
+    as a host loop -- the oracle's restatement of PTDirectKernel (src/pathtrace.cu:279-328) over the reference's intersection
+    code, OpenMP over rows; no GPU involved."""
+    import numpy as np
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import binding as ob
+    from restir_amd import scenes
+    from tests.common import oracle_scene
+    sd = scenes.cornell_box()
+    w = h = 256
+    scene = oracle_scene(sd)
+    cam = ob.camera_update(sd.camera(w, h))
+    img = np.zeros((w * h, 3), np.float32)
+    ob.pt_direct(scene, cam, img, 0, 0)                    # untimed: thread-pool start-up
+    rays, frames = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        rays += ob.pt_direct(scene, cam, img, 0, frames)
+        frames += 1
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "ms_per_frame": dt / frames * 1e3,
+            "sample": f"{frames} frames of Cornell box 256x256, 1 spp pathTraceDirect (primary + one shadow ray per shaded pixel), host loop only"}
+
+
 def cpu_reference_loop(sd, threads):
     """The baseline north_star names: a host-side loop over the reference's own intersections.h / bvh.h -- DevScene::intersect's
     traversal around the reference's compiled AABB::intersect / intersectTriangle on the reference builder's tree
@@ -126,6 +152,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--orbit", action="store_true", help="orbit the camera (runCuda animateCamera) instead of the static default")
     args = ap.parse_args()
+    if os.environ.get("BENCH_WATCHDOG"):                 # debugging aid: Python stack of every thread if the run takes longer than this
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
 
     import numpy as np
     import torch
@@ -198,6 +227,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Before the warm-up: the library measures once per scene whether GBuffer::render is walked together with the primary rays
+    # (frames 2-13 of a new rs_restir, restir.hip); those frames run here, so that warm-up and timed frames all use the form it
+    # chose.  Strips too small for the fused launch have nothing to choose (-2).
+    # The count is the same on every rank (a frame exchanges halo rows with the neighbours).
+    calibration_frames = 16
+    for _ in range(calibration_frames):
+        frame()
+    barrier()
     for _ in range(args.warmup):
         frame()
     barrier()
@@ -209,6 +246,21 @@ def main():
     counted = min(args.steps, 1024)
     # G-buffer rays: only the strip's own rows count (the +-5 halo rows a strip re-renders are overhead, not throughput)
     local_rays = backend.restir.ray_total(counted) / counted * args.steps + rows * WIDTH * args.steps
+
+    # latency of one frame when nothing overlaps: the reference's own mode (every call synchronises, cudaUtil.h:15)
+    capi.set_sync(True)
+    sync_ms = []
+    for _ in range(12):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        frame()
+        for k in range(len(pending)):
+            if pending[k] is not None:
+                pending[k].wait(); pending[k] = None
+        torch.cuda.synchronize()
+        sync_ms.append((time.perf_counter() - ts) * 1e3)
+    capi.set_sync(False)
+    barrier()
 
     # per-pass times of a few extra (untimed) frames, HIP events on the library's stream; the G-buffer render is kept on
     # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
@@ -267,6 +319,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_frame_synchronous": float(np.median(sync_ms[2:])),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -276,7 +329,8 @@ def main():
                                    "32 RIS candidates, spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update",
                        "camera": "orbit" if args.orbit else "static",
                        "launches": "asynchronous (rs_set_sync(0)): consecutive frames overlap on the library's auxiliary streams; GBuffer::render is walked "
-                                   "together with the primary rays when the library measures that to be faster (frames 4-19 of the run measure)",
+                                   "together with the primary rays when the library measures that to be faster (it measures in untimed frames before the warm-up); "
+                                   "ms_per_frame_synchronous is one frame alone with a synchronisation after every call, the reference's mode",
                        "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in strips.bounds) + " rows (cost-balanced by measurement), "
                                   "5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0") if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
@@ -287,9 +341,11 @@ def main():
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }
-        out["config"]["launch_choice"] = {-1: "not decided within this run", 0: "two launches", 1: "one fused launch"}[backend.restir.launch_choice()]
+        out["config"]["launch_choice"] = {-2: "two launches (nothing to choose: launch too small to fuse)", -1: "not decided within this run", 0: "two launches", 1: "one fused launch"}[backend.restir.launch_choice()]
+        out["config"]["calibration_frames_before_warmup"] = calibration_frames
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(sd, args.cpu_frames)
+            out["cpu_config1"] = cpu_config1(out["cpu_baseline"]["cores"])
             ref_loop = cpu_reference_loop(sd, out["cpu_baseline"]["cores"])
             if ref_loop is not None:
                 out["cpu_reference_loop"] = ref_loop

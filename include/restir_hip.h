@@ -148,7 +148,7 @@ int  rs_set_sync(int sync);
  * passes.  Results are identical; output buffers are valid in library-stream order as before.  GBuffer::render can in addition
  * be deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal:
  * 4 % faster on a full Sponza-class frame, slower where a few long tiles set the launch time, so by default
- * every rs_restir measures the frame period both ways once per scene (frames 4..19) and keeps the faster.
+ * every rs_restir measures the frame period both ways once per scene (frames 2..13) and keeps the faster.
  *   0 = everything on the library stream (also RS_SIDE_STREAM=0)
  *   1 = overlapped frames, the render always its own launch (also RS_FUSE_GBUFFER=0)
  *   2 = overlapped frames, the render always deferred for launches of at least three rounds of the chip's wave slots (RS_FUSE_GBUFFER=1)
@@ -270,8 +270,9 @@ int  rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam
 int  rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                        float* devDirectIllum, int iter, int reuse, int y0, int y1);
 int  rs_restir_end_frame(rs_restir* r);
-/* What the measurement of rs_set_side_stream's mode 4 decided for this object and its current scene: -1 still measuring (or
- * nothing to choose), 0 GBuffer::render and the primary rays as two launches, 1 as one. */
+/* What the measurement of rs_set_side_stream's mode 4 decided for this object and its current scene: 0 GBuffer::render and the
+ * primary rays as two launches, 1 as one, -1 still measuring (decided once 14 frames with such a launch have been enqueued; a
+ * caller that times frames runs those first), -2 nothing to choose (synchronous launches, launches too small to fuse, a forced mode). */
 int  rs_restir_launch_choice(const rs_restir* r, int* choice);
 #define RS_SPATIAL_HALO_ROWS 5           /* taps reach y-4..y+5 (src/restir.cu:49-56) */
 /* bytes needed for `rows` rows of published reservoirs */
@@ -335,6 +336,12 @@ int  rs_copy_imagei_to_pbo(void* devPBO, const int* devImage, int width, int hei
 /* ---- EAW denoiser (src/denoiser.h:33-43,72-74) -------------------------------------------- */
 int  rs_eaw_create(int width, int height, int level, rs_eaw** f);   /* LeveledEAWFilter::create */
 int  rs_eaw_destroy(rs_eaw* f);
+/* The members the viewer edits between frames (src/preview.cpp:262-265: LeveledEAWFilter::level and
+ * waveletFilter.sigLumin / sigNormal / sigDepth, src/denoiser.h:18-27,41).  create() sets 64 / .2 / 1 (src/denoiser.cu:455).
+ * `level` is stored and reported like the reference's member; LeveledEAWFilter::filter runs its five levels whatever it
+ * holds (src/denoiser.cu:463-477), and so does rs_eaw_filter. */
+int  rs_eaw_set_params(rs_eaw* f, float sigLumin, float sigNormal, float sigDepth, int level);
+int  rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level);
 /* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
  * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
 int  rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);
@@ -347,6 +354,10 @@ int  rs_eaw_level_rows(rs_eaw* f, float* devColorOut, const float* devColorIn, c
 /* SpatioTemporalFilter::create / destroy (src/denoiser.cu:479-504); wavelet sigmas 4 / 128 / 1 as in the reference */
 int  rs_svgf_create(int width, int height, int level, rs_svgf** f);
 int  rs_svgf_destroy(rs_svgf* f);
+/* SpatioTemporalFilter::level and waveletFilter.sig* (src/preview.cpp:278-286, src/denoiser.h:59); create() sets 4 / 128 / 1
+ * (src/denoiser.cu:488).  As in the reference the filter always runs five levels. */
+int  rs_svgf_set_params(rs_svgf* f, float sigLumin, float sigNormal, float sigDepth, int level);
+int  rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level);
 /* SpatioTemporalFilter::filter (src/denoiser.cu:532-564): temporal accumulation (alpha .2), variance estimate, five
  * variance-guided a-trous levels.  *devColorOut is the reference's `glm::vec3*& devColorOut`: it is swapped with the
  * filter's buffers (the level-0 result becomes the history), so the caller continues with the pointer it gets back

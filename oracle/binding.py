@@ -514,6 +514,18 @@ def eaw_filter(gbuf, cam, color_in):
     return out if p == out.ctypes.data else tmp
 
 
+def eaw_filter_with(gbuf, cam, color_in, sig_lumin, sig_normal, sig_depth):
+    """LeveledEAWFilter::filter (src/denoiser.cu:463-477) with the sigmas the viewer may have set (src/preview.cpp:263-265)."""
+    n = gbuf.width * gbuf.height
+    src = np.ascontiguousarray(color_in, np.float32).reshape(-1).copy()
+    bufs = [np.zeros(n * 3, np.float32), np.zeros(n * 3, np.float32)]
+    for level in range(5):
+        dst = bufs[level % 2]
+        lib().orc_eaw_level(C.byref(gbuf.c), C.byref(cam), src, dst, sig_depth, sig_normal, sig_lumin, level)
+        src = dst
+    return src.reshape(n, 3)
+
+
 def camera_update(cam):
     lib().orc_camera_update(C.byref(cam))
     return cam

@@ -105,7 +105,7 @@ EXPORTS = [
     "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
-    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
+    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
@@ -199,6 +199,10 @@ def lib():
     for name in ("rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo"):
         getattr(L, name).argtypes = [vp, vp, ci, ci]
     L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
+    for name in ("rs_eaw_set_params", "rs_svgf_set_params"):
+        getattr(L, name).argtypes = [vp, C.c_float, C.c_float, C.c_float, ci]
+    for name in ("rs_eaw_get_params", "rs_svgf_get_params"):
+        getattr(L, name).argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(ci)]
     L.rs_eaw_destroy.argtypes = [vp]
     L.rs_eaw_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
     L.rs_eaw_positions_rows.argtypes = [vp, vp, C.POINTER(Camera), ci, ci]
@@ -225,6 +229,11 @@ def init(device=0):
 
 def set_sync(sync):
     check(lib().rs_set_sync(1 if sync else 0))
+
+
+def set_stream(hip_stream):
+    """The stream the library enqueues on (rs_set_stream); 0 / None = the legacy default stream."""
+    check(lib().rs_set_stream(C.c_void_p(int(hip_stream or 0))))
 
 
 def set_side_stream(enable):
@@ -573,7 +582,7 @@ class ReSTIR:
         check(lib().rs_restir_end_frame(self.handle))
 
     def launch_choice(self):
-        """-1 still measuring / nothing to choose, 0 two launches, 1 GBuffer::render walked together with the primary rays."""
+        """0 two launches, 1 GBuffer::render walked together with the primary rays, -1 still measuring, -2 nothing to choose."""
         c = C.c_int(-1)
         check(lib().rs_restir_launch_choice(self.handle, C.byref(c)))
         return c.value
@@ -648,6 +657,15 @@ class EAWFilter:
         check(lib().rs_eaw_filter(self.handle, C.byref(p), in_ptr, gbuf.handle, C.byref(cam)))
         return p.value
 
+    def set_params(self, sig_lumin, sig_normal, sig_depth, level=5):
+        """waveletFilter.sigLumin / sigNormal / sigDepth and level, the members the viewer edits (src/preview.cpp:262-265)."""
+        check(lib().rs_eaw_set_params(self.handle, sig_lumin, sig_normal, sig_depth, level))
+
+    def get_params(self):
+        a, b, c, lv = C.c_float(), C.c_float(), C.c_float(), C.c_int()
+        check(lib().rs_eaw_get_params(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(lv)))
+        return a.value, b.value, c.value, lv.value
+
     def positions_rows(self, gbuf, cam, y0, y1):
         check(lib().rs_eaw_positions_rows(self.handle, gbuf.handle, C.byref(cam), y0, y1))
 
@@ -676,6 +694,15 @@ class SVGFFilter:
         check(lib().rs_svgf_filter(self.handle, C.byref(p), in_ptr, gbuf.handle, C.byref(cam)))
         self.out_ptr = p.value
         return self.out_ptr
+
+    def set_params(self, sig_lumin, sig_normal, sig_depth, level=5):
+        """waveletFilter.sig* and level of SpatioTemporalFilter (src/preview.cpp:278-286)."""
+        check(lib().rs_svgf_set_params(self.handle, sig_lumin, sig_normal, sig_depth, level))
+
+    def get_params(self):
+        a, b, c, lv = C.c_float(), C.c_float(), C.c_float(), C.c_int()
+        check(lib().rs_svgf_get_params(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(lv)))
+        return a.value, b.value, c.value, lv.value
 
     def next_frame(self):
         check(lib().rs_svgf_next_frame(self.handle))

@@ -271,6 +271,20 @@ int rs_eaw_create(int width, int height, int level, rs_eaw** out) {
     return 0;
 }
 
+int rs_eaw_set_params(rs_eaw* f, float sigLumin, float sigNormal, float sigDepth, int level) {
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_set_params: null filter");
+    f->sigLumin = sigLumin; f->sigNormal = sigNormal; f->sigDepth = sigDepth; f->level = level;
+    return 0;
+}
+int rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level) {
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_get_params: null filter");
+    if (sigLumin) *sigLumin = f->sigLumin;
+    if (sigNormal) *sigNormal = f->sigNormal;
+    if (sigDepth) *sigDepth = f->sigDepth;
+    if (level) *level = f->level;
+    return 0;
+}
+
 int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
     RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: null argument");
@@ -325,6 +339,20 @@ int rs_svgf_destroy(rs_svgf* f) {
     rs_dev_free(f->devVariance); rs_dev_free(f->devTempVariance); rs_dev_free(f->devFilteredVariance);
     rs_dev_free(f->devTempColor); rs_dev_free(f->devPos);
     delete f;
+    return 0;
+}
+
+int rs_svgf_set_params(rs_svgf* f, float sigLumin, float sigNormal, float sigDepth, int level) {
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_set_params: null filter");
+    f->sigLumin = sigLumin; f->sigNormal = sigNormal; f->sigDepth = sigDepth; f->level = level;
+    return 0;
+}
+int rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level) {
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_get_params: null filter");
+    if (sigLumin) *sigLumin = f->sigLumin;
+    if (sigNormal) *sigNormal = f->sigNormal;
+    if (sigDepth) *sigDepth = f->sigDepth;
+    if (level) *level = f->level;
     return 0;
 }
 

@@ -5,6 +5,9 @@
 // stay coherent during the closest-hit walk (the walk is the cost; the 36 B/px of plane writes are
 // coalesced in 8-pixel row segments).  HBM per pixel: write albedo 12 + normal 12 + id 4 + depth 4
 // + motion 4 = 36 B; BVH node/triangle reads are data dependent and mostly served by L2 / MALL.
+#include <algorithm>
+#include <mutex>
+
 #include "rs_internal.h"
 
 using namespace rs;
@@ -30,6 +33,19 @@ __global__ void __launch_bounds__(256, 8) k_render_gbuffer(DevScene s, CamParams
 
 namespace {
 
+// G-buffers that hold a render which has been requested but not launched yet.  The record keeps a pointer to the scene, so
+// rs_scene_destroy launches (or drops) every pending render of the scene it is about to free (rs_gbuffer_release_scene).
+std::mutex g_deferredMutex;
+std::vector<const rs_gbuffer*> g_deferred;
+void deferred_register(const rs_gbuffer* g) {
+    std::lock_guard<std::mutex> lock(g_deferredMutex);
+    if (std::find(g_deferred.begin(), g_deferred.end(), g) == g_deferred.end()) g_deferred.push_back(g);
+}
+void deferred_unregister(const rs_gbuffer* g) {
+    std::lock_guard<std::mutex> lock(g_deferredMutex);
+    g_deferred.erase(std::remove(g_deferred.begin(), g_deferred.end(), g), g_deferred.end());
+}
+
 void launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, const rs_camera* lastCam, int y0, int y1, hipStream_t st) {
     const int c = g->cur();
     GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
@@ -46,6 +62,7 @@ void launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* 
 int flush_deferred(const rs_gbuffer* g) {
     if (!g->deferred.valid) return 0;
     g->deferred.valid = false;
+    deferred_unregister(g);
     hipStream_t aux = rs_aux_stream(0);
     if (aux) RS_TRY(rs_gbuffer_order_before_render(g, aux));
     else aux = rs_stream();                                 // (the mode was switched in between: plain launch on the library stream)
@@ -69,6 +86,25 @@ int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream) {
     return 0;
 }
 
+// ReSTIRDirect has launched the deferred render itself (restir.hip k_gbuffer_primary)
+void rs_gbuffer_deferred_taken(const rs_gbuffer* g) {
+    g->deferred.valid = false;
+    deferred_unregister(g);
+}
+
+// rs_scene_destroy: every render of `scene` that is still only recorded is launched now, while the scene's arrays exist (the
+// caller then waits for all streams before freeing them), so that no G-buffer keeps a pointer to a dead scene.
+int rs_gbuffer_release_scene(const rs_scene* scene) {
+    std::vector<const rs_gbuffer*> mine;
+    {
+        std::lock_guard<std::mutex> lock(g_deferredMutex);
+        for (const rs_gbuffer* g : g_deferred) if (g->deferred.valid && g->deferred.scene == scene) mine.push_back(g);
+    }
+    int e = 0;
+    for (const rs_gbuffer* g : mine) { const int r = flush_deferred(g); if (r && !e) e = r; }
+    return e;
+}
+
 // the library stream waits for a render still running on an auxiliary stream; a deferred render is launched first
 int rs_gbuffer_join(const rs_gbuffer* g) {
     if (!g) return 0;
@@ -82,6 +118,8 @@ extern "C" {
 
 int rs_gbuffer_destroy(rs_gbuffer* g) {
     if (!g) return 0;
+    g->deferred.valid = false;                          // a render nobody asked the result of
+    deferred_unregister(g);
     (void)rs_synchronize();                             // also a render still running on the auxiliary stream
     for (int i = 0; i < rs_gbuffer::kSets; i++) {
         rs_dev_free(g->albedo[i]); rs_dev_free(g->motion[i]); rs_dev_free(g->normal[i]); rs_dev_free(g->primId[i]); rs_dev_free(g->depth[i]);
@@ -140,6 +178,7 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
         RS_TRY(flush_deferred(g));                          // an earlier render of this frame goes first
         g->deferred.valid = true; g->deferred.rerender = g->renderedSinceUpdate;
         g->deferred.scene = scene; g->deferred.cam = *cam; g->deferred.lastCam = g->lastCamera; g->deferred.y0 = y0; g->deferred.y1 = y1;
+        deferred_register(g);
         g->renderedSinceUpdate = true;
         if (!rs_fuse_enabled()) RS_TRY(flush_deferred(g));
         return 0;

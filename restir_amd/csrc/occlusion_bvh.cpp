@@ -206,16 +206,27 @@ int rs_reference_chain_tables(int bvhSize, const int* order0 /* 3 ints per node 
     parent.assign((size_t)bvhSize, -1);
     leafOfPrim.assign((size_t)numPrims, -1);
     // order0[i] = {prim, origId, next}; subtree of i = [i, next); children of an inner node: i+1 and next(i+1)
+    // (a caller-supplied table is only known to have forward links: every index is checked before it is used, and a table in
+    // which some node is reached twice is not a tree)
     std::vector<int> stack;
+    std::vector<char> seen((size_t)bvhSize, 0);
     stack.push_back(0);
+    size_t visits = 0;
     while (!stack.empty()) {
         const int i = stack.back(); stack.pop_back();
+        if (++visits > (size_t)bvhSize) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: the threaded order is not a tree");
         const int prim = order0[(size_t)i * 3], orig = order0[(size_t)i * 3 + 1];
+        if (orig < 0 || orig >= bvhSize || seen[(size_t)orig]) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: boundingBoxId out of range or used twice");
+        seen[(size_t)orig] = 1;
         if (prim >= 0) { if (prim < numPrims) leafOfPrim[(size_t)prim] = orig; continue; }
-        const int a = i + 1, b = order0[(size_t)a * 3 + 2];
-        if (b >= bvhSize) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: malformed tree");
-        parent[(size_t)order0[(size_t)a * 3 + 1]] = orig;
-        parent[(size_t)order0[(size_t)b * 3 + 1]] = orig;
+        const int a = i + 1;
+        if (a >= bvhSize) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: inner node without children");
+        const int b = order0[(size_t)a * 3 + 2];
+        if (b <= a || b >= bvhSize) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: malformed tree");
+        const int oa = order0[(size_t)a * 3 + 1], ob = order0[(size_t)b * 3 + 1];
+        if (oa < 0 || oa >= bvhSize || ob < 0 || ob >= bvhSize) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: boundingBoxId out of range");
+        parent[(size_t)oa] = orig;
+        parent[(size_t)ob] = orig;
         stack.push_back(b); stack.push_back(a);
     }
     for (int p = 0; p < numPrims; p++) if (leafOfPrim[(size_t)p] < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: primitive without a leaf");

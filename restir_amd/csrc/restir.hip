@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256, 8) k_primary(DevScene s, CamParams cam, S
 // still pending -- rs_gbuffer_render_rows defers it): per 8x8 tile the pixel-centre ray and the jittered ray are walked together
 // (walk_two_packet), then each is stored as k_render_gbuffer / k_primary store it.  Tiles are laid out from the G-buffer rows
 // [gy0, gy1); the shading ray is active on rows [y0, y1).
+constexpr int kTuneA = 2, kTuneB = 8, kTuneC = 14;          // frames at which the measured launch choice takes its time stamps
 constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
 
 #ifndef RS_FUSED_BLOCKS
@@ -641,8 +642,12 @@ int rs_restir_enable_timing(rs_restir* r, int enable) {
     return 0;
 }
 
-int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
-                      int looper, int reuse, int y0, int y1) {
+}  // extern "C"
+
+namespace {
+// `last`: the call ends with rs_after_launch (which synchronises in synchronous mode); ReSTIRDirect passes false for its two
+// inner calls and synchronises once at its end
+int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, int looper, int reuse, int y0, int y1, bool last) {
     RS_TRY(check_frame_args(r, scene, cam, g));
     if (y0 < 0) y0 = 0;
     if (y1 > r->height) y1 = r->height;
@@ -683,13 +688,13 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     bool fuse = aux && fuseMode != 0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
                 (fuseMode == 2 || (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves);
     if (fuse && fuseMode == 3) {                                  // measured choice (end_frame advances the measurement)
-        if (r->tuneScene != scene) { r->tuneScene = scene; r->tuneFrame = 0; r->tuneChoice = -1; }
+        if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
         r->tuneCounted = true;
-        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= 12 && r->tuneFrame < 20);
+        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
     }
     if (fuse) {
         RS_TRY(rs_gbuffer_order_before_render(g, aux));
-        g->deferred.valid = false;
+        rs_gbuffer_deferred_taken(g);
         const int c = g->cur();
         const GBufWrite gw{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
         const int gTilesY = (d.y1 - d.y0 + 7) / 8;
@@ -723,11 +728,11 @@ int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
                        r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
     mark(r, 3);
-    return rs_after_launch("ReSTIR Direct (phase A)");
+    return last ? rs_after_launch("ReSTIR Direct (phase A)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase A)");
 }
 
-int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
-                      float* devDirectIllum, int iter, int reuse, int y0, int y1) {
+int phase_b_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                 float* devDirectIllum, int iter, int reuse, int y0, int y1, bool last) {
     RS_TRY(check_frame_args(r, scene, cam, g));
     if (!devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: null radiance buffer");
     if (y0 < 0) y0 = 0;
@@ -739,13 +744,27 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(kBThreads), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
                        r->cur, r->temp, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);
-    return rs_after_launch("ReSTIR Direct (phase B)");
+    return last ? rs_after_launch("ReSTIR Direct (phase B)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase B)");
+}
+}  // namespace
+
+extern "C" {
+
+int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                      int looper, int reuse, int y0, int y1) {
+    return phase_a_impl(r, scene, cam, g, looper, reuse, y0, y1, true);
 }
 
-// -1 still measuring (or nothing to choose: synchronous launches, small launches, a forced mode), 0 two launches, 1 one fused launch
+int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
+                      float* devDirectIllum, int iter, int reuse, int y0, int y1) {
+    return phase_b_impl(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1, true);
+}
+
+// 0 two launches, 1 one fused launch, -1 still measuring, -2 nothing to choose (no frame so far had a launch the choice applies to:
+// synchronous launches, launches below three rounds of wave slots, a forced mode)
 int rs_restir_launch_choice(const rs_restir* r, int* choice) {
     if (!r || !choice) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_launch_choice: null argument");
-    *choice = r->tuneChoice;
+    *choice = r->tuneChoice >= 0 ? r->tuneChoice : (r->tuneFrame > 0 || r->tuneCounted) ? -1 : -2;
     return 0;
 }
 
@@ -758,20 +777,19 @@ int rs_restir_end_frame(rs_restir* r) {
     else r->surfFreeValid[r->surfSet] = false;
     r->surfSet ^= 1;
     r->phaseACalls = 0;
-    // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames 4, 12 and 20 begin; once the last
-    // one has passed the shorter of the two 8-frame spans decides, with 3 % in favour of two launches
+    // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA, kTuneB and kTuneC begin (two
+    // launches in the first span, one fused launch in the second); at frame kTuneC the host waits once for the last stamp (the GPU
+    // still has that frame's predecessors queued) and the shorter span decides, with 3 % in favour of two launches.  A caller that
+    // times frames runs kTuneC + 1 frames first (bench.py does, before its warm-up) and then sees one launch form only.
     if (r->tuneCounted && r->tuneChoice < 0) {
         const int f = ++r->tuneFrame;
-        if (f == 4 || f == 12 || f == 20) RS_HIP(hipEventRecord(r->tuneEv[f == 4 ? 0 : f == 12 ? 1 : 2], rs_stream()));
-        // The host can run many frames ahead of the GPU.  The stamp is polled for a while; after eight more frames the host waits
-        // for it once (the GPU has those frames queued and stays busy), so that the choice is made by frame 28 at the latest.
-        hipError_t ready = f >= 28 ? hipEventSynchronize(r->tuneEv[2]) : f >= 20 ? hipEventQuery(r->tuneEv[2]) : hipErrorNotReady;
-        if (f >= 20 && ready != hipSuccess) (void)hipGetLastError();      // "not ready" must not look like a launch error later
-        if (ready == hipSuccess) {
+        if (f == kTuneA || f == kTuneB || f == kTuneC) RS_HIP(hipEventRecord(r->tuneEv[f == kTuneA ? 0 : f == kTuneB ? 1 : 2], rs_stream()));
+        if (f >= kTuneC) {
             float separate = 0.f, fused = 0.f;
-            if (hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess && hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
+            if (hipEventSynchronize(r->tuneEv[2]) == hipSuccess && hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess &&
+                hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
                 r->tuneChoice = fused < 0.97f * separate ? 1 : 0;
-            else r->tuneChoice = 0;
+            else { (void)hipGetLastError(); r->tuneChoice = 0; }
         }
     }
     r->tuneCounted = false;
@@ -781,12 +799,10 @@ int rs_restir_end_frame(rs_restir* r) {
 int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                      float* devDirectIllum, int iter, int looper, int reuse) {
     RS_TRY(check_frame_args(r, scene, cam, g));
-    const bool sync = rs_sync_enabled();
-    rs_set_sync(0);                                               // one synchronisation for the whole call
-    int e = rs_restir_phase_a(r, scene, cam, g, looper, reuse, 0, r->height);
-    if (!e) e = rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, 0, r->height);
-    rs_set_sync(sync ? 1 : 0);
-    if (e) return e;
+    // one synchronisation for the whole call (synchronous mode); the library's mode itself is not touched, so the two phases
+    // stay on the library stream in synchronous mode and use the auxiliary streams in asynchronous mode only
+    RS_TRY(phase_a_impl(r, scene, cam, g, looper, reuse, 0, r->height, false));
+    RS_TRY(phase_b_impl(r, scene, cam, g, devDirectIllum, iter, reuse, 0, r->height, false));
     RS_TRY(rs_restir_end_frame(r));
     return rs_after_launch("ReSTIR Direct");
 }

@@ -70,6 +70,7 @@ struct rs_scene {
     std::vector<rs_material> hMaterials;
     float sumLightPower = 0.f;
     int numPrims = 0, bvhSize = 0, numLights = 0;
+    unsigned long long id = 0;       // unique per rs_scene_create (a freed scene's address can come back; its id cannot)
 };
 
 // ---- G-buffer (src/gbuffer.h:41-58) ------------------------------------------------------------
@@ -114,6 +115,10 @@ struct rs_gbuffer {
 // the library stream waits for a render that is still on the auxiliary stream (and a deferred one is launched first); every
 // reader of the planes calls it first
 int rs_gbuffer_join(const rs_gbuffer* g);
+// a deferred render was launched by someone else (ReSTIRDirect, fused with its primary rays): forget the record
+void rs_gbuffer_deferred_taken(const rs_gbuffer* g);
+// launches every render of `scene` that is still only recorded (rs_scene_destroy calls it before it frees the arrays)
+int rs_gbuffer_release_scene(const rs_scene* scene);
 // orders `stream` after the last readers of the set a (deferred) render is about to write
 int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream);
 bool rs_fuse_enabled();
@@ -224,8 +229,8 @@ struct rs_restir {
     hipEvent_t auxFork = nullptr, auxDone = nullptr;
     int phaseACalls = 0;             // since the last end_frame
     // one traversal for the G-buffer ray and the shading ray of a pixel, or two?  Measured once per scene (rs_fuse_mode() == 3):
-    // frames 4..11 with two launches, 12..19 with one, timed by events on the library stream at the frame ends
-    const rs_scene* tuneScene = nullptr;
+    // frames 2..7 with two launches, 8..13 with one, timed by events on the library stream at the frame ends
+    unsigned long long tuneSceneId = 0;
     int tuneFrame = 0;               // frames with a fusable launch since tuning began
     int tuneChoice = -1;             // -1 measuring, 0 separate, 1 fused
     bool tuneCounted = false;        // this frame had a launch the choice applies to

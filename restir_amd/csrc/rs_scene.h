@@ -29,9 +29,12 @@
 
 namespace rs {
 
+// field order: the packet walk reads a record through the scalar cache and feeds SGPR pairs to packed FP32 instructions, which
+// want (min.x, min.y), (min.z, max.z), (max.x, max.y) in aligned pairs; node_unpack() restores the (min | prim), (max | next)
+// view the per-lane walks are written with (register renaming, no instructions)
 struct __attribute__((aligned(16))) BvhNode {
-    float bminx, bminy, bminz; int primId;
-    float bmaxx, bmaxy, bmaxz; int next;
+    float bminx, bminy, bminz, bmaxz;
+    float bmaxx, bmaxy; int primId; int next;
 };
 struct __attribute__((aligned(16))) TriRec {
     float v0x, v0y, v0z, pad0;
@@ -68,6 +71,7 @@ struct DevScene {
     f3 occRootLo, occRootHi;      // the reference's root box
     bool occNested;               // every reference box lies inside its parent's (enables the leaf shortcut)
     bool axisCull;                // boxes contain their children and triangles (enables skip_far_on_axis)
+    bool linksNested;             // in every threaded order the miss links nest: c in (a, link(a)) => link(c) <= link(a)
     int occCount;
     unsigned long long* walkStats;   // null unless built with -DRS_WALK_STATS (tools/walk_stats.py)
     int bvhSize;
@@ -282,6 +286,11 @@ RS_HD int mtbvh_order(f3 dir) {
 __device__ __forceinline__ float4 ld16(const char* base, unsigned off) {
     return *reinterpret_cast<const float4*>(base + off);
 }
+// the two 16-byte halves of a BvhNode as loaded -> lo = {min.xyz, bits(primId)}, hi = {max.xyz, bits(next)}
+__device__ __forceinline__ void node_unpack(const float4& ra, const float4& rb, float4& lo, float4& hi) {
+    lo = make_float4(ra.x, ra.y, ra.z, rb.z);
+    hi = make_float4(rb.x, rb.y, ra.w, rb.w);
+}
 
 // General-case slab test (bvh.h:124-156 with none of the special cases): valid when every
 // |d.c| is in [1e-6, 1-1e-6].  Then all t are finite, so glm::min/max equal fminf/fmaxf up to the
@@ -307,7 +316,7 @@ __device__ __forceinline__ void load_tri(const TriRec* tris, int prim, f3& v0, f
 struct WalkResult {
     float closest; int prim; float bx, by; bool any;
 #ifdef RS_WALK_STATS
-    unsigned steps;
+    unsigned steps, nearSteps, enteredSteps, leafSteps;
 #endif
 };
 
@@ -322,7 +331,8 @@ __device__ __forceinline__ WalkResult walk(const DevScene& s, const Ray& ray, co
     const unsigned endOff = first + (unsigned)s.bvhSize * 32u;
     unsigned cur = first;
     while (cur != endOff) {
-        const float4 lo = ld16(base, cur), hi = ld16(base, cur + 16);
+        float4 lo, hi;
+        node_unpack(ld16(base, cur), ld16(base, cur + 16), lo, hi);
         float tb;
         bool bh;
         if (GENERAL) bh = box_hit_general(ctx.o, ctx.dinv, lo, hi, tb);
@@ -377,7 +387,8 @@ __device__ __forceinline__ WalkResult walk_paired(const DevScene& s, const Ray& 
         const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);      // even lane's node, split over the pair
         const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);      // odd lane's node
         const float4 s1 = dpp_swap1(r1), s2 = dpp_swap1(r2);
-        const float4 lo = odd ? s2 : r1, hi = odd ? r2 : s1;
+        float4 lo, hi;
+        node_unpack(odd ? s2 : r1, odd ? r2 : s1, lo, hi);
         if (cur != endOff) {
             float tb;
             bool bh;
@@ -458,7 +469,8 @@ __device__ __forceinline__ bool walk_anyhit_deferred(const DevScene& s, const Ra
         const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);
         const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);
         const float4 s1 = dpp_swap1(r1), s2 = dpp_swap1(r2);
-        const float4 lo = odd ? s2 : r1, hi = odd ? r2 : s1;
+        float4 lo, hi;
+        node_unpack(odd ? s2 : r1, odd ? r2 : s1, lo, hi);
         if (walking) {
             float tb;
             bool bh;
@@ -564,7 +576,8 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                 RS_STAT(4, 1); RS_STAT(7, __popcll(__ballot(verify >= 0)));
                 if (verify >= 0) {
                     const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
-                    const float4 lo = rec[0], hi = rec[1];
+                    float4 lo, hi;
+                    node_unpack(rec[0], rec[1], lo, hi);
                     // the general case of AABB::intersect (box_hit_general), spelled out for the margins below
                     const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
                     const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
@@ -669,6 +682,105 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- the fast form of the packet walk ---------------------------------------------------------------------------------------
+// For general-case rays (none of AABB::intersect's special cases) whose direction has the same component signs in every lane of
+// the wave (all but the ~1 % of 8x8 tiles that straddle a sign change), on a proper box table with nested miss links
+// (DevScene::axisCull && linksNested).  Same nodes per lane, same order, same arithmetic on the values that decide -- what
+// changes is how little the wave does per node.  Measured on the r01 loop: 54 VALU + ~30 SALU instructions per union node, and
+// both units issue one instruction per SIMD every four cycles, so the scalar side counts as much as the vector side:
+//   * near / far plane of each axis: with lo <= hi, (lo - o) * dinv <= (hi - o) * dinv for dinv > 0 and the other way round for
+//     dinv < 0, because IEEE subtraction and multiplication round monotonically -- the reference's glm::min / glm::max
+//     (bvh.h:128-129) pick a known operand (same floats up to the sign of a zero, which no comparison sees).  The sign pattern
+//     NEG is a template parameter (eight loop bodies, one runs), so the choice costs no instruction at all;
+//   * AABB::intersect's general case is overlap & tMax >= 0 & tMax >= tMin (bvh.h:147-153) and the walk then asks
+//     tMin < closest.  A conjunction can be evaluated in any order: the distance part comes first (tMax >= max(tMin, 0)), and
+//     the three overlap comparisons, which cost as much as everything else, only run when some lane passed it;
+//   * no reduction for the next node.  The walks of a wave all move forward through one pre-order array whose miss links nest
+//     (link(c) <= link(a) for c inside (a, link(a)), checked by rs_scene_create).  A lane that is not at c waits at a node
+//     p > c which it reached by rejecting some a < c, so p = link(a) with c inside a's span, hence link(c) <= p; the lanes
+//     at c go to c + 1 (entered) or link(c).  The minimum of all pending targets is therefore c + 1 if any lane entered and
+//     link(c) otherwise: one ballot instead of a 64-lane DPP minimum.  For the same reason a lane's own target after a node
+//     nobody entered is max(myNext, link(c)) -- one instruction, no mask.
+typedef float vf2 __attribute__((ext_vector_type(2)));
+// Slab distances of one record held in SGPRs {min.x, min.y, min.z, max.z | max.x, max.y, prim, next}: three packed subtractions
+// and three packed multiplications, each the reference's (p - ori) * dirInv on two components
+struct SlabT { vf2 xy1, xy2, z12; };      // (t1.x, t1.y), (t2.x, t2.y), (t1.z, t2.z)
+__device__ __forceinline__ SlabT slabs(vf2 oxy, vf2 ozz, vf2 dxy, vf2 dzz, const float4& ra, const float4& rb) {
+    SlabT t;
+    t.xy1 = (vf2{ ra.x, ra.y } - oxy) * dxy;
+    t.xy2 = (vf2{ rb.x, rb.y } - oxy) * dxy;
+    t.z12 = (vf2{ ra.z, ra.w } - ozz) * dzz;
+    return t;
+}
+template <int NEG> __device__ __forceinline__ float near_x(const SlabT& t) { return (NEG & 1) ? t.xy2.x : t.xy1.x; }
+template <int NEG> __device__ __forceinline__ float far_x(const SlabT& t) { return (NEG & 1) ? t.xy1.x : t.xy2.x; }
+template <int NEG> __device__ __forceinline__ float near_y(const SlabT& t) { return (NEG & 2) ? t.xy2.y : t.xy1.y; }
+template <int NEG> __device__ __forceinline__ float far_y(const SlabT& t) { return (NEG & 2) ? t.xy1.y : t.xy2.y; }
+template <int NEG> __device__ __forceinline__ float near_z(const SlabT& t) { return (NEG & 4) ? t.z12.y : t.z12.x; }
+template <int NEG> __device__ __forceinline__ float far_z(const SlabT& t) { return (NEG & 4) ? t.z12.x : t.z12.y; }
+// Both parts end in ONE float comparison whose operand carries the other conditions (a lane that already failed compares against
+// an infinity): the result of a comparison is a lane mask in SGPRs that a ballot can use as it is, where a boolean combined
+// from several would first be turned into 0 / 1 per lane and compared again.
+template <int NEG>
+__device__ __forceinline__ bool slab_distance_part(const SlabT& t, bool part, float closest) {
+    const float tMin = fmaxf(fmaxf(near_x<NEG>(t), near_y<NEG>(t)), near_z<NEG>(t));
+    const float tMax = fminf(fminf(far_x<NEG>(t), far_y<NEG>(t)), far_z<NEG>(t));
+    const bool ok = part && (tMax >= fmaxf(tMin, 0.f));
+    return tMin < (ok ? closest : -__builtin_inff());
+}
+template <int NEG>
+__device__ __forceinline__ bool slab_overlap_part(const SlabT& t, bool near) {
+    const float nx = near_x<NEG>(t), ny = near_y<NEG>(t), nz = near_z<NEG>(t), fx = far_x<NEG>(t), fy = far_y<NEG>(t), fz = far_z<NEG>(t);
+    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+    const bool ok = near && (dy + dz > fz - ny) && (dz + dx > fx - nz);
+    return dx + dy > (ok ? fy - nx : __builtin_inff());
+}
+
+template <int NEG>
+__device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, bool mine, const Ray& ray, const RayBoxCtx& ctx, WalkResult& r) {
+    const char* __restrict__ base = reinterpret_cast<const char*>(s.nodesAll + (size_t)order * (size_t)s.bvhSize);
+    const unsigned end = (unsigned)s.bvhSize;
+    const vf2 oxy = { ctx.o.x, ctx.o.y }, ozz = { ctx.o.z, ctx.o.z }, dxy = { ctx.dinv.x, ctx.dinv.y }, dzz = { ctx.dinv.z, ctx.dinv.z };
+    unsigned myNext = mine ? 0u : end;
+    unsigned c = 0;                                           // wave-uniform
+    float4 ra = *reinterpret_cast<const float4*>(base), rb = *reinterpret_cast<const float4*>(base + 16);      // uniform addresses -> scalar loads
+    while (c != end) {
+#ifdef RS_WALK_STATS
+        r.steps++;
+#endif
+        const int prim = __float_as_int(rb.z);
+        const unsigned nxt = (unsigned)__float_as_int(rb.w);
+        // the record after this one is requested before this one is tested: it is the successor whenever a lane enters
+        const float4 pa = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u), pb = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u + 16u);
+        const SlabT t = slabs(oxy, ozz, dxy, dzz, ra, rb);
+        const bool near = slab_distance_part<NEG>(t, myNext == c, r.closest);
+        if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+#ifdef RS_WALK_STATS
+            r.nearSteps++;
+#endif
+            const bool entered = slab_overlap_part<NEG>(t, near);
+            if (__builtin_amdgcn_ballot_w64(entered) != 0ull) {
+#ifdef RS_WALK_STATS
+                r.enteredSteps++; if (prim != kNullPrim) r.leafSteps++;
+#endif
+                if (prim != kNullPrim) {                      // uniform branch
+                    const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);      // uniform -> scalar
+                    const float4 a = tp[0], b = tp[1], e = tp[2];
+                    float bx, by, dist;
+                    const bool hit = tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist);
+                    if (entered && hit && dist < r.closest) { r.closest = dist; r.bx = bx; r.by = by; r.prim = prim; }
+                }
+                myNext = entered ? c + 1u : max(myNext, nxt);
+                c = c + 1u; ra = pa; rb = pb;
+                continue;
+            }
+        }
+        myNext = max(myNext, nxt);
+        c = nxt;
+        ra = *reinterpret_cast<const float4*>(base + c * 32u); rb = *reinterpret_cast<const float4*>(base + c * 32u + 16u);
+    }
+}
+
 template <bool GENERAL>
 __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, bool mine, const Ray& ray,
                                                   const RayBoxCtx& ctx, WalkResult& r) {
@@ -678,16 +790,17 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
     unsigned c = 0;                                           // wave-uniform
     // uniform addresses -> scalar loads.  The record after the current one is requested before the current
     // one is tested: c+1 is the successor whenever any lane enters the node (about half of the steps), and
-    // then the scalar-load latency is off the wave's critical path (it sets the duration of the slowest
-    // tiles, and with it the floor of a kernel on a small strip).  nodes[end] is readable (next order / padding).
+    // then the scalar-load latency is off the wave's critical path.  nodes[end] is readable (next order / padding).
     const float4* np0 = reinterpret_cast<const float4*>(nodes);
-    float4 lo = np0[0], hi = np0[1];
+    float4 lo, hi;
+    node_unpack(np0[0], np0[1], lo, hi);
     while (c != end) {
 #ifdef RS_WALK_STATS
         r.steps++;
 #endif
         const float4* nq = reinterpret_cast<const float4*>(nodes + c + 1);
-        const float4 plo = nq[0], phi = nq[1];
+        float4 plo, phi;
+        node_unpack(nq[0], nq[1], plo, phi);
         const int prim = __float_as_int(lo.w);
         const unsigned nxt = (unsigned)__float_as_int(hi.w);
         const bool part = myNext == c;
@@ -711,8 +824,22 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
         else {
             c = wave_min_u32(myNext);
             const float4* np = reinterpret_cast<const float4*>(nodes + c);
-            lo = np[0]; hi = np[1];
+            node_unpack(np[0], np[1], lo, hi);
         }
+    }
+}
+
+// the bits of `neg`: a direction component is negative in the lanes that take part (the same in all of them)
+__device__ __forceinline__ void packet_walk_fast_dispatch(int neg, const DevScene& s, int order, bool mine, const Ray& ray, const RayBoxCtx& ctx, WalkResult& r) {
+    switch (neg) {
+        case 0: packet_walk_fast<0>(s, order, mine, ray, ctx, r); break;
+        case 1: packet_walk_fast<1>(s, order, mine, ray, ctx, r); break;
+        case 2: packet_walk_fast<2>(s, order, mine, ray, ctx, r); break;
+        case 3: packet_walk_fast<3>(s, order, mine, ray, ctx, r); break;
+        case 4: packet_walk_fast<4>(s, order, mine, ray, ctx, r); break;
+        case 5: packet_walk_fast<5>(s, order, mine, ray, ctx, r); break;
+        case 6: packet_walk_fast<6>(s, order, mine, ray, ctx, r); break;
+        default: packet_walk_fast<7>(s, order, mine, ray, ctx, r); break;
     }
 }
 
@@ -727,7 +854,7 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     const int order = mtbvh_order(-ray.d);
     unsigned long long todo = __ballot(active);
 #ifdef RS_WALK_STATS
-    w.steps = 0;
+    w.steps = w.nearSteps = w.enteredSteps = w.leafSteps = 0;
     unsigned norders = 0;
 #endif
     while (todo) {                                            // one pass per threaded order present in the wave
@@ -737,8 +864,12 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
         const int lead = __ffsll((long long)todo) - 1;
         const int k = __builtin_amdgcn_readlane(order, lead);
         const bool mine = active && order == k;
-        todo &= ~__ballot(mine);
+        const unsigned long long mm = __ballot(mine);
+        todo &= ~mm;
+        const unsigned long long sx = __ballot(mine && ray.d.x < 0.f), sy = __ballot(mine && ray.d.y < 0.f), sz = __ballot(mine && ray.d.z < 0.f);
+        const bool uniformSigns = (sx == 0 || sx == mm) && (sy == 0 || sy == mm) && (sz == 0 || sz == mm);
         if (anySpecial) packet_walk_order<false>(s, k, mine, ray, ctx, w);
+        else if (uniformSigns && s.axisCull && s.linksNested) packet_walk_fast_dispatch((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0), s, k, mine, ray, ctx, w);
         else packet_walk_order<true>(s, k, mine, ray, ctx, w);
     }
 #ifdef RS_WALK_STATS
@@ -746,6 +877,8 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
         atomicAdd(&s.walkStats[16], 1ull); atomicAdd(&s.walkStats[17], (unsigned long long)w.steps);
         atomicMax(&s.walkStats[18], (unsigned long long)w.steps); atomicAdd(&s.walkStats[19], (unsigned long long)norders);
         atomicAdd(&s.walkStats[20], anySpecial ? 1ull : 0ull);
+        atomicAdd(&s.walkStats[21], (unsigned long long)w.nearSteps); atomicAdd(&s.walkStats[22], (unsigned long long)w.enteredSteps);
+        atomicAdd(&s.walkStats[23], (unsigned long long)w.leafSteps);
         atomicAdd(&s.walkStats[24 + (w.steps ? 31 - __clz((int)w.steps) : 0)], 1ull);
     }
 #endif
@@ -770,7 +903,7 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
 // The G-buffer ray (pixel centre) and the shading ray (jittered inside the pixel) of an 8x8 tile visit nearly the same nodes.
 // Walked together, every node record is fetched once and the loop control and the next-node reduction are shared; each ray
 // keeps its own walk state and makes exactly the visits of DevScene::intersect, so both results are those of separate walks
-// (tools/probe_fused_walk.py: -10.6 % against two packet walks).  Must be called by all 64 lanes.
+// (measured with a throw-away probe kernel in round 1: -10.6 % against two packet walks).  Must be called by all 64 lanes.
 template <bool GENERAL>
 __device__ __forceinline__ void packet_walk_order2(const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra, const RayBoxCtx& ca,
                                                    const Ray& rb, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
@@ -779,10 +912,12 @@ __device__ __forceinline__ void packet_walk_order2(const DevScene& s, int order,
     unsigned nextA = mineA ? 0u : end, nextB = mineB ? 0u : end;
     unsigned c = 0;
     const float4* np0 = reinterpret_cast<const float4*>(nodes);
-    float4 lo = np0[0], hi = np0[1];
+    float4 lo, hi;
+    node_unpack(np0[0], np0[1], lo, hi);
     while (c != end) {
         const float4* nq = reinterpret_cast<const float4*>(nodes + c + 1);
-        const float4 plo = nq[0], phi = nq[1];
+        float4 plo, phi;
+        node_unpack(nq[0], nq[1], plo, phi);
         const int prim = __float_as_int(lo.w);
         const unsigned nxt = (unsigned)__float_as_int(hi.w);
         const bool partA = nextA == c, partB = nextB == c;
@@ -807,8 +942,61 @@ __device__ __forceinline__ void packet_walk_order2(const DevScene& s, int order,
         else {
             c = wave_min_u32(want);
             const float4* np = reinterpret_cast<const float4*>(nodes + c);
-            lo = np[0]; hi = np[1];
+            node_unpack(np[0], np[1], lo, hi);
         }
+    }
+}
+
+// the fast form (packet_walk_fast) for two rays per lane: the 128 walks of the wave nest like 64 do
+template <int NEG>
+__device__ __forceinline__ void packet_walk_fast2(const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra_, const RayBoxCtx& ca,
+                                                  const Ray& rb_, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
+    const char* __restrict__ base = reinterpret_cast<const char*>(s.nodesAll + (size_t)order * (size_t)s.bvhSize);
+    const unsigned end = (unsigned)s.bvhSize;
+    const vf2 aoxy = { ca.o.x, ca.o.y }, aozz = { ca.o.z, ca.o.z }, adxy = { ca.dinv.x, ca.dinv.y }, adzz = { ca.dinv.z, ca.dinv.z };
+    const vf2 boxy = { cb.o.x, cb.o.y }, bozz = { cb.o.z, cb.o.z }, bdxy = { cb.dinv.x, cb.dinv.y }, bdzz = { cb.dinv.z, cb.dinv.z };
+    unsigned nextA = mineA ? 0u : end, nextB = mineB ? 0u : end;
+    unsigned c = 0;
+    float4 ra = *reinterpret_cast<const float4*>(base), rb = *reinterpret_cast<const float4*>(base + 16);
+    while (c != end) {
+        const int prim = __float_as_int(rb.z);
+        const unsigned nxt = (unsigned)__float_as_int(rb.w);
+        const float4 pa = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u), pb = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u + 16u);
+        const SlabT sa = slabs(aoxy, aozz, adxy, adzz, ra, rb), sb = slabs(boxy, bozz, bdxy, bdzz, ra, rb);
+        const bool nearA = slab_distance_part<NEG>(sa, nextA == c, wa.closest), nearB = slab_distance_part<NEG>(sb, nextB == c, wb.closest);
+        if (__builtin_amdgcn_ballot_w64(nearA || nearB) != 0ull) {
+            const bool inA = slab_overlap_part<NEG>(sa, nearA), inB = slab_overlap_part<NEG>(sb, nearB);
+            if (__builtin_amdgcn_ballot_w64(inA || inB) != 0ull) {
+                if (prim != kNullPrim) {
+                    const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);
+                    const float4 a = tp[0], b = tp[1], e = tp[2];
+                    float bx, by, dist;
+                    if (inA) { if (tri_hit(ra_.o, ra_.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wa.closest) { wa.closest = dist; wa.bx = bx; wa.by = by; wa.prim = prim; } }
+                    if (inB) { if (tri_hit(rb_.o, rb_.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wb.closest) { wb.closest = dist; wb.bx = bx; wb.by = by; wb.prim = prim; } }
+                }
+                nextA = inA ? c + 1u : max(nextA, nxt);
+                nextB = inB ? c + 1u : max(nextB, nxt);
+                c = c + 1u; ra = pa; rb = pb;
+                continue;
+            }
+        }
+        nextA = max(nextA, nxt); nextB = max(nextB, nxt);
+        c = nxt;
+        ra = *reinterpret_cast<const float4*>(base + c * 32u); rb = *reinterpret_cast<const float4*>(base + c * 32u + 16u);
+    }
+}
+
+__device__ __forceinline__ void packet_walk_fast2_dispatch(int neg, const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra, const RayBoxCtx& ca,
+                                                           const Ray& rb, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
+    switch (neg) {
+        case 0: packet_walk_fast2<0>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        case 1: packet_walk_fast2<1>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        case 2: packet_walk_fast2<2>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        case 3: packet_walk_fast2<3>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        case 4: packet_walk_fast2<4>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        case 5: packet_walk_fast2<5>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        case 6: packet_walk_fast2<6>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
+        default: packet_walk_fast2<7>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
     }
 }
 
@@ -825,8 +1013,15 @@ __device__ __forceinline__ void walk_two_packet(const DevScene& s, const Ray& ra
         if (todoA) k = __builtin_amdgcn_readlane(oa, __ffsll((long long)todoA) - 1);
         else k = __builtin_amdgcn_readlane(ob, __ffsll((long long)todoB) - 1);
         const bool mineA = activeA && oa == k && ((todoA >> __lane_id()) & 1ull), mineB = activeB && ob == k && ((todoB >> __lane_id()) & 1ull);
-        todoA &= ~__ballot(mineA); todoB &= ~__ballot(mineB);
+        const unsigned long long ma = __ballot(mineA), mb = __ballot(mineB);
+        todoA &= ~ma; todoB &= ~mb;
+        // direction signs of all rays walked in this pass (both rays of every lane that takes part)
+        const unsigned long long px = __ballot((mineA && !(ra.d.x < 0.f)) || (mineB && !(rb.d.x < 0.f))), nx = __ballot((mineA && ra.d.x < 0.f) || (mineB && rb.d.x < 0.f));
+        const unsigned long long py = __ballot((mineA && !(ra.d.y < 0.f)) || (mineB && !(rb.d.y < 0.f))), ny = __ballot((mineA && ra.d.y < 0.f) || (mineB && rb.d.y < 0.f));
+        const unsigned long long pz = __ballot((mineA && !(ra.d.z < 0.f)) || (mineB && !(rb.d.z < 0.f))), nz = __ballot((mineA && ra.d.z < 0.f) || (mineB && rb.d.z < 0.f));
+        const bool uniformSigns = (px == 0 || nx == 0) && (py == 0 || ny == 0) && (pz == 0 || nz == 0);
         if (anySpecial) packet_walk_order2<false>(s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
+        else if (uniformSigns && s.axisCull && s.linksNested) packet_walk_fast2_dispatch((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0), s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
         else packet_walk_order2<true>(s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
     }
 }

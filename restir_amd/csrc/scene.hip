@@ -1,5 +1,6 @@
 // scene.hip -- DevScene::create / destroy (src/scene.cpp:435-532) re-laid-out for CDNA4 (see
 // rs_scene.h), Scene::buildDevData as one call, and batched ray entry points for parity tests.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -46,12 +47,14 @@ int build_occlusion_side(rs_scene* s) {
     for (size_t p = 0; p < np; p++) std::memcpy(&primBoxes[p * 6], &s->hBoxes[(size_t)leafOf[p] * 6], 6 * sizeof(float));
     std::vector<BvhNode> nodes;
     std::vector<int> leafPrims;
-    RS_TRY(rs_build_occlusion_bvh(s->numPrims, primBoxes.data(), nodes, leafPrims));
+    // a scene the second tree cannot be built for (RS_ERR_UNSUPPORTED: e.g. all vertices in one point, so that the grid has no
+    // extent) is still a scene the reference renders: the fast path stays off and shadow rays walk the reference's tree
+    if (int e = rs_build_occlusion_bvh(s->numPrims, primBoxes.data(), nodes, leafPrims)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
     const size_t no = nodes.size();
     if (no * 16 >= 0xffffffffull || nn * sizeof(BvhNode) >= 0xffffffffull || np >= (1u << 27)) return 0;
     float base[3], scale[3];
     std::vector<unsigned> packed;
-    RS_TRY(rs_quantize_occlusion_bvh(nodes, base, scale, packed));
+    if (int e = rs_quantize_occlusion_bvh(nodes, base, scale, packed)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
     std::vector<BvhNode> chain(nn);
     for (size_t i = 0; i < nn; i++) {
         const float* b = &s->hBoxes[i * 6];
@@ -91,7 +94,8 @@ int build_occlusion_side(rs_scene* s) {
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
-    (void)rs_synchronize();                             // asynchronous mode: kernels on the library / auxiliary streams may still read the scene
+    (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
+    (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
     rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
@@ -124,6 +128,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     const size_t np = (size_t)d->numPrims, nn = (size_t)d->bvhSize, nl = (size_t)(d->numLights > 0 ? d->numLights : 0);
     const size_t nlp = nl - (hasEnv ? 1 : 0);          // light primitives; the environment map is the last sampler entry
     rs_scene* s = new rs_scene();
+    { static std::atomic<unsigned long long> counter{0}; s->id = ++counter; }
     s->numPrims = d->numPrims; s->bvhSize = d->bvhSize; s->numLights = (int)nl;
     s->sumLightPower = d->sumLightPower;
     s->hVertices.assign(d->vertices, d->vertices + np * 9);
@@ -289,6 +294,23 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
                 for (int k = 0; k < 3; k++) { const float x = s->hVertices[p * 9 + v * 3 + k]; proper = proper && c[k] <= x && x <= c[3 + k]; }
         }
         s->dev.axisCull = proper;
+    }
+    // Do the miss links of every threaded order nest (a node inside the span (a, link(a)) never links beyond link(a))?  They do
+    // for a pre-order layout with link = end of the subtree, which is what BVHBuilder::buildMTBVH produces (src/bvh.cpp:160-202);
+    // the packet walk's next-node shortcut (rs_scene.h packet_walk_order) relies on it and is off for any other table.
+    {
+        bool nested = true;
+        std::vector<int> open;
+        for (int k = 0; k < 6 && nested; k++) {
+            open.clear();
+            for (size_t i = 0; i < nn && nested; i++) {
+                while (!open.empty() && open.back() <= (int)i) open.pop_back();
+                const int link = s->hNodes[k][i * 3 + 2];
+                if (!open.empty() && link > open.back()) nested = false;
+                open.push_back(link);
+            }
+        }
+        s->dev.linksNested = nested;
     }
 #ifdef RS_WALK_STATS
     if (int e = rs_dev_alloc(&s->dWalkStats, 64)) { rs_scene_destroy(s); return e; }

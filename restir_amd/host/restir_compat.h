@@ -189,12 +189,30 @@ inline void copyImageToPBO(void* devPBO, int* devImage, int width, int height) {
 }
 
 // ---- src/denoiser.h:33-43,72-74 -------------------------------------------------------------------------
+// src/denoiser.h:15-31: the public members the viewer edits (src/preview.cpp:262-286); the kernels live behind rs_eaw / rs_svgf
+struct EAWaveletFilter {
+    EAWaveletFilter() = default;
+    EAWaveletFilter(int width, int height, float sigLumin, float sigNormal, float sigDepth) :
+        sigLumin(sigLumin), sigNormal(sigNormal), sigDepth(sigDepth), width(width), height(height) {}
+    float sigLumin = 0.f;
+    float sigNormal = 0.f;
+    float sigDepth = 0.f;
+    int width = 0;
+    int height = 0;
+};
 struct LeveledEAWFilter {
     rs_eaw* impl = nullptr;
+    EAWaveletFilter waveletFilter;
     int level = 0;
-    void create(int width, int height, int lv) { level = lv; rsc::check(rs_eaw_create(width, height, lv, &impl), "EAW create"); }
+    void create(int width, int height, int lv) {
+        level = lv;
+        waveletFilter = EAWaveletFilter(width, height, 64.f, .2f, 1.f);                     // src/denoiser.cu:455
+        rsc::check(rs_eaw_create(width, height, lv, &impl), "EAW create");
+    }
     void destroy() { rs_eaw_destroy(impl); impl = nullptr; }
     void filter(rsc::vec3*& devColorOut, rsc::vec3* devColorIn, const GBuffer& gBuffer, const Camera& cam) {
+        // the members may have been edited since the last call (ImGui sliders write them directly)
+        rsc::check(rs_eaw_set_params(impl, waveletFilter.sigLumin, waveletFilter.sigNormal, waveletFilter.sigDepth, level), "EAW Filter");
         float* out = reinterpret_cast<float*>(devColorOut);
         rsc::check(rs_eaw_filter(impl, &out, reinterpret_cast<const float*>(devColorIn), gBuffer.impl, &cam), "EAW Filter");
         devColorOut = reinterpret_cast<rsc::vec3*>(out);
@@ -203,10 +221,16 @@ struct LeveledEAWFilter {
 // src/denoiser.h:45-70 (filter / nextFrame; the three sub-steps are internal to rs_svgf_filter)
 struct SpatioTemporalFilter {
     rs_svgf* impl = nullptr;
+    EAWaveletFilter waveletFilter;
     int level = 0;
-    void create(int width, int height, int lv) { level = lv; rsc::check(rs_svgf_create(width, height, lv, &impl), "SVGF create"); }
+    void create(int width, int height, int lv) {
+        level = lv;
+        waveletFilter = EAWaveletFilter(width, height, 4.f, 128.f, 1.f);                    // src/denoiser.cu:488
+        rsc::check(rs_svgf_create(width, height, lv, &impl), "SVGF create");
+    }
     void destroy() { rs_svgf_destroy(impl); impl = nullptr; }
     void filter(rsc::vec3*& devColorOut, rsc::vec3* devColorIn, const GBuffer& gBuffer, const Camera& cam) {
+        rsc::check(rs_svgf_set_params(impl, waveletFilter.sigLumin, waveletFilter.sigNormal, waveletFilter.sigDepth, level), "SpatioTemporalFilter::filter");
         float* out = reinterpret_cast<float*>(devColorOut);
         rsc::check(rs_svgf_filter(impl, &out, reinterpret_cast<const float*>(devColorIn), gBuffer.impl, &cam), "SpatioTemporalFilter::filter");
         devColorOut = reinterpret_cast<rsc::vec3*>(out);

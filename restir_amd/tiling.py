@@ -259,6 +259,9 @@ class HipBackend:
         self.capi = capi
         self.scene, self.cam = scene, cam
         self.W, self.H = width, height
+        # c10d orders a collective after the work on torch's CURRENT stream, and the buffers it sends are packed by copies the
+        # library enqueues on ITS stream: they must be the same stream (by default both are the legacy default stream)
+        capi.set_stream(torch.cuda.current_stream().cuda_stream)
         self.gbuf = capi.GBuffer(width, height)
         self.restir = capi.ReSTIR(width, height)
         self.image = torch.zeros((width * height, 3), dtype=torch.float32, device="cuda")

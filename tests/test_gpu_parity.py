@@ -543,6 +543,34 @@ def test_eaw_filter(hip):
     assert np.abs(ref - a).max() > 1e-3               # the filter did something
 
 
+def test_eaw_filter_with_edited_sigmas(hip):
+    """The viewer edits LeveledEAWFilter::waveletFilter.sig* between frames (src/preview.cpp:262-265): rs_eaw_set_params, with
+    sigmas that are not powers of two (the kernels then divide as the reference does) and with power-of-two ones."""
+    import torch
+    sd = get_scene("sponza:0.03")
+    W, H = 160, 96
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    o.frame(3); h.frame(3)
+    f = hip.EAWFilter(W, H, 5)
+    assert f.get_params() == (64.0, np.float32(0.2), 1.0, 5)
+    for sig in ((3.7, 0.35, 0.6), (8.0, 0.25, 2.0)):
+        f.set_params(*sig, level=3)                      # the level is stored, the filter still runs five (src/denoiser.cu:463-477)
+        assert f.get_params()[3] == 3
+        out = torch.zeros_like(h.image)
+        # gbuf.update() ran in frame(): the planes the filter reads are the "last" ones now, so render again as runCuda would
+        o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+        ref = ob.eaw_filter_with(o.gbuf, o.cam, o.image, *sig)
+        p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+        hip.synchronize()
+        res = torch.empty_like(h.image)
+        hip.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+        got = res.cpu().numpy()
+        assert np.allclose(ref, got, rtol=1e-5, atol=1e-6), (sig, float(np.abs(ref - got).max()))
+        o.gbuf.update(o.cam); h.gbuf.update(h.cam)
+    f.destroy()
+
+
 def test_eaw_row_strip_form_equals_filter(hip):
     """rs_eaw_positions_rows + rs_eaw_level_rows (the form the strip tiling drives, restir_amd/tiling.py eaw_filter) over the
     whole frame, in bands, give the image of rs_eaw_filter bit for bit."""
@@ -728,7 +756,7 @@ def test_overlapped_frames_equal_synchronous_frames(hip, fused):
 
 def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     """Default asynchronous mode: ReSTIRDirect measures once per scene whether walking the G-buffer ray with the shading ray is
-    faster (frames 12..19 run fused, 4..11 and all others until the decision separately).  Whatever it picks, a full-size run of
+    faster (frames 8..13 run fused, 2..7 and all others until the decision separately).  Whatever it picks, a full-size run of
     30 frames equals the synchronous run bit for bit."""
     import torch
     from restir_amd.scenes import orbit_position
@@ -759,7 +787,40 @@ def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     choices = []
     for a, b in zip(run(False), run(True)):
         assert bits_equal(a, b)
-    assert choices[0] == -1 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided by frame 28
+    assert choices[0] == -2 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided at frame 14
+
+
+def test_scene_destroyed_while_a_render_is_only_recorded(hip):
+    """Asynchronous mode defers GBuffer::render (it is launched by the next reader of the planes).  Destroying the scene in
+    between must launch the recorded render while the scene still exists: the planes then equal those of a synchronous
+    render, and nothing dereferences the freed scene afterwards (update, a second scene, more renders)."""
+    sd = get_scene("cornell")
+    W, H = 96, 64
+    ref = HipRenderer(hip, sd, W, H)
+    ref.gbuf.render(ref.scene, ref.cam)
+    want = ref.gbuf.download()
+    scene = hip_scene(hip, sd)
+    h = HipRenderer(hip, sd, W, H, scene=scene)
+    hip.set_sync(False)
+    hip.set_side_stream(3)
+    try:
+        h.gbuf.render(scene, h.cam)                 # recorded only
+        scene.destroy()                              # launches it, waits, frees the arrays
+        h.scene = None
+        got = h.gbuf.download()
+        for k in ("albedo", "motion"):
+            assert bits_equal(got[k], want[k]), k
+        for k in ("normal", "prim_id", "depth"):
+            assert bits_equal(got[k][0], want[k][0]), k
+        h.gbuf.update(h.cam)
+        other = hip_scene(hip, sd)                   # may reuse the freed scene's address
+        h.gbuf.render(other, h.cam)
+        h.restir.direct(other, h.cam, h.gbuf, h.image.data_ptr(), 0, 0, 3)
+        h.gbuf.update(h.cam)
+        hip.synchronize()
+    finally:
+        hip.set_sync(True)
+        hip.set_side_stream(4)
 
 
 def test_phase_b_in_row_bands_equals_one_call(hip):
