@@ -195,7 +195,7 @@ int rs_quantize_occlusion_bvh(const std::vector<BvhNode>& nodes, float base[3], 
         o[0] = ql[0] | (ql[1] << 16);
         o[1] = ql[2] | (qh[0] << 16);
         o[2] = qh[1] | (qh[2] << 16);
-        o[3] = n.primId >= 0 ? ~(unsigned)n.primId : (unsigned)n.next;      // leaf: ~code (sign bit set), inner: miss link
+        o[3] = n.primId >= 0 ? ~(unsigned)n.primId : (unsigned)n.next * 16u;      // leaf: ~code (sign bit set), inner: miss link as a byte offset
     }
     return 0;
 }

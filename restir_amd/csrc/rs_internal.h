@@ -235,6 +235,9 @@ struct rs_restir {
     int tuneChoice = -1;             // -1 measuring, 0 separate, 1 fused
     bool tuneCounted = false;        // this frame had a launch the choice applies to
     hipEvent_t tuneEv[3] = { nullptr, nullptr, nullptr };
+    // shadow rays handed from k_shadow_temporal to k_shadow_finish (restir.hip ParkedRays): a counter and 32 bytes per pixel
+    unsigned* dParkCount = nullptr;
+    uint4* dParkEntries = nullptr;
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
     int raySlot = 0;
     // timing

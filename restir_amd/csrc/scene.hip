@@ -51,7 +51,7 @@ int build_occlusion_side(rs_scene* s) {
     // extent) is still a scene the reference renders: the fast path stays off and shadow rays walk the reference's tree
     if (int e = rs_build_occlusion_bvh(s->numPrims, primBoxes.data(), nodes, leafPrims)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
     const size_t no = nodes.size();
-    if (no * 16 >= 0xffffffffull || nn * sizeof(BvhNode) >= 0xffffffffull || np >= (1u << 27)) return 0;
+    if (no * 16 >= 0x7fffffffull || nn * sizeof(BvhNode) >= 0xffffffffull || np >= (1u << 27)) return 0;
     float base[3], scale[3];
     std::vector<unsigned> packed;
     if (int e = rs_quantize_occlusion_bvh(nodes, base, scale, packed)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
@@ -423,13 +423,62 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevScene s, int n, const 
     st3(norm + (size_t)i * 3, h.norm);
 }
 
-__global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ) {
-    // same wave-level service the ReSTIR shadow pass uses: every lane of the wave takes part
+// testOcclusion for a batch of segments: the two-launch form of the ReSTIR shadow pass (restir.hip) -- waves of the first launch
+// park their unfinished rays once half of their lanes are done, the second launch finishes them -- so that the parity tests of
+// rs_trace_occlusion cover the walk, the parking and the resumption
+__device__ __forceinline__ void occlusion_segment(const float* seg, size_t j, Ray& ray, float& range) {
+    const f3 x = ld3(seg + j * 6), y = ld3(seg + j * 6 + 3);
+    f3 dir = y - x;
+    float dist = length(dir);
+    dir = dir / dist;
+    ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
+    range = dist - 1e-4f * 2.f;
+}
+
+__global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ, ParkedRays park) {
+    __shared__ unsigned leafQ[kOccQueue * 256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const size_t j = active ? (size_t)i : 0;
-    const bool o = trace_occluded_wave(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active);
-    if (active) occ[i] = o ? 1 : 0;
+    if (!s.occNodes) {
+        const bool o = trace_occluded_wave(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active);
+        if (active) occ[i] = o ? 1 : 0;
+        return;
+    }
+    Ray ray; float range;
+    occlusion_segment(seg, j, ray, range);
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
+    const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
+    const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
+    const unsigned endOff = (unsigned)s.occCount * 16u;
+    OccState st;
+    st.cur = (active && !slow) ? 0u : endOff; st.qn = 0;
+    bool parked;
+    bool o = occ_walk<256>(s, ray, ctx, range, st, leafQ, park.entries ? 32 : 0, parked);
+    if (__any(slow)) o = walk_anyhit_deferred<false>(s, ray, ctx, range, slow) || o;
+    const bool unfinished = parked && !o && (st.cur != endOff || st.qn > 0);
+    if (parked) park_unfinished<256>(park, unfinished, (unsigned)i, st, leafQ);
+    if (active && !unfinished) occ[i] = o ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_trace_occlusion_finish(DevScene s, const float* __restrict__ seg, int* __restrict__ occ, ParkedRays park) {
+    __shared__ unsigned leafQ[kOccQueue * 256];
+    const unsigned n = *park.count;
+    if (blockIdx.x * 256u >= n) return;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const bool active = e < n;
+    const uint4 e0 = active ? park.entries[2 * (size_t)e] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 e1 = active ? park.entries[2 * (size_t)e + 1] : make_uint4(0u, 0u, 0u, 0u);
+    Ray ray; float range;
+    occlusion_segment(seg, (size_t)e0.x, ray, range);
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
+    OccState st;
+    unpark<256>(e0, e1, active, (unsigned)s.occCount * 16u, st, leafQ);
+    bool parked;
+    const bool o = occ_walk<256>(s, ray, ctx, range, st, leafQ, 0, parked);
+    if (active) occ[e0.x] = o ? 1 : 0;
 }
 
 extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {
@@ -442,6 +491,20 @@ extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, 
 extern "C" int rs_trace_occlusion(const rs_scene* s, int n, const float* devSegments, int* devOccluded) {
     if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_occlusion: bad argument");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_trace_occlusion, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devSegments, devOccluded);
+    ParkedRays park{ nullptr, nullptr };
+    if (s->dev.occNodes && !std::getenv("RS_PARK_OFF_IN_TRACE")) {
+        RS_TRY(rs_dev_alloc(&park.count, 1));
+        if (int e = rs_dev_alloc(&park.entries, 2 * (size_t)n)) { rs_dev_free(park.count); return e; }
+        (void)hipMemsetAsync(park.count, 0, 4, rs_stream());
+    }
+    hipLaunchKernelGGL(k_trace_occlusion, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devSegments, devOccluded, park);
+    if (park.entries) hipLaunchKernelGGL(k_trace_occlusion_finish, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, devSegments, devOccluded, park);
+    int e = rs_check_hip(hipGetLastError(), "rs_trace_occlusion");
+    if (park.entries) {                                 // (the queue is scratch of this call)
+        const int e2 = rs_check_hip(hipStreamSynchronize(rs_stream()), "rs_trace_occlusion");
+        if (!e) e = e2;
+        rs_dev_free(park.count); rs_dev_free(park.entries);
+    }
+    if (e) return e;
     return rs_after_launch("rs_trace_occlusion");
 }
