@@ -270,24 +270,12 @@ __device__ __forceinline__ void temporal_publish(const SurfPlanes& sp, const GBu
     resv_store(cur, index, r);
 }
 
-// makeOffsetedRay + range of testOcclusion (src/scene.h:286-293, intersections.h:13-15)
-__device__ __forceinline__ void shadow_segment(f3 x, f3 y, Ray& ray, float& range) {
-    f3 dir = y - x;
-    float dist = length(dir);
-    dir = dir / dist;
-    ray.o = x + dir * 1e-5f; ray.d = dir;
-    range = dist - 1e-4f * 2.f;
-}
-
-#ifndef RS_PARK_LANES
-#define RS_PARK_LANES 32
-#endif
-
-// 8 blocks per CU = 8 waves per SIMD
+// 8 blocks per CU = 8 waves per SIMD: caps the kernel at 64 VGPRs (the few spilled dwords are outside the walk)
 __global__ void __launch_bounds__(256, 8) k_shadow_temporal(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last,
-                                                         ResvPlanes cur, TempPlanes temp, ParkedRays park, int first, int reuse,
+                                                         ResvPlanes cur, TempPlanes temp, int first, int reuse,
                                                          int y0, int y1, int tilesX) {
-    __shared__ unsigned leafQ[kOccQueue * 256];
+    __shared__ uint4 occTop[kOccTopRecords];             // the top levels of the shadow tree (rs_scene.h walk_occlusion_tree<true>)
+    stage_occlusion_top(s, occTop);
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
     const bool inside = x < g.width && y < y1;
@@ -303,31 +291,8 @@ __global__ void __launch_bounds__(256, 8) k_shadow_temporal(DevScene s, SurfPlan
     r.M = kReservoirSize; r.W = cw.w;
 
     // every lane of the wave takes part in the cooperative any-hit walk (restir.cu:172-176)
-    bool occluded = false, unfinished = false;
-    if (s.occNodes) {
-        Ray ray; float range;
-        shadow_segment(pos, pos + r.wi * r.dist, ray, range);
-        RayBoxCtx ctx = make_box_ctx(ray);
-        ctx.cull = s.axisCull;
-        const bool special = shaded && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
-        const bool slow = shaded && (special || !occlusion_tree_usable(s, ray.o));
-        OccState st;
-        st.cur = (shaded && !slow) ? 0u : (unsigned)s.occCount * 16u; st.qn = 0;
-#ifdef RS_DBG_NOWALK                                      // timing experiments only (tools/build_variant.sh): results are wrong
-        st.cur = (unsigned)s.occCount * 16u;
-#endif
-        bool parked;
-        occluded = occ_walk<256>(s, ray, ctx, range, st, leafQ, park.entries ? RS_PARK_LANES : 0, parked);
-        if (__any(slow)) occluded = walk_anyhit_deferred<false>(s, ray, ctx, range, slow) || occluded;
-        unfinished = parked && !occluded && (st.cur != (unsigned)s.occCount * 16u || st.qn > 0);
-        if (parked) park_unfinished<256>(park, unfinished, (unsigned)index, st, leafQ);
-    }
-    else
-        occluded = trace_occluded_wave(s, pos, pos + r.wi * r.dist, shaded);
-    if (!inside || unfinished) return;
-#ifdef RS_DBG_NOPUBLISH
-    if (!occluded) return;
-#endif
+    const bool occluded = trace_occluded_wave_top(s, pos, pos + r.wi * r.dist, shaded, occTop);
+    if (!inside) return;
     const int gid = g.primId[index];
     const float gdepth = g.depth[index];
     if (!shaded) {
@@ -337,35 +302,6 @@ __global__ void __launch_bounds__(256, 8) k_shadow_temporal(DevScene s, SurfPlan
         return;
     }
     temporal_publish(sp, g, last, cur, temp, first, reuse, index, r, occluded, gid, gdepth);
-}
-
-// the parked rays of k_shadow_temporal, one per lane: same segment (same arithmetic on the same planes), the walk resumed where it
-// stopped, then the pixel's temporal merge and publication
-__global__ void __launch_bounds__(256, 8) k_shadow_finish(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp,
-                                                       ParkedRays park, int first, int reuse) {
-    __shared__ unsigned leafQ[kOccQueue * 256];
-    const unsigned n = *park.count;
-    if (blockIdx.x * 256u >= n) return;
-    const unsigned e = blockIdx.x * 256u + threadIdx.x;
-    const bool active = e < n;
-    const uint4 e0 = active ? park.entries[2 * (size_t)e] : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 e1 = active ? park.entries[2 * (size_t)e + 1] : make_uint4(0u, 0u, 0u, 0u);
-    const int index = (int)e0.x;
-    const float4 pm = sp.posMat[index], cl = sp.candLi[index], cw = sp.candWi[index];      // (index 0 is readable for idle lanes)
-    const f3 pos = mk3(pm.x, pm.y, pm.z);
-    Resv r;
-    r.Li = mk3(cl.x, cl.y, cl.z); r.wi = mk3(cw.x, cw.y, cw.z); r.dist = cl.w;
-    r.M = kReservoirSize; r.W = cw.w;
-    Ray ray; float range;
-    shadow_segment(pos, pos + r.wi * r.dist, ray, range);
-    RayBoxCtx ctx = make_box_ctx(ray);
-    ctx.cull = s.axisCull;
-    OccState st;
-    unpark<256>(e0, e1, active, (unsigned)s.occCount * 16u, st, leafQ);
-    bool parked;
-    const bool occluded = occ_walk<256>(s, ray, ctx, range, st, leafQ, 0, parked);
-    if (!active) return;
-    temporal_publish(sp, g, last, cur, temp, first, reuse, index, r, occluded, g.primId[index], g.depth[index]);
 }
 
 // ---- phase B: spatial reuse + shade --------------------------------------------------------------
@@ -654,7 +590,7 @@ int rs_restir_free(rs_restir* r) {
     for (auto& f : r->surf) {
         rs_dev_free(f.posKind); rs_dev_free(f.norm); rs_dev_free(f.wo); rs_dev_free(f.rngMat); rs_dev_free(f.candLi); rs_dev_free(f.candWi);
     }
-    rs_dev_free(r->dRayCount); rs_dev_free(r->dParkCount); rs_dev_free(r->dParkEntries);
+    rs_dev_free(r->dRayCount);
     rs_dev_free(r->indResv[0]); rs_dev_free(r->indResv[1]);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
@@ -693,8 +629,6 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     for (auto& ev : r->tuneEv) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxFork, hipEventDisableTiming), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxDone, hipEventDisableTiming), "hipEventCreate");
-    if (!e) e = rs_dev_alloc(&r->dParkCount, 1);
-    if (!e) e = rs_dev_alloc(&r->dParkEntries, 2 * n);
     if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots * kRaySub * kRayStride);
     if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * (size_t)kRaySlots * kRaySub * kRayStride), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
@@ -801,16 +735,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
-    // shadow rays in two launches: a wave of the first stops when half of its lanes have finished and parks the rest; the second
-    // walks the parked rays on, 64 to a wave (RS_PARK=0: one launch, every wave runs as long as its longest ray)
-    static const bool parkRays = []{ const char* e = std::getenv("RS_PARK"); return !(e && e[0] == '0'); }();
-    const ParkedRays park{ r->dParkCount, (parkRays && scene->dev.occNodes) ? r->dParkEntries : nullptr };
-    if (park.entries) RS_HIP(hipMemsetAsync(r->dParkCount, 0, 4, rs_stream()));
     hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
-                       r->last, r->cur, r->temp, park, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
-    if (park.entries)
-        hipLaunchKernelGGL(k_shadow_finish, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
-                           r->last, r->cur, r->temp, park, r->firstFrame ? 1 : 0, reuse);
+                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
     mark(r, 3);
     return last ? rs_after_launch("ReSTIR Direct (phase A)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase A)");
 }

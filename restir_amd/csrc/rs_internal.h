@@ -60,6 +60,8 @@ struct rs_scene {
     int envMapTexId = -1;
     bool textured = false;                        // any material map or an environment map: kernels take the textured variant
     uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
+    uint4* dOccTop = nullptr;        // its top levels (the LDS image) and the array whose links point into them
+    uint4* dOccCut = nullptr;
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
     unsigned long long* dWalkStats = nullptr;   // -DRS_WALK_STATS builds only
@@ -235,9 +237,6 @@ struct rs_restir {
     int tuneChoice = -1;             // -1 measuring, 0 separate, 1 fused
     bool tuneCounted = false;        // this frame had a launch the choice applies to
     hipEvent_t tuneEv[3] = { nullptr, nullptr, nullptr };
-    // shadow rays handed from k_shadow_temporal to k_shadow_finish (restir.hip ParkedRays): a counter and 32 bytes per pixel
-    unsigned* dParkCount = nullptr;
-    uint4* dParkEntries = nullptr;
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
     int raySlot = 0;
     // timing

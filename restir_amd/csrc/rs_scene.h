@@ -18,11 +18,19 @@
 //   occNodes   uint4[occCount]    16 B: the shadow-ray tree (occlusion_bvh.cpp): box on a 16-bit grid over the
 //                                 scene bounds {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16}, w = miss link of an
 //                                 inner node (as a byte offset: index * 16) or ~(firstTriangle*8+count) of a leaf.  Null when the fast path is off.
+//   occTop / occCut               the same tree cut below its top levels: occTop = those levels (<= kOccTopRecords records of
+//                                 16 B, copied into LDS by every block of the shadow pass), occCut = occNodes whose links into
+//                                 the top levels are LDS references; a node reference is a byte offset into occCut (even) or
+//                                 slot * 16 + 1 for an LDS slot
 //   occChain   BvhNode[bvhSize]   32 B: the reference's boxes by ORIGINAL node id with primId = next = parent id
 //                                 (-1 at the root): the path a candidate occluder is verified against
 //   occTris    TriRec[numPrims]   the same pre-differenced triangles in the shadow tree's leaf order,
 //                                 pad0 = bit pattern of the triangle's reference leaf node id
 #pragma once
+
+#ifndef RS_OCC_TOP_RECORDS
+#define RS_OCC_TOP_RECORDS 768      // 12 KB of LDS per block: depth <= 8 of a full binary top (511 nodes + 256 link records)
+#endif
 
 #include "rs_math.h"
 #include "../../include/restir_hip.h"
@@ -65,6 +73,9 @@ struct DevScene {
     int envTex, envLen;           // envMap = textures + envTex (src/scene.cpp:495-498), -1 = none
     float sumLightPowerInv;       // src/scene.cpp:489
     const uint4*   occNodes;
+    const uint4*   occTop;        // the levels of the shadow tree nearest the root, as the image a block copies into LDS (walk_occlusion_tree<true>)
+    const uint4*   occCut;        // occNodes with every link into those levels replaced by an LDS reference
+    int occTopCount;              // records of occTop (<= kOccTopRecords); 0 = no cut tree
     const BvhNode* occChain;
     const TriRec*  occTris;
     f3 occBase, occScale;         // grid plane q on axis c = occBase.c + q * occScale.c
@@ -74,6 +85,7 @@ struct DevScene {
     bool linksNested;             // in every threaded order the miss links nest: c in (a, link(a)) => link(c) <= link(a)
     int occCount;
     unsigned long long* walkStats;   // null unless built with -DRS_WALK_STATS (tools/walk_stats.py)
+    const unsigned char* occDepth;   // depth of every occNodes record (-DRS_WALK_STATS builds only)
     int bvhSize;
     int numPrims;
     int numLights;
@@ -514,8 +526,17 @@ __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
            gabs(o.z - s.occBase.z) <= reach * s.occScale.z;
 }
 
-__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
-    const char* nodes = reinterpret_cast<const char*>(s.occNodes);
+// TOP: the levels nearest the root are read from LDS.  Measured on the benchmark scene (tools/walk_stats.py, pmc_cache.sh): the
+// shadow pass is bound by L1 look-ups -- one per lane and step, 92 % busy -- and 45 % of all steps visit the 511 nodes of depth
+// <= 8 (54 % the 1 023 of depth <= 9).  A block copies those levels (DevScene::occTop) into `topLds` once; a node reference is
+// then either a byte offset into occCut (even) or slot * 16 + 1.  Stepping to "the next record" works in both spaces; where the
+// pre-order successor of an LDS record lives in global memory (the first child of an inner node of the last LDS level), the next
+// slot holds a link record (bit 1 of its last dword set) that is followed whatever its box test says: one extra LDS step on the
+// way down, nothing else changes.
+constexpr int kOccTopRecords = RS_OCC_TOP_RECORDS;
+template <bool TOP>
+__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active, const uint4* topLds = nullptr) {
+    const char* nodes = reinterpret_cast<const char*>(TOP ? s.occCut : s.occNodes);
     const unsigned endOff = (unsigned)s.occCount * 16u;
     // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
     const f3 A = mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z);
@@ -524,7 +545,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
                                     fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
                               fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
-    unsigned cur = active ? 0u : endOff;
+    unsigned cur = active ? (TOP ? 1u : 0u) : endOff;            // TOP: the root is LDS slot 0
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
     bool occluded = false;
 #ifdef RS_WALK_STATS
@@ -538,7 +559,12 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
         while (__any(cur != endOff)) {
             RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
             if (cur != endOff) {
-                const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+                uint4 n;
+                if (TOP && (cur & 1u)) n = topLds[cur >> 4];
+                else n = *reinterpret_cast<const uint4*>(nodes + cur);
+#ifdef RS_WALK_STATS
+                if (!TOP && s.walkStats && s.occDepth) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
+#endif
                 const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
                 const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
                 const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
@@ -549,6 +575,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                 const bool push = pass & leaf;
                 q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn += push ? 1 : 0;
                 cur = (pass | leaf) ? cur + 16u : (unsigned)meta;
+                if (TOP) { if (!leaf && (meta & 2)) cur = (unsigned)(meta & ~2); }      // a link record: always followed
             }
             if (__any(qn == kLeafQueue)) break;
         }
@@ -612,130 +639,6 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     return occluded;
 }
 
-// ---- the same walk, resumable, for compaction across waves -------------------------------------------------------------------
-// A wave of walk_occlusion_tree runs as long as its longest ray (139 iterations for rays of 70 steps on the benchmark scene:
-// 54 % lane utilisation).  This form can stop when few lanes are left and hand the unfinished rays over -- a ray's whole
-// state between two outer iterations is {cur, leaf queue} -- so that a second launch finishes them 64 to a wave.
-// The queue of leaf codes lives in LDS (kOccQueue dwords per thread, slot i of thread t at ldsQ[i * blockDim.x + t]): pushing
-// is one ds_write under the lanes that push, where the register queue shifted four registers in every step of every lane.
-constexpr int kOccQueue = 4;
-struct OccState {
-    unsigned cur;        // byte offset of the next node in occNodes; occCount * 16 = walk ended
-    int qn;              // queued leaf codes (in LDS, or in q[] while the ray is parked)
-};
-
-// minLanes > 0: stop ("park") as soon as that many lanes or fewer are still walking.  Returns this lane's verdict; `parked` is
-// wave-uniform and says that the lanes with st.cur != end or st.qn > 0 (and not occluded) are unfinished.
-// BS = threads per block (the stride of the LDS queue).
-template <int BS>
-__device__ __forceinline__ bool occ_walk(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, OccState& st, unsigned* ldsQ,
-                                         int minLanes, bool& parked) {
-    const char* nodes = reinterpret_cast<const char*>(s.occNodes);
-    const unsigned endOff = (unsigned)s.occCount * 16u;
-    unsigned* myQ = ldsQ + threadIdx.x;                       // slot i at myQ[i * BS]
-    const f3 A = mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z);
-    const f3 B = mk3((s.occBase.x - ctx.o.x) * ctx.dinv.x, (s.occBase.y - ctx.o.y) * ctx.dinv.y, (s.occBase.z - ctx.o.z) * ctx.dinv.z);
-    const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
-                                    fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
-                              fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
-    unsigned cur = st.cur;
-    int qn = st.qn;
-    bool occluded = false;
-    parked = false;
-    for (;;) {
-        // walk phase: until some lane's leaf queue is full, every walk has ended, or too few lanes are left
-        for (;;) {
-            const unsigned long long wm = __builtin_amdgcn_ballot_w64(cur != endOff);
-            if (wm == 0ull) break;
-            if (__popcll(wm) <= minLanes) { parked = true; break; }
-            if (cur != endOff) {
-                const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
-                const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
-                const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
-                const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
-                const int meta = (int)n.w;
-                const bool leaf = meta < 0;
-                if (pass && leaf) { myQ[qn * BS] = (unsigned)~meta; qn++; }
-                cur = (pass || leaf) ? cur + 16u : (unsigned)meta;         // inner nodes hold their miss link as a byte offset
-            }
-            if (__builtin_amdgcn_ballot_w64(qn == kOccQueue) != 0ull) break;
-        }
-        if (parked) break;
-        if (__builtin_amdgcn_ballot_w64(qn > 0) == 0ull) break;
-        // leaf round: every lane takes its newest queued leaf and tests its triangles; a hit becomes a candidate, and the rest
-        // of the leaf waits for its verdict
-        int tri = 0, cnt = 0, verify = -1;
-        if (qn > 0) { qn--; const unsigned code = myQ[qn * BS]; tri = (int)(code >> 3); cnt = (int)(code & 7u); }
-        for (;;) {
-            while (__builtin_amdgcn_ballot_w64((cnt > 0) & (verify < 0)) != 0ull) {
-                if ((cnt > 0) & (verify < 0)) {
-                    const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
-                    const float4 a = p[0], b = p[1], c = p[2];
-                    float bx, by, dist;
-                    tri++; cnt--;
-                    if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit)
-                        verify = __float_as_int(a.w) | 0x40000000;          // reference leaf of the candidate, bit 30 = first step
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(verify >= 0) == 0ull) break;
-            // candidates: the reference's own test along the path to the triangle's leaf (see walk_occlusion_tree)
-            while (__builtin_amdgcn_ballot_w64(verify >= 0) != 0ull) {
-                if (verify >= 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
-                    float4 lo, hi;
-                    node_unpack(rec[0], rec[1], lo, hi);
-                    const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
-                    const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
-                    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
-                    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
-                    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
-                    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
-                    const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
-                    const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
-                    const bool first = (verify & 0x40000000) != 0;
-                    const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
-                    const int parent = __float_as_int(lo.w);
-                    const bool done = open & ((parent < 0) | (first & clear & s.occNested));
-                    if (done) { occluded = true; cur = endOff; qn = 0; cnt = 0; }
-                    verify = (open & !done) ? parent : -1;          // closed: the reference never reaches the triangle
-                }
-            }
-        }
-    }
-    st.cur = cur; st.qn = qn;
-    return occluded;
-}
-
-// Rays whose wave stopped before they had finished (occ_walk with minLanes > 0): {id, cur, qn, q0 | q1, q2, q3, -}, 32 bytes
-// each, appended wave by wave; a second launch walks them on, 64 to a wave.
-struct ParkedRays {
-    unsigned* count;
-    uint4* entries;      // null: waves run to the end
-};
-// all lanes of the wave call it; `unfinished` lanes append their state (ldsQ as in occ_walk)
-template <int BS>
-__device__ __forceinline__ void park_unfinished(const ParkedRays& park, bool unfinished, unsigned id, const OccState& st, const unsigned* ldsQ) {
-    const unsigned long long um = __builtin_amdgcn_ballot_w64(unfinished);
-    if (um == 0ull) return;
-    unsigned base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(park.count, (unsigned)__popcll(um));
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (unfinished) {
-        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-        unsigned q[kOccQueue];
-        for (int i = 0; i < kOccQueue; i++) q[i] = i < st.qn ? ldsQ[i * BS + threadIdx.x] : 0u;
-        park.entries[2 * (size_t)slot] = make_uint4(id, st.cur, (unsigned)st.qn, q[0]);
-        park.entries[2 * (size_t)slot + 1] = make_uint4(q[1], q[2], q[3], 0u);
-    }
-}
-template <int BS>
-__device__ __forceinline__ void unpark(const uint4& e0, const uint4& e1, bool active, unsigned endOff, OccState& st, unsigned* ldsQ) {
-    st.cur = active ? e0.y : endOff; st.qn = active ? (int)e0.z : 0;
-    ldsQ[threadIdx.x] = e0.w; ldsQ[BS + threadIdx.x] = e1.x; ldsQ[2 * BS + threadIdx.x] = e1.y; ldsQ[3 * BS + threadIdx.x] = e1.z;
-}
-
 // all 64 lanes of the wave must call this
 template <bool ANYHIT>
 __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active) {
@@ -747,7 +650,7 @@ __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, co
         r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f;
         if (s.occNodes) {
             const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
-            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !slow);
+            r.any = walk_occlusion_tree<false>(s, ray, ctx, limit, active && !slow);
             if (__any(slow)) r.any = walk_anyhit_deferred<false>(s, ray, ctx, limit, slow) || r.any;
         }
         else
@@ -1199,6 +1102,28 @@ __device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool a
     Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
     dist -= 1e-4f * 2.f;
     return walk_dispatch_paired<true>(s, ray, dist, active).any;
+}
+
+// The same for kernels that hold the top of the shadow tree in LDS: stage_occlusion_top() once per block (it ends in a barrier),
+// then trace_occluded_wave_top() as often as needed.  Scenes without a cut tree (occTopCount == 0) take the plain walk.
+__device__ __forceinline__ void stage_occlusion_top(const DevScene& s, uint4* topLds) {
+    for (int i = threadIdx.x; i < s.occTopCount; i += blockDim.x) topLds[i] = s.occTop[i];
+    __syncthreads();
+}
+__device__ inline bool trace_occluded_wave_top(const DevScene& s, f3 x, f3 y, bool active, const uint4* topLds) {
+    if (!s.occTopCount) return trace_occluded_wave(s, x, y, active);
+    f3 dir = y - x;
+    float dist = length(dir);
+    dir = dir / dist;
+    Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
+    dist -= 1e-4f * 2.f;
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
+    const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
+    const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
+    bool any = walk_occlusion_tree<true>(s, ray, ctx, dist, active && !slow, topLds);
+    if (__any(slow)) any = walk_anyhit_deferred<false>(s, ray, ctx, dist, slow) || any;
+    return any;
 }
 
 // DevScene::testOcclusion (src/scene.h:286-316): any hit between x and y

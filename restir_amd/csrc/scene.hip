@@ -1,7 +1,9 @@
 // scene.hip -- DevScene::create / destroy (src/scene.cpp:435-532) re-laid-out for CDNA4 (see
 // rs_scene.h), Scene::buildDevData as one call, and batched ray entry points for parity tests.
 #include <atomic>
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -55,6 +57,52 @@ int build_occlusion_side(rs_scene* s) {
     float base[3], scale[3];
     std::vector<unsigned> packed;
     if (int e = rs_quantize_occlusion_bvh(nodes, base, scale, packed)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
+    // The cut tree (rs_scene.h walk_occlusion_tree<true>): the deepest level D whose records (nodes of depth <= D plus one link
+    // record per inner node of depth D) fit kOccTopRecords; slots in pre-order; links into the top become LDS references.
+    std::vector<unsigned> top, cut;
+    {
+        std::vector<int> depth(no), ends;
+        for (size_t i = 0; i < no; i++) {
+            while (!ends.empty() && ends.back() <= (int)i) ends.pop_back();
+            depth[i] = (int)ends.size();
+            ends.push_back(nodes[i].next);
+        }
+        int D = -1;
+        for (int d = 0; d < 30; d++) {
+            size_t cnt = 1;                                   // the closing link record
+            for (size_t i = 0; i < no; i++) if (depth[i] <= d) cnt += (depth[i] == d && nodes[i].primId < 0) ? 2 : 1;
+            if (cnt > (size_t)kOccTopRecords) break;
+            D = d;
+        }
+        if (D >= 1 && !std::getenv("RS_NO_OCC_TOP")) {
+            std::vector<int> slot(no + 1, -1);
+            int nslots = 0;
+            for (size_t i = 0; i < no; i++)
+                if (depth[i] <= D) { slot[i] = nslots++; if (depth[i] == D && nodes[i].primId < 0) nslots++; }
+            auto ref = [&](size_t target) -> unsigned {          // a link to pre-order index `target`
+                if (target >= no) return (unsigned)no * 16u;    // the end of the walk
+                return slot[target] >= 0 ? (unsigned)slot[target] * 16u + 1u : (unsigned)target * 16u;
+            };
+            // the last record of the tree may be one of the top records (a shallow right-most leaf): "the next record" after
+            // the last LDS slot is a link record to the end of the walk (tools/models/cut_tree_walk.py is the model of all this)
+            nslots++;
+            cut = packed;
+            top.assign((size_t)nslots * 4, 0u);
+            top[(size_t)(nslots - 1) * 4 + 3] = (unsigned)no * 16u + 2u;
+            for (size_t i = 0; i < no; i++) {
+                const bool inner = nodes[i].primId < 0;
+                if (inner) cut[i * 4 + 3] = ref((size_t)nodes[i].next);
+                if (slot[i] < 0) continue;
+                unsigned* t = &top[(size_t)slot[i] * 4];
+                t[0] = packed[i * 4]; t[1] = packed[i * 4 + 1]; t[2] = packed[i * 4 + 2]; t[3] = cut[i * 4 + 3];
+                if (inner && depth[i] == D) {                   // its first child is record i + 1 of the global array
+                    unsigned* j = t + 4;
+                    j[0] = j[1] = j[2] = 0u;
+                    j[3] = (unsigned)(i + 1) * 16u + 2u;                     // bit 1: a link record, always followed
+                }
+            }
+        }
+    }
     std::vector<BvhNode> chain(nn);
     for (size_t i = 0; i < nn; i++) {
         const float* b = &s->hBoxes[i * 6];
@@ -79,8 +127,35 @@ int build_occlusion_side(rs_scene* s) {
     s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
     RS_TRY(rs_dev_alloc(&s->dOccNodes, no));
     RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), no * 16, hipMemcpyHostToDevice));
+    if (!top.empty()) {
+        RS_TRY(rs_dev_alloc(&s->dOccTop, top.size() / 4));
+        RS_HIP(hipMemcpy(s->dOccTop, top.data(), top.size() * 4, hipMemcpyHostToDevice));
+        RS_TRY(rs_dev_alloc(&s->dOccCut, no));
+        RS_HIP(hipMemcpy(s->dOccCut, cut.data(), no * 16, hipMemcpyHostToDevice));
+        s->dev.occTop = s->dOccTop; s->dev.occCut = s->dOccCut; s->dev.occTopCount = (int)(top.size() / 4);
+    }
     RS_TRY(upload(&s->dOccChain, chain));
     RS_TRY(upload(&s->dOccTris, rec));
+#ifdef RS_WALK_STATS
+    {   // depth of every record of the pre-order array (spans nest: a stack of span ends)
+        std::vector<unsigned char> depth(no);
+        std::vector<int> ends;
+        for (size_t i = 0; i < no; i++) {
+            while (!ends.empty() && ends.back() <= (int)i) ends.pop_back();
+            depth[i] = (unsigned char)std::min<size_t>(ends.size(), 255);
+            ends.push_back(nodes[i].next);
+        }
+        unsigned char* d = nullptr;
+        RS_TRY(rs_dev_alloc(&d, no));
+        RS_HIP(hipMemcpy(d, depth.data(), no, hipMemcpyHostToDevice));
+        s->dev.occDepth = d;                              // (measurement builds: never freed)
+        size_t perDepth[20] = {};
+        for (size_t i = 0; i < no; i++) perDepth[std::min<int>(depth[i], 19)]++;
+        std::fprintf(stderr, "occlusion tree: %zu nodes; per depth:", no);
+        for (int k = 0; k < 20; k++) std::fprintf(stderr, " %zu", perDepth[k]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     s->dev.occNodes = s->dOccNodes;
     s->dev.occChain = s->dOccChain;
     s->dev.occTris = s->dOccTris;
@@ -96,7 +171,7 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
     (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
     (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
-    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccTop); rs_dev_free(s->dOccCut); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords);
@@ -270,8 +345,9 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.numLights = s->numLights;
     s->dev.numMaterials = d->numMaterials;
     s->dev.occNodes = nullptr; s->dev.occChain = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
+    s->dev.occTop = nullptr; s->dev.occCut = nullptr; s->dev.occTopCount = 0;
     s->dev.occBase = splat(0.f); s->dev.occScale = splat(0.f);
-    s->dev.walkStats = nullptr;
+    s->dev.walkStats = nullptr; s->dev.occDepth = nullptr;
     s->dev.occNested = false; s->dev.occRootLo = splat(0.f); s->dev.occRootHi = splat(0.f);
     // Is the box table a proper hierarchy (finite, min <= max, every box inside its parent's, every leaf box
     // around its triangle)?  Tables from rs_build_bvh are; the two shortcuts that rely on it (skip_far_on_axis and
@@ -423,62 +499,15 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevScene s, int n, const 
     st3(norm + (size_t)i * 3, h.norm);
 }
 
-// testOcclusion for a batch of segments: the two-launch form of the ReSTIR shadow pass (restir.hip) -- waves of the first launch
-// park their unfinished rays once half of their lanes are done, the second launch finishes them -- so that the parity tests of
-// rs_trace_occlusion cover the walk, the parking and the resumption
-__device__ __forceinline__ void occlusion_segment(const float* seg, size_t j, Ray& ray, float& range) {
-    const f3 x = ld3(seg + j * 6), y = ld3(seg + j * 6 + 3);
-    f3 dir = y - x;
-    float dist = length(dir);
-    dir = dir / dist;
-    ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
-    range = dist - 1e-4f * 2.f;
-}
-
-__global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ, ParkedRays park) {
-    __shared__ unsigned leafQ[kOccQueue * 256];
+__global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ) {
+    // same wave-level service the ReSTIR shadow pass uses: every lane of the wave takes part
+    __shared__ uint4 occTop[kOccTopRecords];
+    stage_occlusion_top(s, occTop);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const size_t j = active ? (size_t)i : 0;
-    if (!s.occNodes) {
-        const bool o = trace_occluded_wave(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active);
-        if (active) occ[i] = o ? 1 : 0;
-        return;
-    }
-    Ray ray; float range;
-    occlusion_segment(seg, j, ray, range);
-    RayBoxCtx ctx = make_box_ctx(ray);
-    ctx.cull = s.axisCull;
-    const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
-    const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
-    const unsigned endOff = (unsigned)s.occCount * 16u;
-    OccState st;
-    st.cur = (active && !slow) ? 0u : endOff; st.qn = 0;
-    bool parked;
-    bool o = occ_walk<256>(s, ray, ctx, range, st, leafQ, park.entries ? 32 : 0, parked);
-    if (__any(slow)) o = walk_anyhit_deferred<false>(s, ray, ctx, range, slow) || o;
-    const bool unfinished = parked && !o && (st.cur != endOff || st.qn > 0);
-    if (parked) park_unfinished<256>(park, unfinished, (unsigned)i, st, leafQ);
-    if (active && !unfinished) occ[i] = o ? 1 : 0;
-}
-
-__global__ void __launch_bounds__(256) k_trace_occlusion_finish(DevScene s, const float* __restrict__ seg, int* __restrict__ occ, ParkedRays park) {
-    __shared__ unsigned leafQ[kOccQueue * 256];
-    const unsigned n = *park.count;
-    if (blockIdx.x * 256u >= n) return;
-    const unsigned e = blockIdx.x * 256u + threadIdx.x;
-    const bool active = e < n;
-    const uint4 e0 = active ? park.entries[2 * (size_t)e] : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 e1 = active ? park.entries[2 * (size_t)e + 1] : make_uint4(0u, 0u, 0u, 0u);
-    Ray ray; float range;
-    occlusion_segment(seg, (size_t)e0.x, ray, range);
-    RayBoxCtx ctx = make_box_ctx(ray);
-    ctx.cull = s.axisCull;
-    OccState st;
-    unpark<256>(e0, e1, active, (unsigned)s.occCount * 16u, st, leafQ);
-    bool parked;
-    const bool o = occ_walk<256>(s, ray, ctx, range, st, leafQ, 0, parked);
-    if (active) occ[e0.x] = o ? 1 : 0;
+    const bool o = trace_occluded_wave_top(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active, occTop);
+    if (active) occ[i] = o ? 1 : 0;
 }
 
 extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {
@@ -491,20 +520,6 @@ extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, 
 extern "C" int rs_trace_occlusion(const rs_scene* s, int n, const float* devSegments, int* devOccluded) {
     if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_occlusion: bad argument");
     if (n == 0) return 0;
-    ParkedRays park{ nullptr, nullptr };
-    if (s->dev.occNodes && !std::getenv("RS_PARK_OFF_IN_TRACE")) {
-        RS_TRY(rs_dev_alloc(&park.count, 1));
-        if (int e = rs_dev_alloc(&park.entries, 2 * (size_t)n)) { rs_dev_free(park.count); return e; }
-        (void)hipMemsetAsync(park.count, 0, 4, rs_stream());
-    }
-    hipLaunchKernelGGL(k_trace_occlusion, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devSegments, devOccluded, park);
-    if (park.entries) hipLaunchKernelGGL(k_trace_occlusion_finish, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, devSegments, devOccluded, park);
-    int e = rs_check_hip(hipGetLastError(), "rs_trace_occlusion");
-    if (park.entries) {                                 // (the queue is scratch of this call)
-        const int e2 = rs_check_hip(hipStreamSynchronize(rs_stream()), "rs_trace_occlusion");
-        if (!e) e = e2;
-        rs_dev_free(park.count); rs_dev_free(park.entries);
-    }
-    if (e) return e;
+    hipLaunchKernelGGL(k_trace_occlusion, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devSegments, devOccluded);
     return rs_after_launch("rs_trace_occlusion");
 }

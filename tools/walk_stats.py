@@ -33,6 +33,13 @@ for i, n in enumerate(names):
     print("  %-28s %10.2f" % (n, out[i] / w))
 print("  walking lanes per walk iteration %.1f, verifying lanes per verify iteration %.1f, lanes per triangle iteration %.1f" %
       (out[6] / max(out[5], 1), out[7] / max(out[4], 1), out[9] / max(out[3], 1)))
+tot = sum(out[44:64])
+if tot:
+    print("shadow-tree steps by node depth (19 = 19 and deeper), fraction and cumulative:")
+    acc = 0
+    for d in range(20):
+        acc += out[44 + d]
+        print("   depth %2d  %6.3f  %6.3f" % (d, out[44 + d] / tot, acc / tot))
 pw = out[16]
 print("closest-hit packet walks (G-buffer + primary), per wave: union nodes mean %.1f max %d, orders %.2f, waves on the special-case path %.4f" %
       (out[17] / pw, out[18], out[19] / pw, out[20] / pw))
