@@ -11,11 +11,13 @@ std::mutex g_errMutex;
 std::string g_lastError;
 hipStream_t g_stream = nullptr;
 bool g_sync = true;
-// Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 the primary-ray + RIS kernels of ReSTIRDirect.
+// Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 + k the primary-ray + RIS + shadow-ray kernels of every
+// kChains-th frame (frames take the chains in turn, so that these chains of consecutive frames overlap each other
+// as well as the passes of the frames before).
 // Neither reads what the temporal / spatial passes of the previous frame write, so with the per-frame surface planes
 // double-buffered and the G-buffer planes in a ring of three they run next to those passes; the objects own the events
 // that order them (rs_gbuffer, rs_restir).
-hipStream_t g_aux[2] = { nullptr, nullptr };
+hipStream_t g_aux[1 + rs_restir::kChains] = {};
 int g_auxMode = -1;                                     // -1: not decided yet; 0 off; 1 on
 int g_fuseMode = -1;                                    // deferred G-buffer render walked with the primary rays: -1 from the environment
 }  // namespace

@@ -1,14 +1,14 @@
 // restir.hip -- ReSTIRDirect (src/restir.cu:20-231,418-518) for CDNA4.
 //
 // The reference is one fused kernel per frame with a block-level __syncthreads() standing in for a
-// grid-wide dependency.  Here the frame is four launches on one stream, which gives
+// grid-wide dependency.  Here the frame is five launches in stream order, which gives
 // the two-phase contract by construction (stream order is the grid barrier):
 //
 //   phase A  k_primary          jittered primary ray, wave-cooperative packet walk of
 //                               the MTBVH, material after its texture maps            restir.cu:127-153
 //            k_ris / k_ris_lds  32-candidate RIS over the light table (no rays)       restir.cu:155-170
-//            k_shadow_temporal  shadow ray on the RIS winner (shadow tree), temporal
-//                               merge, publish reservoirs                             restir.cu:172-194,211-212
+//            k_shadow           shadow ray on the RIS winner (shadow tree)            restir.cu:172-176
+//            k_temporal         temporal merge, publish reservoirs                    restir.cu:178-194,211-212
 //   phase B  k_spatial_shade    5-tap spatial reuse from an LDS-staged tile+halo,
 //                               shade, accumulate                                     restir.cu:196-230
 //
@@ -220,11 +220,45 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
     p.m[i] = r.M;
 }
 
-// The second half of phase A.3 for one shaded pixel: W of an occluded winner is cleared (restir.cu:172-176), temporal merge
-// (findTemporalNeighbor + preClampedMerge<20>, restir.cu:20-45,178-190), validity check, publish.
-__device__ __forceinline__ void temporal_publish(const SurfPlanes& sp, const GBufView& g, const ResvPlanes& last, const ResvPlanes& cur, const TempPlanes& temp,
-                                                 int first, int reuse, int index, Resv r, bool occluded, int gid, float gdepth) {
-    if (occluded) r.W = 0.f;
+// Phase A.3 is two launches.  The shadow ray (restir.cu:172-176) depends on this frame's RIS winner only, so it belongs to the
+// chain primary rays -> RIS -> shadow rays that no other frame feeds -- the auxiliary streams run it next to the previous frame's
+// passes -- and its whole effect is to clear the weight of an occluded winner, which it does in place (candWi.w).  What is left on
+// the library stream, the only chain that links consecutive frames, is the streaming half: temporal merge, validity check, publish.
+// (As one kernel the pass lasted as long as its slowest wave's walk, 0.2 ms on a 1/8 strip however few rows it has.)
+// 8 blocks per CU = 8 waves per SIMD.
+__global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
+    int x, y;
+    pixel_of_lane(tilesX, y0, x, y);
+    const bool inside = x < width && y < y1;
+    const int index = inside ? y * width + x : 0;
+    const float4 pm = inside ? sp.posMat[index] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool shaded = inside && mk_kind(__float_as_int(pm.w)) == kKindShaded;
+    float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
+    if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
+    const f3 pos = mk3(pm.x, pm.y, pm.z), wi = mk3(cw.x, cw.y, cw.z);
+    // every lane of the wave takes part in the cooperative any-hit walk
+    const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded);
+    if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
+}
+
+__global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp,
+                                                  int first, int reuse, int n0, int n1) {
+    const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= n1) return;
+    const uint2 rm = sp.rngMat[index];
+    const bool shaded = mk_kind((int)rm.y) == kKindShaded;
+    const int gid = g.primId[index];
+    const float gdepth = g.depth[index];
+    if (!shaded) {
+        // early-exit pixels publish no reservoir (Q1: their slot keeps its stale value); only the
+        // G-buffer half of the tap record is refreshed
+        if (reuse & 2) reinterpret_cast<float2*>(temp.tap + index)[1] = make_float2(__int_as_float(gid), gdepth);
+        return;
+    }
+    const float4 cl = sp.candLi[index], cw = sp.candWi[index];
+    Resv r;
+    r.Li = mk3(cl.x, cl.y, cl.z); r.wi = mk3(cw.x, cw.y, cw.z); r.dist = cl.w;
+    r.M = kReservoirSize; r.W = cw.w;                             // 0 if the shadow ray was blocked (k_shadow)
 
     if (!first && (reuse & 1)) {                                  // findTemporalNeighbor, restir.cu:20-45
         const int primId = gid;
@@ -246,10 +280,9 @@ __device__ __forceinline__ void temporal_publish(const SurfPlanes& sp, const GBu
             t.W = last.w[lastIdx]; t.M = last.m[lastIdx];
         }
         if (!resv_invalid(t.W)) {
-            unsigned* rs = reinterpret_cast<unsigned*>(sp.rngMat + index);
-            Rng rng; rng.x = rs[0];
+            Rng rng; rng.x = rm.x;
             const float u = rng.uniform();
-            rs[0] = rng.x;
+            reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;
             // preClampedMerge<20> (restir.h:95-102)
             if (r.M > 0) {
                 const int cap = (20 - 1) * r.M;
@@ -268,40 +301,6 @@ __device__ __forceinline__ void temporal_publish(const SurfPlanes& sp, const GBu
         temp.tap[index] = make_float4(r.W, __int_as_float(r.M), __int_as_float(gid), gdepth);
     }
     resv_store(cur, index, r);
-}
-
-// 8 blocks per CU = 8 waves per SIMD: caps the kernel at 64 VGPRs (the few spilled dwords are outside the walk)
-__global__ void __launch_bounds__(256, 8) k_shadow_temporal(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes last,
-                                                         ResvPlanes cur, TempPlanes temp, int first, int reuse,
-                                                         int y0, int y1, int tilesX) {
-    __shared__ uint4 occTop[kOccTopRecords];             // the top levels of the shadow tree (rs_scene.h walk_occlusion_tree<true>)
-    stage_occlusion_top(s, occTop);
-    int x, y;
-    pixel_of_lane(tilesX, y0, x, y);
-    const bool inside = x < g.width && y < y1;
-    const int index = inside ? y * g.width + x : 0;
-    const float4 pm = inside ? sp.posMat[index] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool shaded = inside && mk_kind(__float_as_int(pm.w)) == kKindShaded;
-    float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
-    if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
-    const f3 pos = mk3(pm.x, pm.y, pm.z);
-
-    Resv r;
-    r.Li = mk3(cl.x, cl.y, cl.z); r.wi = mk3(cw.x, cw.y, cw.z); r.dist = cl.w;
-    r.M = kReservoirSize; r.W = cw.w;
-
-    // every lane of the wave takes part in the cooperative any-hit walk (restir.cu:172-176)
-    const bool occluded = trace_occluded_wave_top(s, pos, pos + r.wi * r.dist, shaded, occTop);
-    if (!inside) return;
-    const int gid = g.primId[index];
-    const float gdepth = g.depth[index];
-    if (!shaded) {
-        // early-exit pixels publish no reservoir (Q1: their slot keeps its stale value); only the
-        // G-buffer half of the tap record is refreshed
-        if (reuse & 2) reinterpret_cast<float2*>(temp.tap + index)[1] = make_float2(__int_as_float(gid), gdepth);
-        return;
-    }
-    temporal_publish(sp, g, last, cur, temp, first, reuse, index, r, occluded, gid, gdepth);
 }
 
 // ---- phase B: spatial reuse + shade --------------------------------------------------------------
@@ -667,7 +666,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // frame's own set of surface planes: in asynchronous mode they go to an auxiliary stream, ordered after the frame
     // that last used the set (or, for a second call within one frame, after everything enqueued so far), and the library
     // stream joins them before the temporal pass.  Their heavy-tile tails then overlap the other frame's passes.
-    const hipStream_t aux = r->timing ? nullptr : rs_aux_stream(1);
+    static const bool parityStreams = []{ const char* e = std::getenv("RS_PARITY_STREAMS"); return !(e && e[0] == '0'); }();
+    const hipStream_t aux = r->timing ? nullptr : rs_aux_stream(parityStreams ? 1 + r->chain : 1);
     const hipStream_t st = aux ? aux : rs_stream();
     if (aux) {
         if (r->phaseACalls > 0) {
@@ -729,14 +729,15 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     else
         hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
     mark(r, 2);
+    hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
     if (aux) {
-        RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS)"));
+        RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS / shadow rays)"));
         RS_HIP(hipEventRecord(r->auxDone, aux));
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
-    hipLaunchKernelGGL(k_shadow_temporal, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, gbuf_view(g),
-                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0, y1, tilesX);
+    hipLaunchKernelGGL(k_temporal, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), sp, gbuf_view(g),
+                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W);
     mark(r, 3);
     return last ? rs_after_launch("ReSTIR Direct (phase A)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase A)");
 }
@@ -785,7 +786,8 @@ int rs_restir_end_frame(rs_restir* r) {
     // every reader of this frame's surface planes has been enqueued: the set is free for the frame after the next one
     if (!rs_sync_enabled()) { RS_HIP(hipEventRecord(r->surfFree[r->surfSet], rs_stream())); r->surfFreeValid[r->surfSet] = true; }
     else r->surfFreeValid[r->surfSet] = false;
-    r->surfSet ^= 1;
+    r->surfSet = (r->surfSet + 1) % rs_restir::kSurfSets;
+    r->chain = (r->chain + 1) % rs_restir::kChains;
     r->phaseACalls = 0;
     // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA, kTuneB and kTuneC begin (two
     // launches in the first span, one fused launch in the second); at frame kTuneC the host waits once for the last stamp (the GPU

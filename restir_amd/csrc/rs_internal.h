@@ -15,7 +15,8 @@ hipStream_t rs_stream();
 bool rs_sync_enabled();
 // after a launch: hipGetLastError (+ stream sync when sync mode is on), like checkCUDAError
 int rs_after_launch(const char* what);
-// auxiliary streams of the asynchronous mode (api_common.hip): 0 = GBuffer::render, 1 = primary rays + RIS; nullptr = not in use
+// auxiliary streams of the asynchronous mode (api_common.hip): 0 = GBuffer::render, 1 + k = primary rays + RIS + shadow rays of every
+// kChains-th frame; nullptr = not in use
 hipStream_t rs_aux_stream(int i);
 int rs_aux_synchronize();
 
@@ -60,8 +61,6 @@ struct rs_scene {
     int envMapTexId = -1;
     bool textured = false;                        // any material map or an environment map: kernels take the textured variant
     uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
-    uint4* dOccTop = nullptr;        // its top levels (the LDS image) and the array whose links point into them
-    uint4* dOccCut = nullptr;
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
     unsigned long long* dWalkStats = nullptr;   // -DRS_WALK_STATS builds only
@@ -208,6 +207,12 @@ struct TempPlanes {
 };
 
 struct rs_restir {
+    // The chain primary rays -> RIS -> shadow rays of a frame depends on no other frame.  Frames put theirs on kChains auxiliary
+    // streams in turn, so that consecutive frames' chains overlap: on a 1/8 strip a chain lasts 0.4 ms however few rows it has.
+    // A chain writes one of kSurfSets sets of surface planes, which the frame's temporal / spatial passes read afterwards; with as
+    // many sets as chains a chain would have to wait until those passes of the frame two back have finished, with one more it
+    // starts as soon as its stream is free.  (Three chains, i.e. five streams on the runtime's four hardware queues: slower.)
+    static constexpr int kChains = 2, kSurfSets = 3;
     int width = 0, height = 0;
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
@@ -215,8 +220,8 @@ struct rs_restir {
     rs_indirect_reservoir* indResv[2] = { nullptr, nullptr };   // devIndTemporalReservoir / devIndLastTemporalReservoir (gi.hip), allocated on first use
     bool firstFrame = true;
     // per-pixel state carried between the passes of one frame (implementation bytes, not in the
-    // reference: its single fused kernel keeps these in registers).  Two sets, alternating per frame: the primary-ray
-    // and RIS kernels of frame f + 1 (auxiliary stream) fill one while the temporal / spatial passes of frame f read the other.
+    // reference: its single fused kernel keeps these in registers).  kSurfSets sets, used in turn: the primary-ray,
+    // RIS and shadow-ray kernels of the next frames (auxiliary streams) fill theirs while the temporal / spatial passes of frame f read this one.
     struct Surf {
         float4* posKind = nullptr;   // hit position xyz, w = bit pattern of (matId | kind<<24)
         float4* norm = nullptr;      // shading normal xyz (flipped to wo side)
@@ -224,10 +229,10 @@ struct rs_restir {
         uint2*  rngMat = nullptr;    // { RNG state, matId | kind<<24 }
         float4* candLi = nullptr;    // RIS winner: Li xyz, w = dist
         float4* candWi = nullptr;    // RIS winner: wi xyz, w = weight (sum of candidate weights)
-    } surf[2];
-    int surfSet = 0;
-    hipEvent_t surfFree[2] = { nullptr, nullptr };   // recorded by end_frame: the frame that used the set has been enqueued
-    bool surfFreeValid[2] = { false, false };
+    } surf[kSurfSets];
+    int surfSet = 0, chain = 0;      // of the frame in flight
+    hipEvent_t surfFree[kSurfSets] = {};             // recorded by end_frame: the frame that used the set has been enqueued
+    bool surfFreeValid[kSurfSets] = {};
     hipEvent_t auxFork = nullptr, auxDone = nullptr;
     int phaseACalls = 0;             // since the last end_frame
     // one traversal for the G-buffer ray and the shading ray of a pixel, or two?  Measured once per scene (rs_fuse_mode() == 3):

@@ -18,19 +18,11 @@
 //   occNodes   uint4[occCount]    16 B: the shadow-ray tree (occlusion_bvh.cpp): box on a 16-bit grid over the
 //                                 scene bounds {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16}, w = miss link of an
 //                                 inner node (as a byte offset: index * 16) or ~(firstTriangle*8+count) of a leaf.  Null when the fast path is off.
-//   occTop / occCut               the same tree cut below its top levels: occTop = those levels (<= kOccTopRecords records of
-//                                 16 B, copied into LDS by every block of the shadow pass), occCut = occNodes whose links into
-//                                 the top levels are LDS references; a node reference is a byte offset into occCut (even) or
-//                                 slot * 16 + 1 for an LDS slot
 //   occChain   BvhNode[bvhSize]   32 B: the reference's boxes by ORIGINAL node id with primId = next = parent id
 //                                 (-1 at the root): the path a candidate occluder is verified against
 //   occTris    TriRec[numPrims]   the same pre-differenced triangles in the shadow tree's leaf order,
 //                                 pad0 = bit pattern of the triangle's reference leaf node id
 #pragma once
-
-#ifndef RS_OCC_TOP_RECORDS
-#define RS_OCC_TOP_RECORDS 768      // 12 KB of LDS per block: depth <= 8 of a full binary top (511 nodes + 256 link records)
-#endif
 
 #include "rs_math.h"
 #include "../../include/restir_hip.h"
@@ -73,9 +65,6 @@ struct DevScene {
     int envTex, envLen;           // envMap = textures + envTex (src/scene.cpp:495-498), -1 = none
     float sumLightPowerInv;       // src/scene.cpp:489
     const uint4*   occNodes;
-    const uint4*   occTop;        // the levels of the shadow tree nearest the root, as the image a block copies into LDS (walk_occlusion_tree<true>)
-    const uint4*   occCut;        // occNodes with every link into those levels replaced by an LDS reference
-    int occTopCount;              // records of occTop (<= kOccTopRecords); 0 = no cut tree
     const BvhNode* occChain;
     const TriRec*  occTris;
     f3 occBase, occScale;         // grid plane q on axis c = occBase.c + q * occScale.c
@@ -526,17 +515,8 @@ __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
            gabs(o.z - s.occBase.z) <= reach * s.occScale.z;
 }
 
-// TOP: the levels nearest the root are read from LDS.  Measured on the benchmark scene (tools/walk_stats.py, pmc_cache.sh): the
-// shadow pass is bound by L1 look-ups -- one per lane and step, 92 % busy -- and 45 % of all steps visit the 511 nodes of depth
-// <= 8 (54 % the 1 023 of depth <= 9).  A block copies those levels (DevScene::occTop) into `topLds` once; a node reference is
-// then either a byte offset into occCut (even) or slot * 16 + 1.  Stepping to "the next record" works in both spaces; where the
-// pre-order successor of an LDS record lives in global memory (the first child of an inner node of the last LDS level), the next
-// slot holds a link record (bit 1 of its last dword set) that is followed whatever its box test says: one extra LDS step on the
-// way down, nothing else changes.
-constexpr int kOccTopRecords = RS_OCC_TOP_RECORDS;
-template <bool TOP>
-__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active, const uint4* topLds = nullptr) {
-    const char* nodes = reinterpret_cast<const char*>(TOP ? s.occCut : s.occNodes);
+__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
+    const char* nodes = reinterpret_cast<const char*>(s.occNodes);
     const unsigned endOff = (unsigned)s.occCount * 16u;
     // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
     const f3 A = mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z);
@@ -545,7 +525,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
                                     fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
                               fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
-    unsigned cur = active ? (TOP ? 1u : 0u) : endOff;            // TOP: the root is LDS slot 0
+    unsigned cur = active ? 0u : endOff;
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
     bool occluded = false;
 #ifdef RS_WALK_STATS
@@ -559,11 +539,9 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
         while (__any(cur != endOff)) {
             RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
             if (cur != endOff) {
-                uint4 n;
-                if (TOP && (cur & 1u)) n = topLds[cur >> 4];
-                else n = *reinterpret_cast<const uint4*>(nodes + cur);
+                const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
 #ifdef RS_WALK_STATS
-                if (!TOP && s.walkStats && s.occDepth) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
+                if (s.walkStats && s.occDepth) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
 #endif
                 const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
                 const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
@@ -575,7 +553,6 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                 const bool push = pass & leaf;
                 q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn += push ? 1 : 0;
                 cur = (pass | leaf) ? cur + 16u : (unsigned)meta;
-                if (TOP) { if (!leaf && (meta & 2)) cur = (unsigned)(meta & ~2); }      // a link record: always followed
             }
             if (__any(qn == kLeafQueue)) break;
         }
@@ -650,7 +627,7 @@ __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, co
         r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f;
         if (s.occNodes) {
             const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
-            r.any = walk_occlusion_tree<false>(s, ray, ctx, limit, active && !slow);
+            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !slow);
             if (__any(slow)) r.any = walk_anyhit_deferred<false>(s, ray, ctx, limit, slow) || r.any;
         }
         else
@@ -1102,28 +1079,6 @@ __device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool a
     Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
     dist -= 1e-4f * 2.f;
     return walk_dispatch_paired<true>(s, ray, dist, active).any;
-}
-
-// The same for kernels that hold the top of the shadow tree in LDS: stage_occlusion_top() once per block (it ends in a barrier),
-// then trace_occluded_wave_top() as often as needed.  Scenes without a cut tree (occTopCount == 0) take the plain walk.
-__device__ __forceinline__ void stage_occlusion_top(const DevScene& s, uint4* topLds) {
-    for (int i = threadIdx.x; i < s.occTopCount; i += blockDim.x) topLds[i] = s.occTop[i];
-    __syncthreads();
-}
-__device__ inline bool trace_occluded_wave_top(const DevScene& s, f3 x, f3 y, bool active, const uint4* topLds) {
-    if (!s.occTopCount) return trace_occluded_wave(s, x, y, active);
-    f3 dir = y - x;
-    float dist = length(dir);
-    dir = dir / dist;
-    Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
-    dist -= 1e-4f * 2.f;
-    RayBoxCtx ctx = make_box_ctx(ray);
-    ctx.cull = s.axisCull;
-    const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
-    const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
-    bool any = walk_occlusion_tree<true>(s, ray, ctx, dist, active && !slow, topLds);
-    if (__any(slow)) any = walk_anyhit_deferred<false>(s, ray, ctx, dist, slow) || any;
-    return any;
 }
 
 // DevScene::testOcclusion (src/scene.h:286-316): any hit between x and y

@@ -57,52 +57,6 @@ int build_occlusion_side(rs_scene* s) {
     float base[3], scale[3];
     std::vector<unsigned> packed;
     if (int e = rs_quantize_occlusion_bvh(nodes, base, scale, packed)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
-    // The cut tree (rs_scene.h walk_occlusion_tree<true>): the deepest level D whose records (nodes of depth <= D plus one link
-    // record per inner node of depth D) fit kOccTopRecords; slots in pre-order; links into the top become LDS references.
-    std::vector<unsigned> top, cut;
-    {
-        std::vector<int> depth(no), ends;
-        for (size_t i = 0; i < no; i++) {
-            while (!ends.empty() && ends.back() <= (int)i) ends.pop_back();
-            depth[i] = (int)ends.size();
-            ends.push_back(nodes[i].next);
-        }
-        int D = -1;
-        for (int d = 0; d < 30; d++) {
-            size_t cnt = 1;                                   // the closing link record
-            for (size_t i = 0; i < no; i++) if (depth[i] <= d) cnt += (depth[i] == d && nodes[i].primId < 0) ? 2 : 1;
-            if (cnt > (size_t)kOccTopRecords) break;
-            D = d;
-        }
-        if (D >= 1 && !std::getenv("RS_NO_OCC_TOP")) {
-            std::vector<int> slot(no + 1, -1);
-            int nslots = 0;
-            for (size_t i = 0; i < no; i++)
-                if (depth[i] <= D) { slot[i] = nslots++; if (depth[i] == D && nodes[i].primId < 0) nslots++; }
-            auto ref = [&](size_t target) -> unsigned {          // a link to pre-order index `target`
-                if (target >= no) return (unsigned)no * 16u;    // the end of the walk
-                return slot[target] >= 0 ? (unsigned)slot[target] * 16u + 1u : (unsigned)target * 16u;
-            };
-            // the last record of the tree may be one of the top records (a shallow right-most leaf): "the next record" after
-            // the last LDS slot is a link record to the end of the walk (tools/models/cut_tree_walk.py is the model of all this)
-            nslots++;
-            cut = packed;
-            top.assign((size_t)nslots * 4, 0u);
-            top[(size_t)(nslots - 1) * 4 + 3] = (unsigned)no * 16u + 2u;
-            for (size_t i = 0; i < no; i++) {
-                const bool inner = nodes[i].primId < 0;
-                if (inner) cut[i * 4 + 3] = ref((size_t)nodes[i].next);
-                if (slot[i] < 0) continue;
-                unsigned* t = &top[(size_t)slot[i] * 4];
-                t[0] = packed[i * 4]; t[1] = packed[i * 4 + 1]; t[2] = packed[i * 4 + 2]; t[3] = cut[i * 4 + 3];
-                if (inner && depth[i] == D) {                   // its first child is record i + 1 of the global array
-                    unsigned* j = t + 4;
-                    j[0] = j[1] = j[2] = 0u;
-                    j[3] = (unsigned)(i + 1) * 16u + 2u;                     // bit 1: a link record, always followed
-                }
-            }
-        }
-    }
     std::vector<BvhNode> chain(nn);
     for (size_t i = 0; i < nn; i++) {
         const float* b = &s->hBoxes[i * 6];
@@ -127,13 +81,6 @@ int build_occlusion_side(rs_scene* s) {
     s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
     RS_TRY(rs_dev_alloc(&s->dOccNodes, no));
     RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), no * 16, hipMemcpyHostToDevice));
-    if (!top.empty()) {
-        RS_TRY(rs_dev_alloc(&s->dOccTop, top.size() / 4));
-        RS_HIP(hipMemcpy(s->dOccTop, top.data(), top.size() * 4, hipMemcpyHostToDevice));
-        RS_TRY(rs_dev_alloc(&s->dOccCut, no));
-        RS_HIP(hipMemcpy(s->dOccCut, cut.data(), no * 16, hipMemcpyHostToDevice));
-        s->dev.occTop = s->dOccTop; s->dev.occCut = s->dOccCut; s->dev.occTopCount = (int)(top.size() / 4);
-    }
     RS_TRY(upload(&s->dOccChain, chain));
     RS_TRY(upload(&s->dOccTris, rec));
 #ifdef RS_WALK_STATS
@@ -171,7 +118,7 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
     (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
     (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
-    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccTop); rs_dev_free(s->dOccCut); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords);
@@ -345,7 +292,6 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.numLights = s->numLights;
     s->dev.numMaterials = d->numMaterials;
     s->dev.occNodes = nullptr; s->dev.occChain = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
-    s->dev.occTop = nullptr; s->dev.occCut = nullptr; s->dev.occTopCount = 0;
     s->dev.occBase = splat(0.f); s->dev.occScale = splat(0.f);
     s->dev.walkStats = nullptr; s->dev.occDepth = nullptr;
     s->dev.occNested = false; s->dev.occRootLo = splat(0.f); s->dev.occRootHi = splat(0.f);
@@ -501,12 +447,10 @@ __global__ void __launch_bounds__(256) k_trace_closest(DevScene s, int n, const 
 
 __global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, const float* __restrict__ seg, int* __restrict__ occ) {
     // same wave-level service the ReSTIR shadow pass uses: every lane of the wave takes part
-    __shared__ uint4 occTop[kOccTopRecords];
-    stage_occlusion_top(s, occTop);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const size_t j = active ? (size_t)i : 0;
-    const bool o = trace_occluded_wave_top(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active, occTop);
+    const bool o = trace_occluded_wave(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active);
     if (active) occ[i] = o ? 1 : 0;
 }
 

@@ -3,10 +3,11 @@
 The scene is replicated; the WxH framebuffer is cut into `world` contiguous row strips.  Per frame a
 rank (one process per GPU, torch.distributed over RCCL/xGMI) does
 
-    G-buffer for its rows +- HALO          (recomputed locally: cheaper than exchanging 20 B/px)
+    G-buffer for its rows                  (only its own: on a 1/8 strip of a 1080p frame re-rendering +-5 halo rows in 8-row
+                                            tiles was +15 % G-buffer work)
     phase A on its rows                    (primary hit, RIS, shadow ray, temporal merge, publish)
-    exchange HALO rows of published reservoirs with the strip above and below   <- point-to-point
-                                            send/recv, 40 B/px: 384 KB per edge at 1080p
+    exchange HALO rows of published reservoirs AND of the G-buffer id / normal / depth planes with the strip above and
+                                            below   <- point-to-point send/recv, 48 + 20 B/px: 653 KB per edge at 1080p
     phase B on its rows                    (spatial reuse, shade, accumulate): the interior rows while the
                                             halo is in flight, the two 5-row border bands after it arrived
 
@@ -84,7 +85,7 @@ class StripRenderer:
         self.y0, self.y1 = self.bounds[rank]
         if world > 1 and min(b[1] - b[0] for b in self.bounds) < HALO:
             raise ValueError("strips must be at least HALO rows tall")
-        self.gy0, self.gy1 = max(0, self.y0 - HALO), min(height, self.y1 + HALO)
+        self.gy0, self.gy1 = self.y0, self.y1            # G-buffer rows rendered here (the halo rows' planes arrive with the halo)
         self.up = rank - 1 if rank > 0 else None
         self.down = rank + 1 if rank + 1 < world else None
         self.max_rows = max(b[1] - b[0] for b in self.bounds)
@@ -282,9 +283,12 @@ class HipBackend:
         self.restir.end_frame()
         self.gbuf.update(self.cam)
 
+    # halo = published reservoirs (48 B/px) + the G-buffer id / normal / depth rows the spatial taps compare against (20 B/px)
     def halo_pack(self, y0, rows):
-        buf = self.empty(self.restir.halo_bytes(rows))
+        nr = self.restir.halo_bytes(rows)
+        buf = self.empty(nr + self.gbuf.rows_bytes(rows))
         self.restir.halo_pack(y0, rows, buf.data_ptr())
+        self.gbuf.rows_pack(0, y0, rows, buf.data_ptr() + nr)
         return buf
 
     # LeveledEAWFilter on strips: level l reads input l (the radiance image for l = 0, else the output of level l - 1) and
@@ -324,6 +328,7 @@ class HipBackend:
 
     def halo_unpack(self, y0, rows, buf):
         self.restir.halo_unpack(y0, rows, buf.data_ptr())
+        self.gbuf.rows_unpack(0, y0, rows, buf.data_ptr() + self.restir.halo_bytes(rows))
 
     # history = reservoirs the next temporal merge reads (buffer 1 after end_frame) + "last" G-buffer planes
     def history_bytes(self, rows):

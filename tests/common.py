@@ -151,11 +151,16 @@ class OracleBackend:
     def _rows(self, arr, y0, rows):
         return arr[y0 * self.W:(y0 + rows) * self.W]
 
+    # halo = published reservoirs + the G-buffer id / normal / depth rows the spatial taps compare against (as HipBackend)
     def halo_pack(self, y0, rows):
-        return self.torch.from_numpy(self._rows(self.restir.temp, y0, rows).copy().view(np.uint8).reshape(-1))
+        res = self.torch.from_numpy(self._rows(self.restir.temp, y0, rows).copy().view(np.uint8).reshape(-1))
+        return self.torch.cat([res, self.gbuffer_rows_get(y0, rows)])
 
     def halo_unpack(self, y0, rows, buf):
-        self._rows(self.restir.temp, y0, rows)[:] = buf.numpy().view(RESERVOIR_DTYPE)
+        n = rows * self.W * RESERVOIR_DTYPE.itemsize
+        b = buf.contiguous()
+        self._rows(self.restir.temp, y0, rows)[:] = b[:n].numpy().view(RESERVOIR_DTYPE)
+        self.gbuffer_rows_put(y0, rows, b[n:])
 
     # LeveledEAWFilter on strips (the interface of HipBackend): two full-frame buffers, the oracle's level on the whole frame
     # (rows outside the strip and its exchanged border hold stale values and are never looked at)

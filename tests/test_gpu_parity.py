@@ -675,15 +675,19 @@ def test_strip_tiling_equals_full_frame(hip):
         ref = full.frame(3)
         # phase A on each strip
         for r, (y0, y1) in zip(ranks, bounds):
-            r.gbuf.render(r.scene, r.cam, max(0, y0 - halo), min(H, y1 + halo))    # G-buffer halo is recomputed locally
+            r.gbuf.render(r.scene, r.cam, y0, y1)                                   # its own rows only
             r.restir.phase_a(r.scene, r.cam, r.gbuf, r.looper, 3, y0, y1)
-        # halo exchange of published reservoirs (what RCCL send/recv carries between neighbours)
-        nbytes = ranks[0].restir.halo_bytes(halo)
-        up = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); down = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        # halo exchange (what RCCL send/recv carries between neighbours): published reservoirs + G-buffer id / normal / depth rows
+        nr, ng = ranks[0].restir.halo_bytes(halo), ranks[0].gbuf.rows_bytes(halo)
+        up = torch.empty(nr + ng, dtype=torch.uint8, device="cuda"); down = torch.empty(nr + ng, dtype=torch.uint8, device="cuda")
         ranks[0].restir.halo_pack(bounds[0][1] - halo, halo, down.data_ptr())       # rank0's last rows -> rank1
+        ranks[0].gbuf.rows_pack(0, bounds[0][1] - halo, halo, down.data_ptr() + nr)
         ranks[1].restir.halo_pack(bounds[1][0], halo, up.data_ptr())                # rank1's first rows -> rank0
+        ranks[1].gbuf.rows_pack(0, bounds[1][0], halo, up.data_ptr() + nr)
         ranks[1].restir.halo_unpack(bounds[0][1] - halo, halo, down.data_ptr())
+        ranks[1].gbuf.rows_unpack(0, bounds[0][1] - halo, halo, down.data_ptr() + nr)
         ranks[0].restir.halo_unpack(bounds[1][0], halo, up.data_ptr())
+        ranks[0].gbuf.rows_unpack(0, bounds[1][0], halo, up.data_ptr() + nr)
         for r, (y0, y1) in zip(ranks, bounds):
             r.restir.phase_b(r.scene, r.cam, r.gbuf, r.image.data_ptr(), 0, 3, y0, y1)
             r.restir.end_frame()
