@@ -304,6 +304,42 @@ int  rs_restir_enable_timing(rs_restir* r, int enable);
  * pseudo-random samples so a test can assert the band really covers it. */
 int  rs_debug_tap_estimate_error(int n, float* maxErr);
 
+/* ---- framebuffer tiling across the GPUs of one node: the row-strip frame of one rank ------------------------------------------
+ * One process per GPU, the scene replicated, the framebuffer of runCuda (src/main.cpp:146-185) cut into `world` row strips.  A rank
+ * renders the G-buffer and phase A on its rows, sends its 5 border rows of published reservoirs and of the G-buffer id / normal /
+ * depth planes to the strip above and below (68 B/px, the only exchange; taps reach y-4..y+5, src/restir.cu:49-56), runs phase B on
+ * its interior rows while they travel and on the two border bands after they have arrived.  Results equal the full-frame
+ * rs_restir_direct bit for bit.  (restir_amd/tiling.py drives the same calls from Python; the moving-camera history exchange and
+ * the EAW filter on strips exist there only.) */
+typedef struct rs_comm rs_comm;
+typedef struct rs_strips rs_strips;
+/* The exchange, as two grouped operations on device buffers.  stream_ordered != 0: send / recv enqueue on `hipStream` and the
+ * buffers are touched in stream order (RCCL); 0: they are host calls that complete at group_end at the latest (the frame then
+ * hands over a finished library stream and waits for group_end before it unpacks). */
+typedef struct rs_transport {
+    void* ctx;
+    int (*group_begin)(void* ctx);                 /* may be null */
+    int (*send)(void* ctx, const void* devBuffer, size_t bytes, int peer, void* hipStream);
+    int (*recv)(void* ctx, void* devBuffer, size_t bytes, int peer, void* hipStream);
+    int (*group_end)(void* ctx);                   /* may be null */
+    int stream_ordered;
+} rs_transport;
+/* ncclComm: an ncclComm_t of `world` ranks created by the caller (ncclCommInitRank); librccl.so is opened at run time, the
+ * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on a stream of the strip driver */
+int  rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** comm);
+int  rs_comm_create(const rs_transport* transport, int rank, int world, rs_comm** comm);
+int  rs_comm_destroy(rs_comm* comm);
+/* one-rank check of a transport: `bytes` of devSend travel to this rank itself into devRecv, grouped and ordered as in a frame */
+int  rs_comm_self_exchange(rs_comm* comm, const void* devSend, void* devRecv, size_t bytes);
+/* bounds: world + 1 row offsets (bounds[0] = 0, bounds[world] = height, strips of at least 5 rows), or null for equal heights */
+int  rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs_strips** strips);
+int  rs_strips_destroy(rs_strips* strips);
+int  rs_strips_rows(const rs_strips* strips, int* y0, int* y1);
+/* GBuffer::render + ReSTIRDirect of this rank's rows; GBuffer::update stays with the caller, as in runCuda.  Afterwards rows
+ * [y0, y1) of devDirectIllum hold the frame's radiance. */
+int  rs_strips_frame(rs_strips* strips, rs_restir* r, const rs_scene* scene, const rs_camera* cam, rs_gbuffer* g,
+                     float* devDirectIllum, int iter, int looper, int reuse);
+
 /* ---- path-trace baseline (src/pathtrace.h:12-16) ---------------------------------------- */
 int  rs_path_trace_init(void);            /* pathTraceInit (src/pathtrace.cu:23-25) */
 int  rs_path_trace_free(void);            /* pathTraceFree (:27-28) */

@@ -19,6 +19,19 @@ class RestirHipError(RuntimeError):
     pass
 
 
+RS_ERR_INVALID_ARGUMENT, RS_ERR_UNSUPPORTED = 10001, 10002
+
+# rs_transport (include/restir_hip.h): the exchange of the strip driver as callbacks
+TRANSPORT_GROUP = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TRANSPORT_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+TRANSPORT_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("group_begin", TRANSPORT_GROUP), ("send", TRANSPORT_SEND), ("recv", TRANSPORT_RECV),
+                ("group_end", TRANSPORT_GROUP), ("stream_ordered", C.c_int)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("numPrims", C.c_int),
@@ -106,7 +119,7 @@ EXPORTS = [
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
-    "rs_add_image", "rs_add_image3",
+    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
 
@@ -198,6 +211,13 @@ def lib():
     L.rs_copy_image_to_pbo.argtypes = [vp, vp, ci, ci, ci, cf]
     for name in ("rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo"):
         getattr(L, name).argtypes = [vp, vp, ci, ci]
+    L.rs_comm_create_rccl.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    L.rs_comm_create.argtypes = [C.POINTER(Transport), ci, ci, C.POINTER(vp)]
+    L.rs_comm_destroy.argtypes = [vp]
+    L.rs_strips_create.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(vp)]
+    L.rs_strips_destroy.argtypes = [vp]
+    L.rs_strips_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.rs_strips_frame.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci]
     L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
     for name in ("rs_eaw_set_params", "rs_svgf_set_params"):
         getattr(L, name).argtypes = [vp, C.c_float, C.c_float, C.c_float, ci]
@@ -642,6 +662,63 @@ class ReSTIR:
             self.destroy()
         except Exception:
             pass
+
+
+class Comm:
+    """rs_comm: the exchange of the strip driver.  Comm.rccl(nccl_comm_ptr, rank, world) wraps an ncclComm_t; Comm(callbacks...)
+    takes host callbacks send(dev_ptr, nbytes, peer) / recv(dev_ptr, nbytes, peer) / group_begin() / group_end() (tests)."""
+
+    def __init__(self, rank, world, send, recv, group_begin=None, group_end=None):
+        def guard(fn):
+            def call(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:                      # an exception must not cross the C frame
+                    print("transport callback failed:", repr(e), flush=True)
+                    return RS_ERR_UNSUPPORTED
+            return call
+        self._cbs = (TRANSPORT_GROUP(guard(lambda ctx: group_begin() if group_begin else None)),
+                     TRANSPORT_SEND(guard(lambda ctx, p, n, peer, st: send(p, n, peer))),
+                     TRANSPORT_RECV(guard(lambda ctx, p, n, peer, st: recv(p, n, peer))),
+                     TRANSPORT_GROUP(guard(lambda ctx: group_end() if group_end else None)))
+        t = Transport(None, self._cbs[0], self._cbs[1], self._cbs[2], self._cbs[3], 0)
+        self.handle = C.c_void_p()
+        check(lib().rs_comm_create(C.byref(t), rank, world, C.byref(self.handle)))
+
+    @classmethod
+    def rccl(cls, nccl_comm_ptr, rank, world):
+        self = cls.__new__(cls)
+        self._cbs = ()
+        self.handle = C.c_void_p()
+        check(lib().rs_comm_create_rccl(C.c_void_p(nccl_comm_ptr), rank, world, C.byref(self.handle)))
+        return self
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class Strips:
+    """rs_strips: the row-strip frame of one rank (include/restir_hip.h), the C form of tiling.StripRenderer for a static camera."""
+
+    def __init__(self, comm, width, height, bounds=None):
+        self.comm = comm
+        self.handle = C.c_void_p()
+        b = (C.c_int * len(bounds))(*bounds) if bounds is not None else None
+        check(lib().rs_strips_create(comm.handle, width, height, b, C.byref(self.handle)))
+        y0, y1 = C.c_int(), C.c_int()
+        check(lib().rs_strips_rows(self.handle, C.byref(y0), C.byref(y1)))
+        self.y0, self.y1 = y0.value, y1.value
+
+    def frame(self, restir, scene, cam, gbuf, dev_direct_illum_ptr, iter_, looper, reuse):
+        check(lib().rs_strips_frame(self.handle, restir.handle, scene.handle, C.byref(cam), gbuf.handle, dev_direct_illum_ptr, iter_, looper, reuse))
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_strips_destroy(self.handle)
+            self.handle = C.c_void_p()
 
 
 class EAWFilter:

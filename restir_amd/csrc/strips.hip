@@ -1,0 +1,219 @@
+// strips.hip -- the row-strip frame of one rank for a C / C++ caller (include/restir_hip.h rs_comm_*, rs_strips_*):
+// the framebuffer of runCuda (src/main.cpp:146-185) cut into `world` row strips, one process per GPU.
+//
+//     GBuffer::render on the strip's rows
+//     ReSTIRDirect phase A on the strip's rows                      (restir.cu:127-194)
+//     5 border rows of published reservoirs + G-buffer id / normal / depth  ->  the strip above / below      <- the only exchange
+//     phase B on the interior rows while the border rows travel, then on the two 5-row bands (restir.cu:196-230)
+//
+// The exchange goes through a transport of two operations, send and recv of a device buffer, grouped:
+//   * RCCL: ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd on a stream of this driver that is ordered after the packing
+//     copies and before the unpacking copies by events, so that the interior rows of phase B (library stream) run while the rows
+//     travel over xGMI.  librccl is opened at run time (dlopen): a single-GPU caller does not need it.
+//   * caller-supplied callbacks (rs_comm_create): tests drive the same frame code with torch.distributed / gloo underneath.
+// restir_amd/tiling.py is the Python form of the same schedule (test harness, bench.py); tests compare the two.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "rs_internal.h"
+
+struct rs_comm {
+    rs_transport t{};
+    int rank = 0, world = 1;
+    // RCCL transport
+    void* lib = nullptr;
+    void* nccl = nullptr;                          // ncclComm_t
+    int (*pSend)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*pRecv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*pGroupStart)() = nullptr;
+    int (*pGroupEnd)() = nullptr;
+    const char* (*pErr)(int) = nullptr;
+};
+
+struct rs_strips {
+    rs_comm* comm = nullptr;
+    int width = 0, height = 0;
+    std::vector<int> bounds;                       // world + 1 row offsets
+    int y0 = 0, y1 = 0;
+    size_t haloBytes = 0;                          // one edge: reservoirs + G-buffer rows
+    char* sendUp = nullptr; char* recvUp = nullptr; char* sendDown = nullptr; char* recvDown = nullptr;
+    hipStream_t commStream = nullptr;              // carries the transfers
+    hipEvent_t packed = nullptr, arrived = nullptr;
+};
+
+namespace {
+
+constexpr int kHalo = RS_SPATIAL_HALO_ROWS;
+
+int rccl_fail(rs_comm* c, int e, const char* what) {
+    std::string m = std::string(what) + ": " + (c->pErr ? c->pErr(e) : "RCCL error");
+    return rs_fail(RS_ERR_UNSUPPORTED, m.c_str());
+}
+int rccl_group_begin(void* ctx) { rs_comm* c = (rs_comm*)ctx; const int e = c->pGroupStart(); return e ? rccl_fail(c, e, "ncclGroupStart") : 0; }
+int rccl_group_end(void* ctx) { rs_comm* c = (rs_comm*)ctx; const int e = c->pGroupEnd(); return e ? rccl_fail(c, e, "ncclGroupEnd") : 0; }
+int rccl_send(void* ctx, const void* buf, size_t bytes, int peer, void* stream) {
+    rs_comm* c = (rs_comm*)ctx;
+    const int e = c->pSend(buf, bytes, /*ncclUint8*/ 1, peer, c->nccl, (hipStream_t)stream);
+    return e ? rccl_fail(c, e, "ncclSend") : 0;
+}
+int rccl_recv(void* ctx, void* buf, size_t bytes, int peer, void* stream) {
+    rs_comm* c = (rs_comm*)ctx;
+    const int e = c->pRecv(buf, bytes, /*ncclUint8*/ 1, peer, c->nccl, (hipStream_t)stream);
+    return e ? rccl_fail(c, e, "ncclRecv") : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_comm_destroy(rs_comm* c) {
+    if (!c) return 0;
+    if (c->lib) dlclose(c->lib);
+    delete c;
+    return 0;
+}
+
+int rs_comm_create(const rs_transport* t, int rank, int world, rs_comm** out) {
+    if (!t || !out || world < 1 || rank < 0 || rank >= world || !t->send || !t->recv)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_comm_create: bad argument");
+    rs_comm* c = new rs_comm();
+    c->t = *t; c->rank = rank; c->world = world;
+    *out = c;
+    return 0;
+}
+
+int rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** out) {
+    if (!ncclComm || !out || world < 1 || rank < 0 || rank >= world) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_comm_create_rccl: bad argument");
+    rs_comm* c = new rs_comm();
+    c->rank = rank; c->world = world; c->nccl = ncclComm;
+    // the caller's process has created the communicator, so the library is loaded already; RTLD_NOLOAD would do, a plain open is the same handle
+    for (const char* name : { "librccl.so", "librccl.so.1" }) { c->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (c->lib) break; }
+    if (!c->lib) { delete c; return rs_fail(RS_ERR_UNSUPPORTED, "rs_comm_create_rccl: librccl.so cannot be opened"); }
+    c->pSend = (decltype(c->pSend))dlsym(c->lib, "ncclSend");
+    c->pRecv = (decltype(c->pRecv))dlsym(c->lib, "ncclRecv");
+    c->pGroupStart = (decltype(c->pGroupStart))dlsym(c->lib, "ncclGroupStart");
+    c->pGroupEnd = (decltype(c->pGroupEnd))dlsym(c->lib, "ncclGroupEnd");
+    c->pErr = (decltype(c->pErr))dlsym(c->lib, "ncclGetErrorString");
+    if (!c->pSend || !c->pRecv || !c->pGroupStart || !c->pGroupEnd) { rs_comm_destroy(c); return rs_fail(RS_ERR_UNSUPPORTED, "rs_comm_create_rccl: librccl.so lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"); }
+    c->t.ctx = c; c->t.group_begin = rccl_group_begin; c->t.group_end = rccl_group_end; c->t.send = rccl_send; c->t.recv = rccl_recv;
+    c->t.stream_ordered = 1;
+    *out = c;
+    return 0;
+}
+
+// Sends `bytes` of devSend to this rank itself and receives them into devRecv, through the transport exactly as rs_strips_frame
+// uses it (group, stream order, events): a one-rank check of a transport, e.g. of the run-time binding to librccl on a single GPU.
+int rs_comm_self_exchange(rs_comm* c, const void* devSend, void* devRecv, size_t bytes) {
+    if (!c || !devSend || !devRecv) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_comm_self_exchange: null argument");
+    hipStream_t ts = nullptr;
+    RS_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+    hipEvent_t before = nullptr, after = nullptr;
+    RS_HIP(hipEventCreateWithFlags(&before, hipEventDisableTiming));
+    RS_HIP(hipEventCreateWithFlags(&after, hipEventDisableTiming));
+    int e = 0;
+    if (c->t.stream_ordered) { e = rs_check_hip(hipEventRecord(before, rs_stream()), "event"); if (!e) e = rs_check_hip(hipStreamWaitEvent(ts, before, 0), "wait"); }
+    else e = rs_synchronize();
+    if (!e && c->t.group_begin) e = c->t.group_begin(c->t.ctx);
+    if (!e) e = c->t.send(c->t.ctx, devSend, bytes, c->rank, ts);
+    if (!e) e = c->t.recv(c->t.ctx, devRecv, bytes, c->rank, ts);
+    if (!e && c->t.group_end) e = c->t.group_end(c->t.ctx);
+    if (!e && c->t.stream_ordered) { e = rs_check_hip(hipEventRecord(after, ts), "event"); if (!e) e = rs_check_hip(hipStreamWaitEvent(rs_stream(), after, 0), "wait"); }
+    if (!e) e = rs_check_hip(hipStreamSynchronize(ts), "rs_comm_self_exchange");
+    if (!e) e = rs_check_hip(hipStreamSynchronize(rs_stream()), "rs_comm_self_exchange");
+    (void)hipEventDestroy(before); (void)hipEventDestroy(after); (void)hipStreamDestroy(ts);
+    return e;
+}
+
+int rs_strips_destroy(rs_strips* s) {
+    if (!s) return 0;
+    (void)rs_synchronize();
+    if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
+    if (s->packed) (void)hipEventDestroy(s->packed);
+    if (s->arrived) (void)hipEventDestroy(s->arrived);
+    rs_dev_free(s->sendUp); rs_dev_free(s->recvUp); rs_dev_free(s->sendDown); rs_dev_free(s->recvDown);
+    delete s;
+    return 0;
+}
+
+int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs_strips** out) {
+    if (!comm || !out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_create: bad argument");
+    *out = nullptr;
+    rs_strips* s = new rs_strips();
+    s->comm = comm; s->width = width; s->height = height;
+    s->bounds.resize((size_t)comm->world + 1);
+    for (int r = 0; r <= comm->world; r++) {
+        if (bounds) s->bounds[(size_t)r] = bounds[r];
+        else {                                                   // heights that differ by at most one row (tiling.strip_bounds)
+            const int base = height / comm->world, rem = height % comm->world;
+            s->bounds[(size_t)r] = r * base + (r < rem ? r : rem);
+        }
+    }
+    bool ok = s->bounds[0] == 0 && s->bounds[(size_t)comm->world] == height;
+    for (int r = 0; r < comm->world && ok; r++) ok = s->bounds[(size_t)r + 1] - s->bounds[(size_t)r] >= (comm->world > 1 ? kHalo : 1);
+    if (!ok) { delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_create: the bounds must tile [0, height) in rank order with strips of at least 5 rows"); }
+    s->y0 = s->bounds[(size_t)comm->rank]; s->y1 = s->bounds[(size_t)comm->rank + 1];
+    s->haloBytes = (size_t)width * kHalo * (48u + 20u);          // rs_restir_halo_bytes + rs_gbuffer_rows_bytes
+    int e = 0;
+    if (comm->rank > 0) { e = rs_dev_alloc(&s->sendUp, s->haloBytes); if (!e) e = rs_dev_alloc(&s->recvUp, s->haloBytes); }
+    if (!e && comm->rank + 1 < comm->world) { e = rs_dev_alloc(&s->sendDown, s->haloBytes); if (!e) e = rs_dev_alloc(&s->recvDown, s->haloBytes); }
+    if (!e && comm->world > 1) {
+        e = rs_check_hip(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
+        if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->packed, hipEventDisableTiming), "hipEventCreate");
+        if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->arrived, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (e) { rs_strips_destroy(s); return e; }
+    *out = s;
+    return 0;
+}
+
+int rs_strips_rows(const rs_strips* s, int* y0, int* y1) {
+    if (!s || !y0 || !y1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_rows: null argument");
+    *y0 = s->y0; *y1 = s->y1;
+    return 0;
+}
+
+// One runCuda frame of this rank: GBuffer::render, ReSTIRDirect, (the caller tone-maps / gathers its rows), GBuffer::update is
+// the caller's, as in the reference.  Radiance rows [y0, y1) of devDirectIllum are valid afterwards.
+int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_camera* cam, rs_gbuffer* g,
+                    float* devDirectIllum, int iter, int looper, int reuse) {
+    if (!s || !r || !scene || !cam || !g || !devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_frame: null argument");
+    if (g->width != s->width || g->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_frame: G-buffer size differs from the strips' frame");
+    const int y0 = s->y0, y1 = s->y1;
+    const rs_comm* c = s->comm;
+    RS_TRY(rs_gbuffer_render_rows(g, scene, cam, y0, y1));
+    RS_TRY(rs_restir_phase_a(r, scene, cam, g, looper, reuse, y0, y1));
+    const bool up = c->rank > 0, down = c->rank + 1 < c->world;
+    if (!(reuse & 2) || (!up && !down)) {
+        RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1));
+        return rs_restir_end_frame(r);
+    }
+    const size_t nr = rs_restir_halo_bytes(r, kHalo);
+    // pack the border rows (library stream)
+    if (up) { RS_TRY(rs_restir_halo_pack(r, y0, kHalo, s->sendUp)); RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, kHalo, s->sendUp + nr)); }
+    if (down) { RS_TRY(rs_restir_halo_pack(r, y1 - kHalo, kHalo, s->sendDown)); RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - kHalo, kHalo, s->sendDown + nr)); }
+    // the transfers: on the driver's stream after the packing copies (a transport that is not stream-ordered reads the buffers
+    // from the host side: it gets a finished library stream instead)
+    hipStream_t ts = s->commStream;
+    if (c->t.stream_ordered) { RS_HIP(hipEventRecord(s->packed, rs_stream())); RS_HIP(hipStreamWaitEvent(ts, s->packed, 0)); }
+    else RS_TRY(rs_synchronize());
+    if (c->t.group_begin) RS_TRY(c->t.group_begin(c->t.ctx));
+    if (up) { RS_TRY(c->t.send(c->t.ctx, s->sendUp, s->haloBytes, c->rank - 1, ts)); RS_TRY(c->t.recv(c->t.ctx, s->recvUp, s->haloBytes, c->rank - 1, ts)); }
+    if (down) { RS_TRY(c->t.send(c->t.ctx, s->sendDown, s->haloBytes, c->rank + 1, ts)); RS_TRY(c->t.recv(c->t.ctx, s->recvDown, s->haloBytes, c->rank + 1, ts)); }
+    if (c->t.group_end) RS_TRY(c->t.group_end(c->t.ctx));       // RCCL: the grouped transfers are enqueued here; a host-side transport completes here
+    // interior rows (their taps stay inside the strip) while the border rows travel
+    const int topEnd = up ? (y0 + kHalo < y1 ? y0 + kHalo : y1) : y0;
+    const int botStart = down ? (y1 - kHalo > topEnd ? y1 - kHalo : topEnd) : y1;
+    if (botStart > topEnd) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, topEnd, botStart));
+    if (c->t.stream_ordered) {
+        RS_HIP(hipEventRecord(s->arrived, ts));
+        RS_HIP(hipStreamWaitEvent(rs_stream(), s->arrived, 0));
+    }
+    if (up) { RS_TRY(rs_restir_halo_unpack(r, y0 - kHalo, kHalo, s->recvUp)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - kHalo, kHalo, s->recvUp + nr)); }
+    if (down) { RS_TRY(rs_restir_halo_unpack(r, y1, kHalo, s->recvDown)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, kHalo, s->recvDown + nr)); }
+    if (topEnd > y0) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, topEnd));
+    if (y1 > botStart) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, botStart, y1));
+    return rs_restir_end_frame(r);
+}
+
+}  // extern "C"

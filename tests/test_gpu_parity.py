@@ -863,6 +863,18 @@ def test_multi_process_strips_on_one_gpu():
     assert r.stdout.count("strips == full frame: True") == 6, r.stdout[-2000:]
 
 
+def test_strip_driver_binds_to_rccl():
+    """The C++ caller of the strip driver over RCCL in the form one GPU can run (restir_amd/host/strips_rccl_check.cpp): a
+    one-rank ncclComm, 1 MiB sent to the rank itself through the library's run-time binding to librccl (ncclSend / ncclRecv in a
+    group, ordered by events as in a frame), and a strip frame of a one-rank world equal to rs_restir_direct."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "restir_amd", "host", "strips_rccl_check")
+    assert os.path.exists(exe), "built by restir_amd/csrc/Makefile (__graft_entry__.build)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "strips_rccl_check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_config4_4k_eight_strips_equal_full_frame(hip):
     """BASELINE config 4: the bench scene at 3840x2160 cut into 8 row strips with the 5-row reservoir halo -- the
     eight ranks are run one after the other on this GPU -- against the full-frame result, bit for bit."""

@@ -53,6 +53,63 @@ for moving, overlapped, denoise in ((False, False, False), (True, False, False),
         print("world %d, %s camera, %s launches%s: strips == full frame: %s" %
               (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", ", EAW filter" if denoise else "", same), flush=True)
         ok = ok and same
+
+# ---- the C-ABI strip driver (rs_comm / rs_strips, include/restir_hip.h) with gloo under its transport callbacks -------------------
+# What a C++ caller runs over RCCL (rs_comm_create_rccl); here send / recv stage through host memory and torch.distributed.
+class GlooTransport:
+    def __init__(self):
+        self.ops, self.recvs, self.keep = [], [], []
+    def send(self, ptr, nbytes, peer):
+        t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        capi.hip_memcpy_d2d(t.data_ptr(), ptr, nbytes)
+        h = t.cpu(); self.keep.append(h)
+        self.ops.append(dist.isend(h, peer))
+    def recv(self, ptr, nbytes, peer):
+        h = torch.empty(nbytes, dtype=torch.uint8)
+        self.ops.append(dist.irecv(h, peer)); self.recvs.append((ptr, h))
+    def begin(self):
+        self.ops, self.recvs, self.keep = [], [], []
+    def end(self):
+        for w in self.ops:
+            w.wait()
+        for ptr, h in self.recvs:
+            d = h.cuda()
+            capi.hip_memcpy_d2d(ptr, d.data_ptr(), d.numel())
+            torch.cuda.synchronize()
+
+for overlapped in (False, True):
+    capi.set_sync(not overlapped)
+    cam = capi.camera_update(sd.camera(W, H))
+    tr = GlooTransport()
+    comm = capi.Comm(rank, world, tr.send, tr.recv, tr.begin, tr.end)
+    drv = capi.Strips(comm, W, H)
+    gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
+    image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
+    full = StripRenderer(HipBackend(capi, scene, cam, W, H), 1, 0, H) if rank == 0 else None
+    ref_py = StripRenderer(HipBackend(capi, scene, cam, W, H), world, rank, H, dist=dist)       # the Python form of the same schedule
+    for frame in range(FRAMES):
+        drv.frame(restir, scene, cam, gbuf, image.data_ptr(), 0, frame, 3)
+        gbuf.update(cam)
+        ref_py.frame(3, 0)
+        if full is not None:
+            full.frame(3, 0)
+    torch.cuda.synchronize(); capi.synchronize()
+    capi.set_sync(True)
+    mine = image[drv.y0 * W:drv.y1 * W].contiguous()
+    same_as_python = bool(torch.equal(mine.view(torch.int32), ref_py.b.image[drv.y0 * W:drv.y1 * W].view(torch.int32)))
+    assert (drv.y0, drv.y1) == (ref_py.y0, ref_py.y1)
+    pad = torch.zeros((ref_py.max_rows * W, 3), dtype=torch.float32, device="cuda"); pad[:mine.shape[0]] = mine
+    out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, out, dst=0)
+    flags = [None] * world
+    dist.all_gather_object(flags, same_as_python)
+    if rank == 0:
+        got = torch.cat([out[r][:(b[1] - b[0]) * W] for r, b in enumerate(ref_py.bounds)]).cpu().numpy()
+        same = np.array_equal(got.view(np.uint32), full.b.image.cpu().numpy().view(np.uint32))
+        print("world %d, C-ABI strip driver, %s launches: strips == full frame: %s, == tiling.py on every rank: %s" %
+              (world, "overlapped" if overlapped else "synchronous", same, all(flags)), flush=True)
+        ok = ok and same and all(flags)
+    drv.destroy(); comm.destroy()
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
