@@ -926,6 +926,116 @@ def test_full_size_properties(hip):
     assert (ids >= -2).all() and (ids < len(sd.materials)).all()
 
 
+def test_config3_full_size_orbit_of_64_frames(hip):
+    """BASELINE config 3, second half: the 64-frame camera orbit (runCuda animateCamera, reprojection through devMotion every
+    frame) at 1920x1080 on the full Sponza-class scene.  Frames enqueued without a host synchronisation (they overlap on the
+    auxiliary streams) equal the synchronous run bit for bit -- images along the way, the final reservoirs and G-buffer -- and
+    the temporal history is really in use (M grows beyond the 32 candidates of a single frame)."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:1.0")
+    W, H, frames = 1920, 1080, 64
+    scene = hip_scene(hip, sd)
+
+    def run(overlapped):
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        keep = []
+        hip.set_sync(not overlapped)
+        try:
+            for frame in range(frames):
+                h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=1.0))
+                h.gbuf.render(h.scene, h.cam)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                h.looper += 1
+                if frame in (0, 17, 40, 63):
+                    keep.append(h.image.clone())
+                h.gbuf.update(h.cam)
+            hip.synchronize(); torch.cuda.synchronize()
+        finally:
+            hip.set_sync(True)
+        resv = h.restir.download(1)
+        return [t.cpu().numpy() for t in keep], resv, h.gbuf.download()
+
+    ia, ra, ga = run(True)
+    ib, rb, gb = run(False)
+    for a, b in zip(ia, ib):
+        assert bits_equal(a, b)
+        assert np.isfinite(a).all() and a.mean() > 1e-3
+    assert ra.tobytes() == rb.tobytes()
+    assert bits_equal(ga["depth"][0], gb["depth"][0]) and bits_equal(ga["depth"][1], gb["depth"][1])
+    assert not bits_equal(ia[0], ia[-1])                               # the camera moved
+    m = ra["numSamples"]
+    assert m.max() == 32 * 20 and (m > 32).mean() > 0.3                # preClampedMerge<20>: history up to 19 x 32 on top of 32
+
+
+def test_config5_bistro_class_with_eaw(hip):
+    """BASELINE config 5 on one GPU: the Bistro-class scene at its stated size (2.83 M triangles, 10 240 emissive ones -- the RIS
+    kernel that reads the light table from global memory), 1920x1080, spatiotemporal ReSTIR-DI with the 5-level EAW filter in the
+    loop (runCuda's order: render, ReSTIRDirect, filter, update).  Full size: two independent runs, one of them with overlapped
+    frames, agree bit for bit (radiance, filtered image, reservoirs); everything finite; ray accounting; the filter changes the
+    image.  Oracle parity with the filter in the loop: the same pipeline on the scene at 5 % size, 240x136, radiance bit-exact
+    and the filtered image within the EAW tolerance (expf)."""
+    import torch
+    sd = get_scene("bistro:1.0")
+    assert 2.7e6 < sd.num_prims < 2.9e6
+    lights = int((sd.materials["type"][sd.material_ids] == 4).sum())
+    assert lights == 10240
+    W, H = 1920, 1080
+    scene = hip_scene(hip, sd)
+
+    def run(overlapped):
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        f = hip.EAWFilter(W, H, 5)
+        out = torch.zeros_like(h.image)
+        res = torch.empty_like(h.image)
+        hip.set_sync(not overlapped)
+        rays = []
+        try:
+            for frame in range(3):
+                h.gbuf.render(h.scene, h.cam)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                h.looper += 1
+                p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+                hip.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+                h.gbuf.update(h.cam)
+                if not overlapped:
+                    rays.append(h.restir.ray_count())
+            hip.synchronize(); torch.cuda.synchronize()
+        finally:
+            hip.set_sync(True)
+        f.destroy()
+        return h.image.cpu().numpy(), res.cpu().numpy(), h.restir.download(1), rays
+
+    ia, fa, ra, _ = run(True)
+    ib, fb, rb, rays = run(False)
+    assert bits_equal(ia, ib) and bits_equal(fa, fb) and ra.tobytes() == rb.tobytes()
+    assert np.isfinite(ia).all() and np.isfinite(fa).all() and ia.mean() > 1e-3
+    assert np.abs(fa - ia).max() > 1e-3                                 # the filter did something
+    assert all(W * H <= r <= 2 * W * H for r in rays)                   # a shading ray per pixel + a shadow ray per shaded pixel
+    del scene
+
+    # the same loop against the oracle, on a scene and a frame the oracle finishes in seconds
+    sd = get_scene("bistro:0.05")
+    w, h_ = 240, 136
+    o = OracleRenderer(sd, w, h_)
+    g = HipRenderer(hip, sd, w, h_)
+    f = hip.EAWFilter(w, h_, 5)
+    out = torch.zeros_like(g.image)
+    for frame in range(3):
+        o.gbuf.render(o.scene, o.cam); g.gbuf.render(g.scene, g.cam)
+        o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, frame, 3)
+        g.restir.direct(g.scene, g.cam, g.gbuf, g.image.data_ptr(), 0, frame, 3)
+        ref = ob.eaw_filter(o.gbuf, o.cam, o.image)
+        p = f.filter(out.data_ptr(), g.image.data_ptr(), g.gbuf, g.cam)
+        hip.synchronize()
+        res = torch.empty_like(g.image)
+        hip.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+        assert bits_equal(o.image, g.image.cpu().numpy()), frame
+        assert np.allclose(ref, res.cpu().numpy(), rtol=1e-5, atol=1e-6), frame
+        o.gbuf.update(o.cam); g.gbuf.update(g.cam)
+    f.destroy()
+
+
 def test_headless_viewer_drop_in(hip, tmp_path):
     """The reference's main()/runCuda() call sequence compiled against restir_compat.h
     (restir_amd/host/headless_viewer.cpp) produces the same RGBA8 frame as the oracle."""
