@@ -134,7 +134,18 @@ typedef struct rs_gbuffer_view {
 
 /* ---- library ------------------------------------------------------------------------- */
 const char* rs_last_error(void);
-/* Selects the HIP device for this process (hipSetDevice). */
+/* Contexts.  The reference keeps its state in globals (State::scene, Settings::*, one device, the default stream); here that
+ * state -- device, stream, synchronous / asynchronous launches, the internal streams of the asynchronous mode -- is a context.
+ * Every object (scene, G-buffer, reservoirs, filters, strip driver) belongs to the context that was current in its host thread
+ * when it was created, and calls on it run under that context whatever thread makes them, so several host threads, devices or
+ * launch modes can use the library side by side.  A caller that never creates one uses the default context (the reference's
+ * single-threaded viewer does); rs_init and the rs_set_* calls below configure the CURRENT context of the calling thread.
+ * Objects handed to one call (scene + G-buffer + reservoirs) must belong to one context. */
+typedef struct rs_context rs_context;
+int  rs_context_create(int device, rs_context** ctx);
+int  rs_context_destroy(rs_context* ctx);           /* after the objects created under it */
+int  rs_context_set_current(rs_context* ctx);       /* for the calling thread; NULL = back to the default context */
+/* Selects the HIP device of the default context (hipSetDevice). */
 int  rs_init(int device);
 /* All work is enqueued on this hipStream_t (NULL = default stream). */
 int  rs_set_stream(void* hipStream);

@@ -108,7 +108,7 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_synchronize",
+    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
@@ -145,6 +145,9 @@ def lib():
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.rs_last_error.restype = C.c_char_p
     L.rs_init.argtypes = [ci]
+    L.rs_context_create.argtypes = [ci, C.POINTER(vp)]
+    L.rs_context_destroy.argtypes = [vp]
+    L.rs_context_set_current.argtypes = [vp]
     L.rs_set_stream.argtypes = [vp]
     L.rs_set_sync.argtypes = [ci]
     L.rs_set_side_stream.argtypes = [ci]
@@ -245,6 +248,26 @@ def _p(a):
 
 def init(device=0):
     check(lib().rs_init(device))
+
+
+class Context:
+    """rs_context: device, stream, launch mode and internal streams of the objects created while it is current (per thread)."""
+
+    def __init__(self, device=0):
+        self.handle = C.c_void_p()
+        check(lib().rs_context_create(device, C.byref(self.handle)))
+
+    def make_current(self):
+        check(lib().rs_context_set_current(self.handle))
+
+    @staticmethod
+    def use_default():
+        check(lib().rs_context_set_current(None))
+
+    def destroy(self):
+        if self.handle:
+            lib().rs_context_destroy(self.handle)
+            self.handle = C.c_void_p()
 
 
 def set_sync(sync):

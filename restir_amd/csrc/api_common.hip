@@ -9,18 +9,20 @@
 namespace {
 std::mutex g_errMutex;
 std::string g_lastError;
-hipStream_t g_stream = nullptr;
-bool g_sync = true;
-// Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 + k the primary-ray + RIS + shadow-ray kernels of every
-// kChains-th frame (frames take the chains in turn, so that these chains of consecutive frames overlap each other
-// as well as the passes of the frames before).
-// Neither reads what the temporal / spatial passes of the previous frame write, so with the per-frame surface planes
-// double-buffered and the G-buffer planes in a ring of three they run next to those passes; the objects own the events
-// that order them (rs_gbuffer, rs_restir).
-hipStream_t g_aux[1 + rs_restir::kChains] = {};
-int g_auxMode = -1;                                     // -1: not decided yet; 0 off; 1 on
-int g_fuseMode = -1;                                    // deferred G-buffer render walked with the primary rays: -1 from the environment
+rs_context g_default;                                   // what rs_init / rs_set_* configure for threads that never create a context
+thread_local rs_context* t_current = nullptr;           // rs_context_set_current
+thread_local rs_context* t_scoped = nullptr;            // the object's context while an entry point runs
+thread_local int t_device = -1;                         // the device this thread last selected
 }  // namespace
+
+rs_context* rs_ctx() { return t_scoped ? t_scoped : (t_current ? t_current : &g_default); }
+
+rs_ctx_scope::rs_ctx_scope(rs_context* c) : prev(t_scoped) {
+    if (c) t_scoped = c;
+    const int dev = rs_ctx()->device;
+    if (t_device != dev && hipSetDevice(dev) == hipSuccess) t_device = dev;
+}
+rs_ctx_scope::~rs_ctx_scope() { t_scoped = prev; }
 
 int rs_fail(int code, const char* msg) {
     std::lock_guard<std::mutex> lock(g_errMutex);
@@ -34,42 +36,49 @@ int rs_check_hip(hipError_t e, const char* what) {
     return rs_fail((int)e, m.c_str());
 }
 
-hipStream_t rs_stream() { return g_stream; }
-bool rs_sync_enabled() { return g_sync; }
+hipStream_t rs_stream() { return rs_ctx()->stream; }
+bool rs_sync_enabled() { return rs_ctx()->sync; }
 
-// The auxiliary stream i, or nullptr when launches are synchronous (rs_set_sync(1): nothing to overlap) or the feature is
-// off (rs_set_side_stream(0) / RS_SIDE_STREAM=0).
+// Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 + k the primary-ray + RIS + shadow-ray kernels of every
+// kChains-th frame (frames take the chains in turn, so that these chains of consecutive frames overlap each other
+// as well as the passes of the frames before).
+// Neither reads what the temporal / spatial passes of the previous frame write, so with the per-frame surface planes
+// in three sets and the G-buffer planes in a ring of three they run next to those passes; the objects own the events
+// that order them (rs_gbuffer, rs_restir).
+// The auxiliary stream i of the current context, or nullptr when launches are synchronous (rs_set_sync(1): nothing to overlap)
+// or the feature is off (rs_set_side_stream(0) / RS_SIDE_STREAM=0).
 hipStream_t rs_aux_stream(int i) {
-    if (g_auxMode < 0) {
+    rs_context* c = rs_ctx();
+    if (c->auxMode < 0) {
         const char* e = std::getenv("RS_SIDE_STREAM");
-        g_auxMode = (e && e[0] == '0') ? 0 : 1;
+        c->auxMode = (e && e[0] == '0') ? 0 : 1;
     }
-    if (g_sync || !g_auxMode) return nullptr;
-    if (!g_aux[i] && hipStreamCreateWithFlags(&g_aux[i], hipStreamNonBlocking) != hipSuccess) { g_aux[i] = nullptr; g_auxMode = 0; return nullptr; }
-    return g_aux[i];
+    if (c->sync || !c->auxMode || i < 0 || i >= rs_context::kAux) return nullptr;
+    if (!c->aux[i] && hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess) { c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
+    return c->aux[i];
 }
 // In asynchronous mode GBuffer::render can be deferred and launched by ReSTIRDirect together with its primary rays (the two rays
-// of a pixel in one packet walk).  That saves 10 % of the walk work, 4 % of a Sponza-class 1080p frame, but the slowest tile of
-// the launch takes almost twice as long, which costs 28 % on the Bistro-class scene whose closest-hit kernels are tails of a
-// few long tiles: by default every rs_restir measures the frame period both ways once and keeps the
-// faster (restir.hip).  RS_FUSE_GBUFFER=0 / 1 force it off / on.
+// of a pixel in one packet walk).  That saves walk work on a full frame, but the slowest tile of the launch takes longer, which
+// costs on scenes whose closest-hit kernels are tails of a few long tiles: by default every rs_restir measures the
+// frame period both ways once and keeps the faster (restir.hip).  RS_FUSE_GBUFFER=0 / 1 force it off / on.
 // 0 never, 1 always (launches of at least three rounds of wave slots), 2 always (any size), 3 decided per rs_restir by measuring
 int rs_fuse_mode() {
-    if (g_fuseMode < 0) {
+    rs_context* c = rs_ctx();
+    if (c->fuseMode < 0) {
         const char* e = std::getenv("RS_FUSE_GBUFFER");
-        g_fuseMode = !e ? 3 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : 3;
+        c->fuseMode = !e ? 3 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : 3;
     }
-    return g_fuseMode;
+    return c->fuseMode;
 }
 bool rs_fuse_enabled() { return rs_fuse_mode() != 0; }
 int rs_aux_synchronize() {
-    for (hipStream_t st : g_aux) if (st) RS_HIP(hipStreamSynchronize(st));
+    for (hipStream_t st : rs_ctx()->aux) if (st) RS_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
 int rs_after_launch(const char* what) {
     RS_TRY(rs_check_hip(hipGetLastError(), what));
-    if (g_sync) RS_TRY(rs_check_hip(hipStreamSynchronize(g_stream), what));
+    if (rs_ctx()->sync) RS_TRY(rs_check_hip(hipStreamSynchronize(rs_ctx()->stream), what));
     return 0;
 }
 
@@ -109,23 +118,57 @@ int rs_init(int device) {
     if (n <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_init: no HIP device visible (the MI355X path has no CPU fallback)");
     if (device < 0 || device >= n) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_init: device index out of range");
     RS_HIP(hipSetDevice(device));
+    t_device = device;
+    g_default.device = device;
+    return 0;
+}
+
+int rs_context_create(int device, rs_context** out) {
+    if (!out) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_context_create: null output");
+    *out = nullptr;
+    int n = 0;
+    RS_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_context_create: device index out of range");
+    rs_context* c = new rs_context();
+    c->device = device;
+    *out = c;
+    return 0;
+}
+int rs_context_destroy(rs_context* c) {
+    if (!c || c == &g_default) return 0;
+    {
+        rs_ctx_scope scope(c);
+        (void)rs_synchronize();
+        for (hipStream_t& st : c->aux) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+        if (c->ptRayCount) { (void)hipFree(c->ptRayCount); c->ptRayCount = nullptr; }
+    }
+    if (t_current == c) t_current = nullptr;
+    delete c;
+    return 0;
+}
+int rs_context_set_current(rs_context* c) {
+    t_current = c;
+    rs_ctx_scope scope(nullptr);                        // selects the context's device for this thread
     return 0;
 }
 
 int rs_set_stream(void* hipStream) {
-    if ((hipStream_t)hipStream != g_stream) RS_TRY(rs_synchronize());   // events recorded on the old stream order the auxiliary ones
-    g_stream = (hipStream_t)hipStream;
+    rs_context* c = rs_ctx();
+    if ((hipStream_t)hipStream != c->stream) RS_TRY(rs_synchronize());   // events recorded on the old stream order the auxiliary ones
+    c->stream = (hipStream_t)hipStream;
     return 0;
 }
-int rs_set_sync(int sync) { g_sync = sync != 0; return 0; }
+int rs_set_sync(int sync) { rs_ctx()->sync = sync != 0; return 0; }
 int rs_set_side_stream(int enable) {
-    g_auxMode = enable ? 1 : 0;                         // work already enqueued on the auxiliary streams is still joined by its consumers
-    g_fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : enable == 4 ? 3 : 0;      // 2 always, 3 always and at any size (tests), 4 measured
+    rs_context* c = rs_ctx();
+    c->auxMode = enable ? 1 : 0;                        // work already enqueued on the auxiliary streams is still joined by its consumers
+    c->fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : enable == 4 ? 3 : 0;      // 2 always, 3 always and at any size (tests), 4 measured
     return 0;
 }
 int rs_synchronize(void) {
+    rs_ctx_scope scope(nullptr);
     RS_TRY(rs_aux_synchronize());
-    RS_TRY(rs_check_hip(hipStreamSynchronize(g_stream), "rs_synchronize"));
+    RS_TRY(rs_check_hip(hipStreamSynchronize(rs_ctx()->stream), "rs_synchronize"));
     return rs_aux_synchronize();                        // (an auxiliary launch may have been waiting for the library stream)
 }
 

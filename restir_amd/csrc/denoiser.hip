@@ -253,6 +253,7 @@ int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer
 extern "C" {
 
 int rs_eaw_destroy(rs_eaw* f) {
+    RS_SCOPE(f);
     if (!f) return 0;
     rs_dev_free(f->devTempImg); rs_dev_free(f->devPos);
     delete f;
@@ -263,6 +264,8 @@ int rs_eaw_create(int width, int height, int level, rs_eaw** out) {
     if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_create: bad size");
     *out = nullptr;
     rs_eaw* f = new rs_eaw();
+    f->ctx = rs_ctx();
+    rs_ctx_scope scope(f->ctx);
     f->width = width; f->height = height; f->level = level;
     int e = rs_dev_alloc(&f->devTempImg, (size_t)width * height * 3);
     if (!e) e = rs_dev_alloc(&f->devPos, (size_t)width * height * 3);
@@ -272,11 +275,13 @@ int rs_eaw_create(int width, int height, int level, rs_eaw** out) {
 }
 
 int rs_eaw_set_params(rs_eaw* f, float sigLumin, float sigNormal, float sigDepth, int level) {
+    RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_set_params: null filter");
     f->sigLumin = sigLumin; f->sigNormal = sigNormal; f->sigDepth = sigDepth; f->level = level;
     return 0;
 }
 int rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level) {
+    RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_get_params: null filter");
     if (sigLumin) *sigLumin = f->sigLumin;
     if (sigNormal) *sigNormal = f->sigNormal;
@@ -286,6 +291,7 @@ int rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float*
 }
 
 int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
+    RS_SCOPE(f);
     RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
@@ -308,6 +314,7 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
 // its input, the G-buffer ids / normals and the positions up to 2 << level rows outside the strip, so between the levels the
 // caller exchanges those rows of the colour buffer with the neighbouring strips (restir_amd/tiling.py).
 int rs_eaw_positions_rows(rs_eaw* f, const rs_gbuffer* g, const rs_camera* cam, int y0, int y1) {
+    RS_SCOPE(f);
     RS_TRY(rs_gbuffer_join(g));
     if (!f || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW positions: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
@@ -322,6 +329,7 @@ int rs_eaw_positions_rows(rs_eaw* f, const rs_gbuffer* g, const rs_camera* cam, 
 }
 
 int rs_eaw_level_rows(rs_eaw* f, float* devColorOut, const float* devColorIn, const rs_gbuffer* g, int level, int y0, int y1) {
+    RS_SCOPE(f);
     RS_TRY(rs_gbuffer_join(g));
     if (!f || !devColorOut || !devColorIn || !g || level < 0 || level > 30) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW level: bad argument");
     if (g->width != f->width || g->height != f->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
@@ -334,6 +342,7 @@ int rs_eaw_level_rows(rs_eaw* f, float* devColorOut, const float* devColorIn, co
 
 // ---- SpatioTemporalFilter (src/denoiser.cu:479-568) -----------------------------------------------------------
 int rs_svgf_destroy(rs_svgf* f) {
+    RS_SCOPE(f);
     if (!f) return 0;
     for (int i = 0; i < 2; i++) { rs_dev_free(f->devAccumColor[i]); rs_dev_free(f->devAccumMoment[i]); }
     rs_dev_free(f->devVariance); rs_dev_free(f->devTempVariance); rs_dev_free(f->devFilteredVariance);
@@ -343,11 +352,13 @@ int rs_svgf_destroy(rs_svgf* f) {
 }
 
 int rs_svgf_set_params(rs_svgf* f, float sigLumin, float sigNormal, float sigDepth, int level) {
+    RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_set_params: null filter");
     f->sigLumin = sigLumin; f->sigNormal = sigNormal; f->sigDepth = sigDepth; f->level = level;
     return 0;
 }
 int rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level) {
+    RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_get_params: null filter");
     if (sigLumin) *sigLumin = f->sigLumin;
     if (sigNormal) *sigNormal = f->sigNormal;
@@ -360,6 +371,8 @@ int rs_svgf_create(int width, int height, int level, rs_svgf** out) {
     if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_create: bad size");
     *out = nullptr;
     rs_svgf* f = new rs_svgf();
+    f->ctx = rs_ctx();
+    rs_ctx_scope scope(f->ctx);
     f->width = width; f->height = height; f->level = level;
     const size_t n = (size_t)width * height;
     int e = 0;
@@ -378,12 +391,14 @@ int rs_svgf_create(int width, int height, int level, rs_svgf** out) {
 }
 
 int rs_svgf_next_frame(rs_svgf* f) {                          // SpatioTemporalFilter::nextFrame (:566-568)
+    RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_next_frame: null filter");
     f->frameIdx ^= 1;
     return 0;
 }
 
 int rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* v) {
+    RS_SCOPE(f);
     if (!f || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_get_view: null argument");
     for (int i = 0; i < 2; i++) { v->devAccumColor[i] = f->devAccumColor[i]; v->devAccumMoment[i] = f->devAccumMoment[i]; }
     v->devVariance = f->devVariance; v->frameIdx = f->frameIdx; v->width = f->width; v->height = f->height;
@@ -394,6 +409,7 @@ int rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* v) {
 // it is swapped with devAccumColor[frameIdx], so the caller's buffer becomes the filter's history and the caller
 // continues with one of the filter's buffers; as in the reference the caller must keep using the pointer it gets back.
 int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
+    RS_SCOPE(f);
     RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
@@ -435,6 +451,7 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
 }
 
 int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {
+    RS_SCOPE(g);
     RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!devImage || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "modulateAlbedo: null argument");
     const int n = g->width * g->height;
@@ -443,6 +460,7 @@ int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {
 }
 
 int rs_add_image(float* devImage, const float* devIn, int width, int height) {
+    rs_ctx_scope scope(nullptr);
     if (!devImage || !devIn || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "addImage: bad argument");
     const int n = width * height * 3;
     hipLaunchKernelGGL(k_add, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devImage, devImage, devIn, n);
@@ -450,6 +468,7 @@ int rs_add_image(float* devImage, const float* devIn, int width, int height) {
 }
 
 int rs_add_image3(float* devOut, const float* devIn1, const float* devIn2, int width, int height) {
+    rs_ctx_scope scope(nullptr);
     if (!devOut || !devIn1 || !devIn2 || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "addImage: bad argument");
     const int n = width * height * 3;
     hipLaunchKernelGGL(k_add, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devOut, devIn1, devIn2, n);

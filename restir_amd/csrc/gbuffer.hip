@@ -117,6 +117,7 @@ int rs_gbuffer_join(const rs_gbuffer* g) {
 extern "C" {
 
 int rs_gbuffer_destroy(rs_gbuffer* g) {
+    RS_SCOPE(g);
     if (!g) return 0;
     g->deferred.valid = false;                          // a render nobody asked the result of
     deferred_unregister(g);
@@ -135,6 +136,8 @@ int rs_gbuffer_create(int width, int height, rs_gbuffer** out) {
     if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_create: bad size");
     *out = nullptr;
     rs_gbuffer* g = new rs_gbuffer();
+    g->ctx = rs_ctx();
+    rs_ctx_scope scope(g->ctx);
     g->width = width; g->height = height;
     const size_t n = (size_t)width * height;
     int e = 0;
@@ -164,6 +167,7 @@ int rs_gbuffer_create(int width, int height, rs_gbuffer** out) {
 }
 
 int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, int y0, int y1) {
+    RS_SCOPE(g);
     if (!g || !scene || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_render: null argument");
     if (cam->resolution[0] != g->width || cam->resolution[1] != g->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_render: camera resolution differs from the G-buffer size");
@@ -190,10 +194,12 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
 }
 
 int rs_gbuffer_render(rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam) {
+    RS_SCOPE(g);
     return rs_gbuffer_render_rows(g, scene, cam, 0, g ? g->height : 0);
 }
 
 int rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam) {
+    RS_SCOPE(g);
     if (!g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_update: null argument");
     RS_TRY(rs_gbuffer_join(g));                         // a render nobody consumed (possibly still deferred) belongs to the frame that ends here
     g->lastCamera = *cam;
@@ -214,9 +220,10 @@ int rs_gbuffer_update(rs_gbuffer* g, const rs_camera* cam) {
 
 // rows of the id / normal / depth planes, packed [id rows][normal rows][depth rows] (20 B / px);
 // sel 0 = the planes of the current frameIdx, 1 = the "last" planes (what findTemporalNeighbor reads)
-size_t rs_gbuffer_rows_bytes(const rs_gbuffer* g, int rows) { return g ? (size_t)g->width * (size_t)(rows > 0 ? rows : 0) * 20u : 0; }
+size_t rs_gbuffer_rows_bytes(const rs_gbuffer* g, int rows) { RS_SCOPE(g); return g ? (size_t)g->width * (size_t)(rows > 0 ? rows : 0) * 20u : 0; }
 
 int rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* devBuffer) {
+    RS_SCOPE(g);
     if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_pack: bad argument");
     RS_TRY(rs_gbuffer_join(g));
     const int f = sel ? g->prev() : g->cur();
@@ -229,6 +236,7 @@ int rs_gbuffer_rows_pack(const rs_gbuffer* g, int sel, int y0, int rows, void* d
 }
 
 int rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void* devBuffer) {
+    RS_SCOPE(g);
     if (!g || !devBuffer || (sel != 0 && sel != 1) || y0 < 0 || rows < 0 || y0 + rows > g->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_rows_unpack: bad argument");
     RS_TRY(rs_gbuffer_join(g));
     const int f = sel ? g->prev() : g->cur();
@@ -241,6 +249,7 @@ int rs_gbuffer_rows_unpack(rs_gbuffer* g, int sel, int y0, int rows, const void*
 }
 
 int rs_gbuffer_get_view(const rs_gbuffer* g, rs_gbuffer_view* v) {
+    RS_SCOPE(g);
     if (!g || !v) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_gbuffer_get_view: null argument");
     RS_TRY(rs_gbuffer_join(g));                         // the caller is about to use the planes on the library stream
     const int c = g->cur(), l = g->prev(), f = g->frameIdx;

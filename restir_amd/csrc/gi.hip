@@ -302,6 +302,7 @@ extern "C" {
 
 int rs_path_trace(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, float* devIndirectIllum,
                   int iter, int looper, int maxDepth, unsigned long long* rays) {
+    RS_SCOPE(scene);
     if (!scene || !cam || !devDirectIllum || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTrace: null argument");
     RS_TRY(gi_counters());
     GBufView none{};
@@ -312,6 +313,7 @@ int rs_path_trace(const rs_scene* scene, const rs_camera* cam, float* devDirectI
 
 int rs_path_trace_indirect(const rs_scene* scene, const rs_camera* cam, float* devIndirectIllum, int iter, int looper, int maxDepth,
                            unsigned long long* rays) {
+    RS_SCOPE(scene);
     if (!scene || !cam || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceIndirect: null argument");
     RS_TRY(gi_counters());
     GBufView none{};
@@ -322,6 +324,7 @@ int rs_path_trace_indirect(const rs_scene* scene, const rs_camera* cam, float* d
 
 int rs_restir_indirect(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, float* devIndirectIllum,
                        int iter, int looper, int reuse, int maxDepth, unsigned long long* rays) {
+    RS_SCOPE(r);
     RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!r || !scene || !cam || !g || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRIndirect: null argument");
     if (cam->resolution[0] != r->width || cam->resolution[1] != r->height || g->width != r->width || g->height != r->height)
@@ -342,6 +345,7 @@ int rs_restir_indirect(rs_restir* r, const rs_scene* scene, const rs_camera* cam
 }
 
 int rs_restir_download_indirect(rs_restir* r, int which, rs_indirect_reservoir* host) {
+    RS_SCOPE(r);
     if (!r || !host || which < 0 || which > 1 || !r->indResv[which]) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_download_indirect: bad argument");
     RS_HIP(hipStreamSynchronize(rs_stream()));
     RS_HIP(hipMemcpy(host, r->indResv[which], (size_t)r->width * r->height * sizeof(rs_indirect_reservoir), hipMemcpyDeviceToHost));

@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(256) k_send_debug_to_pbo(uchar4* __restrict__ 
                          (unsigned char)iclamp(f2i(c.z * 255.f), 0, 255), 0);
 }
 
-unsigned long long* g_ptRayCount = nullptr;
 
 int copy_debug(void* devPBO, const void* devImage, int width, int height, int kind) {
+    rs_ctx_scope scope(nullptr);                         // no object: the thread's current context
     if (!devPBO || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "copyImageToPBO: bad argument");
     const int n = width * height;
     hipLaunchKernelGGL(k_send_debug_to_pbo, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, width, height, kind);
@@ -135,32 +135,35 @@ int copy_debug(void* devPBO, const void* devImage, int width, int height, int ki
 extern "C" {
 
 int rs_path_trace_init(void) {
-    if (!g_ptRayCount) RS_TRY(rs_dev_alloc(&g_ptRayCount, 1));
+    rs_ctx_scope scope(nullptr);
+    if (!rs_ctx()->ptRayCount) RS_TRY(rs_dev_alloc(&rs_ctx()->ptRayCount, 1));
     return 0;
 }
-int rs_path_trace_free(void) { rs_dev_free(g_ptRayCount); return 0; }
+int rs_path_trace_free(void) { rs_ctx_scope scope(nullptr); rs_dev_free(rs_ctx()->ptRayCount); return 0; }
 
 int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, int iter, int looper, unsigned long long* rays) {
+    RS_SCOPE(scene);
     if (!scene || !cam || !devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceDirect: null argument");
     RS_TRY(rs_path_trace_init());
-    RS_HIP(hipMemsetAsync(g_ptRayCount, 0, 8, rs_stream()));
+    RS_HIP(hipMemsetAsync(rs_ctx()->ptRayCount, 0, 8, rs_stream()));
     const int W = cam->resolution[0], H = cam->resolution[1];
     const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
     if (scene->textured)
         hipLaunchKernelGGL(k_pt_direct<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
-                           devDirectIllum, looper, iter, tilesX, g_ptRayCount);
+                           devDirectIllum, looper, iter, tilesX, rs_ctx()->ptRayCount);
     else
         hipLaunchKernelGGL(k_pt_direct<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
-                           devDirectIllum, looper, iter, tilesX, g_ptRayCount);
+                           devDirectIllum, looper, iter, tilesX, rs_ctx()->ptRayCount);
     RS_TRY(rs_after_launch("pathTrace"));
     if (rays) {
         RS_HIP(hipStreamSynchronize(rs_stream()));
-        RS_HIP(hipMemcpy(rays, g_ptRayCount, 8, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(rays, rs_ctx()->ptRayCount, 8, hipMemcpyDeviceToHost));
     }
     return 0;
 }
 
 int rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int height, int toneMapping, float scale) {
+    rs_ctx_scope scope(nullptr);                         // no object: the thread's current context
     if (!devPBO || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "copyImageToPBO: bad argument");
     const int n = width * height;
     if (std::getenv("RS_EXACT_GAMMA"))      // test switch: every pixel through the double-precision power

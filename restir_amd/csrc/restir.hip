@@ -570,6 +570,7 @@ SurfPlanes surf_of(rs_restir* r) {                       // the set of the frame
 
 int check_frame_args(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g) {
     if (!r || !scene || !cam || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: null argument");
+    if (scene->ctx != r->ctx || g->ctx != r->ctx) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: the scene, the G-buffer and the reservoirs belong to different contexts");
     if (cam->resolution[0] != r->width || cam->resolution[1] != r->height || g->width != r->width || g->height != r->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: camera / G-buffer size differs from the size given to rs_restir_init");
     return 0;
@@ -582,6 +583,7 @@ void mark(rs_restir* r, int i) { if (r->timing) (void)hipEventRecord(r->ev[i], r
 extern "C" {
 
 int rs_restir_free(rs_restir* r) {
+    RS_SCOPE(r);
     if (!r) return 0;
     (void)rs_synchronize();                                     // also kernels still running on the auxiliary stream
     free_planes(r->cur); free_planes(r->last);
@@ -604,6 +606,8 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     if (!out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_init: bad size");
     *out = nullptr;
     rs_restir* r = new rs_restir();
+    r->ctx = rs_ctx();
+    rs_ctx_scope scope(r->ctx);
     r->width = width; r->height = height;
     const size_t n = (size_t)width * height;
     int e = 0;
@@ -640,12 +644,14 @@ int rs_restir_init(int width, int height, rs_restir** out) {
 }
 
 int rs_restir_reset(rs_restir* r) {
+    RS_SCOPE(r);
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_reset: null");
     r->firstFrame = true;
     return 0;
 }
 
 int rs_restir_enable_timing(rs_restir* r, int enable) {
+    RS_SCOPE(r);
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_enable_timing: null");
     r->timing = enable != 0;
     return 0;
@@ -763,23 +769,27 @@ extern "C" {
 
 int rs_restir_phase_a(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                       int looper, int reuse, int y0, int y1) {
+    RS_SCOPE(r);
     return phase_a_impl(r, scene, cam, g, looper, reuse, y0, y1, true);
 }
 
 int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                       float* devDirectIllum, int iter, int reuse, int y0, int y1) {
+    RS_SCOPE(r);
     return phase_b_impl(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1, true);
 }
 
 // 0 two launches, 1 one fused launch, -1 still measuring, -2 nothing to choose (no frame so far had a launch the choice applies to:
 // synchronous launches, launches below three rounds of wave slots, a forced mode)
 int rs_restir_launch_choice(const rs_restir* r, int* choice) {
+    RS_SCOPE(r);
     if (!r || !choice) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_launch_choice: null argument");
     *choice = r->tuneChoice >= 0 ? r->tuneChoice : (r->tuneFrame > 0 || r->tuneCounted) ? -1 : -2;
     return 0;
 }
 
 int rs_restir_end_frame(rs_restir* r) {
+    RS_SCOPE(r);
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_end_frame: null");
     ResvPlanes t = r->cur; r->cur = r->last; r->last = t;       // std::swap(devDirectReservoir, devLastDirectReservoir)
     r->firstFrame = false;
@@ -810,6 +820,7 @@ int rs_restir_end_frame(rs_restir* r) {
 
 int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                      float* devDirectIllum, int iter, int looper, int reuse) {
+    RS_SCOPE(r);
     RS_TRY(check_frame_args(r, scene, cam, g));
     // one synchronisation for the whole call (synchronous mode); the library's mode itself is not touched, so the two phases
     // stay on the library stream in synchronous mode and use the auxiliary streams in asynchronous mode only
@@ -820,9 +831,11 @@ int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, 
 }
 
 size_t rs_restir_halo_bytes(const rs_restir* r, int rows) {
+    RS_SCOPE(r);
     return r ? (size_t)r->width * (size_t)(rows > 0 ? rows : 0) * 48u : 0;      // li 16 + wi 16 + tap 16
 }
 size_t rs_restir_rows_bytes(const rs_restir* r, int which, int rows) {
+    RS_SCOPE(r);
     if (!r || rows < 0) return 0;
     return (size_t)r->width * (size_t)rows * (which == 2 ? 48u : 40u);         // cur/last: li 16 + wi 16 + w 4 + m 4
 }
@@ -859,15 +872,18 @@ int copy_rows(rs_restir* r, int which, int y0, int rows, char* buf, bool pack, c
 // packed layout of `rows` rows: the planes of the buffer one after the other (cur/last: li, wi, w, m;
 // temp: li, wi, tap)
 int rs_restir_rows_pack(const rs_restir* r, int which, int y0, int rows, void* devBuffer) {
+    RS_SCOPE(r);
     return copy_rows(const_cast<rs_restir*>(r), which, y0, rows, (char*)devBuffer, true, "rs_restir_rows_pack: bad argument");
 }
 int rs_restir_rows_unpack(rs_restir* r, int which, int y0, int rows, const void* devBuffer) {
+    RS_SCOPE(r);
     return copy_rows(r, which, y0, rows, (char*)const_cast<void*>(devBuffer), false, "rs_restir_rows_unpack: bad argument");
 }
-int rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer) { return rs_restir_rows_pack(r, 2, y0, rows, devBuffer); }
-int rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer) { return rs_restir_rows_unpack(r, 2, y0, rows, devBuffer); }
+int rs_restir_halo_pack(const rs_restir* r, int y0, int rows, void* devBuffer) { RS_SCOPE(r); return rs_restir_rows_pack(r, 2, y0, rows, devBuffer); }
+int rs_restir_halo_unpack(rs_restir* r, int y0, int rows, const void* devBuffer) { RS_SCOPE(r); return rs_restir_rows_unpack(r, 2, y0, rows, devBuffer); }
 
 int rs_restir_download(const rs_restir* rc, int which, rs_reservoir* host) {
+    RS_SCOPE(rc);
     rs_restir* r = const_cast<rs_restir*>(rc);
     if (!r || !host || which < 0 || which > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_download: bad argument");
     const size_t n = (size_t)r->width * r->height;
@@ -898,6 +914,7 @@ int rs_restir_download(const rs_restir* rc, int which, rs_reservoir* host) {
 }
 
 int rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host) {
+    RS_SCOPE(r);
     if (!r || !host || which < 0 || which > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_upload: bad argument");
     const size_t n = (size_t)r->width * r->height;
     std::vector<float4> li(n), wi(n);
@@ -928,6 +945,7 @@ int rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host) {
 
 // test hook: largest error of the hardware-trig tap estimate against a double evaluation (see disk_tap)
 int rs_debug_tap_estimate_error(int n, float* maxErr) {
+    rs_ctx_scope scope(nullptr);
     if (n <= 0 || !maxErr) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_tap_estimate_error: bad argument");
     float* d = nullptr;
     RS_TRY(rs_dev_alloc(&d, 1));
@@ -940,6 +958,7 @@ int rs_debug_tap_estimate_error(int n, float* maxErr) {
 }
 
 int rs_restir_ray_count(rs_restir* r, unsigned long long* rays) {
+    RS_SCOPE(r);
     if (!r || !rays) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_count: null");
     RS_HIP(hipStreamSynchronize(rs_stream()));
     unsigned long long h[kRaySub * kRayStride];
@@ -950,6 +969,7 @@ int rs_restir_ray_count(rs_restir* r, unsigned long long* rays) {
 }
 
 int rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays) {
+    RS_SCOPE(r);
     if (!r || !rays || frames < 0 || frames > kRaySlots) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_total: frames must be in [0, 1024]");
     RS_HIP(hipStreamSynchronize(rs_stream()));
     const size_t per = (size_t)kRaySub * kRayStride;
@@ -965,6 +985,7 @@ int rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays) {
 }
 
 int rs_restir_pass_times(rs_restir* r, float ms[4]) {
+    RS_SCOPE(r);
     if (!r || !ms) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_pass_times: null");
     if (!r->timing) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_pass_times: timing is not enabled");
     RS_HIP(hipEventSynchronize(r->ev[4]));

@@ -8,6 +8,31 @@
 
 #include "rs_scene.h"
 
+// ---- contexts ----------------------------------------------------------------------------------
+// What used to be process-wide settings: the device, the stream the library enqueues on, synchronous / asynchronous
+// launches, the auxiliary streams of the asynchronous mode and how GBuffer::render is launched.  Every object
+// (scene, G-buffer, reservoirs, filters, strip driver) belongs to the context that was current in its thread when it
+// was created, and every entry point that takes an object runs under that object's context (rs_ctx_scope), so two
+// contexts -- two host threads, two devices, two streams, a synchronous and an asynchronous caller -- do not see each
+// other's settings.  A thread that never asks for one uses the default context (what rs_init / rs_set_* configure).
+struct rs_context {
+    static constexpr int kAux = 3;        // 0: GBuffer::render, 1 + k: the primary -> RIS -> shadow chain of every second frame (rs_restir::kChains)
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool sync = true;
+    hipStream_t aux[kAux] = {};
+    int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
+    int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
+    unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
+};
+rs_context* rs_ctx();                                   // the context this thread's library code runs under right now
+struct rs_ctx_scope {                                   // entry points: run under the context of the object they were handed
+    rs_context* prev;
+    explicit rs_ctx_scope(rs_context* c);               // null: keep the thread's current context
+    ~rs_ctx_scope();
+};
+#define RS_SCOPE(obj) rs_ctx_scope rs_scope_guard_((obj) ? (obj)->ctx : nullptr)
+
 // ---- error plumbing --------------------------------------------------------------------------
 int rs_fail(int code, const char* msg);                 // records msg, returns code
 int rs_check_hip(hipError_t e, const char* what);       // 0 on success
@@ -40,6 +65,7 @@ static inline void rs_dev_free(T*& p) {
 
 // ---- scene -------------------------------------------------------------------------------------
 struct rs_scene {
+    rs_context* ctx = nullptr;
     rs::DevScene dev{};              // passed to kernels by value (pointers into the arrays below)
     // owned device arrays
     rs::BvhNode* dNodesAll = nullptr;
@@ -80,6 +106,7 @@ struct rs_scene {
 // frame's render (auxiliary stream) never writes what this frame's temporal pass still reads.  frameIdx is still toggled
 // and reported by rs_gbuffer_get_view, whose devNormal[frameIdx] / [frameIdx ^ 1] are the current / last sets.
 struct rs_gbuffer {
+    rs_context* ctx = nullptr;
     static constexpr int kSets = 3;
     float* albedo[kSets] = { nullptr, nullptr, nullptr };
     int* motion[kSets] = { nullptr, nullptr, nullptr };
@@ -207,6 +234,7 @@ struct TempPlanes {
 };
 
 struct rs_restir {
+    rs_context* ctx = nullptr;
     // The chain primary rays -> RIS -> shadow rays of a frame depends on no other frame.  Frames put theirs on kChains auxiliary
     // streams in turn, so that consecutive frames' chains overlap: on a 1/8 strip a chain lasts 0.4 ms however few rows it has.
     // A chain writes one of kSurfSets sets of surface planes, which the frame's temporal / spatial passes read afterwards; with as
@@ -249,7 +277,10 @@ struct rs_restir {
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
+static_assert(rs_context::kAux == 1 + rs_restir::kChains, "one auxiliary stream for GBuffer::render and one per chain");
+
 struct rs_eaw {
+    rs_context* ctx = nullptr;
     int width = 0, height = 0, level = 0;
     float sigLumin = 64.f, sigNormal = .2f, sigDepth = 1.f;     // src/denoiser.cu:455
     float* devTempImg = nullptr;
@@ -258,6 +289,7 @@ struct rs_eaw {
 
 // SpatioTemporalFilter (src/denoiser.h:45-70); EAWaveletFilter(width, height, 4, 128, 1) (src/denoiser.cu:488)
 struct rs_svgf {
+    rs_context* ctx = nullptr;
     int width = 0, height = 0, level = 0;
     float sigLumin = 4.f, sigNormal = 128.f, sigDepth = 1.f;
     float* devAccumColor[2] = { nullptr, nullptr };

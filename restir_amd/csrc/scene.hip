@@ -115,6 +115,7 @@ int build_occlusion_side(rs_scene* s) {
 }  // namespace
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
+    RS_SCOPE(s);
     if (!s) return 0;
     (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
     (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
@@ -150,6 +151,8 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     const size_t np = (size_t)d->numPrims, nn = (size_t)d->bvhSize, nl = (size_t)(d->numLights > 0 ? d->numLights : 0);
     const size_t nlp = nl - (hasEnv ? 1 : 0);          // light primitives; the environment map is the last sampler entry
     rs_scene* s = new rs_scene();
+    s->ctx = rs_ctx();
+    rs_ctx_scope scope(s->ctx);                       // (selects the context's device for the uploads below)
     { static std::atomic<unsigned long long> counter{0}; s->id = ++counter; }
     s->numPrims = d->numPrims; s->bvhSize = d->bvhSize; s->numLights = (int)nl;
     s->sumLightPower = d->sumLightPower;
@@ -347,6 +350,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
 #ifdef RS_WALK_STATS
 // measurement builds only (tools/walk_stats.py): wave-level counters of walk_occlusion_tree
 extern "C" int rs_debug_walk_stats(rs_scene* s, unsigned long long* out64, int reset) {
+    RS_SCOPE(s);
     RS_HIP(hipDeviceSynchronize());
     RS_HIP(hipMemcpy(out64, s->dWalkStats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) RS_HIP(hipMemset(s->dWalkStats, 0, 64 * sizeof(unsigned long long)));
@@ -416,6 +420,7 @@ extern "C" int rs_scene_build_textured(int numPrims, const float* vertices, cons
 }
 
 extern "C" int rs_scene_host_desc(const rs_scene* s, rs_scene_desc* d) {
+    RS_SCOPE(s);
     if (!s || !d) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_host_desc: null argument");
     std::memset(d, 0, sizeof *d);
     d->numPrims = s->numPrims; d->vertices = s->hVertices.data(); d->normals = s->hNormals.data();
@@ -455,6 +460,7 @@ __global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, cons
 }
 
 extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {
+    RS_SCOPE(s);
     if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_closest: bad argument");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_trace_closest, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devRays, devPrimId, devMatId, devPos, devNorm);
@@ -462,6 +468,7 @@ extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, 
 }
 
 extern "C" int rs_trace_occlusion(const rs_scene* s, int n, const float* devSegments, int* devOccluded) {
+    RS_SCOPE(s);
     if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_occlusion: bad argument");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_trace_occlusion, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devSegments, devOccluded);

@@ -32,6 +32,7 @@ struct rs_comm {
 };
 
 struct rs_strips {
+    rs_context* ctx = nullptr;
     rs_comm* comm = nullptr;
     int width = 0, height = 0;
     std::vector<int> bounds;                       // world + 1 row offsets
@@ -126,6 +127,7 @@ int rs_comm_self_exchange(rs_comm* c, const void* devSend, void* devRecv, size_t
 }
 
 int rs_strips_destroy(rs_strips* s) {
+    RS_SCOPE(s);
     if (!s) return 0;
     (void)rs_synchronize();
     if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
@@ -140,6 +142,8 @@ int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs
     if (!comm || !out || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_create: bad argument");
     *out = nullptr;
     rs_strips* s = new rs_strips();
+    s->ctx = rs_ctx();
+    rs_ctx_scope scope(s->ctx);
     s->comm = comm; s->width = width; s->height = height;
     s->bounds.resize((size_t)comm->world + 1);
     for (int r = 0; r <= comm->world; r++) {
@@ -168,6 +172,7 @@ int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs
 }
 
 int rs_strips_rows(const rs_strips* s, int* y0, int* y1) {
+    RS_SCOPE(s);
     if (!s || !y0 || !y1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_rows: null argument");
     *y0 = s->y0; *y1 = s->y1;
     return 0;
@@ -177,6 +182,7 @@ int rs_strips_rows(const rs_strips* s, int* y0, int* y1) {
 // the caller's, as in the reference.  Radiance rows [y0, y1) of devDirectIllum are valid afterwards.
 int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_camera* cam, rs_gbuffer* g,
                     float* devDirectIllum, int iter, int looper, int reuse) {
+    RS_SCOPE(s);
     if (!s || !r || !scene || !cam || !g || !devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_frame: null argument");
     if (g->width != s->width || g->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_frame: G-buffer size differs from the strips' frame");
     const int y0 = s->y0, y1 = s->y1;

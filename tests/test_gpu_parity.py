@@ -852,7 +852,8 @@ def test_multi_process_strips_on_one_gpu():
     """The real multi-process path (one process per rank, StripRenderer + HipBackend + torch.distributed point-to-point
     and all-gather) with two ranks sharing this GPU and gloo standing in for RCCL: tools/rehearse_strips.py compares
     the gathered strips with a full-frame render, static and orbiting camera, synchronous launches and overlapped frames,
-    radiance and the EAW-filtered image (BASELINE config 5's denoiser on strips)."""
+    radiance and the EAW-filtered image (BASELINE config 5's denoiser on strips); then the same strips through the C-ABI strip
+    driver (include/restir_hip.h rs_strips_frame), the form a C++ caller runs over RCCL."""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -860,7 +861,64 @@ def test_multi_process_strips_on_one_gpu():
                         "--master-port", str(port), os.path.join(root, "tools", "rehearse_strips.py")],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("strips == full frame: True") == 6, r.stdout[-2000:]
+    assert r.stdout.count("strips == full frame: True") == 8, r.stdout[-2000:]
+    # ... of which two lines are the C-ABI strip driver (rs_comm / rs_strips with gloo under its transport callbacks), also
+    # compared with tiling.py's strips on every rank
+    assert r.stdout.count("C-ABI strip driver") == 2 and r.stdout.count("== tiling.py on every rank: True") == 2, r.stdout[-2000:]
+
+
+def test_two_contexts_in_two_threads(hip):
+    """Device, stream, launch mode and the internal streams are per context, not per process: two host threads, each with its own
+    context -- one synchronous like the reference, one with overlapped frames -- render the same orbit at the same time with their
+    own objects, and both get the frames of a single-threaded run on the default context."""
+    import threading
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.05")
+    W, H, frames = 320, 180, 10
+
+    def orbit(h):
+        out = []
+        for frame in range(frames):
+            h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.4))
+            h.gbuf.render(h.scene, h.cam)
+            h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, frame, 3)
+            h.gbuf.update(h.cam)
+            if frame % 3 == 0:
+                out.append(h.image.clone())
+        hip.synchronize(); torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in out]
+
+    ref = orbit(HipRenderer(hip, sd, W, H))
+    results, errors = {}, []
+
+    def worker(name, overlapped):
+        try:
+            torch.cuda.set_device(0)
+            ctx = hip.Context(0)
+            ctx.make_current()
+            hip.set_sync(not overlapped)
+            h = HipRenderer(hip, sd, W, H)             # scene, G-buffer, reservoirs of this context
+            results[name] = orbit(h)
+            del h
+            hip.Context.use_default()
+            ctx.destroy()
+        except Exception as e:                          # pragma: no cover
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=("synchronous", False)), threading.Thread(target=worker, args=("overlapped", True))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for name in ("synchronous", "overlapped"):
+        for a, b in zip(ref, results[name]):
+            assert bits_equal(a, b), name
+    # the default context kept its own mode: synchronous launches
+    h = HipRenderer(hip, sd, 96, 64)
+    h.frame(3)
+    assert h.restir.launch_choice() == -2
 
 
 def test_strip_driver_binds_to_rccl():
