@@ -42,15 +42,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per launch from the PMC passes of tools/profile.sh on this same command (FETCH_SIZE x 2 + WRITE_SIZE,
 # the gfx950 correction of MI355X_MICROARCH.md), condensed by tools/summarize_profile.py; counters cannot be read
 # from inside the process, so `roofline.traffic` quotes the committed summary (null if it is absent).
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_hbm_counters.json")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_final_hbm_counters.json")
 
 
 def pmc_traffic(kernel):
+    """(bytes per launch, the kernel's average duration in that profile): the duration lets a reader see whether the committed
+    summary still describes the kernel that ran here."""
     try:
         with open(PMC_SUMMARY) as fh:
-            return float(json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"])
+            k = json.load(fh)["kernels"][kernel]
+            return float(k["hbm_bytes_per_launch"]), (float(k["average_ns"]) / 1e3 if k.get("average_ns") else None)
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def host_threads():
@@ -335,7 +338,9 @@ def main():
                                   "5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0") if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade") if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade")[0] if world == 1 else None,
+                         "traffic_source": "profiles/" + os.path.basename(PMC_SUMMARY) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                           "the kernel lasted %s us there)" % pmc_traffic("k_spatial_shade")[1],
                          "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us,
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
