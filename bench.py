@@ -10,8 +10,8 @@ A step = one frame.  A ray = one BVH walk (intersect or testOcclusion call): 1 G
 shading ray per pixel + 1 shadow ray per shaded pixel; counted by the kernels.
 
 N > 1: the 1920x1080 framebuffer is cut into N row strips (strong scaling: the total work is fixed).
-Every rank renders its strip (+5 G-buffer halo rows), exchanges 5 rows of published reservoirs with
-its strip neighbours over RCCL point-to-point between phase A and phase B (restir_amd/tiling.py),
+Every rank renders its strip, exchanges 5 border rows of published reservoirs and of the G-buffer id / normal / depth planes
+with its strip neighbours over RCCL point-to-point between phase A and phase B (restir_amd/tiling.py),
 tone-maps its strip, and the RGBA8 strips are gathered on rank 0 (asynchronously: the gather of one frame overlaps
 the next frame's kernels; the last gathers are waited for before the clock stops) -- all inside the timed region.
 
@@ -335,7 +335,7 @@ def main():
                                    "together with the primary rays when the library measures that to be faster (it measures in untimed frames before the warm-up); "
                                    "ms_per_frame_synchronous is one frame alone with a synchronisation after every call, the reference's mode",
                        "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in strips.bounds) + " rows (cost-balanced by measurement), "
-                                  "5-row reservoir halo over RCCL p2p, RGBA8 gather to rank 0") if world > 1 else "none",
+                                  "5 border rows of reservoirs + G-buffer id / normal / depth over RCCL p2p (68 B/px), RGBA8 gather to rank 0") if world > 1 else "none",
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade")[0] if world == 1 else None,

@@ -198,6 +198,9 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
                 delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: malformed MTBVH node (links must point forward)");
             }
         }
+    // the reference tree's parent / leaf tables (shadow-ray verification, proper-hierarchy check): derived, and thereby
+    // validated as a tree, before anything is uploaded -- a malformed caller-supplied table is refused on the host
+    if (int e = rs_reference_chain_tables(s->bvhSize, s->hNodes[0].data(), s->hParent, s->hLeafOf, s->numPrims)) { delete s; return e; }
     for (size_t i = 0; i < nl; i++)
         if ((i < nlp && (s->hLightPrimIds[i] < 0 || s->hLightPrimIds[i] >= d->numPrims)) || s->hLightFailId[i] < 0 || s->hLightFailId[i] >= (int)nl) {
             delete s; return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_create: light table index out of range");
@@ -301,7 +304,6 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     // Is the box table a proper hierarchy (finite, min <= max, every box inside its parent's, every leaf box
     // around its triangle)?  Tables from rs_build_bvh are; the two shortcuts that rely on it (skip_far_on_axis and
     // the leaf shortcut of the shadow tree) are switched off for any other caller-supplied table.
-    if (int e = rs_reference_chain_tables(s->bvhSize, s->hNodes[0].data(), s->hParent, s->hLeafOf, s->numPrims)) { rs_scene_destroy(s); return e; }
     {
         bool proper = true;
         for (size_t i = 0; i < nn * 6 && proper; i++) proper = std::isfinite(s->hBoxes[i]);

@@ -867,6 +867,28 @@ def test_multi_process_strips_on_one_gpu():
     assert r.stdout.count("C-ABI strip driver") == 2 and r.stdout.count("== tiling.py on every rank: True") == 2, r.stdout[-2000:]
 
 
+def test_scene_without_extent_renders_without_the_shadow_tree(hip):
+    """A scene whose vertices all coincide has no extent to lay the shadow tree's 16-bit grid over.  The reference renders it
+    (its walk needs no grid: every ray misses the degenerate triangles), so scene creation must succeed with the fast path off
+    (it used to fail with 'degenerate scene bounds') and frames must equal the oracle's."""
+    from restir_amd.scenes import SceneData, TriangleSoup, make_materials, LAMBERTIAN, LIGHT
+    soup = TriangleSoup()
+    p = np.array([0.25, 0.5, -2.0], np.float32)
+    for k in range(4):
+        soup.add(np.array([[p, p, p]]), np.array([[[0, 0, 1]] * 3], np.float32), 0 if k < 3 else 1)
+    sd = SceneData("one_point", soup, make_materials([dict(type=LAMBERTIAN, baseColor=(0.7, 0.7, 0.7)), dict(type=LIGHT, baseColor=(5.0, 5.0, 5.0))]),
+                   dict(position=(0.0, 0.5, 1.0), rotation=(-90.0, 0.0, 0.0), fov_y=30.0, focal_dist=1.0))
+    W, H = 64, 48
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(2):
+        a, b = o.frame(3), h.frame(3)
+        assert bits_equal(a, b) and o.rays == h.rays
+    seg = np.array([[0, 0, 0, 1, 1, 1], [0.25, 0.5, 0.0, 0.25, 0.5, -4.0]], np.float32)
+    import torch
+    assert np.array_equal(hip.trace_occlusion(h.scene, torch.from_numpy(seg).cuda()).cpu().numpy(), o.scene.test_occlusion(seg))
+
+
 def test_two_contexts_in_two_threads(hip):
     """Device, stream, launch mode and the internal streams are per context, not per process: two host threads, each with its own
     context -- one synchronous like the reference, one with overlapped frames -- render the same orbit at the same time with their

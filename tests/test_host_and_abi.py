@@ -160,6 +160,34 @@ def test_argument_errors_are_reported_not_crashed():
         capi.Scene.from_tables(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials, t)
 
 
+def test_malformed_mtbvh_tables_are_refused_on_the_host():
+    """rs_scene_create takes caller-built tables (DevScene::create from the viewer's own BVHBuilder).  Links must point forward
+    and the threaded order must be a tree over distinct boxes: anything else is refused before any device work -- an inner
+    node at the last index used to read one record past the table."""
+    from oracle import binding as ob
+    sd = get_scene("cornell")
+    boxes, nodes = ob.bvh_build(sd.vertices)
+    lp, lr, power = ob.light_table(sd.vertices, sd.material_ids, sd.materials)
+    prob, fail, total = ob.alias_build(power)
+    def tables(n):
+        return dict(boxes=boxes, nodes=n, light_prim_ids=lp, light_radiance=lr, light_prob=prob, light_fail=fail, sum_power=total)
+    def create(n):
+        return capi.Scene.from_tables(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials, tables(n))
+    size = nodes.shape[1]
+    bad = nodes.copy(); bad[0, size - 1, 0] = -1                       # the last record claims to be an inner node
+    with pytest.raises(capi.RestirHipError, match="inner node without children|malformed"):
+        create(bad)
+    bad = nodes.copy(); bad[0, 1, 1] = bad[0, 2, 1]                    # two nodes share a bounding box id
+    with pytest.raises(capi.RestirHipError, match="boundingBoxId"):
+        create(bad)
+    bad = nodes.copy(); bad[0, 1, 2] = 2                               # a subtree that ends before its first child does
+    with pytest.raises(capi.RestirHipError):
+        create(bad)
+    bad = nodes.copy(); bad[3, 5, 2] = 3                               # a backward link in another order
+    with pytest.raises(capi.RestirHipError, match="forward"):
+        create(bad)
+
+
 def test_procedural_scene_budgets():
     sd = scenes.sponza_class(1, 1.0)
     assert sd.num_prims == 262144
