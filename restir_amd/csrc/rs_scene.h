@@ -81,6 +81,11 @@ struct DevScene {
     int numMaterials;
 };
 
+typedef float vf2 __attribute__((ext_vector_type(2)));     // operands of the packed FP32 instructions (v_pk_add / mul / fma_f32)
+#ifndef RS_OCC_PERM
+#define RS_OCC_PERM 1
+#endif
+
 struct Ray { f3 o, d; };
 
 struct Hit {
@@ -528,6 +533,15 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     unsigned cur = active ? 0u : endOff;
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
     bool occluded = false;
+#if RS_OCC_PERM
+    // Which of the two grid planes of an axis is the near one depends on the sign of A only (fma is monotone in q): a byte
+    // permute with a per-ray selector puts {near plane, far plane} of an axis into one dword, and the six min / max of the slab
+    // test are gone.  Node dwords: x = lo.x | lo.y << 16, y = lo.z | hi.x << 16, z = hi.y | hi.z << 16.
+    const unsigned selX = A.x < 0.f ? 0x01000706u : 0x07060100u;      // v_perm_b32(n.y, n.x): bytes 0-3 = n.x, 4-7 = n.y
+    const unsigned selY = A.y < 0.f ? 0x03020504u : 0x05040302u;      // v_perm_b32(n.z, n.x)
+    const unsigned selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;      // v_perm_b32(n.z, n.y)
+    const vf2 Axy = { A.x, A.y }, Bxy = { B.x, B.y }, Azz = { A.z, A.z }, Bzz = { B.z, B.z };
+#endif
 #ifdef RS_WALK_STATS
     unsigned long long st[10] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #define RS_STAT(i, v) st[i] += (v)
@@ -543,16 +557,26 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #ifdef RS_WALK_STATS
                 if (s.walkStats && s.occDepth) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
 #endif
+#if RS_OCC_PERM
+                const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
+                const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
+                const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
+                const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
+                const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
+                const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
+                const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
+#else
                 const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
                 const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
                 const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
                 const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
                 const bool pass = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
+#endif
                 const int meta = (int)n.w;
                 const bool leaf = meta < 0;
-                const bool push = pass & leaf;
-                q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn += push ? 1 : 0;
-                cur = (pass | leaf) ? cur + 16u : (unsigned)meta;
+                const bool push = pass && leaf;
+                q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn = push ? qn + 1 : qn;
+                cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
             }
             if (__any(qn == kLeafQueue)) break;
         }
@@ -705,7 +729,6 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 //     at c go to c + 1 (entered) or link(c).  The minimum of all pending targets is therefore c + 1 if any lane entered and
 //     link(c) otherwise: one ballot instead of a 64-lane DPP minimum.  For the same reason a lane's own target after a node
 //     nobody entered is max(myNext, link(c)) -- one instruction, no mask.
-typedef float vf2 __attribute__((ext_vector_type(2)));
 // Slab distances of one record held in SGPRs {min.x, min.y, min.z, max.z | max.x, max.y, prim, next}: three packed subtractions
 // and three packed multiplications, each the reference's (p - ori) * dirInv on two components
 struct SlabT { vf2 xy1, xy2, z12; };      // (t1.x, t1.y), (t2.x, t2.y), (t1.z, t2.z)
