@@ -44,4 +44,5 @@ pw = out[16]
 print("closest-hit packet walks (G-buffer + primary), per wave: union nodes mean %.1f max %d, orders %.2f, waves on the special-case path %.4f" %
       (out[17] / pw, out[18], out[19] / pw, out[20] / pw))
 print("  of the union nodes: some lane passes the distance part %.1f, some lane enters %.1f, of which leaves %.1f (fast form only)" % (out[21] / pw, out[22] / pw, out[23] / pw))
+print("  nodes at which every lane that passed the distance part clears the overlap part by 2^-19 * tRoot: %.1f" % (out[15] / pw))
 print("  histogram of union nodes per wave (log2 buckets):", " ".join("%d:%d" % (1 << b, out[24 + b]) for b in range(20) if out[24 + b]))
