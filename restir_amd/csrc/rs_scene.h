@@ -792,22 +792,29 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
         r.steps++;
 #endif
         const int prim = __float_as_int(rb.z);
-        const unsigned nxt = (unsigned)__float_as_int(rb.w);
-        // the record after this one is requested before this one is tested: it is the successor whenever a lane enters
-        const float4 pa = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u), pb = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u + 16u);
+        const unsigned nxt = (unsigned)__float_as_int(rb.w), cNext = c + 1u;
         const SlabT t = slabs(oxy, ozz, dxy, dzz, ra, rb);
         float chord;
         const bool near = slab_distance_part<NEG>(t, myNext == c, r.closest, chord);
-        if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+        const unsigned long long nearMask = __builtin_amdgcn_ballot_w64(near);
+        if (nearMask != 0ull) {
+            // the record after this one is requested as soon as some lane may enter (it is the successor then), before the
+            // overlap part and the triangle test; a node every lane rejects on the distance part does not pay for it
+            const float4 pa = *reinterpret_cast<const float4*>(base + cNext * 32u), pb = *reinterpret_cast<const float4*>(base + cNext * 32u + 16u);
 #ifdef RS_WALK_STATS
             r.nearSteps++;
 #endif
+            // (ballots of plain comparisons, combined on the scalar unit: a ballot of a combined boolean costs two vector instructions)
             bool entered = near;
-            if (__builtin_amdgcn_ballot_w64(near && !(chord > margin)) != 0ull) entered = slab_overlap_part<NEG>(t, near);
+            unsigned long long enteredMask = nearMask;
+            if ((nearMask & __builtin_amdgcn_ballot_w64(!(chord > margin))) != 0ull) {
+                entered = slab_overlap_part<NEG>(t, near);
+                enteredMask = __builtin_amdgcn_ballot_w64(entered);
+            }
 #ifdef RS_WALK_STATS
             else r.clearSteps++;
 #endif
-            if (__builtin_amdgcn_ballot_w64(entered) != 0ull) {
+            if (enteredMask != 0ull) {
 #ifdef RS_WALK_STATS
                 r.enteredSteps++; if (prim != kNullPrim) r.leafSteps++;
 #endif
@@ -818,8 +825,8 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
                     const bool hit = tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist);
                     if (entered && hit && dist < r.closest) { r.closest = dist; r.bx = bx; r.by = by; r.prim = prim; }
                 }
-                myNext = entered ? c + 1u : max(myNext, nxt);
-                c = c + 1u; ra = pa; rb = pb;
+                myNext = entered ? cNext : max(myNext, nxt);
+                c = cNext; ra = pa; rb = pb;
                 continue;
             }
         }
@@ -1014,12 +1021,15 @@ __device__ __forceinline__ void packet_walk_fast2(const DevScene& s, int order, 
         const SlabT sa = slabs(aoxy, aozz, adxy, adzz, ra, rb), sb = slabs(boxy, bozz, bdxy, bdzz, ra, rb);
         float chordA, chordB;
         const bool nearA = slab_distance_part<NEG>(sa, nextA == c, wa.closest, chordA), nearB = slab_distance_part<NEG>(sb, nextB == c, wb.closest, chordB);
-        if (__builtin_amdgcn_ballot_w64(nearA || nearB) != 0ull) {
+        const unsigned long long nearMaskA = __builtin_amdgcn_ballot_w64(nearA), nearMaskB = __builtin_amdgcn_ballot_w64(nearB);
+        if ((nearMaskA | nearMaskB) != 0ull) {
             bool inA = nearA, inB = nearB;
-            if (__builtin_amdgcn_ballot_w64((nearA && !(chordA > marginA)) || (nearB && !(chordB > marginB))) != 0ull) {
+            unsigned long long enteredMask = nearMaskA | nearMaskB;
+            if (((nearMaskA & __builtin_amdgcn_ballot_w64(!(chordA > marginA))) | (nearMaskB & __builtin_amdgcn_ballot_w64(!(chordB > marginB)))) != 0ull) {
                 inA = slab_overlap_part<NEG>(sa, nearA); inB = slab_overlap_part<NEG>(sb, nearB);
+                enteredMask = __builtin_amdgcn_ballot_w64(inA) | __builtin_amdgcn_ballot_w64(inB);
             }
-            if (__builtin_amdgcn_ballot_w64(inA || inB) != 0ull) {
+            if (enteredMask != 0ull) {
                 if (prim != kNullPrim) {
                     const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);
                     const float4 a = tp[0], b = tp[1], e = tp[2];
