@@ -252,7 +252,14 @@ __global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, in
 }
 
 __global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp,
-                                                  int first, int reuse, int n0, int n1) {
+                                                  int first, int reuse, int n0, int n1, unsigned long long* rayWork, unsigned long long* rayDone) {
+    // this call's BVH-walk counters are complete (the launch is ordered after the chain that counted): publish them and leave the
+    // working slot zero for its next user, so that the chain itself needs no clearing launch
+    if (blockIdx.x == 0 && threadIdx.x < kRaySub) {
+        const int k = threadIdx.x * kRayStride;
+        rayDone[k] = rayWork[k];
+        rayWork[k] = 0;
+    }
     const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= n1) return;
     const uint2 rm = sp.rngMat[index];
@@ -644,8 +651,8 @@ int rs_restir_init(int width, int height, rs_restir** out) {
     for (auto& ev : r->tuneEv) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxFork, hipEventDisableTiming), "hipEventCreate");
     if (!e) e = rs_check_hip(hipEventCreateWithFlags(&r->auxDone, hipEventDisableTiming), "hipEventCreate");
-    if (!e) e = rs_dev_alloc(&r->dRayCount, (size_t)kRaySlots * kRaySub * kRayStride);
-    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 8 * (size_t)kRaySlots * kRaySub * kRayStride), "memset");
+    if (!e) e = rs_dev_alloc(&r->dRayCount, 2 * (size_t)kRaySlots * kRaySub * kRayStride);     // working slots, then published slots
+    if (!e) e = rs_check_hip(hipMemset(r->dRayCount, 0, 16 * (size_t)kRaySlots * kRaySub * kRayStride), "memset");
     for (auto& ev : r->ev) if (!e) e = rs_check_hip(hipEventCreate(&ev), "hipEventCreate");
     // the clears above are enqueued on the default stream, which the auxiliary streams are not ordered after: finish them
     // before the first primary-ray kernel can be launched there
@@ -678,8 +685,9 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     RS_TRY(check_frame_args(r, scene, cam, g));
     if (y0 < 0) y0 = 0;
     if (y1 > r->height) y1 = r->height;
-    r->raySlot = (r->raySlot + 1) % kRaySlots;                  // one counter slot per frame (ring)
+    r->raySlot = (r->raySlot + 1) % kRaySlots;                  // one counter slot per call (ring): zero here, k_temporal moves it out
     unsigned long long* rayCounter = r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride;
+    unsigned long long* rayDone = rayCounter + (size_t)kRaySlots * kRaySub * kRayStride;
     // The primary-ray and RIS kernels read nothing the previous frame's temporal / spatial passes write and fill this
     // frame's own set of surface planes: in asynchronous mode they go to an auxiliary stream, ordered after the frame
     // that last used the set (or, for a second call within one frame, after everything enqueued so far), and the library
@@ -695,8 +703,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         else if (r->surfFreeValid[r->surfSet]) RS_HIP(hipStreamWaitEvent(aux, r->surfFree[r->surfSet], 0));
     }
     r->phaseACalls++;
-    RS_HIP(hipMemsetAsync(rayCounter, 0, 8 * kRaySub * kRayStride, st));
     if (y1 <= y0) {
+        RS_HIP(hipMemsetAsync(rayDone, 0, 8 * kRaySub * kRayStride, st));
         if (aux) { RS_HIP(hipEventRecord(r->auxDone, aux)); RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0)); }
         return 0;
     }
@@ -755,7 +763,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     }
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     hipLaunchKernelGGL(k_temporal, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), sp, gbuf_view(g),
-                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W);
+                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
     mark(r, 3);
     return last ? rs_after_launch("ReSTIR Direct (phase A)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase A)");
 }
@@ -974,7 +982,7 @@ int rs_restir_ray_count(rs_restir* r, unsigned long long* rays) {
     if (!r || !rays) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_ray_count: null");
     RS_HIP(hipStreamSynchronize(rs_stream()));
     unsigned long long h[kRaySub * kRayStride];
-    RS_HIP(hipMemcpy(h, r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride, sizeof h, hipMemcpyDeviceToHost));
+    RS_HIP(hipMemcpy(h, r->dRayCount + (size_t)(kRaySlots + r->raySlot) * kRaySub * kRayStride, sizeof h, hipMemcpyDeviceToHost));
     *rays = 0;
     for (int i = 0; i < kRaySub; i++) *rays += h[i * kRayStride];
     return 0;
@@ -986,7 +994,7 @@ int rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays) {
     RS_HIP(hipStreamSynchronize(rs_stream()));
     const size_t per = (size_t)kRaySub * kRayStride;
     std::vector<unsigned long long> h((size_t)kRaySlots * per);
-    RS_HIP(hipMemcpy(h.data(), r->dRayCount, 8 * h.size(), hipMemcpyDeviceToHost));
+    RS_HIP(hipMemcpy(h.data(), r->dRayCount + (size_t)kRaySlots * per, 8 * h.size(), hipMemcpyDeviceToHost));
     unsigned long long t = 0;
     for (int i = 0; i < frames; i++) {
         const size_t slot = (size_t)((r->raySlot - i) % kRaySlots + kRaySlots) % kRaySlots;
