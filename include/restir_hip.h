@@ -320,8 +320,10 @@ int  rs_debug_tap_estimate_error(int n, float* maxErr);
  * renders the G-buffer and phase A on its rows, sends its 5 border rows of published reservoirs and of the G-buffer id / normal /
  * depth planes to the strip above and below (68 B/px, the only exchange; taps reach y-4..y+5, src/restir.cu:49-56), runs phase B on
  * its interior rows while they travel and on the two border bands after they have arrived.  Results equal the full-frame
- * rs_restir_direct bit for bit.  (restir_amd/tiling.py drives the same calls from Python; the moving-camera history exchange and
- * the EAW filter on strips exist there only.) */
+ * rs_restir_direct bit for bit.  The EAW filter on the strip (config 5), the history exchange a moving camera needs and the
+ * assembly of the image go through the same transport (rs_strips_eaw_filter / _exchange_history / _gather).  One frame of a rank:
+ *     rs_strips_frame;  [rs_strips_eaw_filter;]  rs_gbuffer_update;  [rs_strips_exchange_history;]  [tone map;  rs_strips_gather]
+ * (restir_amd/tiling.py drives the same calls from Python.) */
 typedef struct rs_comm rs_comm;
 typedef struct rs_strips rs_strips;
 /* The exchange, as two grouped operations on device buffers.  stream_ordered != 0: send / recv enqueue on `hipStream` and the
@@ -350,6 +352,18 @@ int  rs_strips_rows(const rs_strips* strips, int* y0, int* y1);
  * [y0, y1) of devDirectIllum hold the frame's radiance. */
 int  rs_strips_frame(rs_strips* strips, rs_restir* r, const rs_scene* scene, const rs_camera* cam, rs_gbuffer* g,
                      float* devDirectIllum, int iter, int looper, int reuse);
+/* LeveledEAWFilter::filter (src/denoiser.cu:453-477) on the strip's rows of devColor (a full-frame sized image): the 32 G-buffer
+ * rows beyond each edge arrive once, the 2 << level border rows of every level's input before that level.  *devResult is a buffer
+ * of the driver whose rows [y0, y1) equal the full-frame rs_eaw_filter's.  Strips of at least 32 rows; call before
+ * rs_gbuffer_update; the rows of devColor and of the current G-buffer planes just outside the strip are overwritten. */
+int  rs_strips_eaw_filter(rs_strips* strips, rs_eaw* f, rs_gbuffer* g, const rs_camera* cam, float* devColor, float** devResult);
+/* Moving camera (findTemporalNeighbor reads the reprojected pixel of the last frame, src/restir.cu:20-45, which may belong to
+ * another strip): every rank's rows of the reservoirs the next temporal merge reads and of the "last" G-buffer planes travel to
+ * every other rank.  Call after rs_gbuffer_update.  Not needed for a static camera (the reference's default). */
+int  rs_strips_exchange_history(rs_strips* strips, rs_restir* r, rs_gbuffer* g);
+/* Image assembly: rows [y0, y1) of every rank's devImage (full-frame sized, bytesPerPixel bytes per pixel: 12 for the radiance
+ * image, 4 for the display image) arrive in the same rows on rank `root`, or on every rank for root = -1. */
+int  rs_strips_gather(rs_strips* strips, void* devImage, size_t bytesPerPixel, int root);
 
 /* ---- path-trace baseline (src/pathtrace.h:12-16) ---------------------------------------- */
 int  rs_path_trace_init(void);            /* pathTraceInit (src/pathtrace.cu:23-25) */

@@ -119,7 +119,7 @@ EXPORTS = [
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
-    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame",
+    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_exchange_history", "rs_strips_gather",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
 
@@ -221,6 +221,9 @@ def lib():
     L.rs_strips_destroy.argtypes = [vp]
     L.rs_strips_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.rs_strips_frame.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci]
+    L.rs_strips_eaw_filter.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, C.POINTER(vp)]
+    L.rs_strips_exchange_history.argtypes = [vp, vp, vp]
+    L.rs_strips_gather.argtypes = [vp, vp, C.c_size_t, ci]
     L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
     for name in ("rs_eaw_set_params", "rs_svgf_set_params"):
         getattr(L, name).argtypes = [vp, C.c_float, C.c_float, C.c_float, ci]
@@ -724,7 +727,7 @@ class Comm:
 
 
 class Strips:
-    """rs_strips: the row-strip frame of one rank (include/restir_hip.h), the C form of tiling.StripRenderer for a static camera."""
+    """rs_strips: the row-strip frame of one rank (include/restir_hip.h), the C form of tiling.StripRenderer."""
 
     def __init__(self, comm, width, height, bounds=None):
         self.comm = comm
@@ -737,6 +740,19 @@ class Strips:
 
     def frame(self, restir, scene, cam, gbuf, dev_direct_illum_ptr, iter_, looper, reuse):
         check(lib().rs_strips_frame(self.handle, restir.handle, scene.handle, C.byref(cam), gbuf.handle, dev_direct_illum_ptr, iter_, looper, reuse))
+
+    def eaw_filter(self, eaw, gbuf, cam, dev_color_ptr):
+        """LeveledEAWFilter on the strip (before GBuffer.update); returns the device pointer of the driver's result buffer."""
+        p = C.c_void_p()
+        check(lib().rs_strips_eaw_filter(self.handle, eaw.handle, gbuf.handle, C.byref(cam), dev_color_ptr, C.byref(p)))
+        return p.value
+
+    def exchange_history(self, restir, gbuf):
+        """Moving camera: after GBuffer.update, every rank's history rows travel to every other rank."""
+        check(lib().rs_strips_exchange_history(self.handle, restir.handle, gbuf.handle))
+
+    def gather(self, dev_image_ptr, bytes_per_pixel, root=-1):
+        check(lib().rs_strips_gather(self.handle, dev_image_ptr, bytes_per_pixel, root))
 
     def destroy(self):
         if self.handle:

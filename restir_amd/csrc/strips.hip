@@ -12,6 +12,11 @@
 //     travel over xGMI.  librccl is opened at run time (dlopen): a single-GPU caller does not need it.
 //   * caller-supplied callbacks (rs_comm_create): tests drive the same frame code with torch.distributed / gloo underneath.
 // restir_amd/tiling.py is the Python form of the same schedule (test harness, bench.py); tests compare the two.
+//
+// Around the frame, with the same transport: rs_strips_eaw_filter (LeveledEAWFilter on the strip: 32 G-buffer rows once, then the
+// 2 << level border rows of every level's input), rs_strips_exchange_history (moving camera: the rows the next temporal merge may
+// reproject into travel to every rank) and rs_strips_gather (image assembly).  Rows of a row-major image are contiguous, so the
+// colour rows and the assembled image travel from and into place without packing.
 #include <dlfcn.h>
 
 #include <cstring>
@@ -41,6 +46,12 @@ struct rs_strips {
     char* sendUp = nullptr; char* recvUp = nullptr; char* sendDown = nullptr; char* recvDown = nullptr;
     hipStream_t commStream = nullptr;              // carries the transfers
     hipEvent_t packed = nullptr, arrived = nullptr;
+    // rs_strips_eaw_filter: the two full-frame buffers the levels alternate between, staging for the 32 G-buffer rows of an edge
+    float* eawBuf[2] = { nullptr, nullptr };
+    char* eawSend[2] = { nullptr, nullptr }; char* eawRecv[2] = { nullptr, nullptr };
+    // rs_strips_exchange_history: this strip's rows packed, every other strip's rows as they arrive (rank order)
+    char* histSend = nullptr; char* histRecv = nullptr;
+    size_t histSendBytes = 0, histRecvBytes = 0;
 };
 
 namespace {
@@ -62,6 +73,28 @@ int rccl_recv(void* ctx, void* buf, size_t bytes, int peer, void* stream) {
     rs_comm* c = (rs_comm*)ctx;
     const int e = c->pRecv(buf, bytes, /*ncclUint8*/ 1, peer, c->nccl, (hipStream_t)stream);
     return e ? rccl_fail(c, e, "ncclRecv") : 0;
+}
+
+struct Xfer { bool send; void* buf; size_t bytes; int peer; };
+
+// One grouped exchange, ordered after everything enqueued on the library stream so far: on the driver's stream for a stream-ordered
+// transport (RCCL), from the host side of a finished library stream otherwise.  join() makes the library stream continue after it.
+int post(rs_strips* s, const Xfer* ops, size_t n) {
+    const rs_comm* c = s->comm;
+    hipStream_t ts = s->commStream;
+    if (c->t.stream_ordered) { RS_HIP(hipEventRecord(s->packed, rs_stream())); RS_HIP(hipStreamWaitEvent(ts, s->packed, 0)); }
+    else RS_TRY(rs_synchronize());
+    if (c->t.group_begin) RS_TRY(c->t.group_begin(c->t.ctx));
+    for (size_t i = 0; i < n; i++) {
+        if (ops[i].send) RS_TRY(c->t.send(c->t.ctx, ops[i].buf, ops[i].bytes, ops[i].peer, ts));
+        else RS_TRY(c->t.recv(c->t.ctx, ops[i].buf, ops[i].bytes, ops[i].peer, ts));
+    }
+    if (c->t.group_end) RS_TRY(c->t.group_end(c->t.ctx));       // RCCL: the grouped transfers are enqueued here; a host-side transport completes here
+    return 0;
+}
+int join(rs_strips* s) {
+    if (s->comm->t.stream_ordered) { RS_HIP(hipEventRecord(s->arrived, s->commStream)); RS_HIP(hipStreamWaitEvent(rs_stream(), s->arrived, 0)); }
+    return 0;
 }
 
 }  // namespace
@@ -134,6 +167,8 @@ int rs_strips_destroy(rs_strips* s) {
     if (s->packed) (void)hipEventDestroy(s->packed);
     if (s->arrived) (void)hipEventDestroy(s->arrived);
     rs_dev_free(s->sendUp); rs_dev_free(s->recvUp); rs_dev_free(s->sendDown); rs_dev_free(s->recvDown);
+    for (int i = 0; i < 2; i++) { rs_dev_free(s->eawBuf[i]); rs_dev_free(s->eawSend[i]); rs_dev_free(s->eawRecv[i]); }
+    rs_dev_free(s->histSend); rs_dev_free(s->histRecv);
     delete s;
     return 0;
 }
@@ -198,28 +233,129 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
     // pack the border rows (library stream)
     if (up) { RS_TRY(rs_restir_halo_pack(r, y0, kHalo, s->sendUp)); RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, kHalo, s->sendUp + nr)); }
     if (down) { RS_TRY(rs_restir_halo_pack(r, y1 - kHalo, kHalo, s->sendDown)); RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - kHalo, kHalo, s->sendDown + nr)); }
-    // the transfers: on the driver's stream after the packing copies (a transport that is not stream-ordered reads the buffers
-    // from the host side: it gets a finished library stream instead)
-    hipStream_t ts = s->commStream;
-    if (c->t.stream_ordered) { RS_HIP(hipEventRecord(s->packed, rs_stream())); RS_HIP(hipStreamWaitEvent(ts, s->packed, 0)); }
-    else RS_TRY(rs_synchronize());
-    if (c->t.group_begin) RS_TRY(c->t.group_begin(c->t.ctx));
-    if (up) { RS_TRY(c->t.send(c->t.ctx, s->sendUp, s->haloBytes, c->rank - 1, ts)); RS_TRY(c->t.recv(c->t.ctx, s->recvUp, s->haloBytes, c->rank - 1, ts)); }
-    if (down) { RS_TRY(c->t.send(c->t.ctx, s->sendDown, s->haloBytes, c->rank + 1, ts)); RS_TRY(c->t.recv(c->t.ctx, s->recvDown, s->haloBytes, c->rank + 1, ts)); }
-    if (c->t.group_end) RS_TRY(c->t.group_end(c->t.ctx));       // RCCL: the grouped transfers are enqueued here; a host-side transport completes here
+    // the transfers: after the packing copies
+    Xfer ops[4]; size_t n = 0;
+    if (up) { ops[n++] = { true, s->sendUp, s->haloBytes, c->rank - 1 }; ops[n++] = { false, s->recvUp, s->haloBytes, c->rank - 1 }; }
+    if (down) { ops[n++] = { true, s->sendDown, s->haloBytes, c->rank + 1 }; ops[n++] = { false, s->recvDown, s->haloBytes, c->rank + 1 }; }
+    RS_TRY(post(s, ops, n));
     // interior rows (their taps stay inside the strip) while the border rows travel
     const int topEnd = up ? (y0 + kHalo < y1 ? y0 + kHalo : y1) : y0;
     const int botStart = down ? (y1 - kHalo > topEnd ? y1 - kHalo : topEnd) : y1;
     if (botStart > topEnd) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, topEnd, botStart));
-    if (c->t.stream_ordered) {
-        RS_HIP(hipEventRecord(s->arrived, ts));
-        RS_HIP(hipStreamWaitEvent(rs_stream(), s->arrived, 0));
-    }
+    RS_TRY(join(s));
     if (up) { RS_TRY(rs_restir_halo_unpack(r, y0 - kHalo, kHalo, s->recvUp)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - kHalo, kHalo, s->recvUp + nr)); }
     if (down) { RS_TRY(rs_restir_halo_unpack(r, y1, kHalo, s->recvDown)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, kHalo, s->recvDown + nr)); }
     if (topEnd > y0) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, topEnd));
     if (y1 > botStart) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, botStart, y1));
     return rs_restir_end_frame(r);
+}
+
+// LeveledEAWFilter::filter (src/denoiser.cu:453-477) on this strip's rows of devColor.  The taps of level l reach 2 << l rows
+// beyond the strip: the G-buffer rows they compare against (32 at most) come from the neighbouring strips once, and before each
+// level the strips swap the 2 << l border rows of that level's input -- the values a full-frame filter reads there, so rows
+// [y0, y1) of *devResult (a buffer of the driver) equal the full-frame filter's bit for bit.  Call between rs_strips_frame and
+// rs_gbuffer_update.  The rows of devColor and of the current G-buffer planes just outside the strip are overwritten.
+int rs_strips_eaw_filter(rs_strips* s, rs_eaw* f, rs_gbuffer* g, const rs_camera* cam, float* devColor, float** devResult) {
+    RS_SCOPE(s);
+    if (!s || !f || !g || !cam || !devColor || !devResult) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_eaw_filter: null argument");
+    if (g->width != s->width || g->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_eaw_filter: G-buffer size differs from the strips' frame");
+    const rs_comm* c = s->comm;
+    const int W = s->width, y0 = s->y0, y1 = s->y1, kLevels = 5, reach = 2 << (kLevels - 1);
+    const bool up = c->rank > 0, down = c->rank + 1 < c->world;
+    if (c->world > 1)
+        for (int r = 0; r < c->world; r++)
+            if (s->bounds[(size_t)r + 1] - s->bounds[(size_t)r] < reach) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_eaw_filter: strips must be at least 32 rows tall");
+    const size_t image = (size_t)W * s->height * 3 * sizeof(float);
+    for (int i = 0; i < 2; i++)
+        if (!s->eawBuf[i]) { RS_TRY(rs_dev_alloc(&s->eawBuf[i], image / sizeof(float))); RS_HIP(hipMemsetAsync(s->eawBuf[i], 0, image, rs_stream())); }
+    const size_t gBytes = rs_gbuffer_rows_bytes(g, reach);
+    if (up || down) {
+        for (int i = 0; i < 2; i++)
+            if ((i == 0 ? up : down) && !s->eawSend[i]) { RS_TRY(rs_dev_alloc(&s->eawSend[i], gBytes)); RS_TRY(rs_dev_alloc(&s->eawRecv[i], gBytes)); }
+        Xfer ops[4]; size_t n = 0;
+        if (up) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, reach, s->eawSend[0])); ops[n++] = { true, s->eawSend[0], gBytes, c->rank - 1 }; ops[n++] = { false, s->eawRecv[0], gBytes, c->rank - 1 }; }
+        if (down) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - reach, reach, s->eawSend[1])); ops[n++] = { true, s->eawSend[1], gBytes, c->rank + 1 }; ops[n++] = { false, s->eawRecv[1], gBytes, c->rank + 1 }; }
+        RS_TRY(post(s, ops, n));
+        RS_TRY(join(s));
+        if (up) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - reach, reach, s->eawRecv[0]));
+        if (down) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, reach, s->eawRecv[1]));
+    }
+    RS_TRY(rs_eaw_positions_rows(f, g, cam, y0 - reach > 0 ? y0 - reach : 0, y1 + reach < s->height ? y1 + reach : s->height));
+    for (int level = 0; level < kLevels; level++) {
+        float* in = level == 0 ? devColor : s->eawBuf[(level - 1) % 2];
+        float* out = s->eawBuf[level % 2];
+        if (up || down) {
+            const int rows = 2 << level;
+            const size_t bytes = (size_t)rows * W * 3 * sizeof(float);
+            Xfer ops[4]; size_t n = 0;
+            if (up) { ops[n++] = { true, in + (size_t)y0 * W * 3, bytes, c->rank - 1 }; ops[n++] = { false, in + (size_t)(y0 - rows) * W * 3, bytes, c->rank - 1 }; }
+            if (down) { ops[n++] = { true, in + (size_t)(y1 - rows) * W * 3, bytes, c->rank + 1 }; ops[n++] = { false, in + (size_t)y1 * W * 3, bytes, c->rank + 1 }; }
+            RS_TRY(post(s, ops, n));
+            RS_TRY(join(s));
+        }
+        RS_TRY(rs_eaw_level_rows(f, out, in, g, level, y0, y1));
+    }
+    *devResult = s->eawBuf[(kLevels - 1) % 2];
+    return 0;
+}
+
+// Moving camera: the temporal merge of the next frame reads last-frame reservoirs and G-buffer planes at the reprojected pixel
+// (restir.cu:20-45), which may lie in another strip.  Every rank sends the rows it produced -- the reservoirs the next merge reads
+// (which = 1 after rs_restir_end_frame) and the "last" G-buffer planes (after rs_gbuffer_update) -- to every other rank.  Call
+// after rs_gbuffer_update.  A static camera reprojects into its own pixel and does not need this.
+int rs_strips_exchange_history(rs_strips* s, rs_restir* r, rs_gbuffer* g) {
+    RS_SCOPE(s);
+    if (!s || !r || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_exchange_history: null argument");
+    if (g->width != s->width || g->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_exchange_history: G-buffer size differs from the strips' frame");
+    const rs_comm* c = s->comm;
+    if (c->world == 1) return 0;
+    auto resvBytes = [&](int rank) { return rs_restir_rows_bytes(r, 1, s->bounds[(size_t)rank + 1] - s->bounds[(size_t)rank]); };
+    auto bytesOf = [&](int rank) { return resvBytes(rank) + rs_gbuffer_rows_bytes(g, s->bounds[(size_t)rank + 1] - s->bounds[(size_t)rank]); };
+    size_t others = 0;
+    for (int k = 0; k < c->world; k++) if (k != c->rank) others += bytesOf(k);
+    const size_t mine = bytesOf(c->rank);
+    if (s->histSendBytes < mine) { rs_dev_free(s->histSend); s->histSend = nullptr; RS_TRY(rs_dev_alloc(&s->histSend, mine)); s->histSendBytes = mine; }
+    if (s->histRecvBytes < others) { rs_dev_free(s->histRecv); s->histRecv = nullptr; RS_TRY(rs_dev_alloc(&s->histRecv, others)); s->histRecvBytes = others; }
+    RS_TRY(rs_restir_rows_pack(r, 1, s->y0, s->y1 - s->y0, s->histSend));
+    RS_TRY(rs_gbuffer_rows_pack(g, 1, s->y0, s->y1 - s->y0, s->histSend + resvBytes(c->rank)));
+    std::vector<Xfer> ops;
+    size_t off = 0;
+    for (int k = 0; k < c->world; k++) {
+        if (k == c->rank) continue;
+        ops.push_back({ true, s->histSend, mine, k });
+        ops.push_back({ false, s->histRecv + off, bytesOf(k), k });
+        off += bytesOf(k);
+    }
+    RS_TRY(post(s, ops.data(), ops.size()));
+    RS_TRY(join(s));
+    off = 0;
+    for (int k = 0; k < c->world; k++) {
+        if (k == c->rank) continue;
+        const int a = s->bounds[(size_t)k], rows = s->bounds[(size_t)k + 1] - a;
+        RS_TRY(rs_restir_rows_unpack(r, 1, a, rows, s->histRecv + off));
+        RS_TRY(rs_gbuffer_rows_unpack(g, 1, a, rows, s->histRecv + off + resvBytes(k)));
+        off += bytesOf(k);
+    }
+    return 0;
+}
+
+// Image assembly: rows [y0, y1) of every rank's devImage (bytesPerPixel bytes per pixel, row-major, full-frame sized: the radiance
+// image at 12, the display image at 4) travel into the same rows of devImage on `root`, or on every rank for root = -1.
+int rs_strips_gather(rs_strips* s, void* devImage, size_t bytesPerPixel, int root) {
+    RS_SCOPE(s);
+    const rs_comm* c = s ? s->comm : nullptr;
+    if (!s || !devImage || bytesPerPixel == 0 || root < -1 || root >= c->world) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_gather: bad argument");
+    if (c->world == 1) return 0;
+    const size_t row = (size_t)s->width * bytesPerPixel;
+    char* base = (char*)devImage;
+    std::vector<Xfer> ops;
+    for (int k = 0; k < c->world; k++) {
+        if (k == c->rank) continue;
+        if (root < 0 || root == k) ops.push_back({ true, base + (size_t)s->y0 * row, (size_t)(s->y1 - s->y0) * row, k });
+        if (root < 0 || root == c->rank) ops.push_back({ false, base + (size_t)s->bounds[(size_t)k] * row, (size_t)(s->bounds[(size_t)k + 1] - s->bounds[(size_t)k]) * row, k });
+    }
+    RS_TRY(post(s, ops.data(), ops.size()));
+    return join(s);
 }
 
 }  // extern "C"

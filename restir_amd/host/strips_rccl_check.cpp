@@ -67,7 +67,24 @@ int main() {
     }
     for (int frame = 0; frame < 3; frame++) {
         CHECK(rs_strips_frame(strips, r[0], scene, &cam, g[0], img[0], 0, frame, 3));
+        if (frame == 2) {                                         // LeveledEAWFilter through the strip driver and directly
+            rs_eaw* f[2]; float* out[2] = { nullptr, nullptr };
+            CHECK(rs_eaw_create(W, H, 5, &f[0])); CHECK(rs_eaw_create(W, H, 5, &f[1]));
+            if (hipMalloc((void**)&out[1], sizeof(float) * 3 * W * H) != hipSuccess) return 1;
+            CHECK(rs_strips_eaw_filter(strips, f[0], g[0], &cam, img[0], &out[0]));
+            CHECK(rs_eaw_filter(f[1], &out[1], img[0], g[0], &cam));
+            CHECK(rs_synchronize());
+            std::vector<float> u(3 * W * H), v(3 * W * H);
+            (void)hipMemcpy(u.data(), out[0], sizeof(float) * u.size(), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(v.data(), out[1], sizeof(float) * v.size(), hipMemcpyDeviceToHost);
+            if (std::memcmp(u.data(), v.data(), sizeof(float) * u.size()) != 0) { std::fprintf(stderr, "rs_strips_eaw_filter differs from rs_eaw_filter\n"); return 1; }
+            std::printf("rs_strips_eaw_filter (world 1) == rs_eaw_filter\n");
+            rs_eaw_destroy(f[0]); rs_eaw_destroy(f[1]);
+            (void)hipFree(out[1]);                                // whichever buffer the reference-style pointer swap left with the caller
+        }
         CHECK(rs_gbuffer_update(g[0], &cam));
+        CHECK(rs_strips_exchange_history(strips, r[0], g[0]));    // a world of one rank has nobody to tell
+        CHECK(rs_strips_gather(strips, img[0], 12, -1));
         CHECK(rs_gbuffer_render(g[1], scene, &cam));
         CHECK(rs_restir_direct(r[1], scene, &cam, g[1], img[1], 0, frame, 3));
         CHECK(rs_gbuffer_update(g[1], &cam));

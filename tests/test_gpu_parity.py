@@ -853,7 +853,7 @@ def test_multi_process_strips_on_one_gpu():
     and all-gather) with two ranks sharing this GPU and gloo standing in for RCCL: tools/rehearse_strips.py compares
     the gathered strips with a full-frame render, static and orbiting camera, synchronous launches and overlapped frames,
     radiance and the EAW-filtered image (BASELINE config 5's denoiser on strips); then the same strips through the C-ABI strip
-    driver (include/restir_hip.h rs_strips_frame), the form a C++ caller runs over RCCL."""
+    driver (include/restir_hip.h rs_strips_frame / _eaw_filter / _exchange_history / _gather), the form a C++ caller runs over RCCL."""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -861,10 +861,10 @@ def test_multi_process_strips_on_one_gpu():
                         "--master-port", str(port), os.path.join(root, "tools", "rehearse_strips.py")],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("strips == full frame: True") == 8, r.stdout[-2000:]
-    # ... of which two lines are the C-ABI strip driver (rs_comm / rs_strips with gloo under its transport callbacks), also
-    # compared with tiling.py's strips on every rank
-    assert r.stdout.count("C-ABI strip driver") == 2 and r.stdout.count("== tiling.py on every rank: True") == 2, r.stdout[-2000:]
+    assert r.stdout.count("strips == full frame: True") == 10, r.stdout[-2000:]
+    # ... of which four lines are the C-ABI strip driver (rs_comm / rs_strips with gloo under its transport callbacks: static and
+    # orbiting camera, the EAW filter, the image assembled by rs_strips_gather), also compared with tiling.py's strips on every rank
+    assert r.stdout.count("C-ABI strip driver") == 4 and r.stdout.count("== tiling.py on every rank: True") == 4, r.stdout[-2000:]
 
 
 def test_scene_without_extent_renders_without_the_shadow_tree(hip):

@@ -77,37 +77,50 @@ class GlooTransport:
             capi.hip_memcpy_d2d(ptr, d.data_ptr(), d.numel())
             torch.cuda.synchronize()
 
-for overlapped in (False, True):
+for moving, overlapped, denoise in ((False, False, False), (False, True, False), (True, False, False), (True, True, True)):
+    # moving: orbiting camera + rs_strips_exchange_history; denoise: rs_strips_eaw_filter; the image is assembled by rs_strips_gather
     capi.set_sync(not overlapped)
     cam = capi.camera_update(sd.camera(W, H))
     tr = GlooTransport()
     comm = capi.Comm(rank, world, tr.send, tr.recv, tr.begin, tr.end)
     drv = capi.Strips(comm, W, H)
     gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
+    eaw = capi.EAWFilter(W, H, 5) if denoise else None
     image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
     full = StripRenderer(HipBackend(capi, scene, cam, W, H), 1, 0, H) if rank == 0 else None
-    ref_py = StripRenderer(HipBackend(capi, scene, cam, W, H), world, rank, H, dist=dist)       # the Python form of the same schedule
+    ref_py = StripRenderer(HipBackend(capi, scene, cam, W, H), world, rank, H, dist=dist, share_history=moving)    # the Python form of the same schedule
+    result_ptr = image.data_ptr()
     for frame in range(FRAMES):
+        if moving:
+            p = orbit_position(sd.camera_args["position"], frame, radius=0.5)
+            for i in range(3):
+                cam.position[i] = float(p[i])
+            capi.camera_update(cam)
         drv.frame(restir, scene, cam, gbuf, image.data_ptr(), 0, frame, 3)
+        if denoise:
+            result_ptr = drv.eaw_filter(eaw, gbuf, cam, image.data_ptr())
         gbuf.update(cam)
-        ref_py.frame(3, 0)
+        if moving:
+            drv.exchange_history(restir, gbuf)
+        ref_py.frame(3, 0, denoise=denoise)
         if full is not None:
-            full.frame(3, 0)
+            full.frame(3, 0, denoise=denoise)
+    drv.gather(result_ptr, 12, 0)                                     # image assembly on rank 0
     torch.cuda.synchronize(); capi.synchronize()
     capi.set_sync(True)
-    mine = image[drv.y0 * W:drv.y1 * W].contiguous()
-    same_as_python = bool(torch.equal(mine.view(torch.int32), ref_py.b.image[drv.y0 * W:drv.y1 * W].view(torch.int32)))
+    result = torch.empty((W * H, 3), dtype=torch.float32, device="cuda")
+    capi.hip_memcpy_d2d(result.data_ptr(), result_ptr, W * H * 12)
+    torch.cuda.synchronize()
+    py = ref_py.filtered if denoise else ref_py.b.image
+    same_as_python = bool(torch.equal(result[drv.y0 * W:drv.y1 * W].view(torch.int32), py[drv.y0 * W:drv.y1 * W].view(torch.int32)))
     assert (drv.y0, drv.y1) == (ref_py.y0, ref_py.y1)
-    pad = torch.zeros((ref_py.max_rows * W, 3), dtype=torch.float32, device="cuda"); pad[:mine.shape[0]] = mine
-    out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad, out, dst=0)
     flags = [None] * world
     dist.all_gather_object(flags, same_as_python)
     if rank == 0:
-        got = torch.cat([out[r][:(b[1] - b[0]) * W] for r, b in enumerate(ref_py.bounds)]).cpu().numpy()
-        same = np.array_equal(got.view(np.uint32), full.b.image.cpu().numpy().view(np.uint32))
-        print("world %d, C-ABI strip driver, %s launches: strips == full frame: %s, == tiling.py on every rank: %s" %
-              (world, "overlapped" if overlapped else "synchronous", same, all(flags)), flush=True)
+        ref = full.filtered if denoise else full.b.image
+        same = np.array_equal(result.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+        print("world %d, C-ABI strip driver, %s camera, %s launches%s: gathered strips == full frame: %s, == tiling.py on every rank: %s" %
+              (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", ", EAW filter" if denoise else "", same, all(flags)), flush=True)
         ok = ok and same and all(flags)
     drv.destroy(); comm.destroy()
 dist.barrier()
