@@ -755,12 +755,20 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     else
         hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
     mark(r, 2);
-    hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
+    // The shadow rays of a launch that fills the chip several times over go to the library stream, behind the previous frame's
+    // spatial pass: every stream then has slack against the frame period and three or four kernels are in flight at any time,
+    // which is what a frame bound by VALU issue needs (1080p: 1.277 -> 1.245 ms).  A small launch -- a strip -- lasts as long as its
+    // slowest wave, and there the library stream is the one chain that links consecutive frames: its shadow rays stay on the
+    // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  RS_SHADOW_ON_MAIN=0 / 1: never / always.
+    static const int shadowOnMain = []{ const char* e = std::getenv("RS_SHADOW_ON_MAIN"); return e ? std::atoi(e) : 2; }();
+    const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
+    if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
     if (aux) {
         RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS / shadow rays)"));
         RS_HIP(hipEventRecord(r->auxDone, aux));
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
+    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     hipLaunchKernelGGL(k_temporal, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), sp, gbuf_view(g),
                        r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
