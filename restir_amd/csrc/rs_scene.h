@@ -774,7 +774,7 @@ template <int NEG>
 __device__ __forceinline__ bool slab_overlap_part(const SlabT& t, bool near) {
     const float nx = near_x<NEG>(t), ny = near_y<NEG>(t), nz = near_z<NEG>(t), fx = far_x<NEG>(t), fy = far_y<NEG>(t), fz = far_z<NEG>(t);
     const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
-    const bool ok = near && (dy + dz > fz - ny) && (dz + dx > fx - nz);
+    const bool ok = near & (dy + dz > fz - ny) & (dz + dx > fx - nz);     // plain "and": the short-circuit form compiles to nested exec-mask regions
     return dx + dy > (ok ? fy - nx : __builtin_inff());
 }
 
@@ -797,10 +797,13 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
         float chord;
         const bool near = slab_distance_part<NEG>(t, myNext == c, r.closest, chord);
         const unsigned long long nearMask = __builtin_amdgcn_ballot_w64(near);
+        unsigned target = nxt;                                // wave-uniform: the record the wave reads next
+        float4 pa, pb;
+        bool took = false;
         if (nearMask != 0ull) {
             // the record after this one is requested as soon as some lane may enter (it is the successor then), before the
             // overlap part and the triangle test; a node every lane rejects on the distance part does not pay for it
-            const float4 pa = *reinterpret_cast<const float4*>(base + cNext * 32u), pb = *reinterpret_cast<const float4*>(base + cNext * 32u + 16u);
+            pa = *reinterpret_cast<const float4*>(base + cNext * 32u); pb = *reinterpret_cast<const float4*>(base + cNext * 32u + 16u);
 #ifdef RS_WALK_STATS
             r.nearSteps++;
 #endif
@@ -826,13 +829,14 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
                     if (entered && hit && dist < r.closest) { r.closest = dist; r.bx = bx; r.by = by; r.prim = prim; }
                 }
                 myNext = entered ? cNext : max(myNext, nxt);
-                c = cNext; ra = pa; rb = pb;
-                continue;
+                target = cNext; took = true;
             }
         }
-        myNext = max(myNext, nxt);
-        c = nxt;
-        ra = *reinterpret_cast<const float4*>(base + c * 32u); rb = *reinterpret_cast<const float4*>(base + c * 32u + 16u);
+        if (!took) {
+            myNext = max(myNext, nxt);
+            pa = *reinterpret_cast<const float4*>(base + nxt * 32u); pb = *reinterpret_cast<const float4*>(base + nxt * 32u + 16u);
+        }
+        c = target; ra = pa; rb = pb;       // (one tail for both outcomes: with `continue` in the entered branch the compiler carried an undefined record index through the other, one v_readfirstlane per node)
     }
 }
 
@@ -1017,7 +1021,9 @@ __device__ __forceinline__ void packet_walk_fast2(const DevScene& s, int order, 
     while (c != end) {
         const int prim = __float_as_int(rb.z);
         const unsigned nxt = (unsigned)__float_as_int(rb.w);
-        const float4 pa = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u), pb = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u + 16u);
+        float4 pa = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u), pb = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u + 16u);
+        unsigned target = nxt;                                // wave-uniform: the record the wave reads next
+        bool took = false;
         const SlabT sa = slabs(aoxy, aozz, adxy, adzz, ra, rb), sb = slabs(boxy, bozz, bdxy, bdzz, ra, rb);
         float chordA, chordB;
         const bool nearA = slab_distance_part<NEG>(sa, nextA == c, wa.closest, chordA), nearB = slab_distance_part<NEG>(sb, nextB == c, wb.closest, chordB);
@@ -1039,13 +1045,14 @@ __device__ __forceinline__ void packet_walk_fast2(const DevScene& s, int order, 
                 }
                 nextA = inA ? c + 1u : max(nextA, nxt);
                 nextB = inB ? c + 1u : max(nextB, nxt);
-                c = c + 1u; ra = pa; rb = pb;
-                continue;
+                target = c + 1u; took = true;
             }
         }
-        nextA = max(nextA, nxt); nextB = max(nextB, nxt);
-        c = nxt;
-        ra = *reinterpret_cast<const float4*>(base + c * 32u); rb = *reinterpret_cast<const float4*>(base + c * 32u + 16u);
+        if (!took) {
+            nextA = max(nextA, nxt); nextB = max(nextB, nxt);
+            pa = *reinterpret_cast<const float4*>(base + nxt * 32u); pb = *reinterpret_cast<const float4*>(base + nxt * 32u + 16u);
+        }
+        c = target; ra = pa; rb = pb;       // (one tail for both outcomes: with `continue` in the entered branch the compiler carried an undefined record index through the other)
     }
 }
 
