@@ -314,6 +314,10 @@ int  rs_restir_enable_timing(rs_restir* r, int enable);
  * to the exact evaluation inside an error band; this returns the largest estimate error over n
  * pseudo-random samples so a test can assert the band really covers it. */
 int  rs_debug_tap_estimate_error(int n, float* maxErr);
+/* Test hook: the light sampler takes the square root of a uniform variate without the general expansion's range scaling and
+ * class test (rs_surface.h sqrt_of_uniform); this compares it with the exactly rounded sqrtf on every value the generator can
+ * return (2^31 - 2 of them) and returns the number of differing results. */
+int  rs_debug_sqrt_of_uniform_mismatches(unsigned long long* mismatches);
 
 /* ---- framebuffer tiling across the GPUs of one node: the row-strip frame of one rank ------------------------------------------
  * One process per GPU, the scene replicated, the framebuffer of runCuda (src/main.cpp:146-185) cut into `world` row strips.  A rank

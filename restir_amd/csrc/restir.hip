@@ -386,6 +386,16 @@ __device__ __forceinline__ void disk_tap(float rx, float ry, int x, int y, int& 
     if (tap_ambiguous(fx) || tap_ambiguous(fy)) disk_tap_exact(rx, ry, x, y, px, py);
 }
 
+// debug / test hook: every state k of the generator gives uniform() = (float)(k - 1) / 2^31, k - 1 in [0, 2^31 - 3]
+__global__ void k_sqrt_of_uniform_check(unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k <= 0x7ffffffdull; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = (float)(unsigned)k / 2147483648.f;
+        if (__float_as_int(sqrt_of_uniform(x)) != __float_as_int(sqrtf(x))) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // debug / test hook: largest |estimate - exact(double)| of the tap offset over n samples
 __global__ void k_tap_estimate_error(int n, float* maxErr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -968,6 +978,20 @@ int rs_restir_upload(rs_restir* r, int which, const rs_reservoir* host) {
         RS_HIP(hipMemcpy(p->w, w.data(), n * 4, hipMemcpyHostToDevice));
         RS_HIP(hipMemcpy(p->m, m.data(), n * 4, hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+// test hook: sqrt_of_uniform (rs_surface.h) against the compiler's exactly rounded sqrtf on EVERY value Rng::uniform() can return
+int rs_debug_sqrt_of_uniform_mismatches(unsigned long long* mismatches) {
+    rs_ctx_scope scope(nullptr);
+    if (!mismatches) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_sqrt_of_uniform_mismatches: null");
+    unsigned long long* d = nullptr;
+    RS_TRY(rs_dev_alloc(&d, 1));
+    RS_HIP(hipMemsetAsync(d, 0, 8, rs_stream()));
+    hipLaunchKernelGGL(k_sqrt_of_uniform_check, dim3(4096), dim3(256), 0, rs_stream(), d);
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
+    rs_dev_free(d);
     return 0;
 }
 

@@ -139,6 +139,20 @@ __device__ inline float sample_env_nv(const DevScene& s, float r1, float r2, f3&
 // Bit-exact shortcuts: dot(x-y, x-y) == dot(y-x, y-x) and normalize(x-y) == -normalize(y-x), so
 // the pdf conversion (mathUtil.h:182-185) reuses wi and dist instead of re-deriving them.
 // ENV: the scene has an environment map, whose sampler entry is the last one (scene.h:400-403).
+// The exactly rounded square root of a uniform variate.  Rng::uniform() is k * 2^-31 with an integer k, i.e. 0 or a normal number in
+// [2^-31, 1]: the range scaling (x < 2^-96) and the zero / infinity / NaN class test of the general expansion are dead for such an
+// argument (7 of its 16 vector instructions); what is left is the expansion's own refinement of the hardware estimate -- one ulp down
+// or up, decided by the sign of the two exact residuals -- which returns 0 for 0 (the residual of the step down is NaN, of the step
+// up +0: both comparisons fail).  tests/test_gpu_parity.py compares the RIS winners with the oracle's sqrtf bit for bit.
+__device__ __forceinline__ float sqrt_of_uniform(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float down = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float rDown = __builtin_fmaf(-down, s, x), rUp = __builtin_fmaf(-up, s, x);
+    float root = rDown <= 0.f ? down : s;
+    root = rUp > 0.f ? up : root;
+    return root;
+}
+
 template <bool ENV, typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasPtr alias, LightPtr lights, int numLights, f3 pos, f4 r) {
     LightSample o;
@@ -158,7 +172,7 @@ __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasP
     float4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
     f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
     f3 nrm = mk3(a.w, b.w, c.w);
-    float sr = sqrtf(r.w);                         // sampleTriangleUniform(v0,v1,v2, ru=r.z, rv=r.w)
+    float sr = sqrt_of_uniform(r.w);               // sampleTriangleUniform(v0,v1,v2, ru=r.z, rv=r.w); r is always Rng::uniform4()
     float u = 1.f - sr;
     float v = r.z * sr;
     f3 sampled = v1 * u + v2 * v + v0 * (1.f - u - v);

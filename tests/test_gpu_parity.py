@@ -230,6 +230,14 @@ def test_tap_estimate_error_is_inside_the_fallback_band(hip):
     assert 0.0 < err.value < 1e-5, err.value          # 4x margin to kTapErr
 
 
+def test_sqrt_of_uniform_equals_sqrtf_on_every_variate(hip):
+    """The light sampler's square root of a uniform variate skips the range scaling and class test of the exactly rounded
+    expansion (rs_surface.h sqrt_of_uniform): all 2^31 - 2 values Rng::uniform() can return must give sqrtf's bits."""
+    bad = C.c_ulonglong(1)
+    hip.check(hip.lib().rs_debug_sqrt_of_uniform_mismatches(C.byref(bad)))
+    assert bad.value == 0, bad.value
+
+
 def test_spatial_many_frames_large(hip):
     """A larger frame and more frames for the tap-position fast path: every pixel must still agree."""
     sd = get_scene("sponza:0.03")
