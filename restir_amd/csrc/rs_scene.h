@@ -844,7 +844,7 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
         }
         if (!took) {
             myNext = max(myNext, nxt);
-            pa = *reinterpret_cast<const float4*>(base + nxt * 32u); pb = *reinterpret_cast<const float4*>(base + nxt * 32u + 16u);
+            pa = *reinterpret_cast<const float4*>(base + nxt * 32u); pb = *reinterpret_cast<const float4*>(base + nxt * 32u + 16u);     // (requesting it at the top of every step as well: frame 1.20 -> 1.27 ms)
         }
         c = target; ra = pa; rb = pb;       // (one tail for both outcomes: with `continue` in the entered branch the compiler carried an undefined record index through the other, one v_readfirstlane per node)
     }
