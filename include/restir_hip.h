@@ -166,6 +166,10 @@ int  rs_set_sync(int sync);
  *   3 = like 2 for launches of any size
  *   4 = overlapped frames, measured choice (the default) */
 int  rs_set_side_stream(int enable);
+/* The RIS pass keeps the light table (up to 1 024 lights) in LDS, one copy per 1 024-thread block; a launch of fewer than `pixels`
+ * pixels reads it from global memory in 256-thread blocks instead, which spread evenly over the CUs (default 384 Ki pixels, i.e.
+ * about 1.5 of the large blocks per CU; also RS_RIS_GLOBAL_BELOW).  Same results either way; 0 = always LDS. */
+int  rs_set_ris_table_pixels(int pixels);
 int  rs_synchronize(void);
 
 /* ---- host scene build: replaces Scene::buildDevData (src/scene.cpp:159-215) ----------- */

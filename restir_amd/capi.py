@@ -108,7 +108,7 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_synchronize",
+    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
@@ -151,6 +151,7 @@ def lib():
     L.rs_set_stream.argtypes = [vp]
     L.rs_set_sync.argtypes = [ci]
     L.rs_set_side_stream.argtypes = [ci]
+    L.rs_set_ris_table_pixels.argtypes = [ci]
     L.rs_build_bvh.argtypes = [ci, vp, vp, C.POINTER(vp * 6), C.POINTER(ci)]
     L.rs_build_light_table.argtypes = [ci, vp, vp, ci, vp, C.POINTER(ci), vp, vp, vp]
     L.rs_build_alias_table.argtypes = [ci, vp, vp, vp, C.POINTER(cf)]
@@ -287,6 +288,11 @@ def set_side_stream(enable):
     """Overlapped frames when launches are asynchronous (include/restir_hip.h): 0 off, 1 on with GBuffer::render as its own launch,
     2 / 3 on with the render deferred into ReSTIRDirect's primary-ray launch (3: at any size), 4 on with that choice measured."""
     check(lib().rs_set_side_stream(int(enable)))
+
+
+def set_ris_table_pixels(pixels):
+    """Launches of fewer pixels read the RIS light table from global memory instead of LDS (rs_set_ris_table_pixels); 0 = always LDS."""
+    check(lib().rs_set_ris_table_pixels(int(pixels)))
 
 
 def synchronize():

@@ -71,6 +71,15 @@ int rs_fuse_mode() {
     return c->fuseMode;
 }
 bool rs_fuse_enabled() { return rs_fuse_mode() != 0; }
+int rs_ris_global_below() {
+    rs_context* c = rs_ctx();
+    if (c->risGlobalBelow < 0) {
+        const char* e = std::getenv("RS_RIS_GLOBAL_BELOW");
+        c->risGlobalBelow = e ? std::atoi(e) : 384 * 1024;
+        if (c->risGlobalBelow < 0) c->risGlobalBelow = 0;
+    }
+    return c->risGlobalBelow;
+}
 int rs_aux_synchronize() {
     for (hipStream_t st : rs_ctx()->aux) if (st) RS_HIP(hipStreamSynchronize(st));
     return 0;
@@ -163,6 +172,11 @@ int rs_set_side_stream(int enable) {
     rs_context* c = rs_ctx();
     c->auxMode = enable ? 1 : 0;                        // work already enqueued on the auxiliary streams is still joined by its consumers
     c->fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : enable == 4 ? 3 : 0;      // 2 always, 3 always and at any size (tests), 4 measured
+    return 0;
+}
+int rs_set_ris_table_pixels(int pixels) {
+    if (pixels < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_ris_table_pixels: negative");
+    rs_ctx()->risGlobalBelow = pixels;
     return 0;
 }
 int rs_synchronize(void) {

@@ -761,7 +761,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
     // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
     // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
-    static const int risGlobalBelow = []{ const char* e = std::getenv("RS_RIS_GLOBAL_BELOW"); return e ? std::atoi(e) : 384 * 1024; }();
+    const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
     if (scene->envMapTexId >= 0)       // the environment map is one more light (scene.h:400-403)
         hipLaunchKernelGGL(k_ris<true>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
     else if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow)

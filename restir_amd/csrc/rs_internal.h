@@ -22,6 +22,7 @@ struct rs_context {
     bool sync = true;
     hipStream_t aux[kAux] = {};
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
+    int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory: -1 from the environment (RS_RIS_GLOBAL_BELOW) or 384 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
 };
@@ -150,6 +151,7 @@ int rs_gbuffer_release_scene(const rs_scene* scene);
 // orders `stream` after the last readers of the set a (deferred) render is about to write
 int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream);
 bool rs_fuse_enabled();
+int rs_ris_global_below();
 int rs_fuse_mode();     // 0 never, 1 always (large launches), 2 always, 3 measured per rs_restir
 
 // device view of the planes the kernels read

@@ -191,17 +191,23 @@ def _compare_reservoirs(a, b):
 
 @pytest.mark.parametrize("name", list(SCENES))
 @pytest.mark.parametrize("reuse", [0, 1])
-def test_restir_no_spatial_bit_exact(hip, name, reuse):
-    """RIS-only (config 2 semantics) and temporal reuse: bit-exact radiance and reservoirs over 4 frames."""
+@pytest.mark.parametrize("table", ["lds", "global"])
+def test_restir_no_spatial_bit_exact(hip, name, reuse, table):
+    """RIS-only (config 2 semantics) and temporal reuse: bit-exact radiance and reservoirs over 4 frames, with the RIS light table
+    in LDS (what a full frame uses) and read from global memory (what a launch below 384 Ki pixels uses by default)."""
     sd = get_scene(name)
     W, H = SCENES[name]
     o = OracleRenderer(sd, W, H)
-    h = HipRenderer(hip, sd, W, H)
-    for frame in range(4):
-        a = o.frame(reuse); b = h.frame(reuse)
-        assert o.rays == h.rays, (frame, o.rays, h.rays)
-        assert bits_equal(a, b), (frame, radiance_stats(a, b))
-        _compare_reservoirs(o.restir.last, h.restir.download(1))      # the buffer written this frame
+    hip.set_ris_table_pixels(0 if table == "lds" else 1 << 30)
+    try:
+        h = HipRenderer(hip, sd, W, H)
+        for frame in range(4):
+            a = o.frame(reuse); b = h.frame(reuse)
+            assert o.rays == h.rays, (frame, o.rays, h.rays)
+            assert bits_equal(a, b), (frame, radiance_stats(a, b))
+            _compare_reservoirs(o.restir.last, h.restir.download(1))      # the buffer written this frame
+    finally:
+        hip.set_ris_table_pixels(384 * 1024)
 
 
 @pytest.mark.parametrize("name", list(SCENES))
