@@ -193,19 +193,21 @@ __global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int widt
 }
 
 __global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
-    __shared__ LightRec sLights[kRisLdsLights];
+    // The copy is laid out by quarter: the lanes of a wave read the same quarter of 64 random records, and in record order those
+    // 16 bytes lie in 2 of the 8 four-bank groups whatever the light (a 4-fold bank conflict; SQ_LDS_BANK_CONFLICT was 80 % of the
+    // LDS cycles); by quarter, light i's lies in group i mod 8.
+    __shared__ float4 sQuarters[4 * kRisLdsLights];
     __shared__ AliasRec sAlias[kRisLdsLights];
     {
         const float4* src = reinterpret_cast<const float4*>(s.lights);
-        float4* dst = reinterpret_cast<float4*>(sLights);
-        for (int i = threadIdx.x; i < s.numLights * 4; i += kRisThreads) dst[i] = src[i];
+        for (int i = threadIdx.x; i < s.numLights * 4; i += kRisThreads) sQuarters[(i & 3) * kRisLdsLights + (i >> 2)] = src[i];
         for (int i = threadIdx.x; i < s.numLights; i += kRisThreads) sAlias[i] = s.alias[i];
     }
     __syncthreads();
     const int n0 = y0 * width, n1 = y1 * width;
     const int index = n0 + blockIdx.x * kRisThreads + threadIdx.x;
     if (index >= n1) return;
-    ris_pixel<false, const AliasRec*, const LightRec*>(s, sp, sAlias, sLights, index);
+    ris_pixel<false, const AliasRec*, LightQuarters<kRisLdsLights>>(s, sp, sAlias, LightQuarters<kRisLdsLights>{ sQuarters }, index);
 }
 
 // ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------

@@ -153,6 +153,20 @@ __device__ __forceinline__ float sqrt_of_uniform(float x) {
     return root;
 }
 
+// the four 16-byte quarters of a light record: from the record array, or from an LDS copy laid out by quarter (restir.hip k_ris_lds)
+__device__ __forceinline__ void load_light(const LightRec* lights, int id, float4& a, float4& b, float4& c, float4& d) {
+    const float4* lp = reinterpret_cast<const float4*>(&lights[id]);
+    a = lp[0]; b = lp[1]; c = lp[2]; d = lp[3];
+}
+template <int N>
+struct LightQuarters {                      // quarter k of light i at q[k * N + i]
+    const float4* q;
+};
+template <int N>
+__device__ __forceinline__ void load_light(LightQuarters<N> lights, int id, float4& a, float4& b, float4& c, float4& d) {
+    a = lights.q[id]; b = lights.q[N + id]; c = lights.q[2 * N + id]; d = lights.q[3 * N + id];
+}
+
 template <bool ENV, typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasPtr alias, LightPtr lights, int numLights, f3 pos, f4 r) {
     LightSample o;
@@ -168,8 +182,8 @@ __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasP
         o.point = pos + o.wi * 1e6f;                                 // sampleEnvironmentMap's occlusion target (scene.h:387)
         return o;
     }
-    const float4* lp = reinterpret_cast<const float4*>(&lights[id]);
-    float4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
+    float4 a, b, c, d;
+    load_light(lights, id, a, b, c, d);
     f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
     f3 nrm = mk3(a.w, b.w, c.w);
     float sr = sqrt_of_uniform(r.w);               // sampleTriangleUniform(v0,v1,v2, ru=r.z, rv=r.w); r is always Rng::uniform4()
