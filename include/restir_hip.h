@@ -152,13 +152,14 @@ int  rs_set_stream(void* hipStream);
 /* 1 (default): every entry point synchronises and checks errors before returning, like
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);
-/* With rs_set_sync(0), frames overlap: GBuffer::render and the primary-ray + RIS kernels of ReSTIRDirect are enqueued on two
- * internal streams, ordered only after the work that last used their buffers (G-buffer planes in a ring of three, per-frame
- * surface planes double-buffered), and joined into the library stream where their results are first read (the temporal
- * pass, the denoisers, rs_gbuffer_get_view, rs_synchronize).  They then run next to the previous frame's temporal / spatial
+/* With rs_set_sync(0), frames overlap: GBuffer::render goes to an internal stream, the primary-ray -> RIS -> shadow-ray kernels of
+ * ReSTIRDirect to two more, frames taking them in turn (a full-size frame's shadow rays stay on the library stream); each is
+ * ordered only after the work that last used its buffers (G-buffer planes in a ring of three, per-frame surface planes in
+ * three sets) and joined into the library stream where its results are first read (the temporal pass, the denoisers,
+ * rs_gbuffer_get_view, rs_synchronize).  They then run next to the previous frames' temporal / spatial
  * passes.  Results are identical; output buffers are valid in library-stream order as before.  GBuffer::render can in addition
  * be deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal:
- * 4 % faster on a full Sponza-class frame, slower where a few long tiles set the launch time, so by default
+ * faster or slower by a few percent depending on the scene and the launch size, so by default
  * every rs_restir measures the frame period both ways once per scene (frames 2..13) and keeps the faster.
  *   0 = everything on the library stream (also RS_SIDE_STREAM=0)
  *   1 = overlapped frames, the render always its own launch (also RS_FUSE_GBUFFER=0)
