@@ -403,6 +403,26 @@ int  rs_copy_image2_to_pbo(void* devPBO, const float* devImage, int width, int h
 int  rs_copy_imagef_to_pbo(void* devPBO, const float* devImage, int width, int height);
 int  rs_copy_imagei_to_pbo(void* devPBO, const int* devImage, int width, int height);
 
+/* ---- viewer interop (src/main.cpp:105-144,176-181, src/preview.cpp:88,112-133) ---------------------------------------------
+ * The OpenGL pixel-buffer object of the interactive viewer through HIP's graphics interop, one call per reference call:
+ *     cudaGLRegisterBufferObject(pbo)            -> rs_pbo_register(pbo, &p)      (an OpenGL context must be current on the thread)
+ *     cudaGLMapBufferObject((void**)&devPBO,pbo) -> rs_pbo_map(p, &devPBO, NULL)  (ordered on the library stream)
+ *     copyImageToPBO(devPBO, devImage, ...)      -> rs_copy_image_to_pbo(devPBO, devImage, ...)
+ *     cudaGLUnmapBufferObject(pbo)               -> rs_pbo_unmap(p)
+ *     cudaGLUnregisterBufferObject(pbo)          -> rs_pbo_unregister(p)
+ * (cudaGLSetGLDevice(0) is rs_init(0).)  On a node without a GL context rs_pbo_register fails with the runtime's error. */
+typedef struct rs_pbo rs_pbo;
+int  rs_pbo_register(unsigned glBuffer, rs_pbo** pbo);
+int  rs_pbo_map(rs_pbo* pbo, void** devPBO, size_t* bytes /* may be null */);
+int  rs_pbo_unmap(rs_pbo* pbo);
+int  rs_pbo_unregister(rs_pbo* pbo);
+/* saveImage(false) (src/main.cpp:105-144 with Image::setPixel / savePNG, src/image.cpp:36-58): tone map (0 none, 1 filmic, 2 ACES) and
+ * gamma per pixel, stored mirrored in x, clamped, scaled by 255 and truncated; an 8-bit RGB PNG at `path` (the complete file name: the
+ * viewer composes "<imageName>.<time>.<samples>samp.png").  The JPEG form (saveImage(true)) is not provided.  Synchronises. */
+int  rs_save_image(const char* path, const float* devImage, int width, int height, int toneMapping);
+/* the PNG writer by itself (host only): rgb = height rows of width * 3 bytes */
+int  rs_write_png(const char* path, const unsigned char* rgb, int width, int height);
+
 /* ---- EAW denoiser (src/denoiser.h:33-43,72-74) -------------------------------------------- */
 int  rs_eaw_create(int width, int height, int level, rs_eaw** f);   /* LeveledEAWFilter::create */
 int  rs_eaw_destroy(rs_eaw* f);

@@ -115,7 +115,7 @@ EXPORTS = [
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
-    "rs_restir_enable_timing", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_restir_enable_timing", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_write_png", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
@@ -190,6 +190,12 @@ def lib():
     L.rs_restir_rows_bytes.argtypes = [vp, ci, ci]
     L.rs_restir_rows_bytes.restype = C.c_size_t
     L.rs_debug_tap_estimate_error.argtypes = [ci, C.POINTER(cf)]
+    L.rs_pbo_register.argtypes = [C.c_uint, C.POINTER(vp)]
+    L.rs_pbo_map.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.rs_pbo_unmap.argtypes = [vp]
+    L.rs_pbo_unregister.argtypes = [vp]
+    L.rs_save_image.argtypes = [C.c_char_p, vp, ci, ci, ci]
+    L.rs_write_png.argtypes = [C.c_char_p, vp, ci, ci]
     L.rs_debug_sqrt_of_uniform_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
     L.rs_restir_rows_pack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_restir_rows_unpack.argtypes = [vp, ci, ci, ci, vp]
@@ -293,6 +299,18 @@ def set_side_stream(enable):
 def set_ris_table_pixels(pixels):
     """Launches of fewer pixels read the RIS light table from global memory instead of LDS (rs_set_ris_table_pixels); 0 = always LDS."""
     check(lib().rs_set_ris_table_pixels(int(pixels)))
+
+
+def save_image(path, dev_image_ptr, width, height, tone_mapping):
+    """saveImage(false) (src/main.cpp:105-144): tone map + gamma, mirrored in x, 8-bit RGB PNG."""
+    check(lib().rs_save_image(str(path).encode(), dev_image_ptr, width, height, tone_mapping))
+
+
+def write_png(path, rgb):
+    """rgb: uint8 numpy array (height, width, 3)."""
+    import numpy as np
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    check(lib().rs_write_png(str(path).encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
 
 
 def synchronize():

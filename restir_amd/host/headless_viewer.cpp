@@ -4,7 +4,7 @@
 // the same names.  Scene input: a scene file in the reference's text format (Scene(filename), as main() does), or a
 // binary triangle soup written by restir_amd/scenes.py (dump_scene).
 //
-//   headless_viewer scene.txt frames reuse out.ppm                  (resolution and camera from the file)
+//   headless_viewer scene.txt frames reuse out.ppm | out.png        (resolution and camera from the file; .png = saveImage)
 //   headless_viewer scene.bin width height frames reuse out.ppm
 #include <hip/hip_runtime.h>
 
@@ -90,12 +90,19 @@ int main(int argc, char** argv) {
 
     for (int i = 0; i < frames; i++) runCuda(devPBO);       // mainLoop (src/preview.cpp:337-369)
 
-    std::vector<unsigned char> rgba(4 * (size_t)width * height);
-    (void)hipMemcpy(rgba.data(), devPBO, rgba.size(), hipMemcpyDeviceToHost);
-    FILE* o = std::fopen(outName, "wb");
-    std::fprintf(o, "P6\n%d %d\n255\n", width, height);
-    for (size_t i = 0; i < (size_t)width * height; i++) std::fwrite(&rgba[4 * i], 1, 3, o);
-    std::fclose(o);
+    const size_t outLen = std::strlen(outName);
+    if (outLen > 4 && std::strcmp(outName + outLen - 4, ".png") == 0) {
+        // saveImage(false) (src/main.cpp:105-144): tone map + gamma of the radiance image, mirrored in x, as a PNG
+        rsc::check(rs_save_image(outName, reinterpret_cast<const float*>(devDirectIllum), width, height, Settings::toneMapping), "saveImage");
+    }
+    else {                                                  // the bytes the PBO holds, as they are
+        std::vector<unsigned char> rgba(4 * (size_t)width * height);
+        (void)hipMemcpy(rgba.data(), devPBO, rgba.size(), hipMemcpyDeviceToHost);
+        FILE* o = std::fopen(outName, "wb");
+        std::fprintf(o, "P6\n%d %d\n255\n", width, height);
+        for (size_t i = 0; i < (size_t)width * height; i++) std::fwrite(&rgba[4 * i], 1, 3, o);
+        std::fclose(o);
+    }
 
     scene->clear();
     gBuffer.destroy();

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 
@@ -186,6 +187,23 @@ inline void copyImageToPBO(void* devPBO, float* devImage, int width, int height)
 }
 inline void copyImageToPBO(void* devPBO, int* devImage, int width, int height) {
     rsc::check(rs_copy_imagei_to_pbo(devPBO, devImage, width, height), "copyImageToPBO");
+}
+
+// ---- the viewer's pixel-buffer object and screenshot (src/preview.cpp:88,112-133; src/main.cpp:105-144,176-181) -------------------
+// The reference addresses its PBO by the GLuint alone; HIP's interop hands back a resource at registration, kept here per GLuint.
+namespace rsc {
+inline std::map<unsigned, rs_pbo*>& pbos() { static std::map<unsigned, rs_pbo*> m; return m; }
+}
+inline void cudaGLSetGLDevice(int device) { rsc::check(rs_init(device), "cudaGLSetGLDevice"); }
+inline void cudaGLRegisterBufferObject(unsigned pbo) { rsc::check(rs_pbo_register(pbo, &rsc::pbos()[pbo]), "cudaGLRegisterBufferObject"); }
+inline void cudaGLMapBufferObject(void** devPtr, unsigned pbo) { rsc::check(rs_pbo_map(rsc::pbos()[pbo], devPtr, nullptr), "cudaGLMapBufferObject"); }
+inline void cudaGLUnmapBufferObject(unsigned pbo) { rsc::check(rs_pbo_unmap(rsc::pbos()[pbo]), "cudaGLUnmapBufferObject"); }
+inline void cudaGLUnregisterBufferObject(unsigned pbo) { rsc::check(rs_pbo_unregister(rsc::pbos()[pbo]), "cudaGLUnregisterBufferObject"); rsc::pbos().erase(pbo); }
+// saveImage(false) (src/main.cpp:105-144) for a device image: "<imageName>.<time>.<samples>samp.png"
+inline std::string saveImage(const std::string& imageName, const std::string& timeString, int samples, rsc::vec3* devImage, int width, int height, int toneMapping) {
+    const std::string filename = imageName + "." + timeString + "." + std::to_string(samples) + "samp.png";
+    rsc::check(rs_save_image(filename.c_str(), reinterpret_cast<const float*>(devImage), width, height, toneMapping), "saveImage");
+    return filename;
 }
 
 // ---- src/denoiser.h:33-43,72-74 -------------------------------------------------------------------------

@@ -220,3 +220,27 @@ class OracleBackend:
         self._rows(self.gbuf.prim_id[last], y0, rows)[:] = b[o:o + n * 4].view(np.int32); o += n * 4
         self._rows(self.gbuf.normal[last], y0, rows)[:] = b[o:o + n * 12].view(np.float32).reshape(n, 3); o += n * 12
         self._rows(self.gbuf.depth[last], y0, rows)[:] = b[o:o + n * 4].view(np.float32)
+
+
+def read_png_rgb(path):
+    """Decodes an 8-bit RGB PNG whose rows use filter type 0 (what rs_write_png produces) with zlib alone; checks every chunk CRC."""
+    import struct, zlib
+    d = open(path, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    off, idat, size = 8, b"", None
+    while off < len(d):
+        n, = struct.unpack(">I", d[off:off + 4])
+        typ, body = d[off + 4:off + 8], d[off + 8:off + 8 + n]
+        crc, = struct.unpack(">I", d[off + 8 + n:off + 12 + n])
+        assert zlib.crc32(typ + body) & 0xffffffff == crc, typ
+        if typ == b"IHDR":
+            w, h, depth, colour, comp, filt, lace = struct.unpack(">IIBBBBB", body)
+            assert (depth, colour, comp, filt, lace) == (8, 2, 0, 0, 0)
+            size = (h, w)
+        elif typ == b"IDAT":
+            idat += body
+        off += 12 + n
+    h, w = size
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 3).copy()

@@ -1152,3 +1152,44 @@ def test_headless_viewer_drop_in(hip, tmp_path):
     ref = ob.send_image_to_pbo(img, W, H, 2, 1.0)[:, :3]
     diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
     assert diff.max() <= 1 and np.mean(diff > 0) <= 1e-3
+
+
+def test_save_image_is_the_tone_mapped_frame_mirrored(hip, tmp_path):
+    """saveImage(false) (src/main.cpp:105-144): tone map + gamma per pixel, stored at (width - 1 - x, y), clamped, x 255, truncated --
+    the bytes of sendImageToPBO with scale 1, mirrored in x, as an 8-bit RGB PNG; compared with the oracle's bytes (<= 1 LSB on <= 1e-3
+    of them, the display conversion's tolerance), through the C ABI and through the viewer's ".png" output."""
+    import os, subprocess, torch
+    from tests.common import read_png_rgb
+    from restir_amd import scenes
+    sd = get_scene("cornell")
+    W, H, frames = 96, 64, 3
+    h = HipRenderer(hip, sd, W, H)
+    o = OracleRenderer(sd, W, H)
+    for _ in range(frames):
+        img = o.frame(1); h.frame(1)
+    for mode in (0, 1, 2):
+        hip.save_image(tmp_path / ("m%d.png" % mode), h.image.data_ptr(), W, H, mode)
+        got = read_png_rgb(tmp_path / ("m%d.png" % mode))
+        ref = ob.send_image_to_pbo(img, W, H, mode, 1.0)[:, :3].reshape(H, W, 3)[:, ::-1]
+        diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
+        assert diff.max() <= 1 and np.mean(diff > 0) <= 1e-3, mode
+        pbo = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")          # and exactly the library's own PBO bytes, mirrored
+        hip.copy_image_to_pbo(pbo.data_ptr(), h.image.data_ptr(), W, H, mode, 1.0)
+        assert np.array_equal(pbo.cpu().numpy()[:, :3].reshape(H, W, 3)[:, ::-1], got)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "restir_amd", "host", "headless_viewer")
+    scenes.dump_scene(sd, str(tmp_path / "scene.bin"))
+    subprocess.check_call([exe, str(tmp_path / "scene.bin"), str(W), str(H), str(frames), "1", str(tmp_path / "shot.png")])
+    assert np.array_equal(read_png_rgb(tmp_path / "shot.png"), read_png_rgb(tmp_path / "m2.png"))      # Settings::toneMapping = ACES
+
+
+def test_pbo_registration_without_a_gl_context_fails_cleanly(hip):
+    """cudaGLRegisterBufferObject's replacement (rs_pbo_register -> hipGraphicsGLRegisterBuffer) on a node without OpenGL: an error
+    code and a message, no crash, and the library keeps working."""
+    p = C.c_void_p()
+    rc = hip.lib().rs_pbo_register(1, C.byref(p))
+    assert rc != 0 and not p.value
+    assert b"rs_pbo_register" in hip.lib().rs_last_error()
+    assert hip.lib().rs_pbo_unmap(None) != 0 and hip.lib().rs_pbo_unregister(None) == 0
+    sd = get_scene("cornell")
+    h = HipRenderer(hip, sd, 32, 24)
+    assert np.isfinite(h.frame(0)).all()

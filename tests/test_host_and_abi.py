@@ -188,6 +188,21 @@ def test_malformed_mtbvh_tables_are_refused_on_the_host():
         create(bad)
 
 
+def test_png_writer_round_trip(tmp_path):
+    """rs_write_png (the file Image::savePNG writes, src/image.cpp:41-58): sizes around the 65 535-byte stored-block limit, every chunk
+    CRC and the Adler-32 checked by zlib, pixels back bit for bit; bad arguments are refused."""
+    from restir_amd import capi
+    from tests.common import read_png_rgb
+    rng = np.random.default_rng(3)
+    for h, w in ((1, 1), (7, 5), (5, 4369), (300, 421)):          # 5 x (1 + 3 * 4369) = 65 540 bytes: just over one stored block
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        capi.write_png(tmp_path / "t.png", a)
+        assert np.array_equal(read_png_rgb(tmp_path / "t.png"), a)
+    with pytest.raises(capi.RestirHipError):
+        capi.write_png(tmp_path / "no_such_dir" / "t.png", np.zeros((2, 2, 3), np.uint8))
+    assert capi.lib().rs_write_png(b"x.png", None, 2, 2) != 0
+
+
 def test_procedural_scene_budgets():
     sd = scenes.sponza_class(1, 1.0)
     assert sd.num_prims == 262144
