@@ -114,33 +114,36 @@ __global__ void __launch_bounds__(256, 8) k_primary(DevScene s, CamParams cam, S
 }
 
 // GBuffer::render and the primary rays of ReSTIRDirect in one launch (asynchronous mode, when the render of this frame is
-// still pending -- rs_gbuffer_render_rows defers it): per 8x8 tile the pixel-centre ray and the jittered ray are walked together
-// (walk_two_packet), then each is stored as k_render_gbuffer / k_primary store it.  Tiles are laid out from the G-buffer rows
-// [gy0, gy1); the shading ray is active on rows [y0, y1).
+// still pending -- rs_gbuffer_render_rows defers it), each ray stored as k_render_gbuffer / k_primary store it.
 constexpr int kTuneA = 2, kTuneB = 8, kTuneC = 14;          // frames at which the measured launch choice takes its time stamps
 constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
 
-#ifndef RS_FUSED_BLOCKS
-#define RS_FUSED_BLOCKS 8
-#endif
+// The two rays of a pixel sit in two LANES: a wave takes an 8x4 block of pixels, lanes 0-31 walk their pixel-centre rays and lanes
+// 32-63 their jittered rays -- 64 rays in the ordinary one-ray-per-lane packet walk.  The two rays of a pixel visit almost the same
+// nodes, so the wave's union of nodes is that of 32 pixels, not 64: fewer node visits per pixel than two launches over 8x8 tiles, at
+// the single walk's cost per visit.  (Round 1's form walked both rays in one lane, one after the other at every node of an 8x8 tile's
+// union: it paid both slab tests per visit and, after the round-2 walk, measured 1.29 ms per frame against 1.20 for two launches and
+// 1.193 for this form.)  Tiles are 8x4 from the G-buffer rows [gy0, gy1), blocks 32x4 pixels; the shading ray is active on rows [y0, y1).
 template <bool TEX>
-__global__ void __launch_bounds__(256, RS_FUSED_BLOCKS) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
-                                                         int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
-    int x, y;
-    pixel_of_lane(tilesX, gy0, x, y);
-    const bool insideG = x < cam.width && y < gy1;
-    const bool insideP = x < cam.width && y >= y0 && y < y1;
+__global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+                                                                  int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31;
+    const bool shading = lane >= 32;                            // which of the pixel's two rays this lane carries
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const int x = bx * 32 + wave * 8 + (l & 7), y = gy0 + by * 4 + (l >> 3);
+    const bool inside = x < cam.width && (shading ? (y >= y0 && y < y1) : y < gy1);
     const int index = y * cam.width + x;
     Rng rng = seeded_rng(looper, index, 0);
     const f4 r = rng.uniform4();
-    const Ray rayG = camera_center_ray(cam, x, y), rayP = camera_sample(cam, x, y, r.x, r.y);
-    WalkResult wg, wp;
-    walk_two_packet(s, rayG, rayP, insideG, insideP, wg, wp);
-    if (insideG) gbuffer_store<TEX>(s, cam, lastCam, g, index, rayG, hit_of_walk(s, wg));
+    const Ray ray = shading ? camera_sample(cam, x, y, r.x, r.y) : camera_center_ray(cam, x, y);
+    const Hit h = trace_closest_packet(s, ray, inside);
     int shaded = 0;
-    if (insideP) shaded = primary_store<TEX>(s, sp, index, rayP, hit_of_walk(s, wp), rng);
-    const unsigned long long ballotIn = __ballot(insideP), ballotSh = __ballot(shaded);
-    if ((threadIdx.x & 63) == 0) {
+    if (inside) {
+        if (shading) shaded = primary_store<TEX>(s, sp, index, ray, h, rng);
+        else gbuffer_store<TEX>(s, cam, lastCam, g, index, ray, h);
+    }
+    const unsigned long long ballotIn = __ballot(inside && shading), ballotSh = __ballot(shaded);
+    if (lane == 0) {
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
         if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
     }
@@ -727,10 +730,10 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     mark(r, 0);
     // a render of this frame that rs_gbuffer_render_rows deferred (asynchronous mode) is launched here, together with the primary
     // rays: same scene and camera, rows that contain the rows shaded here
-    // ... and a launch large enough to be bound by throughput: in a fused tile one wave walks both rays, which saves 10 % of the
-    // work but makes the slowest tile of the launch take almost twice as long -- on a full 1080p frame (32 400 waves over 8 192
-    // wave slots) the frame gains 4 %, on a half frame and below the long tiles set the launch time and it loses 8-20 %
-    // (tools/strip_balance.py with and without RS_FUSE_GBUFFER=0)
+    // ... and a launch large enough to be bound by throughput: with the two rays of a pixel in one wave the launch does ~5 % less
+    // work than two launches, but its waves are longer (an 8x4 block's 64 rays of two kinds: 253 us against 184 for the slowest tile
+    // of a 1/8 strip), and a launch of less than a few rounds of wave slots lasts as long as its slowest wave: on a full 1080p frame
+    // (64 800 waves over 8 192 slots) the frame gains 0.5 %, on a 1/8 strip it loses 15 % (tools/strip_quick.py, RS_SS=3 against 4)
     const rs_gbuffer::Deferred& d = g->deferred;
     const int fuseMode = rs_fuse_mode();
     bool fuse = aux && fuseMode != 0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
@@ -745,7 +748,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         rs_gbuffer_deferred_taken(g);
         const int c = g->cur();
         const GBufWrite gw{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
-        const int gTilesY = (d.y1 - d.y0 + 7) / 8;
+        const int gTilesY = (d.y1 - d.y0 + 3) / 4;                // 8x4-pixel tiles: two rays per pixel fill the wave
         const CamParams lp = rs_make_cam_params(&d.lastCam);
         if (scene->textured)
             hipLaunchKernelGGL(k_gbuffer_primary<true>, dim3(tilesX * gTilesY), dim3(256), 0, st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);

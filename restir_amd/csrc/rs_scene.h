@@ -968,163 +968,6 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     return h;
 }
 
-// ---- two coherent rays per lane in one packet walk ------------------------------------------------------------------------
-// The G-buffer ray (pixel centre) and the shading ray (jittered inside the pixel) of an 8x8 tile visit nearly the same nodes.
-// Walked together, every node record is fetched once and the loop control and the next-node reduction are shared; each ray
-// keeps its own walk state and makes exactly the visits of DevScene::intersect, so both results are those of separate walks
-// (measured with a throw-away probe kernel in round 1: -10.6 % against two packet walks).  Must be called by all 64 lanes.
-template <bool GENERAL>
-__device__ __forceinline__ void packet_walk_order2(const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra, const RayBoxCtx& ca,
-                                                   const Ray& rb, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
-    const BvhNode* __restrict__ nodes = s.nodesAll + (size_t)order * (size_t)s.bvhSize;
-    const unsigned end = (unsigned)s.bvhSize;
-    unsigned nextA = mineA ? 0u : end, nextB = mineB ? 0u : end;
-    unsigned c = 0;
-    const float4* np0 = reinterpret_cast<const float4*>(nodes);
-    float4 lo, hi;
-    node_unpack(np0[0], np0[1], lo, hi);
-    while (c != end) {
-        const float4* nq = reinterpret_cast<const float4*>(nodes + c + 1);
-        float4 plo, phi;
-        node_unpack(nq[0], nq[1], plo, phi);
-        const int prim = __float_as_int(lo.w);
-        const unsigned nxt = (unsigned)__float_as_int(hi.w);
-        const bool partA = nextA == c, partB = nextB == c;
-        float ta, tb;
-        bool ha, hb;
-        if (GENERAL) { ha = box_hit_general(ca.o, ca.dinv, lo, hi, ta); hb = box_hit_general(cb.o, cb.dinv, lo, hi, tb); }
-        else { ha = box_hit(ca, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), ta); hb = box_hit(cb, mk3(lo.x, lo.y, lo.z), mk3(hi.x, hi.y, hi.z), tb); }
-        const bool inA = partA & ha & (ta < wa.closest), inB = partB & hb & (tb < wb.closest);
-        if (prim != kNullPrim) {
-            if (__any(inA | inB)) {
-                const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);
-                const float4 a = tp[0], b = tp[1], e = tp[2];
-                float bx, by, dist;
-                if (inA) { if (tri_hit(ra.o, ra.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wa.closest) { wa.closest = dist; wa.bx = bx; wa.by = by; wa.prim = prim; } }
-                if (inB) { if (tri_hit(rb.o, rb.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wb.closest) { wb.closest = dist; wb.bx = bx; wb.by = by; wb.prim = prim; } }
-            }
-        }
-        nextA = partA ? (inA ? c + 1u : nxt) : nextA;
-        nextB = partB ? (inB ? c + 1u : nxt) : nextB;
-        const unsigned want = min(nextA, nextB);
-        if (__any(want == c + 1u)) { c = c + 1u; lo = plo; hi = phi; }
-        else {
-            c = wave_min_u32(want);
-            const float4* np = reinterpret_cast<const float4*>(nodes + c);
-            node_unpack(np[0], np[1], lo, hi);
-        }
-    }
-}
-
-// the fast form (packet_walk_fast) for two rays per lane: the 128 walks of the wave nest like 64 do
-template <int NEG>
-__device__ __forceinline__ void packet_walk_fast2(const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra_, const RayBoxCtx& ca,
-                                                  const Ray& rb_, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
-    const char* __restrict__ base = reinterpret_cast<const char*>(s.nodesAll + (size_t)order * (size_t)s.bvhSize);
-    const unsigned end = (unsigned)s.bvhSize;
-    const vf2 aoxy = { ca.o.x, ca.o.y }, aozz = { ca.o.z, ca.o.z }, adxy = { ca.dinv.x, ca.dinv.y }, adzz = { ca.dinv.z, ca.dinv.z };
-    const vf2 boxy = { cb.o.x, cb.o.y }, bozz = { cb.o.z, cb.o.z }, bdxy = { cb.dinv.x, cb.dinv.y }, bdzz = { cb.dinv.z, cb.dinv.z };
-    unsigned nextA = mineA ? 0u : end, nextB = mineB ? 0u : end;
-    unsigned c = 0;
-    float4 ra = *reinterpret_cast<const float4*>(base), rb = *reinterpret_cast<const float4*>(base + 16);
-    const float marginA = overlap_margin(ca.o, ca.dinv, ra, rb), marginB = overlap_margin(cb.o, cb.dinv, ra, rb);
-    while (c != end) {
-        const int prim = __float_as_int(rb.z);
-        const unsigned nxt = (unsigned)__float_as_int(rb.w);
-        float4 pa = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u), pb = *reinterpret_cast<const float4*>(base + (c + 1u) * 32u + 16u);
-        unsigned target = nxt;                                // wave-uniform: the record the wave reads next
-        bool took = false;
-        const SlabT sa = slabs(aoxy, aozz, adxy, adzz, ra, rb), sb = slabs(boxy, bozz, bdxy, bdzz, ra, rb);
-        float chordA, chordB;
-        const bool nearA = slab_distance_part<NEG>(sa, nextA == c, wa.closest, chordA), nearB = slab_distance_part<NEG>(sb, nextB == c, wb.closest, chordB);
-        const unsigned long long nearMaskA = __builtin_amdgcn_ballot_w64(nearA), nearMaskB = __builtin_amdgcn_ballot_w64(nearB);
-        if ((nearMaskA | nearMaskB) != 0ull) {
-            bool inA = nearA, inB = nearB;
-            unsigned long long enteredMask = nearMaskA | nearMaskB;
-            if (((nearMaskA & __builtin_amdgcn_ballot_w64(!(chordA > marginA))) | (nearMaskB & __builtin_amdgcn_ballot_w64(!(chordB > marginB)))) != 0ull) {
-                inA = slab_overlap_part<NEG>(sa, nearA); inB = slab_overlap_part<NEG>(sb, nearB);
-                enteredMask = __builtin_amdgcn_ballot_w64(inA) | __builtin_amdgcn_ballot_w64(inB);
-            }
-            if (enteredMask != 0ull) {
-                if (prim != kNullPrim) {
-                    const float4* tp = reinterpret_cast<const float4*>(s.tris + prim);
-                    const float4 a = tp[0], b = tp[1], e = tp[2];
-                    float bx, by, dist;
-                    if (inA) { if (tri_hit<true>(ra_.o, ra_.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wa.closest) { wa.closest = dist; wa.bx = bx; wa.by = by; wa.prim = prim; } }
-                    if (inB) { if (tri_hit<true>(rb_.o, rb_.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(e.x, e.y, e.z), bx, by, dist) && dist < wb.closest) { wb.closest = dist; wb.bx = bx; wb.by = by; wb.prim = prim; } }
-                }
-                nextA = inA ? c + 1u : max(nextA, nxt);
-                nextB = inB ? c + 1u : max(nextB, nxt);
-                target = c + 1u; took = true;
-            }
-        }
-        if (!took) {
-            nextA = max(nextA, nxt); nextB = max(nextB, nxt);
-            pa = *reinterpret_cast<const float4*>(base + nxt * 32u); pb = *reinterpret_cast<const float4*>(base + nxt * 32u + 16u);
-        }
-        c = target; ra = pa; rb = pb;       // (one tail for both outcomes: with `continue` in the entered branch the compiler carried an undefined record index through the other)
-    }
-}
-
-__device__ __forceinline__ void packet_walk_fast2_dispatch(int neg, const DevScene& s, int order, bool mineA, bool mineB, const Ray& ra, const RayBoxCtx& ca,
-                                                           const Ray& rb, const RayBoxCtx& cb, WalkResult& wa, WalkResult& wb) {
-    switch (neg) {
-        case 0: packet_walk_fast2<0>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        case 1: packet_walk_fast2<1>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        case 2: packet_walk_fast2<2>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        case 3: packet_walk_fast2<3>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        case 4: packet_walk_fast2<4>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        case 5: packet_walk_fast2<5>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        case 6: packet_walk_fast2<6>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-        default: packet_walk_fast2<7>(s, order, mineA, mineB, ra, ca, rb, cb, wa, wb); break;
-    }
-}
-
-__device__ __forceinline__ void walk_two_packet(const DevScene& s, const Ray& ra, const Ray& rb, bool activeA, bool activeB, WalkResult& wa, WalkResult& wb) {
-    wa.closest = wb.closest = 3.402823466e+38f; wa.prim = wb.prim = kNullPrim; wa.bx = wa.by = wb.bx = wb.by = 0.f; wa.any = wb.any = false;
-    RayBoxCtx ca = make_box_ctx(ra), cb = make_box_ctx(rb);
-    ca.cull = cb.cull = s.axisCull;
-    const bool special = (activeA && (ca.mode != 0 || ca.zx || ca.zy || ca.zz || !(ra.d.x == ra.d.x))) || (activeB && (cb.mode != 0 || cb.zx || cb.zy || cb.zz || !(rb.d.x == rb.d.x)));
-    const bool anySpecial = __any(special);
-    const int oa = mtbvh_order(-ra.d), ob = mtbvh_order(-rb.d);
-    unsigned long long todoA = __ballot(activeA), todoB = __ballot(activeB);
-    while (todoA | todoB) {
-        int k;
-        if (todoA) k = __builtin_amdgcn_readlane(oa, __ffsll((long long)todoA) - 1);
-        else k = __builtin_amdgcn_readlane(ob, __ffsll((long long)todoB) - 1);
-        const bool mineA = activeA && oa == k && ((todoA >> __lane_id()) & 1ull), mineB = activeB && ob == k && ((todoB >> __lane_id()) & 1ull);
-        const unsigned long long ma = __ballot(mineA), mb = __ballot(mineB);
-        todoA &= ~ma; todoB &= ~mb;
-        // direction signs of all rays walked in this pass (both rays of every lane that takes part)
-        const unsigned long long px = __ballot((mineA && !(ra.d.x < 0.f)) || (mineB && !(rb.d.x < 0.f))), nx = __ballot((mineA && ra.d.x < 0.f) || (mineB && rb.d.x < 0.f));
-        const unsigned long long py = __ballot((mineA && !(ra.d.y < 0.f)) || (mineB && !(rb.d.y < 0.f))), ny = __ballot((mineA && ra.d.y < 0.f) || (mineB && rb.d.y < 0.f));
-        const unsigned long long pz = __ballot((mineA && !(ra.d.z < 0.f)) || (mineB && !(rb.d.z < 0.f))), nz = __ballot((mineA && ra.d.z < 0.f) || (mineB && rb.d.z < 0.f));
-        const bool uniformSigns = (px == 0 || nx == 0) && (py == 0 || ny == 0) && (pz == 0 || nz == 0);
-        if (anySpecial) packet_walk_order2<false>(s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
-        else if (uniformSigns && s.axisCull && s.linksNested) packet_walk_fast2_dispatch((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0), s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
-        else packet_walk_order2<true>(s, k, mineA, mineB, ra, ca, rb, cb, wa, wb);
-    }
-}
-
-// a Hit from a WalkResult (getIntersecGeomInfo, scene.h:135-151), as trace_closest_packet returns it
-__device__ __forceinline__ Hit hit_of_walk(const DevScene& s, const WalkResult& w) {
-    Hit h;
-    h.primId = w.prim;
-    h.matId = 0;
-    h.pos = splat(0.f);
-    h.norm = splat(0.f);
-    h.bx = w.bx; h.by = w.by;
-    if (w.prim != kNullPrim) {
-        const float* v = s.vertices + (size_t)w.prim * 9;
-        const float* n = s.normals + (size_t)w.prim * 9;
-        const float wgt = 1.f - w.bx - w.by;
-        h.pos = ld3(v + 3) * w.bx + ld3(v + 6) * w.by + ld3(v) * wgt;
-        h.norm = normalize(ld3(n + 3) * w.bx + ld3(n + 6) * w.by + ld3(n) * wgt);
-        h.matId = s.materialIds[w.prim];
-    }
-    return h;
-}
-
 // closest hit for a whole wave of INCOHERENT rays (bounce rays): per-lane walks of the reference's tree with the
 // pair-cooperative node fetch; every lane of the wave must call it, `active` false where there is no ray
 __device__ inline Hit trace_closest_wave(const DevScene& s, const Ray& ray, bool active) {
