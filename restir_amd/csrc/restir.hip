@@ -708,7 +708,16 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // that last used the set (or, for a second call within one frame, after everything enqueued so far), and the library
     // stream joins them before the temporal pass.  Their heavy-tile tails then overlap the other frame's passes.
     static const bool parityStreams = []{ const char* e = std::getenv("RS_PARITY_STREAMS"); return !(e && e[0] == '0'); }();
-    const hipStream_t aux = r->timing ? nullptr : rs_aux_stream(parityStreams ? 1 + r->chain : 1);
+    // A launch below three rounds of wave slots lasts as long as its slowest wave, so what bounds a strip's frame rate is the
+    // length of the chain over the number of chains in flight.  Such a frame takes the fused launch -- nothing then runs on the
+    // render's stream -- and that stream becomes a third chain (RS_SMALL_CHAINS=0: two chains and a separate render, as for large launches).
+    static const bool smallChains = []{ const char* e = std::getenv("RS_SMALL_CHAINS"); return !(e && e[0] == '0'); }();
+    const bool small = smallChains && parityStreams && !r->timing && !rs_sync_enabled() && rs_fuse_mode() == 3 && r->phaseACalls == 0 &&
+                       g->deferred.valid && g->deferred.scene == scene && std::memcmp(&g->deferred.cam, cam, sizeof(rs_camera)) == 0 &&
+                       g->deferred.y0 <= y0 && g->deferred.y1 >= y1 &&
+                       (long long)((r->width + 31) / 32) * ((g->deferred.y1 - g->deferred.y0 + 7) / 8) * 4 < kFuseMinWaves;
+    static const int kSmallStream[rs_restir::kSmallChains] = { 1, 2, 0 };
+    const hipStream_t aux = r->timing ? nullptr : rs_aux_stream(small ? kSmallStream[r->smallChain] : parityStreams ? 1 + r->chain : 1);
     const hipStream_t st = aux ? aux : rs_stream();
     if (aux) {
         if (r->phaseACalls > 0) {
@@ -738,7 +747,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const int fuseMode = rs_fuse_mode();
     bool fuse = aux && fuseMode != 0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
                 (fuseMode == 2 || (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves);
-    if (fuse && fuseMode == 3) {                                  // measured choice (end_frame advances the measurement)
+    if (small && aux) fuse = true;
+    else if (fuse && fuseMode == 3) {                             // measured choice (end_frame advances the measurement)
         if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
         r->tuneCounted = true;
         fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
@@ -845,6 +855,7 @@ int rs_restir_end_frame(rs_restir* r) {
     else r->surfFreeValid[r->surfSet] = false;
     r->surfSet = (r->surfSet + 1) % rs_restir::kSurfSets;
     r->chain = (r->chain + 1) % rs_restir::kChains;
+    r->smallChain = (r->smallChain + 1) % rs_restir::kSmallChains;
     r->phaseACalls = 0;
     // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA, kTuneB and kTuneC begin (two
     // launches in the first span, one fused launch in the second); at frame kTuneC the host waits once for the last stamp (the GPU

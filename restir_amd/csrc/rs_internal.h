@@ -4,6 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#ifndef RS_GBUF_SETS
+#define RS_GBUF_SETS 5
+#endif
+#ifndef RS_SURF_SETS
+#define RS_SURF_SETS 4
+#endif
 #include <vector>
 
 #include "rs_scene.h"
@@ -103,26 +109,28 @@ struct rs_scene {
 
 // ---- G-buffer (src/gbuffer.h:41-58) ------------------------------------------------------------
 // The reference keeps two sets of the id / normal / depth planes and toggles frameIdx.  Here all planes live in a ring of
-// three sets: the set of the frame being rendered, of the previous frame ("last" planes) and a free one, so that the next
-// frame's render (auxiliary stream) never writes what this frame's temporal pass still reads.  frameIdx is still toggled
+// five sets: the set of the previous frame ("last" planes), of the frame whose passes the library stream is at, and of up to
+// three frames whose renders run ahead on the auxiliary streams (a strip has three chains in flight, each with the frame's render
+// in its first launch), so that no render writes what an earlier frame's temporal pass still reads.  frameIdx is still toggled
 // and reported by rs_gbuffer_get_view, whose devNormal[frameIdx] / [frameIdx ^ 1] are the current / last sets.
 struct rs_gbuffer {
     rs_context* ctx = nullptr;
-    static constexpr int kSets = 3;
-    float* albedo[kSets] = { nullptr, nullptr, nullptr };
-    int* motion[kSets] = { nullptr, nullptr, nullptr };
-    float* normal[kSets] = { nullptr, nullptr, nullptr };
-    int* primId[kSets] = { nullptr, nullptr, nullptr };
-    float* depth[kSets] = { nullptr, nullptr, nullptr };
-    int ring = 0;                // set of the current frame; the previous frame's is (ring + 2) % 3
+    static constexpr int kSets = RS_GBUF_SETS;
+    float* albedo[kSets] = {};
+    int* motion[kSets] = {};
+    float* normal[kSets] = {};
+    int* primId[kSets] = {};
+    float* depth[kSets] = {};
+    int ring = 0;                // set of the current frame; the previous frame's is (ring + kSets - 1) % kSets
     int frameIdx = 0;
     rs_camera lastCamera{};      // uninitialised in the reference until the first update (Q14); zero here
     int width = 0, height = 0;
     // ordering of a render on the auxiliary stream (asynchronous mode)
     hipEvent_t forkEv = nullptr;             // "everything enqueued on the library stream so far"
     hipEvent_t doneEv = nullptr;             // the render
-    hipEvent_t useEv[kSets] = { nullptr, nullptr, nullptr };   // recorded by update(): the frame that ended there has been enqueued
-    int useOf[kSets] = { -1, -1, -1 };       // per set: which useEv covers its last readers (-1: none outstanding)
+    hipEvent_t useEv[kSets] = {};   // recorded by update(): the frame that ended there has been enqueued
+    int useOf[kSets];       // per set: which useEv covers its last readers (-1: none outstanding)
+    rs_gbuffer() { for (int i = 0; i < kSets; i++) useOf[i] = -1; }
     int updates = 0;
     bool renderedSinceUpdate = false;
     mutable bool pending = false;            // a render on the auxiliary stream has not been joined yet
@@ -241,8 +249,11 @@ struct rs_restir {
     // streams in turn, so that consecutive frames' chains overlap: on a 1/8 strip a chain lasts 0.4 ms however few rows it has.
     // A chain writes one of kSurfSets sets of surface planes, which the frame's temporal / spatial passes read afterwards; with as
     // many sets as chains a chain would have to wait until those passes of the frame two back have finished, with one more it
-    // starts as soon as its stream is free.  (Three chains, i.e. five streams on the runtime's four hardware queues: slower.)
-    static constexpr int kChains = 2, kSurfSets = 3;
+    // starts as soon as its stream is free.  A third chain next to the render's stream would be a fifth stream on the runtime's
+    // four hardware queues (slower).  A small launch -- a strip, whose kernels last as long as their slowest wave -- therefore
+    // takes the fused launch (render + primary rays, k_gbuffer_primary), after which nothing runs on the render's stream, and
+    // gives that stream to a third chain (kSmallChains; restir.hip phase_a_impl): 8 strips of 1080p 5.96x -> 6.5x.
+    static constexpr int kChains = 2, kSmallChains = 3, kSurfSets = RS_SURF_SETS;
     int width = 0, height = 0;
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
@@ -260,7 +271,7 @@ struct rs_restir {
         float4* candLi = nullptr;    // RIS winner: Li xyz, w = dist
         float4* candWi = nullptr;    // RIS winner: wi xyz, w = weight (sum of candidate weights)
     } surf[kSurfSets];
-    int surfSet = 0, chain = 0;      // of the frame in flight
+    int surfSet = 0, chain = 0, smallChain = 0;      // of the frame in flight
     hipEvent_t surfFree[kSurfSets] = {};             // recorded by end_frame: the frame that used the set has been enqueued
     bool surfFreeValid[kSurfSets] = {};
     hipEvent_t auxFork = nullptr, auxDone = nullptr;
