@@ -119,8 +119,8 @@ typedef struct rs_eaw     rs_eaw;      /* = LeveledEAWFilter                 (sr
 typedef struct rs_svgf    rs_svgf;     /* = SpatioTemporalFilter             (src/denoiser.h:45-70) */
 
 /* Device pointers of a GBuffer's planes (src/gbuffer.h:41-58): [frameIdx] = this frame's, [frameIdx ^ 1] = last frame's.
- * The library keeps the planes in a ring of three sets (so that the next frame's render never overwrites what this frame's
- * temporal pass reads): the pointers are those of the current frame and change at every rs_gbuffer_update -- fetch the
+ * The library keeps the planes in a ring of five sets (so that the renders of the next frames, which run ahead of the library
+ * stream, never overwrite what this frame's temporal pass reads): the pointers are those of the current frame and change at every rs_gbuffer_update -- fetch the
  * view again after it. */
 typedef struct rs_gbuffer_view {
     float* devAlbedo;        /* float[3] / px */
@@ -153,9 +153,10 @@ int  rs_set_stream(void* hipStream);
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);
 /* With rs_set_sync(0), frames overlap: GBuffer::render goes to an internal stream, the primary-ray -> RIS -> shadow-ray kernels of
- * ReSTIRDirect to two more, frames taking them in turn (a full-size frame's shadow rays stay on the library stream); each is
- * ordered only after the work that last used its buffers (G-buffer planes in a ring of three, per-frame surface planes in
- * three sets) and joined into the library stream where its results are first read (the temporal pass, the denoisers,
+ * ReSTIRDirect to two more, frames taking them in turn (a full-size frame's shadow rays stay on the library stream; a frame that
+ * fills the chip less than three times over -- a strip -- renders in the same launch as its primary rays and has three such chains); each is
+ * ordered only after the work that last used its buffers (G-buffer planes in a ring of five, per-frame surface planes in
+ * four sets) and joined into the library stream where its results are first read (the temporal pass, the denoisers,
  * rs_gbuffer_get_view, rs_synchronize).  They then run next to the previous frames' temporal / spatial
  * passes.  Results are identical; output buffers are valid in library-stream order as before.  GBuffer::render can in addition
  * be deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal:

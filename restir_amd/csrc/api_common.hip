@@ -41,9 +41,10 @@ bool rs_sync_enabled() { return rs_ctx()->sync; }
 
 // Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 + k the primary-ray + RIS + shadow-ray kernels of every
 // kChains-th frame (frames take the chains in turn, so that these chains of consecutive frames overlap each other
-// as well as the passes of the frames before).
+// as well as the passes of the frames before); for small launches, whose render is part of the chain's first launch, stream 0 is
+// a third chain.
 // Neither reads what the temporal / spatial passes of the previous frame write, so with the per-frame surface planes
-// in three sets and the G-buffer planes in a ring of three they run next to those passes; the objects own the events
+// in four sets and the G-buffer planes in a ring of five they run next to those passes; the objects own the events
 // that order them (rs_gbuffer, rs_restir).
 // The auxiliary stream i of the current context, or nullptr when launches are synchronous (rs_set_sync(1): nothing to overlap)
 // or the feature is off (rs_set_side_stream(0) / RS_SIDE_STREAM=0).
