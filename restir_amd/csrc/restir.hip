@@ -708,16 +708,34 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // that last used the set (or, for a second call within one frame, after everything enqueued so far), and the library
     // stream joins them before the temporal pass.  Their heavy-tile tails then overlap the other frame's passes.
     static const bool parityStreams = []{ const char* e = std::getenv("RS_PARITY_STREAMS"); return !(e && e[0] == '0'); }();
-    // A launch below three rounds of wave slots lasts as long as its slowest wave, so what bounds a strip's frame rate is the
-    // length of the chain over the number of chains in flight.  Such a frame takes the fused launch -- nothing then runs on the
-    // render's stream -- and that stream becomes a third chain (RS_SMALL_CHAINS=0: two chains and a separate render, as for large launches).
+    const bool asyncMode = !r->timing && rs_aux_stream(1) != nullptr;
+    const int W = r->width;
+    const int tilesX = (W + 31) / 32, tilesY = (y1 > y0 ? y1 - y0 + 7 : 0) / 8;
+    // A render of this frame that rs_gbuffer_render_rows deferred (asynchronous mode) can be launched here, in ONE launch with the
+    // primary rays (k_gbuffer_primary): same scene and camera, rows that contain the rows shaded here.
+    //  * A launch that fills the chip at least three times over: ~5 % less work than two launches, longer waves; the frame period is
+    //    measured both ways once per scene and the faster form kept (full 1080p frame: the fused launch, by 0.5 %).
+    //  * A smaller launch -- a strip -- lasts as long as its slowest wave, and what bounds its frame rate is the length of the chain
+    //    primary rays -> RIS -> shadow rays over the number of chains in flight.  With two chains the fused launch loses (its slowest
+    //    wave: 0.25 ms against 0.18 on a 1/8 strip), but it leaves the render's stream idle, and with that stream as a THIRD chain
+    //    it wins: 8 strips of 1080p 5.96x -> 6.5x (RS_SMALL_CHAINS=0: two chains and a separate render).
+    // Whenever the launch is fused the frame's chain is one of three (a full frame gains another 0.9 % from the third).
     static const bool smallChains = []{ const char* e = std::getenv("RS_SMALL_CHAINS"); return !(e && e[0] == '0'); }();
-    const bool small = smallChains && parityStreams && !r->timing && !rs_sync_enabled() && rs_fuse_mode() == 3 && r->phaseACalls == 0 &&
-                       g->deferred.valid && g->deferred.scene == scene && std::memcmp(&g->deferred.cam, cam, sizeof(rs_camera)) == 0 &&
-                       g->deferred.y0 <= y0 && g->deferred.y1 >= y1 &&
-                       (long long)((r->width + 31) / 32) * ((g->deferred.y1 - g->deferred.y0 + 7) / 8) * 4 < kFuseMinWaves;
-    static const int kSmallStream[rs_restir::kSmallChains] = { 1, 2, 0 };
-    const hipStream_t aux = r->timing ? nullptr : rs_aux_stream(small ? kSmallStream[r->smallChain] : parityStreams ? 1 + r->chain : 1);
+    const rs_gbuffer::Deferred& d = g->deferred;
+    const int fuseMode = rs_fuse_mode();
+    const bool fusable = asyncMode && fuseMode != 0 && y1 > y0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 &&
+                         d.y0 <= y0 && d.y1 >= y1;
+    const bool large = fusable && (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves;
+    const bool small = fusable && !large && smallChains && parityStreams && fuseMode == 3 && r->phaseACalls == 0;
+    bool fuse = fusable && (small || large || fuseMode == 2);
+    if (fuse && large && fuseMode == 3) {                         // measured choice (end_frame advances the measurement)
+        if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
+        r->tuneCounted = true;
+        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
+    }
+    static const int kThreeStreams[rs_restir::kSmallChains] = { 1, 2, 0 };
+    const bool three = fuse && parityStreams && r->phaseACalls == 0;
+    const hipStream_t aux = asyncMode ? rs_aux_stream(three ? kThreeStreams[r->smallChain] : parityStreams ? 1 + r->chain : 1) : nullptr;
     const hipStream_t st = aux ? aux : rs_stream();
     if (aux) {
         if (r->phaseACalls > 0) {
@@ -732,27 +750,9 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         if (aux) { RS_HIP(hipEventRecord(r->auxDone, aux)); RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0)); }
         return 0;
     }
-    const int W = r->width;
-    const int tilesX = (W + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
     const SurfPlanes sp = surf_of(r);
     const CamParams cp = rs_make_cam_params(cam);
     mark(r, 0);
-    // a render of this frame that rs_gbuffer_render_rows deferred (asynchronous mode) is launched here, together with the primary
-    // rays: same scene and camera, rows that contain the rows shaded here
-    // ... and a launch large enough to be bound by throughput: with the two rays of a pixel in one wave the launch does ~5 % less
-    // work than two launches, but its waves are longer (an 8x4 block's 64 rays of two kinds: 253 us against 184 for the slowest tile
-    // of a 1/8 strip), and a launch of less than a few rounds of wave slots lasts as long as its slowest wave: on a full 1080p frame
-    // (64 800 waves over 8 192 slots) the frame gains 0.5 %, on a 1/8 strip it loses 15 % (tools/strip_quick.py, RS_SS=3 against 4)
-    const rs_gbuffer::Deferred& d = g->deferred;
-    const int fuseMode = rs_fuse_mode();
-    bool fuse = aux && fuseMode != 0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 && d.y0 <= y0 && d.y1 >= y1 &&
-                (fuseMode == 2 || (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves);
-    if (small && aux) fuse = true;
-    else if (fuse && fuseMode == 3) {                             // measured choice (end_frame advances the measurement)
-        if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
-        r->tuneCounted = true;
-        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
-    }
     if (fuse) {
         RS_TRY(rs_gbuffer_order_before_render(g, aux));
         rs_gbuffer_deferred_taken(g);
