@@ -859,7 +859,7 @@ int rs_restir_end_frame(rs_restir* r) {
     r->phaseACalls = 0;
     // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA, kTuneB and kTuneC begin (two
     // launches in the first span, one fused launch in the second); at frame kTuneC the host waits once for the last stamp (the GPU
-    // still has that frame's predecessors queued) and the shorter span decides, with 3 % in favour of two launches.  A caller that
+    // still has that frame's predecessors queued) and the shorter span decides.  A caller that
     // times frames runs kTuneC + 1 frames first (bench.py does, before its warm-up) and then sees one launch form only.
     if (r->tuneCounted && r->tuneChoice < 0) {
         const int f = ++r->tuneFrame;
@@ -868,7 +868,7 @@ int rs_restir_end_frame(rs_restir* r) {
             float separate = 0.f, fused = 0.f;
             if (hipEventSynchronize(r->tuneEv[2]) == hipSuccess && hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess &&
                 hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
-                r->tuneChoice = fused < 0.97f * separate ? 1 : 0;
+                r->tuneChoice = fused < separate ? 1 : 0;
             else { (void)hipGetLastError(); r->tuneChoice = 0; }
         }
     }
