@@ -172,6 +172,10 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
     Rng rng; rng.x = sp.rngMat[index].x;
     f3 selLi = splat(0.f), selWi = splat(0.f);
     float selDist = 0.f, wsum = 0.f;
+    // Without an environment map every winner is a triangle-light sample: the loop carries its light and barycentric pair (three
+    // conditional moves per candidate instead of seven) and the sample is evaluated again after the loop (light_sample_again).
+    int selId = -1;
+    float selU = 0.f, selV = 0.f;
     for (int i = 0; i < kReservoirSize; i++) {
         f4 r = rng.uniform4();
         LightSample c = sample_light_nv<ENV, AliasPtr, LightPtr>(s, alias, lights, s.numLights, pos, r);
@@ -180,8 +184,12 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
         if (is_nan_or_inf(weight) || c.pdf <= 0.f) weight = 0.f;
         float u = rng.uniform();
         wsum += weight;                                    // Reservoir::update (restir.h:38-44)
-        if (u * wsum < weight) { selLi = c.Li; selWi = c.wi; selDist = c.dist; }
+        if (u * wsum < weight) {
+            if (ENV) { selLi = c.Li; selWi = c.wi; selDist = c.dist; }
+            else { selId = c.id; selU = c.bu; selV = c.bv; }
+        }
     }
+    if (!ENV && selId >= 0) light_sample_again(lights, selId, selU, selV, pos, selLi, selWi, selDist);
     sp.candLi[index] = make_float4(selLi.x, selLi.y, selLi.z, selDist);
     sp.candWi[index] = make_float4(selWi.x, selWi.y, selWi.z, wsum);
     reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;

@@ -1042,7 +1042,7 @@ RS_HD f3 eval_bsdf(int type, f3 baseColor, float metallic, float roughness, f3 n
 }
 
 // ---- light sampling (src/scene.h:394-459, src/sampler.h:203-207, src/mathUtil.h:94-100,182-185) --
-struct LightSample { float pdf; f3 Li, wi; float dist; f3 point; int id; };
+struct LightSample { float pdf; f3 Li, wi; float dist; f3 point; int id; float bu, bv; };     // bu, bv: the barycentric pair of sampleTriangleUniform
 
 #if defined(__HIPCC__)
 // sampleDirectLightNoVisibility; `lights`/`alias` may point to global memory or to an LDS copy.

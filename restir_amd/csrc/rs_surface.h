@@ -170,7 +170,7 @@ __device__ __forceinline__ void load_light(LightQuarters<N> lights, int id, floa
 template <bool ENV, typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasPtr alias, LightPtr lights, int numLights, f3 pos, f4 r) {
     LightSample o;
-    o.pdf = kInvalidPdf; o.Li = splat(0.f); o.wi = splat(0.f); o.dist = 0.f; o.point = splat(0.f); o.id = 0;
+    o.pdf = kInvalidPdf; o.Li = splat(0.f); o.wi = splat(0.f); o.dist = 0.f; o.point = splat(0.f); o.id = 0; o.bu = o.bv = 0.f;
     if (numLights == 0) return o;
     int pass = imin(f2i((float)numLights * r.x), numLights - 1);      // DevDiscreteSampler1D::sample
     AliasRec al = alias[pass];
@@ -190,7 +190,7 @@ __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasP
     float u = 1.f - sr;
     float v = r.z * sr;
     f3 sampled = v1 * u + v2 * v + v0 * (1.f - u - v);
-    o.point = sampled;
+    o.point = sampled; o.bu = u; o.bv = v;
     f3 toS = sampled - pos;
     if (dot(nrm, toS) > -1e-6f) return o;          // SCENE_LIGHT_SINGLE_SIDED
     float dd = dot(toS, toS);
@@ -200,6 +200,21 @@ __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasP
     o.dist = len;
     o.pdf = d.w * dd / gabs(-dot(nrm, o.wi));
     return o;
+}
+
+// The Li / wi / dist of an accepted triangle-light sample again, from its light and barycentric pair: the same expressions in the same
+// order as above, hence the same bits.  Lets a reservoir loop carry three values per winner instead of seven.
+template <typename LightPtr>
+__device__ __forceinline__ void light_sample_again(LightPtr lights, int id, float u, float v, f3 pos, f3& Li, f3& wi, float& dist) {
+    float4 a, b, c, d;
+    load_light(lights, id, a, b, c, d);
+    const f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
+    const f3 sampled = v1 * u + v2 * v + v0 * (1.f - u - v);
+    const f3 toS = sampled - pos;
+    const float len = sqrtf(dot(toS, toS));
+    Li = mk3(d.x, d.y, d.z);
+    wi = toS * (1.f / len);
+    dist = len;
 }
 
 // sampleDirectLight (src/scene.h:427-459): like the NoVisibility form, but with an occlusion test to
