@@ -562,10 +562,10 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
         // walk phase: a tight loop until some lane's leaf queue is full or every walk has ended
         while (__any(cur != endOff)) {
             RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
-            if (cur != endOff) {
+            {   // every lane, also one whose walk has ended: it reads the record past the end, an empty box linked to itself (scene.hip)
                 const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
 #ifdef RS_WALK_STATS
-                if (s.walkStats && s.occDepth) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
+                if (s.walkStats && s.occDepth && cur != endOff) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
 #endif
 #if RS_OCC_PERM
                 const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);

@@ -79,8 +79,11 @@ int build_occlusion_side(rs_scene* s) {
     s->dev.occNested = s->dev.axisCull;          // a proper hierarchy is in particular nested
     s->dev.occRootLo = ld3(&s->hBoxes[(size_t)root * 6]);
     s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
-    RS_TRY(rs_dev_alloc(&s->dOccNodes, no));
-    RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), no * 16, hipMemcpyHostToDevice));
+    // one record past the end: an empty box (lo = 65535 > hi = 0 on every axis fails the slab test for either sign of the direction)
+    // whose link is its own offset -- a lane whose walk has ended stays there, so the walk loop needs no "has this lane ended" region
+    packed.push_back(0xffffffffu); packed.push_back(0x0000ffffu); packed.push_back(0u); packed.push_back((unsigned)(no * 16));
+    RS_TRY(rs_dev_alloc(&s->dOccNodes, no + 1));
+    RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), (no + 1) * 16, hipMemcpyHostToDevice));
     RS_TRY(upload(&s->dOccChain, chain));
     RS_TRY(upload(&s->dOccTris, rec));
 #ifdef RS_WALK_STATS
