@@ -433,6 +433,10 @@ int  rs_eaw_destroy(rs_eaw* f);
  * holds (src/denoiser.cu:463-477), and so does rs_eaw_filter. */
 int  rs_eaw_set_params(rs_eaw* f, float sigLumin, float sigNormal, float sigDepth, int level);
 int  rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level);
+/* The levels of step 1, 2 and 4 read their 25 taps from an LDS tile of the block's pixels plus halo (default, 15 % faster per
+ * filter call at 1080p) or gather them from memory like the levels of step 8 and 16 (0).  Same arithmetic in the same order: the
+ * results are identical bit for bit (tests/test_gpu_parity.py test_eaw_tiled_levels_equal_plain_gathers). */
+int  rs_eaw_set_tiled(rs_eaw* f, int tiled);
 /* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
  * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
 int  rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);

@@ -118,7 +118,7 @@ EXPORTS = [
     "rs_restir_enable_timing", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_write_png", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
-    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
+    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_exchange_history", "rs_strips_gather",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
@@ -237,6 +237,7 @@ def lib():
         getattr(L, name).argtypes = [vp, C.c_float, C.c_float, C.c_float, ci]
     for name in ("rs_eaw_get_params", "rs_svgf_get_params"):
         getattr(L, name).argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(ci)]
+    L.rs_eaw_set_tiled.argtypes = [vp, ci]
     L.rs_eaw_destroy.argtypes = [vp]
     L.rs_eaw_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
     L.rs_eaw_positions_rows.argtypes = [vp, vp, C.POINTER(Camera), ci, ci]
@@ -801,6 +802,10 @@ class EAWFilter:
     def set_params(self, sig_lumin, sig_normal, sig_depth, level=5):
         """waveletFilter.sigLumin / sigNormal / sigDepth and level, the members the viewer edits (src/preview.cpp:262-265)."""
         check(lib().rs_eaw_set_params(self.handle, sig_lumin, sig_normal, sig_depth, level))
+
+    def set_tiled(self, tiled):
+        """Levels of step 1, 2, 4 from an LDS tile (default) or as plain gathers; same bits."""
+        check(lib().rs_eaw_set_tiled(self.handle, int(bool(tiled))))
 
     def get_params(self):
         a, b, c, lv = C.c_float(), C.c_float(), C.c_float(), C.c_int()

@@ -81,6 +81,68 @@ __global__ void __launch_bounds__(256) k_wavelet(float* __restrict__ colorOut, c
     st3(colorOut + (size_t)idxP * 3, sumW == 0.f ? colorP : sum / sumW);
 }
 
+// The same level for steps 1, 2 and 4 with the block's 32x8 pixels plus the 2 * STEP halo staged in LDS once (id, normal, colour,
+// position: 40 B per pixel as two 16-byte and one 8-byte record): the 25 taps of a pixel are LDS reads instead of 25 x 10 gathers
+// through L1, which is what bounds the plain form.  Same arithmetic in the same order: same bits.
+template <int STEP, int MUL>
+__global__ void __launch_bounds__(256) k_wavelet_tiled(float* __restrict__ colorOut, const float* __restrict__ colorIn,
+                                                       const int* __restrict__ primId, const float* __restrict__ normal,
+                                                       const float* __restrict__ pos, int W, int H,
+                                                       float sigDepth, float sigNormal, float sigLumin, int y0, int y1) {
+    constexpr int kHaloT = 2 * STEP, kRW = 32 + 2 * kHaloT, kRH = 8 + 2 * kHaloT, kRN = kRW * kRH;
+    __shared__ float4 sColId[kRN];          // colour xyz, id bits
+    __shared__ float4 sNormPx[kRN];         // normal xyz, position x
+    __shared__ float2 sPyz[kRN];            // position y, z
+    const int ox = blockIdx.x * 32 - kHaloT, oy = y0 + blockIdx.y * 8 - kHaloT;
+    for (int e = threadIdx.x; e < kRN; e += 256) {
+        const int gx = ox + e % kRW, gy = oy + e / kRW;
+        float4 a = make_float4(0.f, 0.f, 0.f, __int_as_float(-3)), b = make_float4(0.f, 0.f, 0.f, 0.f);      // id -3 matches no pixel
+        float2 c = make_float2(0.f, 0.f);
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            const size_t q = (size_t)gy * W + gx;
+            const f3 col = ld3(colorIn + q * 3), n = ld3(normal + q * 3), p = ld3(pos + q * 3);
+            a = make_float4(col.x, col.y, col.z, __int_as_float(primId[q]));
+            b = make_float4(n.x, n.y, n.z, p.x);
+            c = make_float2(p.y, p.z);
+        }
+        sColId[e] = a; sNormPx[e] = b; sPyz[e] = c;
+    }
+    __syncthreads();
+    const float rLumin = 1.f / sigLumin, rNormal = 1.f / sigNormal, rDepth = 1.f / sigDepth;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x = blockIdx.x * 32 + tx, y = y0 + blockIdx.y * 8 + ty;
+    if (x >= W || y >= y1) return;
+    const int idxP = y * W + x, lp = (ty + kHaloT) * kRW + tx + kHaloT;
+    const float4 pa = sColId[lp], pb = sNormPx[lp];
+    const float2 pc = sPyz[lp];
+    const int idP = __float_as_int(pa.w);
+    const f3 colorP = mk3(pa.x, pa.y, pa.z);
+    if (idP <= kNullPrim) { st3(colorOut + (size_t)idxP * 3, colorP); return; }
+    const f3 normP = mk3(pb.x, pb.y, pb.z), posP = mk3(pb.w, pc.x, pc.y);
+    f3 sum = splat(0.f);
+    float sumW = 0.f;
+#pragma unroll
+    for (int i = -2; i <= 2; i++) {
+#pragma unroll
+        for (int j = -2; j <= 2; j++) {
+            const int lq = lp + i * STEP * kRW + j * STEP;
+            const float4 qa = sColId[lq];
+            if (__float_as_int(qa.w) != idP) continue;         // also a tap outside the image (id -3)
+            const float4 qb = sNormPx[lq];
+            const float2 qc = sPyz[lq];
+            const f3 colorQ = mk3(qa.x, qa.y, qa.z);
+            const f3 dc = colorP - colorQ, dn = normP - mk3(qb.x, qb.y, qb.z), dp = posP - mk3(qb.w, qc.x, qc.y);
+            const float eC = (MUL & 1) ? dot(dc, dc) * rLumin : dot(dc, dc) / sigLumin;
+            const float eN = (MUL & 2) ? dot(dn, dn) * rNormal : dot(dn, dn) / sigNormal;
+            const float eP = (MUL & 4) ? dot(dp, dp) * rDepth : dot(dp, dp) / sigDepth;
+            const float w = expf(-(eC + eN + eP)) * kGaussian5x5[i + 2][j + 2];
+            sum = sum + colorQ * w;
+            sumW += w;
+        }
+    }
+    st3(colorOut + (size_t)idxP * 3, sumW == 0.f ? colorP : sum / sumW);
+}
+
 __global__ void __launch_bounds__(256) k_modulate(float* __restrict__ image, const float* __restrict__ albedo, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -238,12 +300,19 @@ int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer
     dim3 grid((f->width + 31) / 32, (y1 - y0 + 7) / 8);
     const auto pow2 = [](float v) { int e; return v > 0.f && std::isfinite(v) && std::frexp(v, &e) == 0.5f && 1.f / v > 0.f && std::isfinite(1.f / v) && std::isnormal(1.f / v); };
     const int mul = (pow2(f->sigLumin) ? 1 : 0) | (pow2(f->sigNormal) ? 2 : 0) | (pow2(f->sigDepth) ? 4 : 0);
-#define RS_WAVELET(M) hipLaunchKernelGGL(k_wavelet<M>, grid, dim3(256), 0, rs_stream(), out, in, g->primId[g->cur()], g->normal[g->cur()], \
-                                         f->devPos, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin, level, y0, y1)
+#define RS_WAVELET_ARGS out, in, g->primId[g->cur()], g->normal[g->cur()], f->devPos, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin
+#define RS_WAVELET(M) do { \
+        if (tiled && level == 0) hipLaunchKernelGGL((k_wavelet_tiled<1, M>), grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, y0, y1); \
+        else if (tiled && level == 1) hipLaunchKernelGGL((k_wavelet_tiled<2, M>), grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, y0, y1); \
+        else if (tiled && level == 2) hipLaunchKernelGGL((k_wavelet_tiled<4, M>), grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, y0, y1); \
+        else hipLaunchKernelGGL(k_wavelet<M>, grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, level, y0, y1); } while (0)
+    static const bool tiledEnv = []{ const char* e = std::getenv("RS_EAW_TILED"); return !(e && e[0] == '0'); }();
+    const bool tiled = tiledEnv && f->tiled;
     switch (mul) {
         case 0: RS_WAVELET(0); break; case 1: RS_WAVELET(1); break; case 2: RS_WAVELET(2); break; case 3: RS_WAVELET(3); break;
         case 4: RS_WAVELET(4); break; case 5: RS_WAVELET(5); break; case 6: RS_WAVELET(6); break; default: RS_WAVELET(7); break;
     }
+#undef RS_WAVELET_ARGS
 #undef RS_WAVELET
     return rs_after_launch("EAW Filter");
 }
@@ -278,6 +347,13 @@ int rs_eaw_set_params(rs_eaw* f, float sigLumin, float sigNormal, float sigDepth
     RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_set_params: null filter");
     f->sigLumin = sigLumin; f->sigNormal = sigNormal; f->sigDepth = sigDepth; f->level = level;
+    return 0;
+}
+// which form the levels of step 1, 2 and 4 take: 1 (default) the LDS tile, 0 the plain gathers -- same bits, for measurements and tests
+int rs_eaw_set_tiled(rs_eaw* f, int tiled) {
+    RS_SCOPE(f);
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_eaw_set_tiled: null filter");
+    f->tiled = tiled != 0;
     return 0;
 }
 int rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level) {

@@ -298,6 +298,7 @@ struct rs_eaw {
     float sigLumin = 64.f, sigNormal = .2f, sigDepth = 1.f;     // src/denoiser.cu:455
     float* devTempImg = nullptr;
     float* devPos = nullptr;        // per-pixel cam.getPosition(x,y,depth), computed once per filter call
+    bool tiled = true;              // levels of step 1, 2, 4 from an LDS tile (k_wavelet_tiled); rs_eaw_set_tiled, RS_EAW_TILED=0
 };
 
 // SpatioTemporalFilter (src/denoiser.h:45-70); EAWaveletFilter(width, height, 4, 128, 1) (src/denoiser.cu:488)

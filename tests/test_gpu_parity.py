@@ -585,6 +585,69 @@ def test_eaw_filter_with_edited_sigmas(hip):
     f.destroy()
 
 
+def test_eaw_tiled_levels_equal_plain_gathers(hip):
+    """The levels of step 1, 2 and 4 read their taps from an LDS tile (k_wavelet_tiled); the claim is the plain kernel's arithmetic in
+    the same order, so the filtered image must be the plain form's BIT FOR BIT -- checked directly, not through the oracle's rtol:
+    the default sigmas and two edited sets (other division / multiplication instantiations), a frame size that is no multiple of
+    the 32x8 block, and the row-strip form on a row range that starts in the middle of a block."""
+    import torch
+    sd = get_scene("sponza:0.03")
+    W, H = 157, 83
+    h = HipRenderer(hip, sd, W, H)
+    h.frame(3); h.frame(3)
+    h.gbuf.render(h.scene, h.cam)                        # the planes the filter reads are this frame's
+    f = hip.EAWFilter(W, H, 5)
+
+    def filtered(tiled):
+        f.set_tiled(tiled)
+        out = torch.zeros_like(h.image)
+        p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+        hip.synchronize()
+        res = torch.empty_like(h.image)
+        hip.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+        torch.cuda.synchronize()
+        return res.cpu().numpy()
+
+    for sig in (None, (3.7, 0.35, 0.6), (8.0, 0.25, 2.0)):
+        if sig is not None:
+            f.set_params(*sig, level=5)
+        a, b = filtered(True), filtered(False)
+        assert np.isfinite(a).all() and np.abs(a - h.image.cpu().numpy()).max() > 1e-4, sig      # the filter did something
+        assert bits_equal(a, b), (sig, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+    # row-strip form, rows [13, 70): level by level into full-frame buffers, tiled against plain
+    y0, y1 = 13, 70
+    outs = []
+    for tiled in (True, False):
+        f.set_tiled(tiled)
+        f.positions_rows(h.gbuf, h.cam, 0, H)
+        bufs = [torch.zeros_like(h.image), torch.zeros_like(h.image)]
+        src = h.image
+        for level in range(5):
+            # every level reads rows outside [y0, y1): give it a full-frame input (level 0: the image; later: the previous output
+            # over the whole frame, computed with the same form)
+            f.level_rows(bufs[level % 2].data_ptr(), src.data_ptr(), h.gbuf, level, 0, H)
+            src = bufs[level % 2]
+        full = src.clone()
+        part = torch.zeros_like(h.image)
+        # the last level once more on the row range only, from the same input: must equal those rows of the full-frame pass
+        last_in = bufs[(4 - 1) % 2]
+        f.level_rows(part.data_ptr(), last_in.data_ptr(), h.gbuf, 4, y0, y1)
+        hip.synchronize(); torch.cuda.synchronize()
+        assert bits_equal(part[y0 * W:y1 * W].cpu().numpy(), full[y0 * W:y1 * W].cpu().numpy())
+        outs.append(full.cpu().numpy())
+    assert bits_equal(outs[0], outs[1])
+    # a low level on a range that starts inside a block row, tiled against plain
+    rows = []
+    for tiled in (True, False):
+        f.set_tiled(tiled)
+        o = torch.zeros_like(h.image)
+        f.level_rows(o.data_ptr(), h.image.data_ptr(), h.gbuf, 1, y0, y1)
+        hip.synchronize(); torch.cuda.synchronize()
+        rows.append(o[y0 * W:y1 * W].cpu().numpy())
+    assert bits_equal(rows[0], rows[1])
+    f.destroy()
+
+
 def test_eaw_row_strip_form_equals_filter(hip):
     """rs_eaw_positions_rows + rs_eaw_level_rows (the form the strip tiling drives, restir_amd/tiling.py eaw_filter) over the
     whole frame, in bands, give the image of rs_eaw_filter bit for bit."""
