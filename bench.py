@@ -246,6 +246,7 @@ def main():
         frame()
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_form = backend.restir.last_launch()             # (fused, chains) of the timed frames' launches: read before any other mode runs
     counted = min(args.steps, 1024)
     # G-buffer rays: only the strip's own rows count (the +-5 halo rows a strip re-renders are overhead, not throughput)
     local_rays = backend.restir.ray_total(counted) / counted * args.steps + rows * WIDTH * args.steps
@@ -346,7 +347,10 @@ def main():
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
         }
-        out["config"]["launch_choice"] = {-2: "two launches (nothing to choose: launch too small to fuse)", -1: "not decided within this run", 0: "two launches", 1: "one fused launch"}[backend.restir.launch_choice()]
+        fused, chains = timed_form                            # what the timed frames launched, as the library reported it then
+        form = "one fused launch" if fused == 1 else "two launches"
+        how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
+        out["config"]["launch_choice"] = "%s (%s), chains on %d streams in turn" % (form, how, chains)
         out["config"]["calibration_frames_before_warmup"] = calibration_frames
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(sd, args.cpu_frames)

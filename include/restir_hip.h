@@ -291,6 +291,10 @@ int  rs_restir_end_frame(rs_restir* r);
  * primary rays as two launches, 1 as one, -1 still measuring (decided once 14 frames with such a launch have been enqueued; a
  * caller that times frames runs those first), -2 nothing to choose (synchronous launches, launches too small to fuse, a forced mode). */
 int  rs_restir_launch_choice(const rs_restir* r, int* choice);
+/* What the last rs_restir_phase_a / rs_restir_direct call launched, measured or not: *fused = 1 GBuffer::render in the primary rays'
+ * launch, 0 its own launch (-1 before the first call); *chains = how many internal streams the frames' chains take in turn (0 in
+ * synchronous mode).  A launch below three rounds of wave slots (a strip) is fused and on three chains without a measurement. */
+int  rs_restir_last_launch(const rs_restir* r, int* fused, int* chains);
 #define RS_SPATIAL_HALO_ROWS 5           /* taps reach y-4..y+5 (src/restir.cu:49-56) */
 /* bytes needed for `rows` rows of published reservoirs */
 size_t rs_restir_halo_bytes(const rs_restir* r, int rows);

@@ -744,6 +744,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     static const int kThreeStreams[rs_restir::kSmallChains] = { 1, 2, 0 };
     const bool three = fuse && parityStreams && r->phaseACalls == 0;
     const hipStream_t aux = asyncMode ? rs_aux_stream(three ? kThreeStreams[r->smallChain] : parityStreams ? 1 + r->chain : 1) : nullptr;
+    r->lastFused = fuse ? 1 : 0;
+    r->lastChains = !aux ? 0 : three ? rs_restir::kSmallChains : parityStreams ? rs_restir::kChains : 1;
     const hipStream_t st = aux ? aux : rs_stream();
     if (aux) {
         if (r->phaseACalls > 0) {
@@ -846,6 +848,15 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
 
 // 0 two launches, 1 one fused launch, -1 still measuring, -2 nothing to choose (no frame so far had a launch the choice applies to:
 // synchronous launches, launches below three rounds of wave slots, a forced mode)
+// what the last phase-A call actually launched: *fused = 1 the render in the primary rays' launch, 0 its own launch (or no render
+// pending); *chains = number of auxiliary streams the frames' chains take in turn (0: library stream only)
+int rs_restir_last_launch(const rs_restir* r, int* fused, int* chains) {
+    RS_SCOPE(r);
+    if (!r || !fused || !chains) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_last_launch: null argument");
+    *fused = r->lastFused; *chains = r->lastChains;
+    return 0;
+}
+
 int rs_restir_launch_choice(const rs_restir* r, int* choice) {
     RS_SCOPE(r);
     if (!r || !choice) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_launch_choice: null argument");

@@ -281,6 +281,7 @@ struct rs_restir {
     unsigned long long tuneSceneId = 0;
     int tuneFrame = 0;               // frames with a fusable launch since tuning began
     int tuneChoice = -1;             // -1 measuring, 0 separate, 1 fused
+    int lastFused = -1, lastChains = 0;   // form of the last phase-A launch: render fused with the primary rays? how many chain streams in turn? (rs_restir_launch_choice)
     bool tuneCounted = false;        // this frame had a launch the choice applies to
     hipEvent_t tuneEv[3] = { nullptr, nullptr, nullptr };
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
