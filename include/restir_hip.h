@@ -289,7 +289,8 @@ int  rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam
 int  rs_restir_end_frame(rs_restir* r);
 /* What the measurement of rs_set_side_stream's mode 4 decided for this object and its current scene: 0 GBuffer::render and the
  * primary rays as two launches, 1 as one, -1 still measuring (decided once 14 frames with such a launch have been enqueued; a
- * caller that times frames runs those first), -2 nothing to choose (synchronous launches, launches too small to fuse, a forced mode). */
+ * caller that times frames runs those first), -2 nothing was measured (synchronous launches; a forced mode; launches below three
+ * rounds of the chip's wave slots, which are always one launch -- rs_restir_last_launch tells what a frame actually ran). */
 int  rs_restir_launch_choice(const rs_restir* r, int* choice);
 /* What the last rs_restir_phase_a / rs_restir_direct call launched, measured or not: *fused = 1 GBuffer::render in the primary rays'
  * launch, 0 its own launch (-1 before the first call); *chains = how many internal streams the frames' chains take in turn (0 in
