@@ -846,6 +846,15 @@ int rs_restir_phase_b(rs_restir* r, const rs_scene* scene, const rs_camera* cam,
     return phase_b_impl(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1, true);
 }
 
+// what the last phase-A call actually launched: *fused = 1 the render in the primary rays' launch, 0 its own launch (or no render
+// pending); *chains = number of auxiliary streams the frames' chains take in turn (0: library stream only)
+int rs_restir_last_launch(const rs_restir* r, int* fused, int* chains) {
+    RS_SCOPE(r);
+    if (!r || !fused || !chains) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_last_launch: null argument");
+    *fused = r->lastFused; *chains = r->lastChains;
+    return 0;
+}
+
 // 0 two launches, 1 one fused launch, -1 still measuring, -2 nothing measured (no frame so far had a launch the measurement applies
 // to: synchronous launches, a forced mode, launches below three rounds of wave slots -- those are fused without one)
 int rs_restir_launch_choice(const rs_restir* r, int* choice) {
