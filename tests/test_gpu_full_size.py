@@ -1,0 +1,138 @@
+"""GPU parity tests at BASELINE.json's FULL sizes: librestir_hip against the CPU oracle on the complete Sponza-class
+(262 144 triangles) and Bistro-class (2.83 M triangles, 10 240 lights) scenes at 1920x1080 and 3840x2160.
+
+The small-scene tests of test_gpu_parity.py cannot see an error that depends on the scene's extent or on the depth of its
+trees (the shadow tree's 16-bit grid and its margin, the near-zero-axis cull, the packet walk's overlap shortcut, the
+nested-links check on a 524 287-node tree): here both sides see the full-size inputs and every plane is compared bit for bit,
+with the oracle's libm switch on "correctly rounded" (the mode in which the product is exact).
+
+Reference lines under test: src/scene.h:245-316 (intersect / testOcclusion), src/restir.cu:111-231 (ReSTIRDirectKernel),
+src/gbuffer.cu:3-73, src/denoiser.cu:64-134,463-477.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests.common import HipRenderer, OracleRenderer, bits_equal, get_scene, hip_scene, oracle_scene, radiance_stats
+from tests.test_gpu_parity import _compare_reservoirs, _random_rays, _shadow_like_segments
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def exact_libm():
+    ob.set_libm_mode(1)
+    yield
+    ob.set_libm_mode(0)
+
+
+def _compare_gbuffer(o, h, what=""):
+    g = h.gbuf.download()
+    f = g["frame_idx"] ^ 1                                    # the planes rendered last (update() flipped the index)
+    assert f == o.gbuf.frame_idx ^ 1
+    assert np.array_equal(o.gbuf.prim_id[f], g["prim_id"][f]), what
+    assert np.array_equal(o.gbuf.motion, g["motion"]), what
+    assert bits_equal(o.gbuf.albedo, g["albedo"]), what
+    assert bits_equal(o.gbuf.normal[f], g["normal"][f]), what
+    assert bits_equal(o.gbuf.depth[f], g["depth"][f]), what
+
+
+def _frames_equal_oracle(hip, sd, W, H, static_frames, orbit_frames, radius=1.0, before_last_update=None):
+    """runCuda's sequence (render, ReSTIRDirect, [filter], update) on both sides, everything compared after every frame."""
+    from restir_amd.scenes import orbit_position
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    frames = static_frames + orbit_frames
+    for frame in range(frames):
+        if frame >= static_frames:                            # runCuda's animateCamera: reprojection through devMotion
+            p = orbit_position(sd.camera_args["position"], frame - static_frames + 1, radius=radius)
+            o.set_camera_position(p); h.set_camera_position(p)
+        o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+        o.rays = o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, frame, 3)
+        h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, frame, 3)
+        a, b = o.image, h.image.cpu().numpy()
+        assert o.rays == h.restir.ray_count(), (frame, o.rays, h.restir.ray_count())
+        assert bits_equal(a, b), (frame, radiance_stats(a, b))
+        _compare_reservoirs(o.restir.last, h.restir.download(1))      # post-temporal reservoirs kept for the next frame
+        _compare_reservoirs(o.restir.temp, h.restir.download(2))      # what the spatial pass gathered from
+        if frame == frames - 1 and before_last_update is not None:
+            before_last_update(o, h)
+        o.gbuf.update(o.cam); h.gbuf.update(h.cam)
+        _compare_gbuffer(o, h, frame)
+    assert np.isfinite(a).all() and a.mean() > 1e-3
+    return o, h
+
+
+def test_config3_full_size_frames_equal_oracle(hip, exact_libm):
+    """BASELINE config 3 at its size: Sponza-class 262 144 triangles / 1 024 lights, 1920x1080, spatiotemporal reuse, three
+    frames of the static camera and two of the orbit -- radiance, both reservoir buffers and all G-buffer planes bit for bit."""
+    sd = get_scene("sponza:1.0")
+    assert sd.num_prims == 262144
+    o, h = _frames_equal_oracle(hip, sd, 1920, 1080, 3, 2)
+    assert o.restir.last["numSamples"].max() > 32                      # history in use
+
+
+def test_config5_full_size_frames_equal_oracle(hip, exact_libm):
+    """BASELINE config 5 at its size: Bistro-class 2.83 M triangles / 10 240 lights (the RIS kernel that reads the light table
+    from global memory, a reference tree of depth > 30), 1920x1080, spatiotemporal reuse, two frames, then the five-level EAW
+    filter of the second frame against the oracle's (expf: rtol 1e-5, as test_eaw_filter)."""
+    import torch
+    sd = get_scene("bistro:1.0")
+    assert 2.7e6 < sd.num_prims < 2.9e6
+    W, H = 1920, 1080
+
+    def filtered(o, h):                                                # runCuda's order: render, ReSTIRDirect, filter, update
+        ref = ob.eaw_filter(o.gbuf, o.cam, o.image)
+        f = hip.EAWFilter(W, H, 5)
+        out = torch.zeros_like(h.image)
+        p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+        hip.synchronize()
+        res = torch.empty_like(h.image)
+        hip.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+        got = res.cpu().numpy()
+        f.destroy()
+        assert np.abs(ref - o.image).max() > 1e-3                      # the filter did something
+        assert np.allclose(ref, got, rtol=1e-5, atol=1e-6), float(np.abs(ref - got).max())
+
+    _frames_equal_oracle(hip, sd, W, H, 2, 0, before_last_update=filtered)
+
+
+def test_config4_4k_frames_equal_oracle(hip, exact_libm):
+    """BASELINE config 4's frame (the Sponza-class scene at 3840x2160) as one full frame on one GPU against the oracle: two
+    frames, so the temporal merge runs at this size too.  (The strips of config 4 are compared with this full frame by
+    test_config4_4k_eight_strips_equal_full_frame.)"""
+    sd = get_scene("sponza:1.0")
+    _frames_equal_oracle(hip, sd, 3840, 2160, 2, 0)
+
+
+@pytest.mark.parametrize("name", ["sponza:1.0", "bistro:1.0"])
+def test_full_scene_rays_equal_oracle(hip, monkeypatch, name):
+    """DevScene::intersect and testOcclusion on the FULL scenes: 100 000 random / axis-aligned / near-zero-component rays
+    (primitive, material, position, normal) and 400 000 shadow-like, grazing, axis-aligned, far-origin and degenerate segments:
+    the fast paths (packet-free per-lane walk with the axis cull; shadow tree + ancestor verification) = the library's own
+    reference walk (RS_NO_OCCLUSION_TREE) = the oracle, for every ray."""
+    import torch
+    sd = get_scene(name)
+    osc = oracle_scene(sd)
+    fast = hip_scene(hip, sd)
+    rays = _random_rays(sd, 100000, 21)
+    prim, mat, pos, nrm, _ = osc.intersect(rays)
+    gp, gm, gpos, gn = hip.trace_closest(fast, torch.from_numpy(rays).cuda())
+    assert np.array_equal(prim, gp.cpu().numpy())
+    hit = prim >= 0
+    assert hit.sum() > 10000
+    assert np.array_equal(mat[hit], gm.cpu().numpy()[hit])
+    assert bits_equal(pos[hit], gpos.cpu().numpy()[hit]) and bits_equal(nrm[hit], gn.cpu().numpy()[hit])
+
+    seg = _shadow_like_segments(sd, 400000, 22)
+    dseg = torch.from_numpy(seg).cuda()
+    a = hip.trace_occlusion(fast, dseg).cpu().numpy()
+    ref = osc.test_occlusion(seg)
+    assert np.array_equal(ref, a), int((ref != a).sum())
+    assert 0.05 < a.mean() < 0.95
+    del fast
+    monkeypatch.setenv("RS_NO_OCCLUSION_TREE", "1")
+    slow = hip_scene(hip, sd)
+    monkeypatch.delenv("RS_NO_OCCLUSION_TREE")
+    b = hip.trace_occlusion(slow, dseg).cpu().numpy()
+    assert np.array_equal(a, b)
