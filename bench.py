@@ -22,6 +22,7 @@ One JSON line is printed by rank 0; besides the contract's fields it carries
   cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a
                 bounded sample of the same workload (rank 0, N = 1 only)
+  parity        the frames cpu_baseline rendered, rendered again by the GPU and compared bit for bit (differing_pixels, mean_l1)
   cpu_config1   BASELINE config 1 (Cornell 256x256, 1 spp PTDirect) as a host loop on the same cores
 """
 import argparse
@@ -69,21 +70,45 @@ def host_threads():
 
 
 def cpu_baseline(sd, frames):
-    """The oracle on the host cores: `frames` full 1920x1080 spatiotemporal frames (bounded sample)."""
+    """The oracle on the host cores: `frames` full 1920x1080 spatiotemporal frames (bounded sample).  Also returns the images of
+    all frames it rendered (the untimed first one included): the checker's side of the `parity` field."""
     threads = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(threads)          # read by libgomp when liboracle.so is loaded
+    from oracle import binding as ob
     from tests.common import OracleRenderer
+    ob.set_libm_mode(1)                                   # cos / sin of the spatial taps correctly rounded: the mode the product is exact in (DESIGN.md 2)
     o = OracleRenderer(sd, WIDTH, HEIGHT)
-    o.frame(REUSE)                                        # untimed: thread-pool start-up, page faults
+    images = [o.frame(REUSE).copy()]                      # untimed: thread-pool start-up, page faults
     rays = 0
-    t0 = time.perf_counter()
+    dt = 0.0
     for _ in range(frames):
+        t0 = time.perf_counter()
         o.frame(REUSE)
+        dt += time.perf_counter() - t0
         rays += o.rays + WIDTH * HEIGHT
-    dt = time.perf_counter() - t0
+        images.append(o.image.copy())
+    ob.set_libm_mode(0)
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "ms_per_frame": dt / frames * 1e3,
-            "sample": f"{frames} frames of the same workload (1920x1080 spatiotemporal, Sponza-class 262144 tris), OpenMP over rows"}
+            "sample": f"{frames} frames of the same workload (1920x1080 spatiotemporal, Sponza-class 262144 tris), OpenMP over rows"}, images
+
+
+def parity_against(capi, sd, scene, oracle_images):
+    """The frames cpu_baseline rendered (looper 0, 1, ...: static camera, spatiotemporal reuse) once more on the GPU, from fresh
+    reservoirs, in the reference's synchronous mode, compared pixel by pixel: the checker's verdict on the workload that was timed."""
+    import numpy as np
+    from tests.common import HipRenderer
+    capi.set_sync(True)
+    h = HipRenderer(capi, sd, WIDTH, HEIGHT, scene=scene)
+    differing, l1 = 0, 0.0
+    for ref in oracle_images:
+        got = h.frame(REUSE)
+        differing += int(np.count_nonzero((ref.view(np.uint32) != got.view(np.uint32)).any(axis=1)))
+        l1 += float(np.abs(ref.astype(np.float64) - got.astype(np.float64)).sum(axis=1).mean())
+    capi.set_sync(False)
+    return {"frames": len(oracle_images), "pixels_per_frame": WIDTH * HEIGHT, "differing_pixels": differing, "mean_l1": l1 / len(oracle_images),
+            "checker": "oracle/restir_oracle.c (libm mode: correctly rounded), frames looper 0.. of the benchmark workload from fresh reservoirs, "
+                       "radiance compared bit for bit"}
 
 
 def cpu_config1(threads, seconds=3.0):
@@ -353,7 +378,8 @@ def main():
         out["config"]["launch_choice"] = "%s (%s), chains on %d streams in turn" % (form, how, chains)
         out["config"]["calibration_frames_before_warmup"] = calibration_frames
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(sd, args.cpu_frames)
+            out["cpu_baseline"], oracle_images = cpu_baseline(sd, args.cpu_frames)
+            out["parity"] = parity_against(capi, sd, scene, oracle_images)
             out["cpu_config1"] = cpu_config1(out["cpu_baseline"]["cores"])
             ref_loop = cpu_reference_loop(sd, out["cpu_baseline"]["cores"])
             if ref_loop is not None:

@@ -172,6 +172,16 @@ int  rs_set_side_stream(int enable);
  * pixels reads it from global memory in 256-thread blocks instead, which spread evenly over the CUs (default 384 Ki pixels, i.e.
  * about 1.5 of the large blocks per CU; also RS_RIS_GLOBAL_BELOW).  Same results either way; 0 = always LDS. */
 int  rs_set_ris_table_pixels(int pixels);
+/* How the overlapped mode spreads a frame's kernels over the internal streams (a setting of the current context; every argument
+ * -1 = keep).  chainStreams 1 / 2: the primary-ray -> RIS -> shadow-ray chains of all frames on one stream, or of alternating frames on
+ * two (default 2).  smallChains 0 / 1: a launch below three rounds of the chip's wave slots (a strip) takes the fused render and rotates
+ * its chains over three streams (default 1).  shadowOnMain 0 / 1 / 2: the shadow rays never / always / for launches of at least three
+ * rounds of wave slots (default 2) on the library stream.  Results are identical in every setting (tools/soak_async.py); the defaults
+ * are what measured fastest.  Until this is called the context takes its defaults from the environment
+ * variables RS_PARITY_STREAMS (0: one chain stream), RS_SMALL_CHAINS, RS_SHADOW_ON_MAIN, read once per context -- tuning runs only.
+ * No entry point waits on the host in overlapped mode: the measurement of rs_set_side_stream's mode 4 polls its last time stamp
+ * (hipEventQuery at the frame ends) and frames take two launches until it has arrived. */
+int  rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain);
 int  rs_synchronize(void);
 
 /* ---- host scene build: replaces Scene::buildDevData (src/scene.cpp:159-215) ----------- */
@@ -199,6 +209,15 @@ int  rs_build_envmap_pdf(int width, int height, const float* data, float* pdf);
 int  rs_scene_create(const rs_scene_desc* desc, rs_scene** scene);
 /* Host copies of the arrays the scene was created from (valid until rs_scene_destroy). */
 int  rs_scene_host_desc(const rs_scene* scene, rs_scene_desc* desc);
+/* DevScene::sampleSequence (src/scene.h:480; src/scene.cpp:500-506 reads "sobol_10k_200.bin" into it): the table of the Sobol
+ * sampler, numSamples x numDims uint32 in row order (sample index, then dimension), numDims = 200 (SobolSampleDim, src/sampler.h:11;
+ * the reference's table has SobolSampleNum = 10 000 rows).  The reference picks its sampler at compile time (SAMPLER_USE_SOBOL,
+ * src/common.h:4); here the scene carries the choice: once a table is set, every pass that draws random numbers (ReSTIRDirect,
+ * ReSTIRIndirect, pathTrace*) runs the Sobol branch of src/sampler.h:9-36 -- Sampler(looper * 200 + dim, utilhash(index), data),
+ * sample() = (data[ptr++] ^ scramble) * 2^-32, scramble = utilhash(scramble) -- and data == NULL selects the default thrust engine
+ * (src/sampler.h:38-49) again.  In Sobol mode `looper` must stay in [0, numSamples): the caller wraps it as the reference does,
+ * State::looper = (State::looper + 1) % SobolSampleNum (src/restir.cu:441-445; restir_compat.h does).  The table is copied. */
+int  rs_scene_set_sample_sequence(rs_scene* scene, const uint32_t* data, int numSamples, int numDims);
 /* Scene::clear / DevScene::destroy (src/scene.cpp:217-220,511-532). */
 int  rs_scene_destroy(rs_scene* scene);
 
@@ -329,6 +348,8 @@ int  rs_debug_tap_estimate_error(int n, float* maxErr);
  * class test (rs_surface.h sqrt_of_uniform); this compares it with the exactly rounded sqrtf on every value the generator can
  * return (2^31 - 2 of them) and returns the number of differing results. */
 int  rs_debug_sqrt_of_uniform_mismatches(unsigned long long* mismatches);
+/* The same for every value the Sobol sampler can return: 0 and all floats in [2^-32, 1] (2^28 + 2 of them). */
+int  rs_debug_sqrt_of_unit_floats_mismatches(unsigned long long* mismatches);
 
 /* ---- framebuffer tiling across the GPUs of one node: the row-strip frame of one rank ------------------------------------------
  * One process per GPU, the scene replicated, the framebuffer of runCuda (src/main.cpp:146-185) cut into `world` row strips.  A rank

@@ -57,6 +57,7 @@ class OrcScene(C.Structure):
         ("envMapSamplerLength", C.c_int),
         ("envMapProb", C.c_void_p),
         ("envMapFailId", C.c_void_p),
+        ("sampleSequence", C.c_void_p),
     ]
 
 
@@ -92,6 +93,7 @@ def lib():
     L.orc_utilhash.argtypes = [C.c_int, u32p, u32p]
     L.orc_rng_stream.argtypes = [C.c_int, i32p, i32p, i32p, C.c_int, f32p]
     L.orc_rng_stream_raw.argtypes = [C.c_int, i32p, C.c_int, f32p]
+    L.orc_sobol_stream.argtypes = [u32p, C.c_int, i32p, i32p, i32p, C.c_int, f32p]
     L.orc_bsdf.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
     L.orc_camera_sample.argtypes = [C.POINTER(Camera), C.c_int, i32p, f32p, f32p]
     L.orc_camera_raster_coord.argtypes = [C.POINTER(Camera), C.c_int, f32p, i32p]
@@ -325,6 +327,22 @@ class Scene:
         s.envMapProb = self.env_prob.ctypes.data
         s.envMapFailId = self.env_fail.ctypes.data
         self.c = s
+        self.sample_sequence = None
+
+    def set_sample_sequence(self, table):
+        """DevScene::sampleSequence (scene.cpp:500-506): the Sobol table as uint32 [SobolSampleNum, SobolSampleDim]; None selects the
+        default thrust engine again (SAMPLER_USE_SOBOL false)."""
+        if table is None:
+            self.sample_sequence = None
+            self.c.sampleSequence = None
+            return
+        t = np.ascontiguousarray(table, np.uint32)
+        assert t.ndim == 2 and t.shape[1] == 200, t.shape                 # SobolSampleDim (sampler.h:11)
+        # the reference reads data[ptr++] without a bound (sampler.h:20): a guard of zeros behind the table keeps the multi-bounce
+        # kernels of the last rows inside the allocation (the product pads its device copy the same way)
+        self.sample_sequence = np.concatenate([t.reshape(-1), np.zeros(4096, np.uint32)])
+        self.sample_count = t.shape[0]
+        self.c.sampleSequence = self.sample_sequence.ctypes.data
 
     # scene services ---------------------------------------------------------------
     def intersect(self, rays):

@@ -132,7 +132,10 @@ static inline uint32_t utilhash(uint32_t a) {                               /* :
  * detail/mod.h Schrage form, detail/uniform_real_distribution.inl:67-80).  The reference pins no
  * Thrust version (CMakeLists.txt:26); validated here against rocThrust 2.8.5 (oracle/_ref).
  * ---------------------------------------------------------------------------------------- */
-typedef struct { uint32_t x; } rng_t;
+/* One sampler type for both branches of src/sampler.h: data == NULL is the default thrust engine (sampler.h:38-49), data != NULL the
+ * Sobol branch (sampler.h:9-36, SAMPLER_USE_SOBOL): Sampler{ptr, scramble, data}. */
+typedef struct { uint32_t x; const uint32_t* data; uint32_t scramble; int ptr; } rng_t;
+#define SOBOL_SAMPLE_DIM 200      /* sampler.h:11 SobolSampleDim */
 
 #define LCG_A 48271u
 #define LCG_M 2147483647u
@@ -141,10 +144,17 @@ static inline rng_t rng_seed_raw(uint32_t s) {
     rng_t r;
     uint32_t v = s % LCG_M;
     r.x = (v == 0) ? 1u : v;      /* c == 0 and s % m == 0 -> state 1 */
+    r.data = 0; r.scramble = 0u; r.ptr = 0;
     return r;
 }
-/* sampler.h:41-44 */
-static inline rng_t make_seeded_random_engine(int iter, int index, int dim) {
+/* sampler.h:41-44 (default engine); sampler.h:30-32 (Sobol: Sampler(iter * SobolSampleDim + dim, utilhash(index), data)).
+ * `data` is scene->sampleSequence (restir.cu:127, pathtrace.cu:170,288,339), NULL for the default engine. */
+static inline rng_t make_seeded_random_engine(int iter, int index, int dim, const uint32_t* data) {
+    if (data) {
+        rng_t r;
+        r.x = 0u; r.data = data; r.scramble = utilhash((uint32_t)index); r.ptr = iter * SOBOL_SAMPLE_DIM + dim;
+        return r;
+    }
     uint32_t h = utilhash((1u << 31) | ((uint32_t)dim << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
     return rng_seed_raw(h);
 }
@@ -159,6 +169,11 @@ static inline uint32_t rng_next(rng_t* r) {
 }
 /* sampler.h:46-48: uniform_real_distribution<float>(0,1): float(x - min) / (1.f + float(max - min)) */
 static inline float sample1D(rng_t* r) {
+    if (r->data) {                                   /* Sampler::sample, sampler.h:19-23 */
+        uint32_t v = r->data[r->ptr++] ^ r->scramble;
+        r->scramble = utilhash(r->scramble);
+        return (float)v * 0x1p-32f;                  /* `r * 0x1p-32f`: uint32 -> float (round to nearest), then an exact scaling */
+    }
     float result = (float)(uint32_t)(rng_next(r) - 1u);
     result /= (1.f + (float)(uint32_t)(2147483646u - 1u));
     return (result * (1.f - 0.f)) + 0.f;
@@ -1025,7 +1040,7 @@ void orc_pt_direct(const orc_scene* s, const orc_camera* cam, float* directIllum
             v3 direct = v3s(0.f);
             int index = y * W + x;
             int walks = 0;
-            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            rng_t rng = make_seeded_random_engine(looper, index, 0, s->sampleSequence);
             v4 r4 = sample4D(&rng);
             ray_t ray = camera_sample(cam, x, y, r4);
             isect_t it;
@@ -1143,7 +1158,7 @@ void orc_path_trace(const orc_scene* s, const orc_camera* cam, float* directIllu
             v3 direct = v3s(0.f), indirect = v3s(0.f);
             int index = y * W + x;
             int walks = 0;
-            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            rng_t rng = make_seeded_random_engine(looper, index, 0, s->sampleSequence);
             ray_t ray = camera_sample(cam, x, y, sample4D(&rng));
             isect_t it;
             scene_intersect(s, ray, &it);
@@ -1210,7 +1225,7 @@ void orc_pt_indirect(const orc_scene* s, const orc_camera* cam, float* indirectI
             v3 indirect = v3s(0.f);
             int index = y * W + x;
             int walks = 0;
-            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            rng_t rng = make_seeded_random_engine(looper, index, 0, s->sampleSequence);
             ray_t ray = camera_sample(cam, x, y, sample4D(&rng));
             isect_t it;
             scene_intersect(s, ray, &it);
@@ -1360,7 +1375,7 @@ void orc_restir_phase_a(void* state, const orc_scene* s, const orc_camera* cam, 
             ps->kind = 0;
             ps->direct = v3s(0.f);
 
-            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            rng_t rng = make_seeded_random_engine(looper, index, 0, s->sampleSequence);
             v4 r4 = sample4D(&rng);
             ray_t ray = camera_sample(cam, x, y, r4);
             isect_t it;
@@ -1516,7 +1531,7 @@ void orc_restir_indirect(const orc_scene* s, const orc_camera* cam, const orc_gb
             orc_indirect_reservoir smp = ires_default();     /* indirectSample lives in .Lo/.xv/.nv/.xs/.ns of this record */
             int index = y * W + x;
             int walks = 0;
-            rng_t rng = make_seeded_random_engine(looper, index, 0);
+            rng_t rng = make_seeded_random_engine(looper, index, 0, s->sampleSequence);
             ray_t ray = camera_sample(cam, x, y, sample4D(&rng));
             isect_t it;
             scene_intersect(s, ray, &it);
@@ -2320,7 +2335,14 @@ void orc_aabb_intersect(int n, const float* rays, const float* boxes, int* hit, 
 void orc_utilhash(int n, const uint32_t* in, uint32_t* out) { for (int i = 0; i < n; i++) out[i] = utilhash(in[i]); }
 void orc_rng_stream(int n, const int* looper, const int* index, const int* dim, int m, float* out) {
     for (int i = 0; i < n; i++) {
-        rng_t r = make_seeded_random_engine(looper[i], index[i], dim[i]);
+        rng_t r = make_seeded_random_engine(looper[i], index[i], dim[i], 0);
+        for (int k = 0; k < m; k++) out[(size_t)i * m + k] = sample1D(&r);
+    }
+}
+/* src/sampler.h:9-36: m draws of the Sobol-branch sampler for each (looper, index, dim) over the table `data` */
+void orc_sobol_stream(const uint32_t* data, int n, const int* looper, const int* index, const int* dim, int m, float* out) {
+    for (int i = 0; i < n; i++) {
+        rng_t r = make_seeded_random_engine(looper[i], index[i], dim[i], data);
         for (int k = 0; k < m; k++) out[(size_t)i * m + k] = sample1D(&r);
     }
 }

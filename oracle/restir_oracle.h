@@ -112,6 +112,9 @@ typedef struct orc_scene {
     int           envMapSamplerLength; /* width*height of the environment map, 0 = none */
     const float*  envMapProb;          /* alias table over lum(texel)*sin(theta) */
     const int*    envMapFailId;
+    /* DevScene::sampleSequence (scene.h:480, scene.cpp:500-506): the Sobol table, SobolSampleNum x SobolSampleDim uint32
+     * (sampler.h:10-11); NULL selects the default thrust engine (SAMPLER_USE_SOBOL false, common.h:4). */
+    const uint32_t* sampleSequence;
 } orc_scene;
 
 /* Host-memory image of GBuffer (src/gbuffer.h:41-58). */
@@ -137,6 +140,8 @@ void orc_aabb_intersect(int n, const float* rays, const float* boxes, int* hit, 
 void orc_utilhash(int n, const uint32_t* in, uint32_t* out);
 /* src/sampler.h:41-48 + thrust minstd_rand: m draws of sample1D for each (looper,index,dim) */
 void orc_rng_stream(int n, const int* looper, const int* index, const int* dim, int m, float* out);
+/* src/sampler.h:9-36 (SAMPLER_USE_SOBOL): m draws of Sampler::sample for each (looper, index, dim) over `data` */
+void orc_sobol_stream(const uint32_t* data, int n, const int* looper, const int* index, const int* dim, int m, float* out);
 /* src/material.h:218-228 */
 void orc_bsdf(int n, const orc_material* mats, const float* nrm, const float* wo, const float* wi,
               float* out);

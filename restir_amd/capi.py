@@ -108,14 +108,14 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_synchronize",
+    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_stream_plan", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
-    "rs_scene_host_desc", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
+    "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
-    "rs_restir_enable_timing", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_write_png", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_restir_enable_timing", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_write_png", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_debug_sqrt_of_unit_floats_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
@@ -198,6 +198,9 @@ def lib():
     L.rs_save_image.argtypes = [C.c_char_p, vp, ci, ci, ci]
     L.rs_write_png.argtypes = [C.c_char_p, vp, ci, ci]
     L.rs_debug_sqrt_of_uniform_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
+    L.rs_debug_sqrt_of_unit_floats_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
+    L.rs_scene_set_sample_sequence.argtypes = [vp, vp, ci, ci]
+    L.rs_set_stream_plan.argtypes = [ci, ci, ci]
     L.rs_restir_rows_pack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_restir_rows_unpack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_gbuffer_rows_bytes.argtypes = [vp, ci]
@@ -301,6 +304,11 @@ def set_side_stream(enable):
 def set_ris_table_pixels(pixels):
     """Launches of fewer pixels read the RIS light table from global memory instead of LDS (rs_set_ris_table_pixels); 0 = always LDS."""
     check(lib().rs_set_ris_table_pixels(int(pixels)))
+
+
+def set_stream_plan(chain_streams=-1, small_chains=-1, shadow_on_main=-1):
+    """How the overlapped mode spreads a frame's kernels over the internal streams (rs_set_stream_plan); -1 keeps a value."""
+    check(lib().rs_set_stream_plan(int(chain_streams), int(small_chains), int(shadow_on_main)))
 
 
 def save_image(path, dev_image_ptr, width, height, tone_mapping):
@@ -476,6 +484,14 @@ class Scene:
         self.handle = C.c_void_p()
         check(lib().rs_scene_create(C.byref(d), C.byref(self.handle)))
         return self
+
+    def set_sample_sequence(self, table):
+        """DevScene::sampleSequence: uint32 [numSamples, 200] selects the Sobol sampler (src/sampler.h:9-36), None the default engine."""
+        if table is None:
+            check(lib().rs_scene_set_sample_sequence(self.handle, None, 0, 0))
+            return
+        t = np.ascontiguousarray(table, np.uint32)
+        check(lib().rs_scene_set_sample_sequence(self.handle, _p(t), t.shape[0], t.shape[1]))
 
     def host_desc(self):
         """numpy views of the arrays the scene was built from (for parity checks of the host build)."""

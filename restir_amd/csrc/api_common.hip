@@ -12,17 +12,24 @@ std::string g_lastError;
 rs_context g_default;                                   // what rs_init / rs_set_* configure for threads that never create a context
 thread_local rs_context* t_current = nullptr;           // rs_context_set_current
 thread_local rs_context* t_scoped = nullptr;            // the object's context while an entry point runs
-thread_local int t_device = -1;                         // the device this thread last selected
 }  // namespace
 
 rs_context* rs_ctx() { return t_scoped ? t_scoped : (t_current ? t_current : &g_default); }
 
+// An entry point runs with the context's device current and leaves the caller's device as it found it: the host (torch, another
+// library, a second context of this one on another GPU) may call hipSetDevice between two library calls, so the device is asked
+// for, not remembered.
 rs_ctx_scope::rs_ctx_scope(rs_context* c) : prev(t_scoped) {
     if (c) t_scoped = c;
     const int dev = rs_ctx()->device;
-    if (t_device != dev && hipSetDevice(dev) == hipSuccess) t_device = dev;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    if (cur != dev && hipSetDevice(dev) == hipSuccess) prevDevice = cur;
 }
-rs_ctx_scope::~rs_ctx_scope() { t_scoped = prev; }
+rs_ctx_scope::~rs_ctx_scope() {
+    if (prevDevice >= 0) (void)hipSetDevice(prevDevice);
+    t_scoped = prev;
+}
 
 int rs_fail(int code, const char* msg) {
     std::lock_guard<std::mutex> lock(g_errMutex);
@@ -72,6 +79,13 @@ int rs_fuse_mode() {
     return c->fuseMode;
 }
 bool rs_fuse_enabled() { return rs_fuse_mode() != 0; }
+const rs_context* rs_stream_plan() {
+    rs_context* c = rs_ctx();
+    if (c->chainStreams < 0) { const char* e = std::getenv("RS_PARITY_STREAMS"); c->chainStreams = (e && e[0] == '0') ? 1 : 2; }
+    if (c->smallChains < 0) { const char* e = std::getenv("RS_SMALL_CHAINS"); c->smallChains = (e && e[0] == '0') ? 0 : 1; }
+    if (c->shadowOnMain < 0) { const char* e = std::getenv("RS_SHADOW_ON_MAIN"); const int v = e ? std::atoi(e) : 2; c->shadowOnMain = (v >= 0 && v <= 2) ? v : 2; }
+    return c;
+}
 int rs_ris_global_below() {
     rs_context* c = rs_ctx();
     if (c->risGlobalBelow < 0) {
@@ -128,7 +142,6 @@ int rs_init(int device) {
     if (n <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_init: no HIP device visible (the MI355X path has no CPU fallback)");
     if (device < 0 || device >= n) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_init: device index out of range");
     RS_HIP(hipSetDevice(device));
-    t_device = device;
     g_default.device = device;
     return 0;
 }
@@ -158,8 +171,8 @@ int rs_context_destroy(rs_context* c) {
 }
 int rs_context_set_current(rs_context* c) {
     t_current = c;
-    rs_ctx_scope scope(nullptr);                        // selects the context's device for this thread
-    return 0;
+    return rs_check_hip(hipSetDevice(rs_ctx()->device), "rs_context_set_current");      // the context's device becomes this thread's device
+
 }
 
 int rs_set_stream(void* hipStream) {
@@ -173,6 +186,21 @@ int rs_set_side_stream(int enable) {
     rs_context* c = rs_ctx();
     c->auxMode = enable ? 1 : 0;                        // work already enqueued on the auxiliary streams is still joined by its consumers
     c->fuseMode = enable == 2 ? 1 : enable == 3 ? 2 : enable == 4 ? 3 : 0;      // 2 always, 3 always and at any size (tests), 4 measured
+    return 0;
+}
+// How the asynchronous mode spreads a frame's kernels over the auxiliary streams; every value -1 = keep.
+//   chainStreams  1: one stream for every frame's primary -> RIS -> shadow chain; 2: frames alternate between two (default)
+//   smallChains   0 / 1: a launch below three rounds of wave slots (a strip) fuses the render with the primary rays and rotates
+//                 its chains over three streams (default 1)
+//   shadowOnMain  0 never / 1 always / 2 for launches that fill the chip three times over (default): the shadow rays on the library stream
+// Defaults come from RS_PARITY_STREAMS, RS_SMALL_CHAINS, RS_SHADOW_ON_MAIN when set (tuning runs), read once per context.
+int rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain) {
+    rs_context* c = rs_ctx();
+    if (chainStreams > 2 || smallChains > 1 || shadowOnMain > 2 || chainStreams == 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_stream_plan: value out of range");
+    (void)rs_stream_plan();                             // resolve the defaults first
+    if (chainStreams >= 1) c->chainStreams = chainStreams;
+    if (smallChains >= 0) c->smallChains = smallChains;
+    if (shadowOnMain >= 0) c->shadowOnMain = shadowOnMain;
     return 0;
 }
 int rs_set_ris_table_pixels(int pixels) {

@@ -44,8 +44,8 @@ struct PathState {
 // wave-level shadow-tree walk (trace_occluded_wave) and the continuation rays the pair-cooperative walk
 // (trace_closest_wave) instead of per-lane walks inside a divergent loop.  Per lane the sequence of
 // random draws and arithmetic is that of the reference.
-template <int MODE, bool TEX>
-__device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Rng& rng, int maxDepth, bool alive, PathState& st) {
+template <int MODE, bool TEX, typename Sampler>
+__device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Sampler& rng, int maxDepth, bool alive, PathState& st) {
     f3 throughput = splat(1.f);
     f3 norm = h.norm, pos = h.pos;
     f3 wo = -ray.d;
@@ -157,7 +157,7 @@ __device__ inline bool ind_invalid(float W) { return is_nan_or_inf(W) || W < 0.f
 #ifndef RS_PATH_BLOCKS
 #define RS_PATH_BLOCKS 7
 #endif
-template <int MODE, bool TEX>
+template <int MODE, bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamParams cam, float* __restrict__ directIllum, float* __restrict__ indirectIllum,
                                               rs_indirect_reservoir* __restrict__ resvOut, const rs_indirect_reservoir* __restrict__ resvIn,
                                               GBufView g, int looper, int iter, int maxDepth, int first, int reuse, int tilesX,
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     const int y = by * 8 + (lane >> 3);
     const bool inside = x < cam.width && y < cam.height;
     const int index = y * cam.width + x;
-    Rng rng = seeded_rng(looper, index, 0);
+    SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);     // pathtrace.cu:170,339, restir.cu:256
     const f4 r = rng.uniform4();
     const Ray ray = camera_sample(cam, x, y, r.x, r.y);
     const Hit h = trace_closest_packet(s, ray, inside);                // all 64 lanes take part in the wave's walk
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
             }
         }
     }
-    path_loop<MODE, TEX>(s, hh, material, ray, rng, maxDepth, alive, st);                // every lane of the wave takes part
+    path_loop<MODE, TEX, SamplerT<SOBOL>>(s, hh, material, ray, rng, maxDepth, alive, st);                // every lane of the wave takes part
     if (inside) {
         if (MODE == kModePT) {
             if (any_nan_or_inf(st.direct)) st.direct = splat(0.f);
@@ -287,12 +287,20 @@ int launch_path(const rs_scene* scene, const rs_camera* cam, float* direct, floa
     const int W = cam->resolution[0], H = cam->resolution[1];
     const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
     const CamParams cp = rs_make_cam_params(cam);
-    if (scene->textured)
-        hipLaunchKernelGGL((k_path<MODE, true>), dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, direct, indirect, out, in, g,
-                           looper, iter, maxDepth, first, reuse, tilesX, g_giRayCount);
-    else
-        hipLaunchKernelGGL((k_path<MODE, false>), dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, cp, direct, indirect, out, in, g,
-                           looper, iter, maxDepth, first, reuse, tilesX, g_giRayCount);
+    // The Sobol branch reads data[ptr++] without a bound (sampler.h:20); a path draws at most 4 + 7 per bounce + 2 numbers, and the
+    // device table ends in a guard of kSobolGuard zeros: refuse what could read beyond it.
+    const bool sobol = scene->dev.sampleSeq != nullptr;
+    if (sobol) {
+        RS_TRY(rs_check_looper(scene, looper, "pathTrace / ReSTIRIndirect"));
+        if (6 + 7LL * maxDepth > kSobolSampleDim + kSobolGuard) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTrace / ReSTIRIndirect: trace depth too large for the Sobol table's guard");
+    }
+    const dim3 grid(tilesX * tilesY), block(256);
+#define RS_PATH_ARGS scene->dev, cp, direct, indirect, out, in, g, looper, iter, maxDepth, first, reuse, tilesX, g_giRayCount
+    if (scene->textured) { if (sobol) hipLaunchKernelGGL((k_path<MODE, true, true>), grid, block, 0, rs_stream(), RS_PATH_ARGS);
+                           else       hipLaunchKernelGGL((k_path<MODE, true, false>), grid, block, 0, rs_stream(), RS_PATH_ARGS); }
+    else                 { if (sobol) hipLaunchKernelGGL((k_path<MODE, false, true>), grid, block, 0, rs_stream(), RS_PATH_ARGS);
+                           else       hipLaunchKernelGGL((k_path<MODE, false, false>), grid, block, 0, rs_stream(), RS_PATH_ARGS); }
+#undef RS_PATH_ARGS
     return 0;
 }
 

@@ -14,7 +14,7 @@ namespace {
 #ifndef RS_PT_BLOCKS
 #define RS_PT_BLOCKS 8
 #endif
-template <bool TEX>
+template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, RS_PT_BLOCKS) k_pt_direct(DevScene s, CamParams cam, float* __restrict__ directIllum,
                                                    int looper, int iter, int tilesX, unsigned long long* rayCount) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256, RS_PT_BLOCKS) k_pt_direct(DevScene s, Cam
     int walks = 0;
     const bool inside = x < cam.width && y < cam.height;
     const int index = y * cam.width + x;
-    Rng rng = seeded_rng(looper, index, 0);
+    SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, inside ? index : 0, 0);       // pathtrace.cu:288
     f4 r = rng.uniform4();
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
     Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
@@ -144,16 +144,13 @@ int rs_path_trace_free(void) { rs_ctx_scope scope(nullptr); rs_dev_free(rs_ctx()
 int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, int iter, int looper, unsigned long long* rays) {
     RS_SCOPE(scene);
     if (!scene || !cam || !devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceDirect: null argument");
+    RS_TRY(rs_check_looper(scene, looper, "pathTraceDirect"));
     RS_TRY(rs_path_trace_init());
     RS_HIP(hipMemsetAsync(rs_ctx()->ptRayCount, 0, 8, rs_stream()));
     const int W = cam->resolution[0], H = cam->resolution[1];
     const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
-    if (scene->textured)
-        hipLaunchKernelGGL(k_pt_direct<true>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
-                           devDirectIllum, looper, iter, tilesX, rs_ctx()->ptRayCount);
-    else
-        hipLaunchKernelGGL(k_pt_direct<false>, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, rs_make_cam_params(cam),
-                           devDirectIllum, looper, iter, tilesX, rs_ctx()->ptRayCount);
+    RS_LAUNCH2(k_pt_direct, scene->textured, scene->dev.sampleSeq != nullptr, dim3(tilesX * tilesY), dim3(256), rs_stream(), scene->dev,
+               rs_make_cam_params(cam), devDirectIllum, looper, iter, tilesX, rs_ctx()->ptRayCount);
     RS_TRY(rs_after_launch("pathTrace"));
     if (rays) {
         RS_HIP(hipStreamSynchronize(rs_stream()));

@@ -38,6 +38,11 @@ constexpr int kKindMiss = 0, kKindLight = 1, kKindShaded = 2;
 // per-pixel tag: material id (24 bits) | kind << 24 (2 bits) | Material::Type << 26 (3 bits)
 __device__ __forceinline__ int mk_kind(int mk) { return (mk >> 24) & 3; }
 __device__ __forceinline__ int mk_type(int mk) { return (mk >> 26) & 7; }
+// Sobol sampler (src/sampler.h:9-36): the passes carry the scramble in rngMat.x and know the table position from the number of
+// draws made so far -- 4 by the primary ray (restir.cu:129), 5 per RIS candidate (:158,168), and the temporal merge's one draw if it
+// happened (bit 29 of the tag as k_temporal leaves it in rngMat.y).
+constexpr int kDrawsPrimary = 4, kDrawsRis = kDrawsPrimary + 5 * 32;
+constexpr unsigned kTemporalDrewBit = 1u << 29;
 constexpr int kRaySlots = 1024;   // ring of per-frame BVH-walk counters
 constexpr int kRaySub = 64, kRayStride = 8;   // per frame: 64 partial counters, 64 B apart (one hot address cost ~85 us/frame)
 
@@ -60,7 +65,7 @@ __device__ __forceinline__ void pixel_of_lane(int tilesX, int y0, int& x, int& y
 // ---- phase A.1: primary hit ---------------------------------------------------------------------
 // what ReSTIRDirectKernel keeps of its primary hit (restir.cu:127-153) for the later passes; returns whether the pixel is shaded
 template <bool TEX>
-__device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes& sp, int index, const Ray& ray, const Hit& h, const Rng& rng) {
+__device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes& sp, int index, const Ray& ray, const Hit& h, unsigned rngWord) {
     int shaded = 0;
     int kind = kKindMiss, matId = 0, type = 0;
     f3 norm = splat(0.f), wo = splat(0.f), p = h.pos;
@@ -88,11 +93,11 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
     sp.posMat[index] = make_float4(p.x, p.y, p.z, __int_as_float(mk));
     sp.norm[index] = make_float4(norm.x, norm.y, norm.z, metallic);
     if (type == 1) sp.wo[index] = make_float4(wo.x, wo.y, wo.z, roughness);     // only the metallic BSDF reads wo (k_ris, k_spatial_shade)
-    sp.rngMat[index] = make_uint2(rng.x, (unsigned)mk);
+    sp.rngMat[index] = make_uint2(rngWord, (unsigned)mk);
     return shaded;
 }
 
-template <bool TEX>
+template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, 8) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
     int x, y;
@@ -100,11 +105,11 @@ __global__ void __launch_bounds__(256, 8) k_primary(DevScene s, CamParams cam, S
     const bool inside = x < cam.width && y < y1;
     int shaded = 0;
     const int index = y * cam.width + x;
-    Rng rng = seeded_rng(looper, index, 0);
+    SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);     // restir.cu:127
     f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
     Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
-    if (inside) shaded = primary_store<TEX>(s, sp, index, ray, h, rng);
+    if (inside) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
     if ((threadIdx.x & 63) == 0) {
@@ -124,7 +129,7 @@ constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of th
 // the single walk's cost per visit.  (Round 1's form walked both rays in one lane, one after the other at every node of an 8x8 tile's
 // union: it paid both slab tests per visit and, after the round-2 walk, measured 1.29 ms per frame against 1.20 for two launches and
 // 1.193 for this form.)  Tiles are 8x4 from the G-buffer rows [gy0, gy1), blocks 32x4 pixels; the shading ray is active on rows [y0, y1).
-template <bool TEX>
+template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
                                                                   int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31;
@@ -133,13 +138,13 @@ __global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParam
     const int x = bx * 32 + wave * 8 + (l & 7), y = gy0 + by * 4 + (l >> 3);
     const bool inside = x < cam.width && (shading ? (y >= y0 && y < y1) : y < gy1);
     const int index = y * cam.width + x;
-    Rng rng = seeded_rng(looper, index, 0);
+    SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);
     const f4 r = rng.uniform4();
     const Ray ray = shading ? camera_sample(cam, x, y, r.x, r.y) : camera_center_ray(cam, x, y);
     const Hit h = trace_closest_packet(s, ray, inside);
     int shaded = 0;
     if (inside) {
-        if (shading) shaded = primary_store<TEX>(s, sp, index, ray, h, rng);
+        if (shading) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
         else gbuffer_store<TEX>(s, cam, lastCam, g, index, ray, h);
     }
     const unsigned long long ballotIn = __ballot(inside && shading), ballotSh = __ballot(shaded);
@@ -157,8 +162,8 @@ __global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParam
 constexpr int kRisThreads = 1024;
 constexpr int kRisLdsLights = 1024;
 
-template <bool ENV, typename AliasPtr, typename LightPtr>
-__device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& sp, AliasPtr alias, LightPtr lights, int index) {
+template <bool ENV, bool SOBOL, typename AliasPtr, typename LightPtr>
+__device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& sp, AliasPtr alias, LightPtr lights, int index, int looper) {
     const float4 pm = sp.posMat[index];
     const int mk = __float_as_int(pm.w);
     if (mk_kind(mk) != kKindShaded) return;
@@ -169,7 +174,9 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
     f3 wo = splat(0.f);
     if (m.type == 1) { const float4 w4 = sp.wo[index]; wo = mk3(w4.x, w4.y, w4.z); m.roughness = w4.w; }
 
-    Rng rng; rng.x = sp.rngMat[index].x;
+    // Sobol: the table position looper * 200 + 4 + 5 i + k is the same for every pixel -- the table words come through the scalar
+    // cache, one fetch per wave, and a draw is one xor and one utilhash per lane
+    SamplerT<SOBOL> rng = SamplerT<SOBOL>::resume(s.sampleSeq, sp.rngMat[index].x, looper, kDrawsPrimary);
     f3 selLi = splat(0.f), selWi = splat(0.f);
     float selDist = 0.f, wsum = 0.f;
     // Without an environment map every winner is a triangle-light sample: the loop carries its light and barycentric pair (three
@@ -192,18 +199,19 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
     if (!ENV && selId >= 0) light_sample_again(lights, selId, selU, selV, pos, selLi, selWi, selDist);
     sp.candLi[index] = make_float4(selLi.x, selLi.y, selLi.z, selDist);
     sp.candWi[index] = make_float4(selWi.x, selWi.y, selWi.z, wsum);
-    reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;
+    reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.word();
 }
 
-template <bool ENV>
-__global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
+template <bool ENV, bool SOBOL>
+__global__ void __launch_bounds__(256) k_ris(DevScene s, SurfPlanes sp, int width, int y0, int y1, int looper) {
     const int n0 = y0 * width, n1 = y1 * width;
     const int index = n0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= n1) return;
-    ris_pixel<ENV, const AliasRec*, const LightRec*>(s, sp, s.alias, s.lights, index);
+    ris_pixel<ENV, SOBOL, const AliasRec*, const LightRec*>(s, sp, s.alias, s.lights, index, looper);
 }
 
-__global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes sp, int width, int y0, int y1) {
+template <bool SOBOL>
+__global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes sp, int width, int y0, int y1, int looper) {
     // The copy is laid out by quarter: the lanes of a wave read the same quarter of 64 random records, and in record order those
     // 16 bytes lie in 2 of the 8 four-bank groups whatever the light (a 4-fold bank conflict; SQ_LDS_BANK_CONFLICT was 80 % of the
     // LDS cycles); by quarter, light i's lies in group i mod 8.
@@ -218,7 +226,7 @@ __global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes 
     const int n0 = y0 * width, n1 = y1 * width;
     const int index = n0 + blockIdx.x * kRisThreads + threadIdx.x;
     if (index >= n1) return;
-    ris_pixel<false, const AliasRec*, LightQuarters<kRisLdsLights>>(s, sp, sAlias, LightQuarters<kRisLdsLights>{ sQuarters }, index);
+    ris_pixel<false, SOBOL, const AliasRec*, LightQuarters<kRisLdsLights>>(s, sp, sAlias, LightQuarters<kRisLdsLights>{ sQuarters }, index, looper);
 }
 
 // ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------
@@ -264,7 +272,8 @@ __global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, in
     if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
 }
 
-__global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp,
+template <bool SOBOL>
+__global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp, const uint32_t* sampleSeq, int looper,
                                                   int first, int reuse, int n0, int n1, unsigned long long* rayWork, unsigned long long* rayDone) {
     // this call's BVH-walk counters are complete (the launch is ordered after the chain that counted): publish them and leave the
     // working slot zero for its next user, so that the chain itself needs no clearing launch
@@ -310,9 +319,10 @@ __global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, Res
             t.W = ld_stream(last.w + lastIdx); t.M = ld_stream(last.m + lastIdx);
         }
         if (!resv_invalid(t.W)) {
-            Rng rng; rng.x = rm.x;
+            SamplerT<SOBOL> rng = SamplerT<SOBOL>::resume(sampleSeq, rm.x, looper, kDrawsRis);
             const float u = rng.uniform();
-            reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.x;
+            if (SOBOL) sp.rngMat[index] = make_uint2(rng.word(), rm.y | kTemporalDrewBit);      // the spatial pass resumes one table word further
+            else reinterpret_cast<unsigned*>(sp.rngMat + index)[0] = rng.word();
             // preClampedMerge<20> (restir.h:95-102)
             if (r.M > 0) {
                 const int cap = (20 - 1) * r.M;
@@ -408,6 +418,16 @@ __global__ void k_sqrt_of_uniform_check(unsigned long long* mismatches) {
     }
     if (bad) atomicAdd(mismatches, bad);
 }
+// ... and every value the Sobol sampler can return: (float)r * 2^-32 for a 32-bit r is 0 or a float in [2^-32, 1] -- all of them
+__global__ void k_sqrt_of_unit_floats_check(unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    const unsigned lo = 0x2f800000u, hi = 0x3f800000u;                 // 2^-32 .. 1.0
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k <= (unsigned long long)(hi - lo) + 1ull; k += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = k == (unsigned long long)(hi - lo) + 1ull ? 0.f : __uint_as_float(lo + (unsigned)k);
+        if (__float_as_int(sqrt_of_uniform(x)) != __float_as_int(sqrtf(x))) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 // debug / test hook: largest |estimate - exact(double)| of the tap offset over n samples
 __global__ void k_tap_estimate_error(int n, float* maxErr) {
@@ -444,10 +464,10 @@ __device__ __forceinline__ Staged fetch_staged_global(const GBufView& g, const T
 
 // The per-pixel body of phase B (restir.cu:196-230).  STAGED: neighbour records come from the LDS tile
 // `stage` (origin sox, soy); otherwise from global memory.
-template <bool STAGED>
+template <bool STAGED, bool SOBOL>
 __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlanes& sp, const GBufView& g, const ResvPlanes& own,
                                               const TempPlanes& temp, const Staged* stage, int sox, int soy,
-                                              float* __restrict__ directIllum, int iter, bool spatial,
+                                              float* __restrict__ directIllum, int iter, int looper, bool spatial,
                                               int x, int y, int index, uint2 rm, f3 albedo, f3 prev) {
     const int W = g.width, H = g.height;
     const int mk = (int)rm.y;
@@ -460,7 +480,7 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
         direct = mk3(e.x, e.y, e.z);
     }
     if (kind == kKindShaded) {
-        Rng rng; rng.x = rm.x;
+        SamplerT<SOBOL> rng = SamplerT<SOBOL>::resume(s.sampleSeq, rm.x, looper, kDrawsRis + ((rm.y & kTemporalDrewBit) ? 1 : 0));
 
         // own reservoir = what phase A published (post-temporal, validity-checked)
         float W0; int M0; int src = index;
@@ -492,9 +512,9 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
                 const int tM = same ? __float_as_int(q.tap.y) : 0;
                 const int tSrc = same ? py * W + px : -1;
                 const bool valid = !resv_invalid(tW);                  // `if (!spatial.invalid())`: the draw happens only then
-                Rng adv = rng;
+                SamplerT<SOBOL> adv = rng;
                 const float u = adv.uniform();
-                rng.x = valid ? adv.x : rng.x;
+                if (valid) rng = adv;
                 const float nW = aW + tW;                              // Reservoir::merge (restir.h:61-68)
                 aSrc = (valid & (u * nW < tW)) ? tSrc : aSrc;
                 aW = valid ? nW : aW;
@@ -538,8 +558,9 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
     st3(directIllum + (size_t)index * 3, iter == 0 ? acc : acc / (float)(iter + 1));
 }
 
+template <bool SOBOL>
 __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
-                                                             float* __restrict__ directIllum, int iter, int reuse,
+                                                             float* __restrict__ directIllum, int iter, int looper, int reuse,
                                                              int y0, int y1, int tilesX, int numTiles) {
     __shared__ Staged stage[kBStageN];
 
@@ -581,7 +602,7 @@ __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevSce
         __syncthreads();
     }
     if (!inside) return;
-    spatial_pixel<true>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, spatial, x, y, index, rm, albedo, prev);
+    spatial_pixel<true, SOBOL>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, looper, spatial, x, y, index, rm, albedo, prev);
 }
 
 }  // namespace
@@ -706,6 +727,9 @@ namespace {
 // inner calls and synchronises once at its end
 int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, int looper, int reuse, int y0, int y1, bool last) {
     RS_TRY(check_frame_args(r, scene, cam, g));
+    RS_TRY(rs_check_looper(scene, looper, "ReSTIRDirect"));
+    const bool sobol = scene->dev.sampleSeq != nullptr;
+    r->looper = looper;                                         // phase B resumes the samplers of this call's pixels (Sobol: the table row)
     if (y0 < 0) y0 = 0;
     if (y1 > r->height) y1 = r->height;
     r->raySlot = (r->raySlot + 1) % kRaySlots;                  // one counter slot per call (ring): zero here, k_temporal moves it out
@@ -715,7 +739,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // frame's own set of surface planes: in asynchronous mode they go to an auxiliary stream, ordered after the frame
     // that last used the set (or, for a second call within one frame, after everything enqueued so far), and the library
     // stream joins them before the temporal pass.  Their heavy-tile tails then overlap the other frame's passes.
-    static const bool parityStreams = []{ const char* e = std::getenv("RS_PARITY_STREAMS"); return !(e && e[0] == '0'); }();
+    const rs_context* plan = rs_stream_plan();                  // rs_set_stream_plan (defaults: two chain streams, small launches on three, shadow rays of large launches on the library stream)
+    const bool parityStreams = plan->chainStreams == 2;
     const bool asyncMode = !r->timing && rs_aux_stream(1) != nullptr;
     const int W = r->width;
     const int tilesX = (W + 31) / 32, tilesY = (y1 > y0 ? y1 - y0 + 7 : 0) / 8;
@@ -728,7 +753,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     //    wave: 0.25 ms against 0.18 on a 1/8 strip), but it leaves the render's stream idle, and with that stream as a THIRD chain
     //    it wins: 8 strips of 1080p 5.96x -> 6.5x (RS_SMALL_CHAINS=0: two chains and a separate render).
     // Whenever the launch is fused the frame's chain is one of three (a full frame gains another 0.9 % from the third).
-    static const bool smallChains = []{ const char* e = std::getenv("RS_SMALL_CHAINS"); return !(e && e[0] == '0'); }();
+    const bool smallChains = plan->smallChains != 0;
     const rs_gbuffer::Deferred& d = g->deferred;
     const int fuseMode = rs_fuse_mode();
     const bool fusable = asyncMode && fuseMode != 0 && y1 > y0 && d.valid && d.scene == scene && std::memcmp(&d.cam, cam, sizeof(rs_camera)) == 0 &&
@@ -770,36 +795,29 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         const GBufWrite gw{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
         const int gTilesY = (d.y1 - d.y0 + 3) / 4;                // 8x4-pixel tiles: two rays per pixel fill the wave
         const CamParams lp = rs_make_cam_params(&d.lastCam);
-        if (scene->textured)
-            hipLaunchKernelGGL(k_gbuffer_primary<true>, dim3(tilesX * gTilesY), dim3(256), 0, st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
-        else
-            hipLaunchKernelGGL(k_gbuffer_primary<false>, dim3(tilesX * gTilesY), dim3(256), 0, st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
+        RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
         g->pending = true;
     }
-    else if (scene->textured)
-        hipLaunchKernelGGL(k_primary<true>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     else
-        hipLaunchKernelGGL(k_primary<false>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+        RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     mark(r, 1);
     const int npx = (y1 - y0) * W;
     // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
     // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
     // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
     const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
-    if (scene->envMapTexId >= 0)       // the environment map is one more light (scene.h:400-403)
-        hipLaunchKernelGGL(k_ris<true>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
-    else if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow)
-        hipLaunchKernelGGL(k_ris_lds, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), 0, st, scene->dev, sp, W, y0, y1);
-    else
-        hipLaunchKernelGGL(k_ris<false>, dim3((npx + 255) / 256), dim3(256), 0, st, scene->dev, sp, W, y0, y1);
+    if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
+        RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
+    else                               // the environment map is one more light (scene.h:400-403)
+        RS_LAUNCH2(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), st, scene->dev, sp, W, y0, y1, looper);
     mark(r, 2);
     // The shadow rays of a launch that fills the chip several times over go to the library stream, behind the previous frame's
     // spatial pass: every stream then has slack against the frame period and three or four kernels are in flight at any time,
     // which is what a frame bound by VALU issue needs (1080p: 1.277 -> 1.245 ms).  A small launch -- a strip -- lasts as long as its
     // slowest wave, and there the library stream is the one chain that links consecutive frames: its shadow rays stay on the
     // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  RS_SHADOW_ON_MAIN=0 / 1: never / always.
-    static const int shadowOnMain = []{ const char* e = std::getenv("RS_SHADOW_ON_MAIN"); return e ? std::atoi(e) : 2; }();
+    const int shadowOnMain = plan->shadowOnMain;
     const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
     if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
     if (aux) {
@@ -809,8 +827,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     }
     if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
-    hipLaunchKernelGGL(k_temporal, dim3((npx + 255) / 256), dim3(256), 0, rs_stream(), sp, gbuf_view(g),
-                       r->last, r->cur, r->temp, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
+    RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), rs_stream(), sp, gbuf_view(g),
+               r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
     mark(r, 3);
     return last ? rs_after_launch("ReSTIR Direct (phase A)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase A)");
 }
@@ -825,8 +843,8 @@ int phase_b_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
     RS_TRY(rs_gbuffer_join(g));
-    hipLaunchKernelGGL(k_spatial_shade, dim3(numTiles), dim3(kBThreads), 0, rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
-                       r->cur, r->temp, devDirectIllum, iter, reuse, y0, y1, tilesX, numTiles);
+    RS_LAUNCH1(k_spatial_shade, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
+               r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);
     return last ? rs_after_launch("ReSTIR Direct (phase B)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase B)");
 }
@@ -877,18 +895,21 @@ int rs_restir_end_frame(rs_restir* r) {
     r->smallChain = (r->smallChain + 1) % rs_restir::kSmallChains;
     r->phaseACalls = 0;
     // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA, kTuneB and kTuneC begin (two
-    // launches in the first span, one fused launch in the second); at frame kTuneC the host waits once for the last stamp (the GPU
-    // still has that frame's predecessors queued) and the shorter span decides.  A caller that
-    // times frames runs kTuneC + 1 frames first (bench.py does, before its warm-up) and then sees one launch form only.
+    // launches in the first span, one fused launch in the second); from frame kTuneC on every frame end asks (hipEventQuery, no
+    // wait) whether the last stamp has been reached, and the shorter span decides; until then frames take two launches.  A caller that
+    // times frames runs kTuneC + 2 frames and a synchronisation first (bench.py does, before its warm-up) and then sees one launch form only.
     if (r->tuneCounted && r->tuneChoice < 0) {
         const int f = ++r->tuneFrame;
         if (f == kTuneA || f == kTuneB || f == kTuneC) RS_HIP(hipEventRecord(r->tuneEv[f == kTuneA ? 0 : f == kTuneB ? 1 : 2], rs_stream()));
-        if (f >= kTuneC) {
+        if (f >= kTuneC) {                                          // never a host wait: the stamp is asked for at every frame end until it is there
             float separate = 0.f, fused = 0.f;
-            if (hipEventSynchronize(r->tuneEv[2]) == hipSuccess && hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess &&
-                hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
-                r->tuneChoice = fused < separate ? 1 : 0;
-            else { (void)hipGetLastError(); r->tuneChoice = 0; }
+            const hipError_t q = hipEventQuery(r->tuneEv[2]);
+            if (q == hipSuccess) {
+                if (hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess && hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
+                    r->tuneChoice = fused < separate ? 1 : 0;
+                else { (void)hipGetLastError(); r->tuneChoice = 0; }
+            }
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); r->tuneChoice = 0; }
         }
     }
     r->tuneCounted = false;
@@ -1028,6 +1049,20 @@ int rs_debug_sqrt_of_uniform_mismatches(unsigned long long* mismatches) {
     RS_TRY(rs_dev_alloc(&d, 1));
     RS_HIP(hipMemsetAsync(d, 0, 8, rs_stream()));
     hipLaunchKernelGGL(k_sqrt_of_uniform_check, dim3(4096), dim3(256), 0, rs_stream(), d);
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
+    rs_dev_free(d);
+    return 0;
+}
+
+// test hook: the same for every value the Sobol sampler can return (0 and all floats in [2^-32, 1])
+int rs_debug_sqrt_of_unit_floats_mismatches(unsigned long long* mismatches) {
+    rs_ctx_scope scope(nullptr);
+    if (!mismatches) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_sqrt_of_unit_floats_mismatches: null");
+    unsigned long long* d = nullptr;
+    RS_TRY(rs_dev_alloc(&d, 1));
+    RS_HIP(hipMemsetAsync(d, 0, 8, rs_stream()));
+    hipLaunchKernelGGL(k_sqrt_of_unit_floats_check, dim3(4096), dim3(256), 0, rs_stream(), d);
     RS_HIP(hipStreamSynchronize(rs_stream()));
     RS_HIP(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
     rs_dev_free(d);

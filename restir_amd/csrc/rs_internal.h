@@ -30,11 +30,13 @@ struct rs_context {
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory: -1 from the environment (RS_RIS_GLOBAL_BELOW) or 384 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
+    int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
 };
 rs_context* rs_ctx();                                   // the context this thread's library code runs under right now
 struct rs_ctx_scope {                                   // entry points: run under the context of the object they were handed
     rs_context* prev;
+    int prevDevice = -1;                                // the caller's device, restored on exit when the scope had to change it
     explicit rs_ctx_scope(rs_context* c);               // null: keep the thread's current context
     ~rs_ctx_scope();
 };
@@ -70,6 +72,23 @@ static inline void rs_dev_free(T*& p) {
     if (p) { (void)hipFree((void*)p); p = nullptr; }
 }
 
+// kernel<A, B> for two run-time booleans (TEX / ENV x SOBOL variants)
+#define RS_LAUNCH2(kernel, a, b, grid, block, stream, ...)                                                          \
+    do {                                                                                                            \
+        if (a) { if (b) hipLaunchKernelGGL((kernel<true, true>), grid, block, 0, stream, __VA_ARGS__);              \
+                 else   hipLaunchKernelGGL((kernel<true, false>), grid, block, 0, stream, __VA_ARGS__); }           \
+        else   { if (b) hipLaunchKernelGGL((kernel<false, true>), grid, block, 0, stream, __VA_ARGS__);             \
+                 else   hipLaunchKernelGGL((kernel<false, false>), grid, block, 0, stream, __VA_ARGS__); }          \
+    } while (0)
+#define RS_LAUNCH1(kernel, a, grid, block, stream, ...)                                                             \
+    do {                                                                                                            \
+        if (a) hipLaunchKernelGGL((kernel<true>), grid, block, 0, stream, __VA_ARGS__);                             \
+        else   hipLaunchKernelGGL((kernel<false>), grid, block, 0, stream, __VA_ARGS__);                            \
+    } while (0)
+// The Sobol branch indexes its table by the caller's looper (State::looper, kept below SobolSampleNum by the reference's
+// `(looper + 1) % SobolSampleNum`, restir.cu:441-445): a looper outside the table is refused instead of read.
+int rs_check_looper(const struct rs_scene* scene, int looper, const char* what);
+
 // ---- scene -------------------------------------------------------------------------------------
 struct rs_scene {
     rs_context* ctx = nullptr;
@@ -93,6 +112,7 @@ struct rs_scene {
     std::vector<int> hEnvFail;
     int envMapTexId = -1;
     bool textured = false;                        // any material map or an environment map: kernels take the textured variant
+    uint32_t* dSampleSeq = nullptr;  // the Sobol table (rs_scene_set_sample_sequence); null: the default thrust engine
     uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
@@ -160,6 +180,7 @@ int rs_gbuffer_release_scene(const rs_scene* scene);
 int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream);
 bool rs_fuse_enabled();
 int rs_ris_global_below();
+const rs_context* rs_stream_plan();   // the current context with chainStreams / smallChains / shadowOnMain resolved
 int rs_fuse_mode();     // 0 never, 1 always (large launches), 2 always, 3 measured per rs_restir
 
 // device view of the planes the kernels read
@@ -260,6 +281,7 @@ struct rs_restir {
     TempPlanes temp;     // devDirectTemp           (published for the spatial pass)
     rs_indirect_reservoir* indResv[2] = { nullptr, nullptr };   // devIndTemporalReservoir / devIndLastTemporalReservoir (gi.hip), allocated on first use
     bool firstFrame = true;
+    int looper = 0;                  // of the last phase-A call (phase B resumes the per-pixel samplers it left)
     // per-pixel state carried between the passes of one frame (implementation bytes, not in the
     // reference: its single fused kernel keeps these in registers).  kSurfSets sets, used in turn: the primary-ray,
     // RIS and shadow-ray kernels of the next frames (auxiliary streams) fill theirs while the temporal / spatial passes of frame f read this one.

@@ -123,4 +123,39 @@ RS_HD Rng seeded_rng(int iter, int index, int dim) {
     return r;
 }
 
+// ---- the Sobol branch of src/sampler.h:9-36 (SAMPLER_USE_SOBOL): Sampler{ptr, scramble, data} over the table
+// DevScene::sampleSequence, SobolSampleNum x SobolSampleDim uint32 (scene.cpp:500-506).
+constexpr int kSobolSampleDim = 200;          // sampler.h:11
+struct SobolSampler {
+    const uint32_t* data;
+    uint32_t scramble;
+    int ptr;
+    RS_HD float uniform() {                   // Sampler::sample (sampler.h:19-23): `r * 0x1p-32f` converts r to float first
+        const uint32_t r = data[ptr++] ^ scramble;
+        scramble = utilhash(scramble);
+        return (float)r * 0x1p-32f;
+    }
+    RS_HD f2 uniform2() { f2 r; r.x = uniform(); r.y = uniform(); return r; }
+    RS_HD f4 uniform4() { f4 r; r.x = uniform(); r.y = uniform(); r.z = uniform(); r.w = uniform(); return r; }
+};
+
+// One name for both samplers, chosen by a kernel's template parameter.  `seeded` is makeSeededRandomEngine(iter, index, dim, data);
+// `word` / `resume` carry a sampler from one pass of a frame to the next in ONE 32-bit word per pixel: the generator's state, or the
+// scramble -- the table position is then iter * SobolSampleDim + dim + (draws made so far), which the passes of ReSTIRDirect know.
+template <bool SOBOL> struct SamplerT;
+template <> struct SamplerT<false> : Rng {
+    static RS_HD SamplerT seeded(const uint32_t*, int iter, int index, int dim) { SamplerT s; s.x = seeded_rng(iter, index, dim).x; return s; }
+    static RS_HD SamplerT resume(const uint32_t*, uint32_t word, int, int) { SamplerT s; s.x = word; return s; }
+    RS_HD uint32_t word() const { return x; }
+};
+template <> struct SamplerT<true> : SobolSampler {
+    static RS_HD SamplerT seeded(const uint32_t* table, int iter, int index, int dim) {           // sampler.h:30-32
+        SamplerT s; s.data = table; s.scramble = utilhash((uint32_t)index); s.ptr = iter * kSobolSampleDim + dim; return s;
+    }
+    static RS_HD SamplerT resume(const uint32_t* table, uint32_t word, int iter, int drawn) {
+        SamplerT s; s.data = table; s.scramble = word; s.ptr = iter * kSobolSampleDim + drawn; return s;
+    }
+    RS_HD uint32_t word() const { return scramble; }
+};
+
 }  // namespace rs

@@ -79,7 +79,12 @@ struct DevScene {
     int numPrims;
     int numLights;
     int numMaterials;
+    // DevScene::sampleSequence (src/scene.h:480, src/scene.cpp:500-506): the Sobol table, sampleCount x kSobolSampleDim uint32 followed
+    // by a guard of kSobolGuard zeros; null = the default thrust engine (SAMPLER_USE_SOBOL false).  rs_scene_set_sample_sequence.
+    const uint32_t* sampleSeq;
+    int sampleCount;
 };
+constexpr int kSobolGuard = 4096;
 
 typedef float vf2 __attribute__((ext_vector_type(2)));     // operands of the packed FP32 instructions (v_pk_add / mul / fma_f32)
 #ifndef RS_OCC_PERM

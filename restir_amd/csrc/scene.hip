@@ -125,9 +125,41 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
-    rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords);
+    rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords); rs_dev_free(s->dSampleSeq);
     for (float*& p : s->dTexData) rs_dev_free(p);
     delete s;
+    return 0;
+}
+
+// DevScene::sampleSequence (src/scene.cpp:500-506 reads sobol_10k_200.bin into it).  The reference chooses its sampler at compile
+// time (SAMPLER_USE_SOBOL, src/common.h:4); here the scene carries the choice: with a table every kernel that draws random numbers
+// runs its Sobol instantiation (src/sampler.h:9-36), with data == NULL the default thrust engine (:38-49) again.
+extern "C" int rs_scene_set_sample_sequence(rs_scene* s, const uint32_t* data, int numSamples, int numDims) {
+    RS_SCOPE(s);
+    if (!s) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_set_sample_sequence: null scene");
+    if (data && (numSamples <= 0 || numDims != kSobolSampleDim))
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_set_sample_sequence: the table must be numSamples x 200 (SobolSampleDim, src/sampler.h:11)");
+    (void)rs_gbuffer_release_scene(s);
+    RS_TRY(rs_synchronize());                           // kernels in flight may still read the previous table
+    rs_dev_free(s->dSampleSeq);
+    s->dev.sampleSeq = nullptr; s->dev.sampleCount = 0;
+    if (!data) return 0;
+    const size_t n = (size_t)numSamples * numDims;
+    // Sampler::sample reads data[ptr++] without a bound (sampler.h:20): a guard of zeros behind the table keeps the long paths of the
+    // multi-bounce kernels inside the allocation for the last rows too (ReSTIRDirect draws at most 181 < 200 numbers and never gets there)
+    RS_TRY(rs_dev_alloc(&s->dSampleSeq, n + kSobolGuard));
+    RS_HIP(hipMemcpy(s->dSampleSeq, data, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RS_HIP(hipMemset(s->dSampleSeq + n, 0, kSobolGuard * sizeof(uint32_t)));
+    s->dev.sampleSeq = s->dSampleSeq; s->dev.sampleCount = numSamples;
+    return 0;
+}
+
+int rs_check_looper(const rs_scene* scene, int looper, const char* what) {
+    if (scene && scene->dev.sampleSeq && (looper < 0 || looper >= scene->dev.sampleCount)) {
+        static thread_local std::string msg;
+        msg = std::string(what) + ": looper outside the Sobol table (the reference keeps State::looper below SobolSampleNum, restir.cu:441-445)";
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, msg.c_str());
+    }
     return 0;
 }
 

@@ -44,8 +44,15 @@ struct rs_strips {
     int y0 = 0, y1 = 0;
     size_t haloBytes = 0;                          // one edge: reservoirs + G-buffer rows
     char* sendUp = nullptr; char* recvUp = nullptr; char* sendDown = nullptr; char* recvDown = nullptr;
-    hipStream_t commStream = nullptr;              // carries the transfers
+    hipStream_t commStream = nullptr;              // carries the transfers: ONE stream, so that every rank issues its groups in one order
     hipEvent_t packed = nullptr, arrived = nullptr;
+    static constexpr int kGatherSlots = 4;
+    hipEvent_t gathered[kGatherSlots] = {};        // rs_strips_gather_begin / _end: the gather of a slot has finished
+    bool gatherPending[kGatherSlots] = {};
+    // rs_strips_enable_timing: how long the library stream sat idle in join() of the last frame's halo exchange (events on the library stream around the wait)
+    bool timing = false;
+    hipEvent_t waitFrom = nullptr, waitTo = nullptr;
+    bool waitValid = false;
     // rs_strips_eaw_filter: the two full-frame buffers the levels alternate between, staging for the 32 G-buffer rows of an edge
     float* eawBuf[2] = { nullptr, nullptr };
     char* eawSend[2] = { nullptr, nullptr }; char* eawRecv[2] = { nullptr, nullptr };
@@ -85,15 +92,28 @@ int post(rs_strips* s, const Xfer* ops, size_t n) {
     if (c->t.stream_ordered) { RS_HIP(hipEventRecord(s->packed, rs_stream())); RS_HIP(hipStreamWaitEvent(ts, s->packed, 0)); }
     else RS_TRY(rs_synchronize());
     if (c->t.group_begin) RS_TRY(c->t.group_begin(c->t.ctx));
-    for (size_t i = 0; i < n; i++) {
-        if (ops[i].send) RS_TRY(c->t.send(c->t.ctx, ops[i].buf, ops[i].bytes, ops[i].peer, ts));
-        else RS_TRY(c->t.recv(c->t.ctx, ops[i].buf, ops[i].bytes, ops[i].peer, ts));
+    // a group that was begun is always ended (an open ncclGroup would swallow every later call of this thread); the first error is reported
+    int err = 0;
+    for (size_t i = 0; i < n && !err; i++) {
+        if (ops[i].send) err = c->t.send(c->t.ctx, ops[i].buf, ops[i].bytes, ops[i].peer, ts);
+        else err = c->t.recv(c->t.ctx, ops[i].buf, ops[i].bytes, ops[i].peer, ts);
     }
-    if (c->t.group_end) RS_TRY(c->t.group_end(c->t.ctx));       // RCCL: the grouped transfers are enqueued here; a host-side transport completes here
-    return 0;
+    std::string firstError;
+    if (err) firstError = rs_last_error();
+    if (c->t.group_end) {                                        // RCCL: the grouped transfers are enqueued here; a host-side transport completes here
+        const int e2 = c->t.group_end(c->t.ctx);
+        if (err) return rs_fail(err, firstError.c_str());
+        return e2;
+    }
+    return err;
 }
-int join(rs_strips* s) {
-    if (s->comm->t.stream_ordered) { RS_HIP(hipEventRecord(s->arrived, s->commStream)); RS_HIP(hipStreamWaitEvent(rs_stream(), s->arrived, 0)); }
+int join(rs_strips* s, bool timed = false) {
+    if (s->comm->t.stream_ordered) {
+        RS_HIP(hipEventRecord(s->arrived, s->commStream));
+        if (timed && s->timing) RS_HIP(hipEventRecord(s->waitFrom, rs_stream()));
+        RS_HIP(hipStreamWaitEvent(rs_stream(), s->arrived, 0));
+        if (timed && s->timing) { RS_HIP(hipEventRecord(s->waitTo, rs_stream())); s->waitValid = true; }
+    }
     return 0;
 }
 
@@ -117,24 +137,39 @@ int rs_comm_create(const rs_transport* t, int rank, int world, rs_comm** out) {
     return 0;
 }
 
-int rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** out) {
+// The communicator belongs to ONE copy of RCCL -- the one whose ncclCommInitRank made it -- and its handle means nothing to another
+// copy (a process can hold two: PyTorch wheels bundle their own librccl.so next to /opt/rocm/lib's).  Binding order: the path the
+// caller names; else what the process has linked or loaded globally (dlsym in the global scope); else a copy that is already
+// loaded under RCCL's soname (RTLD_NOLOAD: nothing new is mapped); only if the process has no RCCL at all a fresh, local open.
+int rs_comm_create_rccl_lib(void* ncclComm, int rank, int world, const char* librcclPath, rs_comm** out) {
     if (!ncclComm || !out || world < 1 || rank < 0 || rank >= world) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_comm_create_rccl: bad argument");
     rs_comm* c = new rs_comm();
     c->rank = rank; c->world = world; c->nccl = ncclComm;
-    // the caller's process has created the communicator, so the library is loaded already; RTLD_NOLOAD would do, a plain open is the same handle
-    for (const char* name : { "librccl.so", "librccl.so.1" }) { c->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (c->lib) break; }
-    if (!c->lib) { delete c; return rs_fail(RS_ERR_UNSUPPORTED, "rs_comm_create_rccl: librccl.so cannot be opened"); }
-    c->pSend = (decltype(c->pSend))dlsym(c->lib, "ncclSend");
-    c->pRecv = (decltype(c->pRecv))dlsym(c->lib, "ncclRecv");
-    c->pGroupStart = (decltype(c->pGroupStart))dlsym(c->lib, "ncclGroupStart");
-    c->pGroupEnd = (decltype(c->pGroupEnd))dlsym(c->lib, "ncclGroupEnd");
-    c->pErr = (decltype(c->pErr))dlsym(c->lib, "ncclGetErrorString");
+    void* from = nullptr;                                        // handle to look the symbols up in; RTLD_DEFAULT when they are global
+    if (librcclPath && librcclPath[0]) {
+        c->lib = dlopen(librcclPath, RTLD_NOW | RTLD_LOCAL);
+        if (!c->lib) { delete c; return rs_fail(RS_ERR_UNSUPPORTED, "rs_comm_create_rccl_lib: the named librccl cannot be opened"); }
+        from = c->lib;
+    }
+    else if (dlsym(RTLD_DEFAULT, "ncclSend")) from = RTLD_DEFAULT;
+    else {
+        for (const char* name : { "librccl.so.1", "librccl.so" }) { c->lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (c->lib) break; }
+        if (!c->lib) for (const char* name : { "librccl.so.1", "librccl.so" }) { c->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (c->lib) break; }
+        if (!c->lib) { delete c; return rs_fail(RS_ERR_UNSUPPORTED, "rs_comm_create_rccl: librccl.so cannot be opened"); }
+        from = c->lib;
+    }
+    c->pSend = (decltype(c->pSend))dlsym(from, "ncclSend");
+    c->pRecv = (decltype(c->pRecv))dlsym(from, "ncclRecv");
+    c->pGroupStart = (decltype(c->pGroupStart))dlsym(from, "ncclGroupStart");
+    c->pGroupEnd = (decltype(c->pGroupEnd))dlsym(from, "ncclGroupEnd");
+    c->pErr = (decltype(c->pErr))dlsym(from, "ncclGetErrorString");
     if (!c->pSend || !c->pRecv || !c->pGroupStart || !c->pGroupEnd) { rs_comm_destroy(c); return rs_fail(RS_ERR_UNSUPPORTED, "rs_comm_create_rccl: librccl.so lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"); }
     c->t.ctx = c; c->t.group_begin = rccl_group_begin; c->t.group_end = rccl_group_end; c->t.send = rccl_send; c->t.recv = rccl_recv;
     c->t.stream_ordered = 1;
     *out = c;
     return 0;
 }
+int rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** out) { return rs_comm_create_rccl_lib(ncclComm, rank, world, nullptr, out); }
 
 // Sends `bytes` of devSend to this rank itself and receives them into devRecv, through the transport exactly as rs_strips_frame
 // uses it (group, stream order, events): a one-rank check of a transport, e.g. of the run-time binding to librccl on a single GPU.
@@ -166,6 +201,9 @@ int rs_strips_destroy(rs_strips* s) {
     if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
     if (s->packed) (void)hipEventDestroy(s->packed);
     if (s->arrived) (void)hipEventDestroy(s->arrived);
+    for (hipEvent_t& e : s->gathered) if (e) (void)hipEventDestroy(e);
+    if (s->waitFrom) (void)hipEventDestroy(s->waitFrom);
+    if (s->waitTo) (void)hipEventDestroy(s->waitTo);
     rs_dev_free(s->sendUp); rs_dev_free(s->recvUp); rs_dev_free(s->sendDown); rs_dev_free(s->recvDown);
     for (int i = 0; i < 2; i++) { rs_dev_free(s->eawBuf[i]); rs_dev_free(s->eawSend[i]); rs_dev_free(s->eawRecv[i]); }
     rs_dev_free(s->histSend); rs_dev_free(s->histRecv);
@@ -200,6 +238,9 @@ int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs
         e = rs_check_hip(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
         if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->packed, hipEventDisableTiming), "hipEventCreate");
         if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->arrived, hipEventDisableTiming), "hipEventCreate");
+        for (hipEvent_t& ev : s->gathered) if (!e) e = rs_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        if (!e) e = rs_check_hip(hipEventCreate(&s->waitFrom), "hipEventCreate");
+        if (!e) e = rs_check_hip(hipEventCreate(&s->waitTo), "hipEventCreate");
     }
     if (e) { rs_strips_destroy(s); return e; }
     *out = s;
@@ -242,7 +283,7 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
     const int topEnd = up ? (y0 + kHalo < y1 ? y0 + kHalo : y1) : y0;
     const int botStart = down ? (y1 - kHalo > topEnd ? y1 - kHalo : topEnd) : y1;
     if (botStart > topEnd) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, topEnd, botStart));
-    RS_TRY(join(s));
+    RS_TRY(join(s, true));
     if (up) { RS_TRY(rs_restir_halo_unpack(r, y0 - kHalo, kHalo, s->recvUp)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - kHalo, kHalo, s->recvUp + nr)); }
     if (down) { RS_TRY(rs_restir_halo_unpack(r, y1, kHalo, s->recvDown)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, kHalo, s->recvDown + nr)); }
     if (topEnd > y0) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, topEnd));
@@ -356,6 +397,59 @@ int rs_strips_gather(rs_strips* s, void* devImage, size_t bytesPerPixel, int roo
     }
     RS_TRY(post(s, ops.data(), ops.size()));
     return join(s);
+}
+
+// The same assembly without making the library stream wait for it: _begin posts the transfers (after everything enqueued on the
+// library stream so far) and returns; _end makes the library stream wait for them.  A caller with two display buffers begins the
+// gather of frame f into one and ends it before frame f + 2 writes that buffer again (or before root reads it): the rows travel
+// while the next frame's kernels run.  `slot` in [0, 4) names the gather; every rank must begin the same gathers in the same order.
+int rs_strips_gather_begin(rs_strips* s, void* devImage, size_t bytesPerPixel, int root, int slot) {
+    RS_SCOPE(s);
+    const rs_comm* c = s ? s->comm : nullptr;
+    if (!s || !devImage || bytesPerPixel == 0 || root < -1 || root >= c->world || slot < 0 || slot >= rs_strips::kGatherSlots)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_gather_begin: bad argument");
+    if (c->world == 1) return 0;
+    if (s->gatherPending[slot]) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_gather_begin: the slot's previous gather has not been ended");
+    const size_t row = (size_t)s->width * bytesPerPixel;
+    char* base = (char*)devImage;
+    std::vector<Xfer> ops;
+    for (int k = 0; k < c->world; k++) {
+        if (k == c->rank) continue;
+        if (root < 0 || root == k) ops.push_back({ true, base + (size_t)s->y0 * row, (size_t)(s->y1 - s->y0) * row, k });
+        if (root < 0 || root == c->rank) ops.push_back({ false, base + (size_t)s->bounds[(size_t)k] * row, (size_t)(s->bounds[(size_t)k + 1] - s->bounds[(size_t)k]) * row, k });
+    }
+    RS_TRY(post(s, ops.data(), ops.size()));
+    if (c->t.stream_ordered) RS_HIP(hipEventRecord(s->gathered[slot], s->commStream));
+    s->gatherPending[slot] = true;
+    return 0;
+}
+int rs_strips_gather_end(rs_strips* s, int slot) {
+    RS_SCOPE(s);
+    if (!s || slot < 0 || slot >= rs_strips::kGatherSlots) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_gather_end: bad argument");
+    if (!s->gatherPending[slot]) return 0;
+    s->gatherPending[slot] = false;
+    if (s->comm->t.stream_ordered) RS_HIP(hipStreamWaitEvent(rs_stream(), s->gathered[slot], 0));
+    return 0;
+}
+
+// Measurement: with timing on, rs_strips_frame brackets the library stream's wait for the neighbours' border rows with two
+// events; rs_strips_halo_wait_ms returns the span of the last frame that exchanged rows -- the part of the halo latency the
+// interior rows of phase B did not hide (0 when the rows had arrived by the time the interior rows were done).  Waits for that frame.
+int rs_strips_enable_timing(rs_strips* s, int enable) {
+    RS_SCOPE(s);
+    if (!s) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_enable_timing: null");
+    s->timing = enable != 0 && s->waitFrom != nullptr;
+    s->waitValid = false;
+    return 0;
+}
+int rs_strips_halo_wait_ms(rs_strips* s, float* ms) {
+    RS_SCOPE(s);
+    if (!s || !ms) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_halo_wait_ms: null argument");
+    *ms = 0.f;
+    if (!s->waitValid) return 0;
+    RS_HIP(hipEventSynchronize(s->waitTo));
+    RS_HIP(hipEventElapsedTime(ms, s->waitFrom, s->waitTo));
+    return 0;
 }
 
 }  // extern "C"

@@ -21,9 +21,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "../../include/restir_hip.h"
 
@@ -43,6 +45,16 @@ inline void check(int code, const char* msg) {          // checkCUDAError(msg)
 }
 }  // namespace rsc
 
+// ---- src/common.h:4, src/sampler.h:9-11 -----------------------------------------------------------
+// The reference picks its sampler at compile time; a caller built with -DSAMPLER_USE_SOBOL=true gets the Sobol branch: buildDevData
+// reads "sobol_10k_200.bin" from the working directory as DevScene::create does (src/scene.cpp:500-506; tools/make_sobol_table.py
+// writes one) and the launchers wrap State::looper at SobolSampleNum (src/restir.cu:441-445, src/pathtrace.cu:450-454).
+#ifndef SAMPLER_USE_SOBOL
+#define SAMPLER_USE_SOBOL false
+#endif
+#define SobolSampleNum 10000
+#define SobolSampleDim 200
+
 // ---- src/common.h:18-67 -------------------------------------------------------------------------
 struct ToneMapping { enum { None = 0, Filmic = 1, ACES = 2 }; };
 struct ReservoirReuse { enum { None = 0, Temporal = 1, Spatial = 2, Spatiotemporal = 3 }; };
@@ -60,6 +72,27 @@ struct State {
     static inline int looper = 0;
     static inline Scene* scene = nullptr;
 };
+namespace rsc {
+inline void advanceLooper() {                           // the tail of every launcher (src/restir.cu:441-445)
+#if SAMPLER_USE_SOBOL
+    State::looper = (State::looper + 1) % SobolSampleNum;
+#else
+    State::looper++;
+#endif
+}
+// DevScene::create's last step (src/scene.cpp:500-506).  A missing or short file leaves the rest of the table zero, as the
+// reference's unchecked ifstream::read into a zero-filled vector does.
+inline void uploadSampleSequence(rs_scene* devScene) {
+#if SAMPLER_USE_SOBOL
+    std::vector<uint32_t> sobolData((size_t)SobolSampleNum * SobolSampleDim, 0u);
+    std::ifstream sobolFile("sobol_10k_200.bin", std::ios::in | std::ios::binary);
+    sobolFile.read(reinterpret_cast<char*>(sobolData.data()), (std::streamsize)(sobolData.size() * sizeof(uint32_t)));
+    check(rs_scene_set_sample_sequence(devScene, sobolData.data(), SobolSampleNum, SobolSampleDim), "Dev Scene");
+#else
+    (void)devScene;
+#endif
+}
+}  // namespace rsc
 
 // ---- src/sceneStructs.h:22-126 -------------------------------------------------------------------
 struct Camera : rs_camera {
@@ -104,11 +137,13 @@ struct Scene {
         rsc::check(rs_scene_file_get(file, &v), "Dev Scene");
         rsc::check(rs_scene_build_textured(v.numPrims, v.vertices, v.normals, v.texcoords, v.materialIds, v.numMaterials, v.materials,
                                            v.numTextures, v.textures, v.envMapTexId, &devScene), "Dev Scene");
+        rsc::uploadSampleSequence(devScene);
     }
     // buildDevData on an already baked, de-indexed triangle soup
     void buildDevData(int numPrims, const float* vertices, const float* normals, const float* texcoords,
                       const int* materialIds, int numMaterials, const Material* materials) {
         rsc::check(rs_scene_build(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials, &devScene), "Dev Scene");
+        rsc::uploadSampleSequence(devScene);
     }
     // the same with the decoded images of Scene::textures and Scene::envMapTexId (src/scene.h:518-521;
     // createLightSampler's environment-map sampler, src/scene.cpp:136-152, is built by the library)
@@ -117,6 +152,7 @@ struct Scene {
                       int numTextures, const rs_texture* textures, int envMapTexId) {
         rsc::check(rs_scene_build_textured(numPrims, vertices, normals, texcoords, materialIds, numMaterials, materials,
                                            numTextures, textures, envMapTexId, &devScene), "Dev Scene");
+        rsc::uploadSampleSequence(devScene);
     }
     void clear() { rs_scene_destroy(devScene); devScene = nullptr; }     // src/scene.cpp:217-220
 };
@@ -145,7 +181,7 @@ inline void ReSTIRDirect(rsc::vec3* devDirectIllum, int iter, const GBuffer& gBu
     rsc::check(rs_restir_direct(rsc::g_restir, State::scene->devScene, &State::scene->camera, gBuffer.impl,
                                 reinterpret_cast<float*>(devDirectIllum), iter, State::looper, Settings::reservoirReuse),
                "ReSTIR Direct");
-    State::looper++;
+    rsc::advanceLooper();
 }
 
 // ---- src/pathtrace.h:8-16 ----------------------------------------------------------------------------
@@ -154,24 +190,24 @@ inline void pathTraceFree() { rs_path_trace_free(); }
 inline void pathTraceDirect(rsc::vec3* devDirectIllum, int iter) {                        // src/pathtrace.cu:457-476
     rsc::check(rs_path_trace_direct(State::scene->devScene, &State::scene->camera, reinterpret_cast<float*>(devDirectIllum),
                                     iter, State::looper, nullptr), "pathTrace");
-    State::looper++;
+    rsc::advanceLooper();
 }
 // multi-bounce kernels (src/pathtrace.h:12-16, src/restir.h:133); Settings::traceDepth is the reference's global
 inline void pathTrace(rsc::vec3* devDirectIllum, rsc::vec3* devIndirectIllum, int iter) {  // src/pathtrace.cu:434-455
     rsc::check(rs_path_trace(State::scene->devScene, &State::scene->camera, reinterpret_cast<float*>(devDirectIllum),
                              reinterpret_cast<float*>(devIndirectIllum), iter, State::looper, Settings::traceDepth, nullptr), "pathTrace");
-    State::looper++;
+    rsc::advanceLooper();
 }
 inline void pathTraceIndirect(rsc::vec3* devIndirectIllum, int iter) {                     // src/pathtrace.cu:478-497
     rsc::check(rs_path_trace_indirect(State::scene->devScene, &State::scene->camera, reinterpret_cast<float*>(devIndirectIllum),
                                       iter, State::looper, Settings::traceDepth, nullptr), "pathTrace");
-    State::looper++;
+    rsc::advanceLooper();
 }
 inline void ReSTIRIndirect(rsc::vec3* devIndirectIllum, int iter, const GBuffer& gBuffer) {   // src/restir.cu:448-476
     rsc::check(rs_restir_indirect(rsc::g_restir, State::scene->devScene, &State::scene->camera, gBuffer.impl,
                                   reinterpret_cast<float*>(devIndirectIllum), iter, State::looper, Settings::reservoirReuse,
                                   Settings::traceDepth, nullptr), "ReSTIR Indirect");
-    State::looper++;
+    rsc::advanceLooper();
 }
 struct uchar4_t { unsigned char x, y, z, w; };
 inline void copyImageToPBO(void* devPBO, rsc::vec3* devImage, int width, int height, int toneMapping, float scale = 1.f) {

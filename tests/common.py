@@ -50,12 +50,21 @@ def get_scene(name):
     raise KeyError(name)
 
 
+def next_looper(looper, sobol_num):
+    """The tail of every launcher (src/restir.cu:441-445): looper++ or, with the Sobol sampler, (looper + 1) % SobolSampleNum."""
+    return looper + 1 if sobol_num is None else (looper + 1) % sobol_num
+
+
 class OracleRenderer:
     """runCuda on the CPU oracle."""
 
-    def __init__(self, sd, width, height, scene=None):
+    def __init__(self, sd, width, height, scene=None, sobol=None):
+        """sobol: the Sobol table (uint32 [SobolSampleNum, 200]) = a build with SAMPLER_USE_SOBOL true; None = the default engine."""
         self.sd = sd
         self.scene = scene or oracle_scene(sd)
+        if sobol is not None or scene is None:
+            self.scene.set_sample_sequence(sobol)
+        self.sobol_num = None if sobol is None else len(sobol)
         self.W, self.H = width, height
         self.cam = ob.camera_update(sd.camera(width, height))
         self.gbuf = ob.GBuffer(width, height)
@@ -75,7 +84,7 @@ class OracleRenderer:
             self.rays = self.restir.direct(self.scene, self.cam, self.gbuf, self.image, iteration, self.looper, reuse)
         else:
             self.rays = ob.pt_direct(self.scene, self.cam, self.image, iteration, self.looper)
-        self.looper += 1
+        self.looper = next_looper(self.looper, self.sobol_num)
         self.gbuf.update(self.cam)
         return self.image
 
@@ -83,12 +92,15 @@ class OracleRenderer:
 class HipRenderer:
     """runCuda on librestir_hip through the C ABI."""
 
-    def __init__(self, capi, sd, width, height, scene=None):
+    def __init__(self, capi, sd, width, height, scene=None, sobol=None):
         import torch
         self.torch = torch
         self.capi = capi
         self.sd = sd
         self.scene = scene or hip_scene(capi, sd)
+        if sobol is not None or scene is None:
+            self.scene.set_sample_sequence(sobol)
+        self.sobol_num = None if sobol is None else len(sobol)
         self.W, self.H = width, height
         self.cam = capi.camera_update(sd.camera(width, height))
         self.gbuf = capi.GBuffer(width, height)
@@ -108,7 +120,7 @@ class HipRenderer:
             self.rays = self.restir.ray_count()
         else:
             self.rays = self.capi.path_trace_direct(self.scene, self.cam, self.image.data_ptr(), iteration, self.looper)
-        self.looper += 1
+        self.looper = next_looper(self.looper, self.sobol_num)
         self.gbuf.update(self.cam)
         return self.image.cpu().numpy()
 

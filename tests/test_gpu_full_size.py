@@ -37,11 +37,11 @@ def _compare_gbuffer(o, h, what=""):
     assert bits_equal(o.gbuf.depth[f], g["depth"][f]), what
 
 
-def _frames_equal_oracle(hip, sd, W, H, static_frames, orbit_frames, radius=1.0, before_last_update=None):
+def _frames_equal_oracle(hip, sd, W, H, static_frames, orbit_frames, radius=1.0, before_last_update=None, sobol=None):
     """runCuda's sequence (render, ReSTIRDirect, [filter], update) on both sides, everything compared after every frame."""
     from restir_amd.scenes import orbit_position
-    o = OracleRenderer(sd, W, H)
-    h = HipRenderer(hip, sd, W, H)
+    o = OracleRenderer(sd, W, H, sobol=sobol)
+    h = HipRenderer(hip, sd, W, H, sobol=sobol)
     frames = static_frames + orbit_frames
     for frame in range(frames):
         if frame >= static_frames:                            # runCuda's animateCamera: reprojection through devMotion
@@ -70,6 +70,14 @@ def test_config3_full_size_frames_equal_oracle(hip, exact_libm):
     assert sd.num_prims == 262144
     o, h = _frames_equal_oracle(hip, sd, 1920, 1080, 3, 2)
     assert o.restir.last["numSamples"].max() > 32                      # history in use
+
+
+def test_config3_full_size_frames_with_the_sobol_sampler(hip, exact_libm):
+    """The same workload with `SAMPLER_USE_SOBOL true` (src/sampler.h:9-36; north_star's "same scene and Sobol seed"): the build's
+    10 000 x 200 table on both sides, two static frames and one of the orbit."""
+    from restir_amd import sobol
+    sd = get_scene("sponza:1.0")
+    _frames_equal_oracle(hip, sd, 1920, 1080, 2, 1, sobol=sobol.sobol_table())
 
 
 def test_config5_full_size_frames_equal_oracle(hip, exact_libm):

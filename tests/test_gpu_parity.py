@@ -212,19 +212,27 @@ def test_restir_no_spatial_bit_exact(hip, name, reuse, table):
 
 @pytest.mark.parametrize("name", list(SCENES))
 @pytest.mark.parametrize("reuse", [2, 3])
-def test_restir_spatial(hip, name, reuse):
+@pytest.mark.parametrize("libm", ["correctly_rounded", "glibc"])
+def test_restir_spatial(hip, name, reuse, libm):
+    """Spatial reuse.  With the oracle's cos / sin correctly rounded (what the device evaluates) every bit
+    of the radiance and of both reservoir buffers must agree; against glibc's cosf / sinf (one ulp off for 1.3 % of the
+    arguments, which moves a tap only when that ulp crosses a pixel boundary) the stated tolerance applies."""
     sd = get_scene(name)
     W, H = SCENES[name]
-    o = OracleRenderer(sd, W, H)
-    h = HipRenderer(hip, sd, W, H)
-    for frame in range(4):
-        a = o.frame(reuse); b = h.frame(reuse)
-        st = radiance_stats(a, b)
-        assert st["mean_l1"] < 1e-4 and st["flip_frac"] <= 1e-3, (frame, st)
-        _compare_reservoirs(o.restir.last, h.restir.download(1))
-        _compare_reservoirs(o.restir.temp, h.restir.download(2))
-    # expected in practice: no mismatch at all
-    assert st["bit_mismatch"] <= 1e-3, st
+    ob.set_libm_mode(1 if libm == "correctly_rounded" else 0)
+    try:
+        o = OracleRenderer(sd, W, H)
+        h = HipRenderer(hip, sd, W, H)
+        for frame in range(4):
+            a = o.frame(reuse); b = h.frame(reuse)
+            st = radiance_stats(a, b)
+            if libm == "correctly_rounded":
+                assert st["bit_mismatch"] == 0, (frame, st)
+            assert st["mean_l1"] < 1e-4 and st["flip_frac"] <= 1e-3, (frame, st)
+            _compare_reservoirs(o.restir.last, h.restir.download(1))
+            _compare_reservoirs(o.restir.temp, h.restir.download(2))
+    finally:
+        ob.set_libm_mode(0)
 
 
 def test_tap_estimate_error_is_inside_the_fallback_band(hip):
@@ -428,8 +436,8 @@ def test_textured_scene_against_glibc_libm(hip):
         assert st["mean_l1"] < 1e-4 and st["flip_frac"] <= 1e-3, (frame, st)
 
 
-def test_restir_moving_camera_temporal(hip):
-    """Orbiting camera (runCuda :149-153 with a fixed dt): reprojection through devMotion."""
+def test_restir_moving_camera_temporal(hip, correctly_rounded_libm):
+    """Orbiting camera (runCuda :149-153 with a fixed dt): reprojection through devMotion; every bit of every frame."""
     from restir_amd.scenes import orbit_position
     sd = get_scene("sponza:0.03")
     W, H = SCENES["sponza:0.03"]
@@ -439,9 +447,8 @@ def test_restir_moving_camera_temporal(hip):
         p = orbit_position(sd.camera_args["position"], frame, radius=0.3)
         o.set_camera_position(p); h.set_camera_position(p)
         a = o.frame(3); b = h.frame(3)
-        st = radiance_stats(a, b)
-        assert st["mean_l1"] < 1e-4 and st["flip_frac"] <= 1e-3, (frame, st)
-    _compare_reservoirs(o.restir.last, h.restir.download(1))
+        assert bits_equal(a, b), (frame, radiance_stats(a, b))
+        _compare_reservoirs(o.restir.last, h.restir.download(1))
 
 
 def test_restir_reset_and_accumulate(hip):
@@ -860,15 +867,22 @@ def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
                     keep.append(h.image.clone())
                 h.gbuf.update(h.cam)
             hip.synchronize(); torch.cuda.synchronize()
+            out = [t.cpu().numpy() for t in keep] + [h.restir.download(1).view(np.uint8), h.gbuf.download()["depth"][0]]
+            # the library never waits on the host for its measurement: it asks at every frame end whether the last time stamp has
+            # been reached, so the decision falls at the first frame end after the GPU has caught up with frame 14
+            h.gbuf.render(h.scene, h.cam)
+            h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+            h.gbuf.update(h.cam)
+            hip.synchronize()
         finally:
             hip.set_sync(True)
         choices.append(h.restir.launch_choice())
-        return [t.cpu().numpy() for t in keep] + [h.restir.download(1).view(np.uint8), h.gbuf.download()["depth"][0]]
+        return out
 
     choices = []
     for a, b in zip(run(False), run(True)):
         assert bits_equal(a, b)
-    assert choices[0] == -2 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided at frame 14
+    assert choices[0] == -2 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided once the stamp of frame 14 is there
 
 
 def test_scene_destroyed_while_a_render_is_only_recorded(hip):
