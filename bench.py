@@ -11,9 +11,16 @@ shading ray per pixel + 1 shadow ray per shaded pixel; c
 
 N > 1: the 1920x1080 framebuffer is cut into N row strips (strong scaling: the total work is fixed).
 Every rank renders its strip, exchanges 5 border rows of published reservoirs and of the G-buffer id / normal / depth planes
-with its strip neighbours over RCCL point-to-point between phase A and phase B (restir_amd/tiling.py),
-tone-maps its strip, and the RGBA8 strips are gathered on rank 0 (asynchronously: the gather of one frame overlaps
-the next frame's kernels; the last gathers are waited for before the clock stops) -- all inside the timed region.
+with its strip neighbours over RCCL point-to-point between phase A and phase B, tone-maps its strip, and the RGBA8 strips are
+gathered on rank 0 (asynchronously: the gather of one frame overlaps the next frame's kernels; the last gathers are waited for
+before the clock stops) -- all inside the timed region.  The frames go through the PRODUCT's strip driver, the C ABI of
+restir_amd/csrc/strips.hip (rs_strips_frame / rs_strips_gather_begin / _end over rs_comm_create_rccl_lib), on an ncclComm_t this
+script creates the way a C++ caller does (ncclGetUniqueId on rank 0, the id broadcast, ncclCommInitRank; restir_amd/rccl.py);
+torch.distributed (gloo) is the control plane only: the id broadcast, barriers, the reduction of the timings.
+  BENCH_STRIP_DRIVER=py      the Python form of the same schedule (restir_amd/tiling.py over torch.distributed) for cross-checks
+  BENCH_STRIP_TRANSPORT=gloo the C driver over host callbacks + gloo: rehearsal on a one-GPU box (with BENCH_DEVICE=0 every rank
+                             uses the same card; RCCL refuses two ranks on one device)
+  BENCH_FORCE_STRIPS=1       N = 1 through the strip driver and a one-rank ncclComm as well
 
 One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its
@@ -194,19 +201,29 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank per GPU")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no fallback"
-    # rehearsal of the N > 1 path on a one-GPU box: BENCH_DIST_BACKEND=gloo BENCH_DEVICE=0 puts every rank on one card
+    # which strip driver runs the frames: "c" = rs_strips_* of librestir_hip (the product; default for N > 1), "py" = restir_amd/tiling.py,
+    # "none" = the plain single-GPU calls (default for N = 1)
+    force_strips = os.environ.get("BENCH_FORCE_STRIPS", "0") == "1"
+    driver = os.environ.get("BENCH_STRIP_DRIVER", "c" if (world > 1 or force_strips) else "none")
+    if world > 1 and driver == "none":
+        driver = "c"
+    transport = os.environ.get("BENCH_STRIP_TRANSPORT", "rccl")
+    # rehearsal of the N > 1 path on a one-GPU box: BENCH_DEVICE=0 puts every rank on one card
     device = int(os.environ.get("BENCH_DEVICE", local_rank))
-    backend_name = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    # control plane: gloo for the C driver (its data path is the library's own RCCL transport); the Python driver's data path IS
+    # torch.distributed, so it takes nccl (= RCCL) unless told otherwise
+    backend_name = os.environ.get("BENCH_DIST_BACKEND", "gloo" if driver == "c" else "nccl")
     torch.cuda.set_device(device)
     if world > 1:
         if backend_name == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend_name)
+    ctl_device = "cuda" if (world > 1 and backend_name == "nccl") else "cpu"      # where control-plane tensors live
 
     from restir_amd import capi, scenes
     from restir_amd.scenes import orbit_position
-    from restir_amd.tiling import HipBackend, StripRenderer, calibrate_bounds
+    from restir_amd.tiling import HipBackend, StripRenderer, calibrate_bounds, strip_bounds
     capi.init(device)
 
     sd = scenes.sponza_class(seed=1, scale=1.0)
@@ -221,36 +238,89 @@ def main():
         bounds = calibrate_bounds(backend, world, rank, HEIGHT, dist, torch.cuda.synchronize, reuse=REUSE)
         torch.cuda.synchronize()
         backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)          # fresh reservoirs and G-buffer for the measured run
-    strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit, bounds=bounds)
-    y0, y1 = strips.y0, strips.y1
-    rows = y1 - y0
-    # RGBA8 strip of this rank; with N > 1 two sets of buffers, so that the gather of frame f (asynchronous, on RCCL's
-    # stream) overlaps the kernels of frame f + 1 and is only waited for before its buffers are written again
-    pbos = [torch.zeros((strips.max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
-    gather_outs = [[torch.empty_like(pbos[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in pbos]
-    pending = [None] * len(pbos)
-    frame_no = [0]
-
+    if bounds is None:
+        bounds = [strip_bounds(HEIGHT, world, r) for r in range(world)]
     base_pos = sd.camera_args["position"]
+    state = {"looper": 0, "frame_no": 0}
 
-    def frame():
+    def move_camera(looper):
         if args.orbit:
-            p = orbit_position(base_pos, strips.looper, radius=1.0)
+            p = orbit_position(base_pos, looper, radius=1.0)
             for i in range(3):
                 cam.position[i] = float(p[i])
             capi.camera_update(cam)
-        strips.frame(REUSE, 0)             # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), GBuffer::update
-        k = frame_no[0] % len(pbos); frame_no[0] += 1
-        if pending[k] is not None:
-            pending[k].wait(); pending[k] = None
-        capi.copy_image_to_pbo(pbos[k].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
-        if world > 1:
-            pending[k] = dist.gather(pbos[k], gather_outs[k], dst=0, async_op=True)
 
-    def barrier():
-        for k in range(len(pending)):      # every frame's image has reached rank 0 before the clock stops
+    rccl = None
+    if driver == "c":
+        # ---- the product's strip driver: strips.hip through the C ABI ---------------------------------------------------------
+        from restir_amd.rccl import GlooTransport, RcclComm
+        if transport == "rccl":
+            def bcast(raw):
+                if world == 1:
+                    return raw
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            rccl = RcclComm(rank, world, bcast)            # before anything else in this process touches RCCL
+            comm = capi.Comm.rccl(rccl.handle.value, rank, world, rccl.path)
+        else:
+            comm = GlooTransport(capi, dist, torch).comm(rank, world)
+        drv = capi.Strips(comm, WIDTH, HEIGHT, [b[0] for b in bounds] + [HEIGHT])
+        y0, y1 = drv.y0, drv.y1
+        assert (y0, y1) == tuple(bounds[rank])
+        rows = y1 - y0
+        # the display image, full-frame sized on every rank (rs_strips_gather addresses rows in place); two of them, so that the
+        # gather of frame f travels while frame f + 1 renders
+        pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+        def frame():
+            move_camera(state["looper"])
+            drv.frame(backend.restir, scene, cam, backend.gbuf, backend.image.data_ptr(), 0, state["looper"], REUSE)
+            backend.gbuf.update(cam)
+            if args.orbit and world > 1:
+                drv.exchange_history(backend.restir, backend.gbuf)
+            state["looper"] += 1
+            k = state["frame_no"] % 2; state["frame_no"] += 1
+            drv.gather_end(k)                                           # the gather that read pbos[k] two frames ago
+            capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * WIDTH * 4, backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+            drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)
+
+        def finish_gathers():
+            drv.gather_end(0); drv.gather_end(1)
+
+        def pbo_ptr():
+            return pbos[0].data_ptr() + y0 * WIDTH * 4
+    else:
+        # ---- restir_amd/tiling.py over torch.distributed (N = 1: the plain calls) -----------------------------------------------
+        strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit, bounds=bounds)
+        y0, y1 = strips.y0, strips.y1
+        rows = y1 - y0
+        # RGBA8 strip of this rank; with N > 1 two sets of buffers, so that the gather of frame f (asynchronous, on RCCL's
+        # stream) overlaps the kernels of frame f + 1 and is only waited for before its buffers are written again
+        pbos = [torch.zeros((strips.max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+        gather_outs = [[torch.empty_like(pbos[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in pbos]
+        pending = [None] * len(pbos)
+
+        def frame():
+            move_camera(strips.looper)
+            strips.frame(REUSE, 0)             # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), GBuffer::update
+            k = state["frame_no"] % len(pbos); state["frame_no"] += 1
             if pending[k] is not None:
                 pending[k].wait(); pending[k] = None
+            capi.copy_image_to_pbo(pbos[k].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+            if world > 1:
+                pending[k] = dist.gather(pbos[k], gather_outs[k], dst=0, async_op=True)
+
+        def finish_gathers():
+            for k in range(len(pending)):
+                if pending[k] is not None:
+                    pending[k].wait(); pending[k] = None
+
+        def pbo_ptr():
+            return pbos[0].data_ptr()
+
+    def barrier():
+        finish_gathers()                   # every frame's image has reached rank 0 before the clock stops
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -258,9 +328,14 @@ def main():
     # Before the warm-up: the library measures once per scene whether GBuffer::render is walked together with the primary rays
     # (frames 2-13 of a new rs_restir, restir.hip); those frames run here, so that warm-up and timed frames all use the form it
     # chose.  Strips too small for the fused launch have nothing to choose (-2).
-    # The count is the same on every rank (a frame exchanges halo rows with the neighbours).
-    calibration_frames = 16
-    for _ in range(calibration_frames):
+    # The count is the same on every rank (a frame exchanges halo rows with the neighbours).  The library decides at the first frame
+    # end after its last time stamp (frame 14) has been reached -- it never waits on the host -- hence the synchronisation and
+    # the two frames after it.
+    calibration_frames = 18
+    for _ in range(calibration_frames - 2):
+        frame()
+    barrier()
+    for _ in range(2):
         frame()
     barrier()
     for _ in range(args.warmup):
@@ -283,9 +358,7 @@ def main():
         torch.cuda.synchronize()
         ts = time.perf_counter()
         frame()
-        for k in range(len(pending)):
-            if pending[k] is not None:
-                pending[k].wait(); pending[k] = None
+        finish_gathers()
         torch.cuda.synchronize()
         sync_ms.append((time.perf_counter() - ts) * 1e3)
     capi.set_sync(False)
@@ -294,6 +367,19 @@ def main():
     # per-pass times of a few extra (untimed) frames, HIP events on the library's stream; the G-buffer render is kept on
     # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
     # primary-ray and RIS kernels from the library's second stream)
+    # how long this rank's library stream sat waiting for the neighbours' border rows (the part of the exchange the interior rows
+    # of phase B did not hide), frames overlapped as in the timed region, read after each frame
+    halo_wait = []
+    if driver == "c" and world > 1:
+        drv.enable_timing(True)
+        for _ in range(20):
+            frame()
+            finish_gathers()
+            torch.cuda.synchronize()
+            halo_wait.append(drv.halo_wait_ms())
+        drv.enable_timing(False)
+        barrier()
+
     capi.set_side_stream(0)
     backend.restir.enable_timing(True)
     spatial_ms, pass_ms = [], np.zeros(4)
@@ -307,14 +393,15 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     gb_ms, pbo_ms = [], []
     for _ in range(10):
-        ev[0].record(); backend.gbuffer_render(strips.gy0 if world > 1 else 0, strips.gy1 if world > 1 else HEIGHT); ev[1].record()
-        ev[2].record(); capi.copy_image_to_pbo(pbos[0].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0); ev[3].record()
+        ev[0].record(); backend.gbuffer_render(y0, y1); ev[1].record()
+        ev[2].record(); capi.copy_image_to_pbo(pbo_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0); ev[3].record()
         torch.cuda.synchronize()
         gb_ms.append(ev[0].elapsed_time(ev[1])); pbo_ms.append(ev[2].elapsed_time(ev[3]))
     capi.set_side_stream(4)
     backend.restir.enable_timing(False)
 
-    t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device="cuda")
+    finish_gathers()
+    t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device=ctl_device)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -360,8 +447,17 @@ def main():
                        "launches": "asynchronous (rs_set_sync(0)): consecutive frames overlap on the library's auxiliary streams; GBuffer::render is walked "
                                    "together with the primary rays when the library measures that to be faster (it measures in untimed frames before the warm-up); "
                                    "ms_per_frame_synchronous is one frame alone with a synchronisation after every call, the reference's mode",
-                       "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in strips.bounds) + " rows (cost-balanced by measurement), "
-                                  "5 border rows of reservoirs + G-buffer id / normal / depth over RCCL p2p (68 B/px), RGBA8 gather to rank 0") if world > 1 else "none",
+                       "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in bounds) + " rows (" +
+                                  ("equal heights" if os.environ.get("BENCH_EVEN_STRIPS", "0") == "1" else "cost-balanced by measurement") + "), "
+                                  "5 border rows of reservoirs + G-buffer id / normal / depth point-to-point (68 B/px), RGBA8 gather to rank 0") if world > 1 else "none",
+                       "strip_driver": {"c": "librestir_hip rs_strips_frame / rs_strips_gather_begin,_end (restir_amd/csrc/strips.hip)",
+                                        "py": "restir_amd/tiling.py over torch.distributed (%s)" % backend_name, "none": "none (single GPU: rs_gbuffer_render + rs_restir_direct)"}[driver],
+                       "transport": ("none" if driver == "none" else "torch.distributed " + backend_name if driver == "py" else
+                                     "RCCL ncclSend / ncclRecv groups on the driver's stream (rs_comm_create_rccl_lib), ncclComm_t made by ncclCommInitRank from " + str(rccl.path)
+                                     if transport == "rccl" else "host callbacks over torch.distributed gloo (rehearsal, not RCCL)"),
+                       "rccl_ranks": (world if (driver == "c" and transport == "rccl") else (world if (driver == "py" and backend_name == "nccl" and world > 1) else 0)),
+                       "strip_rows_per_rank": [b - a for a, b in bounds],
+                       "halo_wait_ms_rank0": (float(np.median(halo_wait)) if halo_wait else None),
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade")[0] if world == 1 else None,

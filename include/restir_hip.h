@@ -376,6 +376,10 @@ typedef struct rs_transport {
 /* ncclComm: an ncclComm_t of `world` ranks created by the caller (ncclCommInitRank); librccl.so is opened at run time, the
  * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on a stream of the strip driver */
 int  rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** comm);
+/* The same, naming the copy of RCCL that created ncclComm (a process can hold two: PyTorch wheels bundle their own librccl.so).
+ * librcclPath NULL or "" = rs_comm_create_rccl's search: symbols the process has linked or loaded globally, else a copy already
+ * loaded under the soname librccl.so.1 (nothing new is mapped), else a fresh local open of librccl.so.1. */
+int  rs_comm_create_rccl_lib(void* ncclComm, int rank, int world, const char* librcclPath, rs_comm** comm);
 int  rs_comm_create(const rs_transport* transport, int rank, int world, rs_comm** comm);
 int  rs_comm_destroy(rs_comm* comm);
 /* one-rank check of a transport: `bytes` of devSend travel to this rank itself into devRecv, grouped and ordered as in a frame */
@@ -400,6 +404,16 @@ int  rs_strips_exchange_history(rs_strips* strips, rs_restir* r, rs_gbuffer* g);
 /* Image assembly: rows [y0, y1) of every rank's devImage (full-frame sized, bytesPerPixel bytes per pixel: 12 for the radiance
  * image, 4 for the display image) arrive in the same rows on rank `root`, or on every rank for root = -1. */
 int  rs_strips_gather(rs_strips* strips, void* devImage, size_t bytesPerPixel, int root);
+/* The same without making the library stream wait: _begin posts the transfers behind what has been enqueued so far, _end makes the
+ * library stream wait for them (call it before devImage is written again or read on root).  slot in [0, 4) names a gather in
+ * flight; every rank begins the same gathers in the same order (all transfers of a strip driver share one stream). */
+int  rs_strips_gather_begin(rs_strips* strips, void* devImage, size_t bytesPerPixel, int root, int slot);
+int  rs_strips_gather_end(rs_strips* strips, int slot);
+/* Measurement: with timing enabled rs_strips_frame brackets the library stream's wait for the neighbours' border rows with two
+ * events; rs_strips_halo_wait_ms returns that span for the last frame -- the part of the exchange's latency that the interior rows
+ * of phase B did not hide (about 0 when the rows had arrived in time).  It waits for that frame. */
+int  rs_strips_enable_timing(rs_strips* strips, int enable);
+int  rs_strips_halo_wait_ms(rs_strips* strips, float* ms);
 
 /* ---- path-trace baseline (src/pathtrace.h:12-16) ---------------------------------------- */
 int  rs_path_trace_init(void);            /* pathTraceInit (src/pathtrace.cu:23-25) */

@@ -119,7 +119,7 @@ EXPORTS = [
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
-    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_exchange_history", "rs_strips_gather",
+    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create_rccl_lib", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_exchange_history", "rs_strips_gather", "rs_strips_gather_begin", "rs_strips_gather_end", "rs_strips_enable_timing", "rs_strips_halo_wait_ms",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
 
@@ -236,6 +236,11 @@ def lib():
     L.rs_strips_eaw_filter.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, C.POINTER(vp)]
     L.rs_strips_exchange_history.argtypes = [vp, vp, vp]
     L.rs_strips_gather.argtypes = [vp, vp, C.c_size_t, ci]
+    L.rs_strips_gather_begin.argtypes = [vp, vp, C.c_size_t, ci, ci]
+    L.rs_strips_gather_end.argtypes = [vp, ci]
+    L.rs_strips_enable_timing.argtypes = [vp, ci]
+    L.rs_strips_halo_wait_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rs_comm_create_rccl_lib.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
     L.rs_eaw_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
     for name in ("rs_eaw_set_params", "rs_svgf_set_params"):
         getattr(L, name).argtypes = [vp, C.c_float, C.c_float, C.c_float, ci]
@@ -762,11 +767,12 @@ class Comm:
         check(lib().rs_comm_create(C.byref(t), rank, world, C.byref(self.handle)))
 
     @classmethod
-    def rccl(cls, nccl_comm_ptr, rank, world):
+    def rccl(cls, nccl_comm_ptr, rank, world, librccl_path=None):
+        """librccl_path: the copy of RCCL that created the communicator (None: the library searches, rs_comm_create_rccl)."""
         self = cls.__new__(cls)
         self._cbs = ()
         self.handle = C.c_void_p()
-        check(lib().rs_comm_create_rccl(C.c_void_p(nccl_comm_ptr), rank, world, C.byref(self.handle)))
+        check(lib().rs_comm_create_rccl_lib(C.c_void_p(nccl_comm_ptr), rank, world, os.fsencode(librccl_path) if librccl_path else None, C.byref(self.handle)))
         return self
 
     def destroy(self):
@@ -802,6 +808,20 @@ class Strips:
 
     def gather(self, dev_image_ptr, bytes_per_pixel, root=-1):
         check(lib().rs_strips_gather(self.handle, dev_image_ptr, bytes_per_pixel, root))
+
+    def gather_begin(self, dev_image_ptr, bytes_per_pixel, root, slot):
+        check(lib().rs_strips_gather_begin(self.handle, dev_image_ptr, bytes_per_pixel, root, slot))
+
+    def gather_end(self, slot):
+        check(lib().rs_strips_gather_end(self.handle, slot))
+
+    def enable_timing(self, enable=True):
+        check(lib().rs_strips_enable_timing(self.handle, 1 if enable else 0))
+
+    def halo_wait_ms(self):
+        ms = C.c_float(0)
+        check(lib().rs_strips_halo_wait_ms(self.handle, C.byref(ms)))
+        return ms.value
 
     def destroy(self):
         if self.handle:

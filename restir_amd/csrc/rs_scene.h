@@ -539,8 +539,12 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     const char* nodes = reinterpret_cast<const char*>(s.occNodes);
     const unsigned endOff = (unsigned)s.occCount * 16u;
     // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
-    const f3 A = mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z);
-    const f3 B = mk3((s.occBase.x - ctx.o.x) * ctx.dinv.x, (s.occBase.y - ctx.o.y) * ctx.dinv.y, (s.occBase.z - ctx.o.z) * ctx.dinv.z);
+    // A lane that enters without a ray of its own (outside the frame, a special-case or far-origin ray that takes the reference walk)
+    // is parked on the sentinel record past the end for the whole walk; it evaluates that record like every other lane, so its
+    // slab distances must fail the test whatever its ray is: q * 0 + (-1) gives tMax = -1 < 0.  (With its own A and B a ray
+    // 2^24 grid extents away would absorb q * A in B, pass the empty box and step beyond the allocation.)
+    const f3 A = active ? mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z) : splat(0.f);
+    const f3 B = active ? mk3((s.occBase.x - ctx.o.x) * ctx.dinv.x, (s.occBase.y - ctx.o.y) * ctx.dinv.y, (s.occBase.z - ctx.o.z) * ctx.dinv.z) : splat(-1.f);
     // largest |slab distance| of the reference's root box
     const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
                                     fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),

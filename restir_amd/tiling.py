@@ -233,7 +233,7 @@ def calibrate_bounds(backend, world, rank, height, dist, synchronize, reuse=3, r
     if world == 1:
         return bounds
     torch = backend.torch
-    device = backend.empty(1).device
+    device = "cpu" if dist.get_backend() == "gloo" else backend.empty(1).device      # timings travel over the control plane
     for _ in range(rounds):
         s = StripRenderer(backend, world, rank, height, bounds=bounds)
         s.start_halo_exchange = lambda: ([], [], [])            # the strip's own kernels only

@@ -40,6 +40,8 @@ state = {"p": out.data_ptr()}
 t = timed(lambda: state.update(p=eaw.filter(state["p"], b.image.data_ptr(), b.gbuf, cam)))
 bytes_eaw = N * (5 * 44 + 16 + 12)            # + the position plane: read depth/id 8 + ... write 12
 print("LeveledEAWFilter   %.1f us / frame, algorithmic %.0f MB -> %.0f GB/s (%.2f of 8 TB/s)" % (t, bytes_eaw / 1e6, bytes_eaw / t / 1e3, bytes_eaw / t / 1e3 / 8000))
+if len(sys.argv) > 1 and sys.argv[1] == "eaw":        # tools/profile_eaw.sh: the EAW filter only
+    sys.exit(0)
 svgf = capi.SVGFFilter(W, H, 5)
 def svgf_frame():
     svgf.filter(b.image.data_ptr(), b.gbuf, cam); svgf.next_frame()

@@ -8,7 +8,8 @@ mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
 export RS_SIDE_STREAM=0
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --cpu-frames 0 > $OUT/trace.log 2>&1
+CMD=${PMC_CMD:-"python $R/bench.py --steps 20 --warmup 3 --cpu-frames 0"}
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

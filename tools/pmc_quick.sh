@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmcq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 6 --warmup 2 --cpu-frames 0"
+CMD=${PMC_CMD:-"python $R/bench.py --steps 6 --warmup 2 --cpu-frames 0"}
 export RS_SIDE_STREAM=0   # counters per kernel: every kernel alone on the library stream
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
