@@ -348,6 +348,9 @@ int  rs_debug_tap_estimate_error(int n, float* maxErr);
  * class test (rs_surface.h sqrt_of_uniform); this compares it with the exactly rounded sqrtf on every value the generator can
  * return (2^31 - 2 of them) and returns the number of differing results. */
 int  rs_debug_sqrt_of_uniform_mismatches(unsigned long long* mismatches);
+/* Test hook: the EAW filter divides by a sigma that is not a power of two in three instructions (Markstein's form, denoiser.hip
+ * div_sigma); this compares it with the IEEE division on every float in [2^-100, 2^100] and returns the number of differing quotients. */
+int  rs_debug_div_sigma_mismatches(float sigma, unsigned long long* mismatches);
 /* The same for every value the Sobol sampler can return: 0 and all floats in [2^-32, 1] (2^28 + 2 of them). */
 int  rs_debug_sqrt_of_unit_floats_mismatches(unsigned long long* mismatches);
 

@@ -34,8 +34,37 @@ __global__ void __launch_bounds__(256) k_positions(CamParams cam, const float* _
     st3(pos + (size_t)i * 3, p);
 }
 
-// MUL: bit 0 / 1 / 2 set = sigLumin / sigNormal / sigDepth is a power of two, so x / sigma == x * (1 / sigma) exactly and
-// the IEEE division (11 VALU) becomes a multiply.  The reference's defaults are 64, 0.2 and 1.
+// ---- the weight of one tap, shared by every form of the colour filter (so that all forms give the same bits) ----------------------
+// x / sigma.  POW2: sigma is a power of two, x * (1 / sigma) is the quotient exactly.  Otherwise Markstein's form of the division
+// with the correctly rounded reciprocal r = RN(1 / sigma): q0 = x * r is within an ulp of the quotient, the residual
+// rem = x - q0 * sigma is exact in one fused operation, and q0 + rem * r rounds to the correctly rounded quotient (Markstein 1990,
+// theorem 8.3 in Muller et al.) wherever no intermediate leaves the normal range -- any x in [2^-100, 2^100] for sigmas between
+// 2^-20 and 2^20; beyond that range it is still within an ulp.  3 instructions for the 10 of the scaled IEEE expansion
+// (v_div_scale x 2, v_rcp, 4 fused steps, v_div_fmas, v_div_fixup), once per tap.  tests: test_eaw_division_by_sigma_is_exact.
+template <bool POW2>
+__device__ __forceinline__ float div_sigma(float x, float sigma, float rsigma) {
+    if (POW2) return x * rsigma;
+    const float q0 = x * rsigma;
+    const float rem = __builtin_fmaf(-q0, sigma, x);
+    return __builtin_fmaf(rem, rsigma, q0);
+}
+// exp(-e) for e >= 0 (or NaN, which passes through).  The reference's three factors min(1, exp(-a)) * min(1, exp(-b)) * min(1, exp(-c))
+// share one exponential (the min() never acts on arguments <= 0): 1e-7-relative rounding differences in w.  The exponential itself is
+// the hardware's 2^t on t = e * -log2(e): t carries a relative rounding error of 2^-24, i.e. an absolute one of |t| * 2^-24, so the
+// weight is off by < 7e-7 relative down to weights of 1.5e-5 and by < 5e-6 relative for every weight above 1e-38 -- a taps' weight
+// enters the result relative to the centre tap's .1621.  Stated tolerance of the filter against the oracle (glibc expf): rtol 1e-5.
+// 2 instructions for the 12 of the library expf (range reduction, v_exp_f32, ldexp, two range tests).
+__device__ __forceinline__ float exp_neg(float e) { return __builtin_amdgcn_exp2f(e * -1.44269504088896340736f); }
+
+template <int MUL>
+__device__ __forceinline__ float tap_weight(f3 dc, f3 dn, f3 dp, float sigLumin, float rLumin, float sigNormal, float rNormal, float sigDepth, float rDepth) {
+    const float eC = div_sigma<(MUL & 1) != 0>(dot(dc, dc), sigLumin, rLumin);
+    const float eN = div_sigma<(MUL & 2) != 0>(dot(dn, dn), sigNormal, rNormal);
+    const float eP = div_sigma<(MUL & 4) != 0>(dot(dp, dp), sigDepth, rDepth);
+    return exp_neg(eC + eN + eP);
+}
+
+// MUL: bit 0 / 1 / 2 set = sigLumin / sigNormal / sigDepth is a power of two (the reference's defaults are 64, 0.2 and 1).
 template <int MUL>
 __global__ void __launch_bounds__(256) k_wavelet(float* __restrict__ colorOut, const float* __restrict__ colorIn,
                                                  const int* __restrict__ primId, const float* __restrict__ normal,
@@ -66,14 +95,7 @@ __global__ void __launch_bounds__(256) k_wavelet(float* __restrict__ colorOut, c
             const f3 colorQ = ld3(colorIn + (size_t)idxQ * 3);
             const f3 posQ = ld3(pos + (size_t)idxQ * 3);
             const f3 dc = colorP - colorQ, dn = normP - normQ, dp = posP - posQ;
-            // reference: min(1, exp(-|dc|^2 / sigLumin)) * min(1, exp(-|dn|^2 / sigNormal)) * min(1, exp(-|dp|^2 / sigDepth)).  The
-            // arguments are <= 0, so the min() never acts (a NaN passes through both forms), and the three factors share ONE
-            // exponential: 1e-7-relative rounding differences in w, inside the filter's stated tolerance (tests: rtol 1e-5),
-            // for a third fewer VALU instructions per tap.
-            const float eC = (MUL & 1) ? dot(dc, dc) * rLumin : dot(dc, dc) / sigLumin;
-            const float eN = (MUL & 2) ? dot(dn, dn) * rNormal : dot(dn, dn) / sigNormal;
-            const float eP = (MUL & 4) ? dot(dp, dp) * rDepth : dot(dp, dp) / sigDepth;
-            const float w = expf(-(eC + eN + eP)) * kGaussian5x5[i + 2][j + 2];
+            const float w = tap_weight<MUL>(dc, dn, dp, sigLumin, rLumin, sigNormal, rNormal, sigDepth, rDepth) * kGaussian5x5[i + 2][j + 2];
             sum = sum + colorQ * w;
             sumW += w;
         }
@@ -81,27 +103,47 @@ __global__ void __launch_bounds__(256) k_wavelet(float* __restrict__ colorOut, c
     st3(colorOut + (size_t)idxP * 3, sumW == 0.f ? colorP : sum / sumW);
 }
 
-// The same level for steps 1, 2 and 4 with the block's 32x8 pixels plus the 2 * STEP halo staged in LDS once (id, normal, colour,
-// position: 40 B per pixel as two 16-byte and one 8-byte record): the 25 taps of a pixel are LDS reads instead of 25 x 10 gathers
-// through L1, which is what bounds the plain form.  Same arithmetic in the same order: same bits.
-template <int STEP, int MUL>
-__global__ void __launch_bounds__(256) k_wavelet_tiled(float* __restrict__ colorOut, const float* __restrict__ colorIn,
-                                                       const int* __restrict__ primId, const float* __restrict__ normal,
-                                                       const float* __restrict__ pos, int W, int H,
-                                                       float sigDepth, float sigNormal, float sigLumin, int y0, int y1) {
-    constexpr int kHaloT = 2 * STEP, kRW = 32 + 2 * kHaloT, kRH = 8 + 2 * kHaloT, kRN = kRW * kRH;
+// The same level from an LDS tile, for every step up to 16.  A level of step s is s independent filters, one per row phase
+// (y mod s): the rows y, y + s, y + 2s ... form an image in which the taps are the vertical neighbours +-1, +-2.  A block takes
+// kTileW x kTileH pixels of ONE phase -- 64 consecutive pixels of 8 rows that lie s apart -- and stages them with 2 rows of that
+// phase above and below and 2s pixels to the left and right: (64 + 4s) x 12 records of 40 B (id, normal, colour, position as two
+// 16-byte and one 8-byte record), read from global memory as row segments, i.e. coalesced at every step.  (The round-2 tile held
+// (32 + 4s) x (8 + 4s) records, 4.5 per pixel at step 4 and too many for steps 8 and 16, whose 25 taps x 10 gathers per pixel
+// through L1 kept the texture addresser 87 % busy and fetched 11.5 x the algorithmic bytes over the fabric: the two levels were
+// half of the filter's time, profiles/r03_eaw_before.txt.)  Staged records per pixel: 1.6 (s = 1) ... 3 (s = 16).
+// POS0 (level 0 of a full-frame filter): the positions are computed while staging -- cam.getPosition of the staged pixel, the same
+// expression as k_positions -- and the block writes the position plane for its own pixels; the later levels read the plane.
+// Same arithmetic in the same order as k_wavelet: same bits.
+constexpr int kTileW = 64, kTileH = 8, kTileThreads = kTileW * kTileH;
+template <int STEP, int MUL, bool POS0>
+__global__ void __launch_bounds__(kTileThreads) k_wavelet_tiled(float* __restrict__ colorOut, const float* __restrict__ colorIn,
+                                                               const int* __restrict__ primId, const float* __restrict__ normal,
+                                                               float* __restrict__ pos, const float* __restrict__ depth, CamParams cam, int W, int H,
+                                                               float sigDepth, float sigNormal, float sigLumin, int y0, int y1) {
+    constexpr int kHaloX = 2 * STEP, kRW = kTileW + 2 * kHaloX, kRH = kTileH + 4, kRN = kRW * kRH;
     __shared__ float4 sColId[kRN];          // colour xyz, id bits
     __shared__ float4 sNormPx[kRN];         // normal xyz, position x
     __shared__ float2 sPyz[kRN];            // position y, z
-    const int ox = blockIdx.x * 32 - kHaloT, oy = y0 + blockIdx.y * 8 - kHaloT;
-    for (int e = threadIdx.x; e < kRN; e += 256) {
-        const int gx = ox + e % kRW, gy = oy + e / kRW;
+    const int phase = blockIdx.y % STEP, group = blockIdx.y / STEP;
+    const int rowBase = y0 + group * (kTileH * STEP) + phase;            // the row of tile row 0; tile row r is row rowBase + r * STEP
+    const int ox = blockIdx.x * kTileW - kHaloX;
+    for (int e = threadIdx.x; e < kRN; e += kTileThreads) {
+        const int lx = e % kRW, lr = e / kRW;
+        const int gx = ox + lx, gy = rowBase + (lr - 2) * STEP;
         float4 a = make_float4(0.f, 0.f, 0.f, __int_as_float(-3)), b = make_float4(0.f, 0.f, 0.f, 0.f);      // id -3 matches no pixel
         float2 c = make_float2(0.f, 0.f);
         if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
             const size_t q = (size_t)gy * W + gx;
-            const f3 col = ld3(colorIn + q * 3), n = ld3(normal + q * 3), p = ld3(pos + q * 3);
-            a = make_float4(col.x, col.y, col.z, __int_as_float(primId[q]));
+            const int id = primId[q];
+            const f3 col = ld3(colorIn + q * 3), n = ld3(normal + q * 3);
+            f3 p;
+            if (POS0) {
+                p = splat(0.f);
+                if (id > kNullPrim) p = camera_get_position(cam, gx, gy, depth[q]);
+                if (lx >= kHaloX && lx < kHaloX + kTileW && lr >= 2 && lr < 2 + kTileH && gy < y1) st3(pos + q * 3, p);
+            }
+            else p = ld3(pos + q * 3);
+            a = make_float4(col.x, col.y, col.z, __int_as_float(id));
             b = make_float4(n.x, n.y, n.z, p.x);
             c = make_float2(p.y, p.z);
         }
@@ -109,10 +151,10 @@ __global__ void __launch_bounds__(256) k_wavelet_tiled(float* __restrict__ color
     }
     __syncthreads();
     const float rLumin = 1.f / sigLumin, rNormal = 1.f / sigNormal, rDepth = 1.f / sigDepth;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int x = blockIdx.x * 32 + tx, y = y0 + blockIdx.y * 8 + ty;
+    const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
+    const int x = blockIdx.x * kTileW + tx, y = rowBase + ty * STEP;
     if (x >= W || y >= y1) return;
-    const int idxP = y * W + x, lp = (ty + kHaloT) * kRW + tx + kHaloT;
+    const int idxP = y * W + x, lp = (ty + 2) * kRW + tx + kHaloX;
     const float4 pa = sColId[lp], pb = sNormPx[lp];
     const float2 pc = sPyz[lp];
     const int idP = __float_as_int(pa.w);
@@ -125,22 +167,31 @@ __global__ void __launch_bounds__(256) k_wavelet_tiled(float* __restrict__ color
     for (int i = -2; i <= 2; i++) {
 #pragma unroll
         for (int j = -2; j <= 2; j++) {
-            const int lq = lp + i * STEP * kRW + j * STEP;
+            const int lq = lp + i * kRW + j * STEP;
             const float4 qa = sColId[lq];
             if (__float_as_int(qa.w) != idP) continue;         // also a tap outside the image (id -3)
             const float4 qb = sNormPx[lq];
             const float2 qc = sPyz[lq];
             const f3 colorQ = mk3(qa.x, qa.y, qa.z);
             const f3 dc = colorP - colorQ, dn = normP - mk3(qb.x, qb.y, qb.z), dp = posP - mk3(qb.w, qc.x, qc.y);
-            const float eC = (MUL & 1) ? dot(dc, dc) * rLumin : dot(dc, dc) / sigLumin;
-            const float eN = (MUL & 2) ? dot(dn, dn) * rNormal : dot(dn, dn) / sigNormal;
-            const float eP = (MUL & 4) ? dot(dp, dp) * rDepth : dot(dp, dp) / sigDepth;
-            const float w = expf(-(eC + eN + eP)) * kGaussian5x5[i + 2][j + 2];
+            const float w = tap_weight<MUL>(dc, dn, dp, sigLumin, rLumin, sigNormal, rNormal, sigDepth, rDepth) * kGaussian5x5[i + 2][j + 2];
             sum = sum + colorQ * w;
             sumW += w;
         }
     }
     st3(colorOut + (size_t)idxP * 3, sumW == 0.f ? colorP : sum / sumW);
+}
+
+// test hook: div_sigma<false> against the IEEE division on every float in [2^-100, 2^100]
+__global__ void k_div_sigma_check(float sigma, unsigned long long* mismatches) {
+    const float rs = 1.f / sigma;
+    const unsigned lo = (127u - 100u) << 23, hi = (127u + 100u) << 23;
+    unsigned long long bad = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k <= (unsigned long long)(hi - lo); k += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo + (unsigned)k);
+        if (__float_as_int(div_sigma<false>(x, sigma, rs)) != __float_as_int(x / sigma)) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 __global__ void __launch_bounds__(256) k_modulate(float* __restrict__ image, const float* __restrict__ albedo, int n) {
@@ -296,23 +347,41 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
     varOut[idxP] = sumW2 < 1.1920928955078125e-7f ? varIn[idxP] : sumVar / sumW2;
 }
 
-int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer* g, int level, int y0, int y1) {
-    dim3 grid((f->width + 31) / 32, (y1 - y0 + 7) / 8);
+// pos0: level 0 computes the positions itself (and writes the plane): only for a full-frame call, whose level 0 visits every pixel
+int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer* g, int level, int y0, int y1, const rs_camera* posCam = nullptr) {
     const auto pow2 = [](float v) { int e; return v > 0.f && std::isfinite(v) && std::frexp(v, &e) == 0.5f && 1.f / v > 0.f && std::isfinite(1.f / v) && std::isnormal(1.f / v); };
     const int mul = (pow2(f->sigLumin) ? 1 : 0) | (pow2(f->sigNormal) ? 2 : 0) | (pow2(f->sigDepth) ? 4 : 0);
-#define RS_WAVELET_ARGS out, in, g->primId[g->cur()], g->normal[g->cur()], f->devPos, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin
-#define RS_WAVELET(M) do { \
-        if (tiled && level == 0) hipLaunchKernelGGL((k_wavelet_tiled<1, M>), grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, y0, y1); \
-        else if (tiled && level == 1) hipLaunchKernelGGL((k_wavelet_tiled<2, M>), grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, y0, y1); \
-        else if (tiled && level == 2) hipLaunchKernelGGL((k_wavelet_tiled<4, M>), grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, y0, y1); \
-        else hipLaunchKernelGGL(k_wavelet<M>, grid, dim3(256), 0, rs_stream(), RS_WAVELET_ARGS, level, y0, y1); } while (0)
-    static const bool tiledEnv = []{ const char* e = std::getenv("RS_EAW_TILED"); return !(e && e[0] == '0'); }();
-    const bool tiled = tiledEnv && f->tiled;
+    static const bool tiledEnv = []{ const char* e = std::getenv("RS_EAW_TILED"); return !(e && e[0] == '0'); }();     // measurement switch
+    const bool tiled = tiledEnv && f->tiled && level <= 4;
+    const int c = g->cur();
+    if (tiled) {
+        const int step = 1 << level;
+        const dim3 grid((f->width + kTileW - 1) / kTileW, ((y1 - y0 + kTileH * step - 1) / (kTileH * step)) * step);
+        const bool pos0 = posCam != nullptr && level == 0;
+        const CamParams cp = pos0 ? rs_make_cam_params(posCam) : CamParams{};
+#define RS_TILED_ARGS out, in, g->primId[c], g->normal[c], f->devPos, g->depth[c], cp, f->width, f->height, f->sigDepth, f->sigNormal, f->sigLumin, y0, y1
+#define RS_TILED(M) do { \
+        if (pos0) hipLaunchKernelGGL((k_wavelet_tiled<1, M, true>), grid, dim3(kTileThreads), 0, rs_stream(), RS_TILED_ARGS); \
+        else if (level == 0) hipLaunchKernelGGL((k_wavelet_tiled<1, M, false>), grid, dim3(kTileThreads), 0, rs_stream(), RS_TILED_ARGS); \
+        else if (level == 1) hipLaunchKernelGGL((k_wavelet_tiled<2, M, false>), grid, dim3(kTileThreads), 0, rs_stream(), RS_TILED_ARGS); \
+        else if (level == 2) hipLaunchKernelGGL((k_wavelet_tiled<4, M, false>), grid, dim3(kTileThreads), 0, rs_stream(), RS_TILED_ARGS); \
+        else if (level == 3) hipLaunchKernelGGL((k_wavelet_tiled<8, M, false>), grid, dim3(kTileThreads), 0, rs_stream(), RS_TILED_ARGS); \
+        else hipLaunchKernelGGL((k_wavelet_tiled<16, M, false>), grid, dim3(kTileThreads), 0, rs_stream(), RS_TILED_ARGS); } while (0)
+        switch (mul) {
+            case 0: RS_TILED(0); break; case 1: RS_TILED(1); break; case 2: RS_TILED(2); break; case 3: RS_TILED(3); break;
+            case 4: RS_TILED(4); break; case 5: RS_TILED(5); break; case 6: RS_TILED(6); break; default: RS_TILED(7); break;
+        }
+#undef RS_TILED
+#undef RS_TILED_ARGS
+        return rs_after_launch("EAW Filter");
+    }
+    const dim3 grid((f->width + 31) / 32, (y1 - y0 + 7) / 8);
+#define RS_WAVELET(M) hipLaunchKernelGGL(k_wavelet<M>, grid, dim3(256), 0, rs_stream(), out, in, g->primId[c], g->normal[c], f->devPos, f->width, f->height, \
+                                         f->sigDepth, f->sigNormal, f->sigLumin, level, y0, y1)
     switch (mul) {
         case 0: RS_WAVELET(0); break; case 1: RS_WAVELET(1); break; case 2: RS_WAVELET(2); break; case 3: RS_WAVELET(3); break;
         case 4: RS_WAVELET(4); break; case 5: RS_WAVELET(5); break; case 6: RS_WAVELET(6); break; default: RS_WAVELET(7); break;
     }
-#undef RS_WAVELET_ARGS
 #undef RS_WAVELET
     return rs_after_launch("EAW Filter");
 }
@@ -320,6 +389,21 @@ int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer
 }  // namespace
 
 extern "C" {
+
+// test hook: the filter's division by a sigma that is not a power of two (div_sigma) against the IEEE division, on every float in
+// [2^-100, 2^100]; returns the number of differing quotients
+int rs_debug_div_sigma_mismatches(float sigma, unsigned long long* mismatches) {
+    rs_ctx_scope scope(nullptr);
+    if (!mismatches || !(sigma > 0.f)) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_div_sigma_mismatches: bad argument");
+    unsigned long long* d = nullptr;
+    RS_TRY(rs_dev_alloc(&d, 1));
+    RS_HIP(hipMemsetAsync(d, 0, 8, rs_stream()));
+    hipLaunchKernelGGL(k_div_sigma_check, dim3(8192), dim3(256), 0, rs_stream(), sigma, d);
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    RS_HIP(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
+    rs_dev_free(d);
+    return 0;
+}
 
 int rs_eaw_destroy(rs_eaw* f) {
     RS_SCOPE(f);
@@ -373,12 +457,16 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
     const int n = f->width * f->height;
-    hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
-                       g->depth[g->cur()], g->primId[g->cur()], f->devPos, 0, n);
-    RS_TRY(rs_after_launch("EAW positions"));
+    static const bool tiledEnv = []{ const char* e = std::getenv("RS_EAW_TILED"); return !(e && e[0] == '0'); }();
+    const bool fusedPositions = tiledEnv && f->tiled;           // the tiled level 0 computes the positions while it stages its tile
+    if (!fusedPositions) {
+        hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
+                           g->depth[g->cur()], g->primId[g->cur()], f->devPos, 0, n);
+        RS_TRY(rs_after_launch("EAW positions"));
+    }
     // LeveledEAWFilter::filter (denoiser.cu:463-477): level 0 into out, then four ping-pongs with the
     // internal buffer; the caller's pointer and the internal one are swapped after each
-    RS_TRY(wavelet_level(f, *devColorOut, devColorIn, g, 0, 0, f->height));
+    RS_TRY(wavelet_level(f, *devColorOut, devColorIn, g, 0, 0, f->height, fusedPositions ? cam : nullptr));
     for (int level = 1; level <= 4; level++) {
         RS_TRY(wavelet_level(f, f->devTempImg, *devColorOut, g, level, 0, f->height));
         float* t = *devColorOut; *devColorOut = f->devTempImg; f->devTempImg = t;

@@ -592,6 +592,15 @@ def test_eaw_filter_with_edited_sigmas(hip):
     f.destroy()
 
 
+@pytest.mark.parametrize("sigma", [0.2, 0.3, 3.0, 7.7, 100.0, 1e-3, 12345.678])
+def test_eaw_division_by_sigma_is_exact(hip, sigma):
+    """The filter divides |dn|^2 by sigNormal = 0.2 (any sigma that is not a power of two) with a reciprocal, an exact residual and
+    one correction (denoiser.hip div_sigma): the IEEE quotient on every float in [2^-100, 2^100], 1.68e9 of them per sigma."""
+    bad = C.c_ulonglong(1)
+    hip.check(hip.lib().rs_debug_div_sigma_mismatches(C.c_float(sigma), C.byref(bad)))
+    assert bad.value == 0, (sigma, bad.value)
+
+
 def test_eaw_tiled_levels_equal_plain_gathers(hip):
     """The levels of step 1, 2 and 4 read their taps from an LDS tile (k_wavelet_tiled); the claim is the plain kernel's arithmetic in
     the same order, so the filtered image must be the plain form's BIT FOR BIT -- checked directly, not through the oracle's rtol:
