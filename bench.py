@@ -187,9 +187,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
     ap.add_argument("--orbit", action="store_true", help="orbit the camera (runCuda animateCamera) instead of the static default")
     args = ap.parse_args()
-    if os.environ.get("BENCH_WATCHDOG"):                 # debugging aid: Python stack of every thread if the run takes longer than this
+    # A rank that waits for a peer that will never answer would hang the whole job: with N > 1 every rank ends itself (Python
+    # stacks of all threads on stderr) if the run takes longer than BENCH_WATCHDOG seconds (default 900; N = 1: only when set).
+    watchdog = os.environ.get("BENCH_WATCHDOG", "900" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
+    if watchdog:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(float(watchdog), exit=True)
 
     import numpy as np
     import torch
@@ -228,6 +231,14 @@ def main():
 
     sd = scenes.sponza_class(seed=1, scale=1.0)
     scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+    # BENCH_SOBOL=1: the reference built with SAMPLER_USE_SOBOL true (src/sampler.h:9-36) -- the 10 000 x 200 table of
+    # restir_amd/sobol.py on the scene, looper wrapped at 10 000; the default (and the headline) is the default engine
+    sobol_num = None
+    if os.environ.get("BENCH_SOBOL", "0") == "1":
+        from restir_amd import sobol
+        table = sobol.sobol_table()
+        scene.set_sample_sequence(table)
+        sobol_num = len(table)
     cam = capi.camera_update(sd.camera(WIDTH, HEIGHT))
     backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
     capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
@@ -251,9 +262,11 @@ def main():
             capi.camera_update(cam)
 
     rccl = None
+    fallback = None
     if driver == "c":
         # ---- the product's strip driver: strips.hip through the C ABI ---------------------------------------------------------
         from restir_amd.rccl import GlooTransport, RcclComm
+        comm = None
         if transport == "rccl":
             def bcast(raw):
                 if world == 1:
@@ -261,9 +274,22 @@ def main():
                 box = [raw]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-            rccl = RcclComm(rank, world, bcast)            # before anything else in this process touches RCCL
-            comm = capi.Comm.rccl(rccl.handle.value, rank, world, rccl.path)
-        else:
+            err = ""
+            try:
+                rccl = RcclComm(rank, world, bcast)        # before anything else in this process touches RCCL
+                comm = capi.Comm.rccl(rccl.handle.value, rank, world, rccl.path)
+            except Exception as e:                         # no RCCL on this box, bootstrap refused ...: the ranks agree on what to do next
+                err = repr(e)
+            if world > 1:
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                err = next((e for e in errs if e), "")
+            if err:
+                # still the C driver, over host callbacks + the control plane: slow (staged through host memory), but it finishes and says so
+                fallback = "RCCL communicator could not be created (%s): the strip driver runs over host callbacks + gloo" % err
+                print("bench.py: " + fallback, file=sys.stderr, flush=True)
+                transport, rccl, comm = "gloo", None, None
+        if comm is None:
             comm = GlooTransport(capi, dist, torch).comm(rank, world)
         drv = capi.Strips(comm, WIDTH, HEIGHT, [b[0] for b in bounds] + [HEIGHT])
         y0, y1 = drv.y0, drv.y1
@@ -279,7 +305,7 @@ def main():
             backend.gbuf.update(cam)
             if args.orbit and world > 1:
                 drv.exchange_history(backend.restir, backend.gbuf)
-            state["looper"] += 1
+            state["looper"] = state["looper"] + 1 if sobol_num is None else (state["looper"] + 1) % sobol_num
             k = state["frame_no"] % 2; state["frame_no"] += 1
             drv.gather_end(k)                                           # the gather that read pbos[k] two frames ago
             capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * WIDTH * 4, backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
@@ -304,6 +330,8 @@ def main():
         def frame():
             move_camera(strips.looper)
             strips.frame(REUSE, 0)             # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), GBuffer::update
+            if sobol_num is not None:
+                strips.looper %= sobol_num
             k = state["frame_no"] % len(pbos); state["frame_no"] += 1
             if pending[k] is not None:
                 pending[k].wait(); pending[k] = None
@@ -444,6 +472,8 @@ def main():
             "config": {"workload": "BASELINE config 3: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 1920x1080, "
                                    "32 RIS candidates, spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update",
                        "camera": "orbit" if args.orbit else "static",
+                       "sampler": "default engine (thrust minstd_rand, SAMPLER_USE_SOBOL false: the reference's default)" if sobol_num is None else
+                                  "Sobol (src/sampler.h:9-36) over the build's own %d x 200 table" % sobol_num,
                        "launches": "asynchronous (rs_set_sync(0)): consecutive frames overlap on the library's auxiliary streams; GBuffer::render is walked "
                                    "together with the primary rays when the library measures that to be faster (it measures in untimed frames before the warm-up); "
                                    "ms_per_frame_synchronous is one frame alone with a synchronisation after every call, the reference's mode",
@@ -457,6 +487,7 @@ def main():
                                      if transport == "rccl" else "host callbacks over torch.distributed gloo (rehearsal, not RCCL)"),
                        "rccl_ranks": (world if (driver == "c" and transport == "rccl") else (world if (driver == "py" and backend_name == "nccl" and world > 1) else 0)),
                        "strip_rows_per_rank": [b - a for a, b in bounds],
+                       "strip_driver_fallback": fallback,
                        "halo_wait_ms_rank0": (float(np.median(halo_wait)) if halo_wait else None),
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -473,7 +504,7 @@ def main():
         how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
         out["config"]["launch_choice"] = "%s (%s), chains on %d streams in turn" % (form, how, chains)
         out["config"]["calibration_frames_before_warmup"] = calibration_frames
-        if world == 1 and args.cpu_frames > 0:
+        if world == 1 and args.cpu_frames > 0 and sobol_num is None:
             out["cpu_baseline"], oracle_images = cpu_baseline(sd, args.cpu_frames)
             out["parity"] = parity_against(capi, sd, scene, oracle_images)
             out["cpu_config1"] = cpu_config1(out["cpu_baseline"]["cores"])

@@ -169,6 +169,8 @@ __global__ void __launch_bounds__(kTileThreads) k_wavelet_tiled(float* __restric
         for (int j = -2; j <= 2; j++) {
             const int lq = lp + i * kRW + j * STEP;
             const float4 qa = sColId[lq];
+            // (adding +0 for a rejected tap instead of skipping it -- same bits, no exec-mask regions -- measured slower, 337 -> 378 us
+            // per call: the filter is bound by VALU issue, and whole waves skip foreign-id and out-of-image taps)
             if (__float_as_int(qa.w) != idP) continue;         // also a tap outside the image (id -3)
             const float4 qb = sNormPx[lq];
             const float2 qc = sPyz[lq];

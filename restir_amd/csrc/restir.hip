@@ -451,7 +451,13 @@ struct __attribute__((aligned(16))) Staged { float4 tap; float nx, ny, nz, pad; 
 #ifndef RS_K4_WAVES
 #define RS_K4_WAVES 6
 #endif
-constexpr int kBTileW = 32, kBTileH = 16, kBThreads = kBTileW * kBTileH;
+#ifndef RS_K4_TILE_W
+#define RS_K4_TILE_W 32
+#endif
+#ifndef RS_K4_TILE_H
+#define RS_K4_TILE_H 16
+#endif
+constexpr int kBTileW = RS_K4_TILE_W, kBTileH = RS_K4_TILE_H, kBThreads = kBTileW * kBTileH;
 constexpr int kBStageW = kBTileW + 2 * kHalo, kBStageH = kBTileH + 2 * kHalo, kBStageN = kBStageW * kBStageH;
 
 __device__ __forceinline__ Staged fetch_staged_global(const GBufView& g, const TempPlanes& temp, int gi) {

@@ -563,6 +563,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #endif
 #ifdef RS_WALK_STATS
     unsigned long long st[10] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int mySteps = 0, myTris = 0;         // of this lane's ray
 #define RS_STAT(i, v) st[i] += (v)
 #else
 #define RS_STAT(i, v)
@@ -571,6 +572,9 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
         // walk phase: a tight loop until some lane's leaf queue is full or every walk has ended
         while (__any(cur != endOff)) {
             RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
+#ifdef RS_WALK_STATS
+            if (cur != endOff) mySteps++;
+#endif
             {   // every lane, also one whose walk has ended: it reads the record past the end, an empty box linked to itself (scene.hip)
                 const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
 #ifdef RS_WALK_STATS
@@ -613,6 +617,9 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                     const float4 a = p[0], b = p[1], c = p[2];
                     float bx, by, dist;
                     tri++; cnt--;
+#ifdef RS_WALK_STATS
+                    myTris++;
+#endif
                     if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit)
                         verify = __float_as_int(a.w) | 0x40000000;          // reference leaf of the candidate, bit 30 = first step
                 }
@@ -654,6 +661,10 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     }
 #ifdef RS_WALK_STATS
     if (s.walkStats && __lane_id() == 0) for (int i = 0; i < 10; i++) atomicAdd(&s.walkStats[i], st[i]);
+    if (s.walkStats && active) {        // per ray: [10] occluded rays, [11] their steps, [12] unoccluded rays, [13] their steps, [14] triangle tests of all
+        atomicAdd(&s.walkStats[occluded ? 10 : 12], 1ull); atomicAdd(&s.walkStats[occluded ? 11 : 13], (unsigned long long)mySteps);
+        atomicAdd(&s.walkStats[14], (unsigned long long)myTris);
+    }
 #endif
 #undef RS_STAT
     return occluded;

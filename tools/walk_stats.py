@@ -10,7 +10,7 @@ from restir_amd.tiling import HipBackend, StripRenderer
 
 W, H = 1920, 1080
 capi.init(0)
-sd = scenes.sponza_class(seed=1, scale=1.0)
+sd = scenes.bistro_class(seed=2, scale=1.0) if (len(sys.argv) > 1 and sys.argv[1] == "bistro") else scenes.sponza_class(seed=1, scale=1.0)
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
 cam = capi.camera_update(sd.camera(W, H))
 backend = HipBackend(capi, scene, cam, W, H)
@@ -33,6 +33,9 @@ for i, n in enumerate(names):
     print("  %-28s %10.2f" % (n, out[i] / w))
 print("  walking lanes per walk iteration %.1f, verifying lanes per verify iteration %.1f, lanes per triangle iteration %.1f" %
       (out[6] / max(out[5], 1), out[7] / max(out[4], 1), out[9] / max(out[3], 1)))
+if out[10] + out[12]:
+    print("per RAY of the shadow-tree walk: %.3f occluded; node steps %.1f for an occluded ray, %.1f for an unoccluded one; triangle tests %.2f per ray" %
+          (out[10] / (out[10] + out[12]), out[11] / max(out[10], 1), out[13] / max(out[12], 1), out[14] / (out[10] + out[12])))
 tot = sum(out[44:64])
 if tot:
     print("shadow-tree steps by node depth (19 = 19 and deeper), fraction and cumulative:")
