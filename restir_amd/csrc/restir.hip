@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParam
 // two such blocks per CU keep 8 waves per SIMD -- and the gathers become ds_read_b128 / ds_read_b64.
 constexpr int kRisThreads = 1024;
 constexpr int kRisLdsLights = 1024;
+constexpr int kRisAliasLdsLights = 16384;        // alias records only: 128 KB of the CU's 160 KB at most
 
 template <bool ENV, bool SOBOL, typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& sp, AliasPtr alias, LightPtr lights, int index, int looper) {
@@ -227,6 +228,20 @@ __global__ void __launch_bounds__(kRisThreads) k_ris_lds(DevScene s, SurfPlanes 
     const int index = n0 + blockIdx.x * kRisThreads + threadIdx.x;
     if (index >= n1) return;
     ris_pixel<false, SOBOL, const AliasRec*, LightQuarters<kRisLdsLights>>(s, sp, sAlias, LightQuarters<kRisLdsLights>{ sQuarters }, index, looper);
+}
+
+// More lights than the LDS copy of the whole table holds (config 5: 10 240): the alias records alone (8 B per light) still fit -- one
+// LDS read and four 16-byte gathers of the light record per candidate instead of five gathers; the light records stay in L2.
+// Dynamic LDS: numLights * 8 bytes.
+template <bool SOBOL>
+__global__ void __launch_bounds__(kRisThreads) k_ris_alias_lds(DevScene s, SurfPlanes sp, int width, int y0, int y1, int looper) {
+    extern __shared__ AliasRec sAliasDyn[];
+    for (int i = threadIdx.x; i < s.numLights; i += kRisThreads) sAliasDyn[i] = s.alias[i];
+    __syncthreads();
+    const int n0 = y0 * width, n1 = y1 * width;
+    const int index = n0 + blockIdx.x * kRisThreads + threadIdx.x;
+    if (index >= n1) return;
+    ris_pixel<false, SOBOL, const AliasRec*, const LightRec*>(s, sp, sAliasDyn, s.lights, index, looper);
 }
 
 // ---- phase A.3: shadow ray, temporal merge, publish -------------------------------------------------
@@ -812,9 +827,21 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
     // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
     // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
+    static const bool aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return !(e && e[0] == '0'); }();      // measurement switch
     const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
     if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
         RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
+    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && aliasLds) {
+        const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
+        static const bool ldsAllowed = []{      // more than 64 KB of dynamic LDS is opt-in
+            const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
+            const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
+            (void)hipGetLastError();
+            return a && b; }();
+        (void)ldsAllowed;
+        if (sobol) hipLaunchKernelGGL(k_ris_alias_lds<true>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
+        else hipLaunchKernelGGL(k_ris_alias_lds<false>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
+    }
     else                               // the environment map is one more light (scene.h:400-403)
         RS_LAUNCH2(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), st, scene->dev, sp, W, y0, y1, looper);
     mark(r, 2);

@@ -18,12 +18,13 @@ for f in range(40):                      # warm-up, and past the frames in which
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); b.end_frame()
 torch.cuda.synchronize()
 t=time.time()
-for f in range(40,60):
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20          # timed frames
+for f in range(40,40+N):
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); p = eaw.filter(out.data_ptr(), b.image.data_ptr(), b.gbuf, cam); b.end_frame()
-torch.cuda.synchronize(); dt=(time.time()-t)/20
+torch.cuda.synchronize(); dt=(time.time()-t)/N
 # per-pass times: one kernel at a time (timing on keeps the primary-ray + RIS kernels on the library stream)
 b.restir.enable_timing(True); capi.set_side_stream(0)
-for f in range(60,65):
+for f in range(40+N,45+N):
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); b.end_frame()
 torch.cuda.synchronize()
 print("config 5 on one GPU: %.2f ms/frame incl. EAW (frames overlapped); pass ms on one stream %s; finite %s" % (dt*1e3, b.restir.pass_times(), bool(torch.isfinite(b.image).all())))
