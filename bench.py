@@ -395,6 +395,17 @@ def main():
     # per-pass times of a few extra (untimed) frames, HIP events on the library's stream; the G-buffer render is kept on
     # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
     # primary-ray and RIS kernels from the library's second stream)
+    # the spatial pass as the timed region runs it: launches where the overlapped mode puts them, only this pass bracketed by events;
+    # read every fourth frame so that frames keep overlapping (the host never waits inside the other three)
+    backend.restir.enable_timing(2)
+    spatial_overlapped_ms = []
+    for i in range(40):
+        frame()
+        if i % 4 == 3:
+            spatial_overlapped_ms.append(backend.restir.pass_times()[3])
+    backend.restir.enable_timing(False)
+    barrier()
+
     # how long this rank's library stream sat waiting for the neighbours' border rows (the part of the exchange the interior rows
     # of phase B did not hide), frames overlapped as in the timed region, read after each frame
     halo_wait = []
@@ -495,6 +506,8 @@ def main():
                          "traffic_source": "profiles/" + os.path.basename(PMC_SUMMARY) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
                                            "the kernel lasted %s us there)" % pmc_traffic("k_spatial_shade")[1],
                          "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us,
+                         "kernel_us_in_overlapped_frame": float(np.median(spatial_overlapped_ms)) * 1e3,
+                         "frac_in_overlapped_frame": algo_bytes / (float(np.median(spatial_overlapped_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},

@@ -338,7 +338,9 @@ int  rs_restir_ray_total(rs_restir* r, int frames, unsigned long long* rays);
 /* Per-pass GPU time (ms) of the last frame, measured with hipEvents on the library's stream:
  * ms[0] primary hit, ms[1] RIS, ms[2] shadow+temporal, ms[3] spatial+shade.  Synchronises. */
 int  rs_restir_pass_times(rs_restir* r, float ms[4]);
-/* Enables the hipEvent bracketing above (off by default: it adds 5 event records per frame). */
+/* Enables the hipEvent bracketing above (off by default: it adds 5 event records per frame).  enable = 2: only the spatial pass is
+ * bracketed (ms[3]) and the launches stay where the overlapped mode puts them: the pass's duration while the kernels of other
+ * frames share the CUs with it. */
 int  rs_restir_enable_timing(rs_restir* r, int enable);
 /* Test hook: the spatial pass estimates tap positions with the hardware sqrt/sin/cos and falls back
  * to the exact evaluation inside an error band; this returns the largest estimate error over n

@@ -726,7 +726,8 @@ class ReSTIR:
         return n.value
 
     def enable_timing(self, on=True):
-        check(lib().rs_restir_enable_timing(self.handle, 1 if on else 0))
+        """True / 1: every pass bracketed, kernels on the library stream; 2: the spatial pass only, launches as in the overlapped mode."""
+        check(lib().rs_restir_enable_timing(self.handle, 2 if on == 2 else (1 if on else 0)))
 
     def pass_times(self):
         ms = (C.c_float * 4)()

@@ -660,7 +660,9 @@ int check_frame_args(rs_restir* r, const rs_scene* scene, const rs_camera* cam, 
     return 0;
 }
 
-void mark(rs_restir* r, int i) { if (r->timing) (void)hipEventRecord(r->ev[i], rs_stream()); }
+// timing 1: every pass bracketed, all kernels on the library stream; 2: only the spatial pass bracketed (events 3 and 4), the launches
+// stay where the overlapped mode puts them -- the pass's duration while other frames' kernels share the CUs
+void mark(rs_restir* r, int i) { if (r->timing == 1 || (r->timing == 2 && i >= 3)) (void)hipEventRecord(r->ev[i], rs_stream()); }
 
 }  // namespace
 
@@ -737,7 +739,7 @@ int rs_restir_reset(rs_restir* r) {
 int rs_restir_enable_timing(rs_restir* r, int enable) {
     RS_SCOPE(r);
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_enable_timing: null");
-    r->timing = enable != 0;
+    r->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return 0;
 }
 
@@ -762,7 +764,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // stream joins them before the temporal pass.  Their heavy-tile tails then overlap the other frame's passes.
     const rs_context* plan = rs_stream_plan();                  // rs_set_stream_plan (defaults: two chain streams, small launches on three, shadow rays of large launches on the library stream)
     const bool parityStreams = plan->chainStreams == 2;
-    const bool asyncMode = !r->timing && rs_aux_stream(1) != nullptr;
+    const bool asyncMode = r->timing != 1 && rs_aux_stream(1) != nullptr;
     const int W = r->width;
     const int tilesX = (W + 31) / 32, tilesY = (y1 > y0 ? y1 - y0 + 7 : 0) / 8;
     // A render of this frame that rs_gbuffer_render_rows deferred (asynchronous mode) can be launched here, in ONE launch with the
@@ -1148,7 +1150,10 @@ int rs_restir_pass_times(rs_restir* r, float ms[4]) {
     if (!r || !ms) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_pass_times: null");
     if (!r->timing) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_pass_times: timing is not enabled");
     RS_HIP(hipEventSynchronize(r->ev[4]));
-    for (int i = 0; i < 4; i++) RS_HIP(hipEventElapsedTime(&ms[i], r->ev[i], r->ev[i + 1]));
+    for (int i = 0; i < 4; i++) {
+        ms[i] = 0.f;
+        if (r->timing == 1 || i == 3) RS_HIP(hipEventElapsedTime(&ms[i], r->ev[i], r->ev[i + 1]));
+    }
     return 0;
 }
 

@@ -309,7 +309,7 @@ struct rs_restir {
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
     int raySlot = 0;
     // timing
-    bool timing = false;
+    int timing = 0;                  // 0 off, 1 every pass on the library stream, 2 the spatial pass only, launches as in the overlapped mode
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
@@ -344,5 +344,6 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam);
 
 // occlusion_bvh.cpp
 int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<rs::BvhNode>& nodes, std::vector<int>& leafPrims);
+int rs_pair_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, const std::vector<unsigned>& packed, std::vector<unsigned>& out, int* count);
 int rs_quantize_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, float base[3], float scale[3], std::vector<unsigned>& out);
 int rs_reference_chain_tables(int bvhSize, const int* order0, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims);

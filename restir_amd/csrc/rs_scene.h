@@ -537,7 +537,11 @@ __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
 
 __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
     const char* nodes = reinterpret_cast<const char*>(s.occNodes);
+#ifdef RS_OCC_PAIR
+    const unsigned endOff = (unsigned)s.occCount * 32u;      // 32-byte pair records (occlusion_bvh.cpp rs_pair_occlusion_bvh)
+#else
     const unsigned endOff = (unsigned)s.occCount * 16u;
+#endif
     // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
     // A lane that enters without a ray of its own (outside the frame, a special-case or far-origin ray that takes the reference walk)
     // is parked on the sentinel record past the end for the whole walk; it evaluates that record like every other lane, so its
@@ -575,6 +579,39 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #ifdef RS_WALK_STATS
             if (cur != endOff) mySteps++;
 #endif
+#if defined(RS_OCC_PAIR) && RS_OCC_PERM
+            {   // pair record: the boxes of both children of an inner node, one dependent fetch for two tests; leaves cost no step
+                const uint4 n0 = *reinterpret_cast<const uint4*>(nodes + cur), n1 = *reinterpret_cast<const uint4*>(nodes + cur + 16);
+                bool passA, passB;
+                {
+                    const unsigned px = __builtin_amdgcn_perm(n0.y, n0.x, selX), py = __builtin_amdgcn_perm(n0.z, n0.x, selY), pz = __builtin_amdgcn_perm(n0.z, n0.y, selZ);
+                    const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
+                    const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
+                    const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
+                    const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x), tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
+                    passA = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
+                }
+                {
+                    const unsigned px = __builtin_amdgcn_perm(n1.x, n0.w, selX), py = __builtin_amdgcn_perm(n1.y, n0.w, selY), pz = __builtin_amdgcn_perm(n1.y, n1.x, selZ);
+                    const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
+                    const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
+                    const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
+                    const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x), tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
+                    passB = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
+                }
+                const unsigned w6 = n1.z, w7 = n1.w;
+                const bool leafA = (w7 & 1u) != 0, leafB = (w7 & 2u) != 0;
+                const unsigned skip = w7 & ~31u;
+                const bool hitLeafA = passA && leafA, hitLeafB = passB && leafB;
+                const bool push = hitLeafA || hitLeafB;
+                const unsigned cA = (w6 >> 24) & 15u, cB = w6 >> 28;
+                const int code = (int)((((w6 & 0xffffffu) + (hitLeafA ? 0u : cA)) << 4) | ((hitLeafA ? cA : 0u) + (hitLeafB ? cB : 0u)));
+                q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? code : q0; qn = push ? qn + 1 : qn;
+                const bool goA = passA && !leafA, goB = passB && !leafB;
+                const unsigned toB = leafA ? cur + 32u : w6;           // B's record follows X's directly when A is a leaf
+                cur = goA ? cur + 32u : (goB ? toB : skip);
+            }
+#else
             {   // every lane, also one whose walk has ended: it reads the record past the end, an empty box linked to itself (scene.hip)
                 const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
 #ifdef RS_WALK_STATS
@@ -601,6 +638,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                 q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn = push ? qn + 1 : qn;
                 cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
             }
+#endif
             if (__any(qn == kLeafQueue)) break;
         }
         if (!__any(qn > 0)) break;
@@ -608,7 +646,11 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
         // tests its triangles; a hit becomes a candidate, and the rest of the leaf waits for its verdict
         RS_STAT(2, 1);
         int tri = 0, cnt = 0, verify = -1;
+#ifdef RS_OCC_PAIR
+        if (qn > 0) { tri = q0 >> 4; cnt = q0 & 15; q0 = q1; q1 = q2; q2 = q3; qn--; }      // up to 8 triangles: two sibling leaves in one entry
+#else
         if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
+#endif
         for (;;) {
             while (__any((cnt > 0) & (verify < 0))) {
                 RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot((cnt > 0) & (verify < 0))));

@@ -56,33 +56,13 @@ for moving, overlapped, denoise in ((False, False, False), (True, False, False),
 
 # ---- the C-ABI strip driver (rs_comm / rs_strips, include/restir_hip.h) with gloo under its transport callbacks -------------------
 # What a C++ caller runs over RCCL (rs_comm_create_rccl); here send / recv stage through host memory and torch.distributed.
-class GlooTransport:
-    def __init__(self):
-        self.ops, self.recvs, self.keep = [], [], []
-    def send(self, ptr, nbytes, peer):
-        t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        capi.hip_memcpy_d2d(t.data_ptr(), ptr, nbytes)
-        h = t.cpu(); self.keep.append(h)
-        self.ops.append(dist.isend(h, peer))
-    def recv(self, ptr, nbytes, peer):
-        h = torch.empty(nbytes, dtype=torch.uint8)
-        self.ops.append(dist.irecv(h, peer)); self.recvs.append((ptr, h))
-    def begin(self):
-        self.ops, self.recvs, self.keep = [], [], []
-    def end(self):
-        for w in self.ops:
-            w.wait()
-        for ptr, h in self.recvs:
-            d = h.cuda()
-            capi.hip_memcpy_d2d(ptr, d.data_ptr(), d.numel())
-            torch.cuda.synchronize()
+from restir_amd.rccl import GlooTransport              # send / recv staged through host memory and torch.distributed (what bench.py's rehearsal mode uses)
 
 for moving, overlapped, denoise in ((False, False, False), (False, True, False), (True, False, False), (True, True, True)):
     # moving: orbiting camera + rs_strips_exchange_history; denoise: rs_strips_eaw_filter; the image is assembled by rs_strips_gather
     capi.set_sync(not overlapped)
     cam = capi.camera_update(sd.camera(W, H))
-    tr = GlooTransport()
-    comm = capi.Comm(rank, world, tr.send, tr.recv, tr.begin, tr.end)
+    comm = GlooTransport(capi, dist, torch).comm(rank, world)
     drv = capi.Strips(comm, W, H)
     gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
     eaw = capi.EAWFilter(W, H, 5) if denoise else None
@@ -105,7 +85,11 @@ for moving, overlapped, denoise in ((False, False, False), (False, True, False),
         ref_py.frame(3, 0, denoise=denoise)
         if full is not None:
             full.frame(3, 0, denoise=denoise)
-    drv.gather(result_ptr, 12, 0)                                     # image assembly on rank 0
+    if moving:
+        drv.gather(result_ptr, 12, 0)                                 # image assembly on rank 0
+    else:                                                             # the form bench.py uses: begun behind the frame, ended before the buffer is read
+        drv.gather_begin(result_ptr, 12, 0, 1)
+        drv.gather_end(1)
     torch.cuda.synchronize(); capi.synchronize()
     capi.set_sync(True)
     result = torch.empty((W * H, 3), dtype=torch.float32, device="cuda")
