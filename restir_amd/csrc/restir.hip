@@ -272,7 +272,24 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
 // the library stream, the only chain that links consecutive frames, is the streaming half: temporal merge, validity check, publish.
 // (As one kernel the pass lasted as long as its slowest wave's walk, 0.2 ms on a 1/8 strip however few rows it has.)
 // 8 blocks per CU = 8 waves per SIMD.
+// Stragglers (measurement build -DRS_HANDOFF_LANES=16; off by default).  A wave walks until its slowest ray is done: 139 iterations
+// for a mean of 74 per ray, and from the 72nd iteration on fewer than 20 of its 64 lanes still walk, from the 120th fewer than 3
+// (tools/walk_stats.py, -DRS_WALK_STATS_TIME).  With the hand-off a wave leaves the walk as soon as no more than kHandoffLanes of
+// its rays have anything left to do and puts those -- ray, range, position in the tree, queued leaves, pixel -- into a pool in LDS;
+// after the block's four waves have done so, ONE wave picks the pool up (at most 4 x 16 = 64 rays) and finishes them.  The same
+// steps per ray, the same result (36 GPU tests), a quarter fewer wave iterations per block -- and no gain: shadow + temporal
+// 457 -> 455 us alone, the overlapped frame 1.083 -> 1.097 ms (profiles/r03_ab_shadow_straggler_handoff.log).  What the pass is bound
+// by is the number of per-LANE fetches (each a look-up of its own in the CU's L1: 74 + 15 per ray), which the hand-off leaves as it
+// is; the wave iterations it removes are the nearly empty ones, which cost issue slots the pass has to spare.
+#ifndef RS_HANDOFF_LANES
+#define RS_HANDOFF_LANES 0
+#endif
+constexpr int kHandoffLanes = RS_HANDOFF_LANES, kHandoffPool = 4 * kHandoffLanes;
+struct __attribute__((aligned(16))) PooledRay { float ox, oy, oz, limit; float dx, dy, dz; unsigned cur; int q0, q1, q2, q3; int qn, index, pad0, pad1; };
+
 __global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
+    __shared__ PooledRay pool[kHandoffPool > 0 ? kHandoffPool : 1];
+    __shared__ int poolCount;
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
     const bool inside = x < width && y < y1;
@@ -282,9 +299,64 @@ __global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, in
     float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
     if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
     const f3 pos = mk3(pm.x, pm.y, pm.z), wi = mk3(cw.x, cw.y, cw.z);
-    // every lane of the wave takes part in the cooperative any-hit walk
-    const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded);
-    if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
+    if (kHandoffLanes == 0 || !s.occNodes) {
+        // every lane of the wave takes part in the cooperative any-hit walk
+        const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded);
+        if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
+        return;
+    }
+    if (threadIdx.x == 0) poolCount = 0;
+    __syncthreads();
+    // testOcclusion's segment (scene.h:286-299), as trace_occluded_wave sets it up
+    const f3 target = pos + wi * cl.w;
+    f3 dir = target - pos;
+    float dist = length(dir);
+    dir = dir / dist;
+    Ray ray; ray.o = pos + dir * 1e-5f; ray.d = dir;
+    dist -= 1e-4f * 2.f;
+    RayBoxCtx ctx = make_box_ctx(ray);
+    ctx.cull = s.axisCull;
+    const bool special = shaded && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
+    const bool slow = shaded && (special || !occlusion_tree_usable(s, ray.o));
+    const bool fast = shaded && !slow;
+    OccState st;
+    bool suspended;
+    bool occluded = walk_occlusion_tree_x<true, false>(s, ray, ctx, dist, fast, st, kHandoffLanes, suspended);
+#ifdef RS_OCC_PAIR
+    const unsigned endOff = (unsigned)s.occCount * 32u;
+#else
+    const unsigned endOff = (unsigned)s.occCount * 16u;
+#endif
+    const bool pending = suspended && fast && !occluded && (st.cur != endOff || st.qn > 0);
+    if (__any(slow)) occluded = walk_anyhit_deferred<false>(s, ray, ctx, dist, slow) || occluded;      // special-case / far-origin rays: the reference walk
+    if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;
+    {
+        const unsigned long long mask = __ballot(pending);
+        if (mask) {
+            int base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(&poolCount, __popcll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pending) {
+                const int slot = base + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+                PooledRay r;
+                r.ox = ray.o.x; r.oy = ray.o.y; r.oz = ray.o.z; r.limit = dist; r.dx = ray.d.x; r.dy = ray.d.y; r.dz = ray.d.z; r.cur = st.cur;
+                r.q0 = st.q0; r.q1 = st.q1; r.q2 = st.q2; r.q3 = st.q3; r.qn = st.qn; r.index = index; r.pad0 = r.pad1 = 0;
+                pool[slot] = r;
+            }
+        }
+    }
+    __syncthreads();
+    const int pooled = poolCount;
+    if ((int)(threadIdx.x & ~63u) >= pooled) return;                    // (at most one wave with kHandoffLanes = 16)
+    const bool mine = (int)threadIdx.x < pooled;
+    const PooledRay r = pool[mine ? threadIdx.x : 0];
+    Ray ray2; ray2.o = mk3(r.ox, r.oy, r.oz); ray2.d = mk3(r.dx, r.dy, r.dz);
+    RayBoxCtx ctx2 = make_box_ctx(ray2);
+    ctx2.cull = s.axisCull;
+    OccState st2; st2.cur = r.cur; st2.q0 = r.q0; st2.q1 = r.q1; st2.q2 = r.q2; st2.q3 = r.q3; st2.qn = r.qn;
+    bool susp2;
+    const bool occ2 = walk_occlusion_tree_x<false, true>(s, ray2, ctx2, r.limit, mine, st2, 0, susp2);
+    if (mine && occ2) reinterpret_cast<float*>(sp.candWi + r.index)[3] = 0.f;
 }
 
 template <bool SOBOL>

@@ -535,7 +535,15 @@ __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
            gabs(o.z - s.occBase.z) <= reach * s.occScale.z;
 }
 
-__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
+// What a lane's walk consists of between two steps: where it is and the leaves it has queued.  HANDOFF: the walk returns
+// (*suspended = true, the states in `st`) as soon as no more than minLanes lanes of the wave have anything left to do, so that the
+// caller can finish those rays elsewhere (k_shadow pools the stragglers of a block's four waves into one wave: from the 72nd of a
+// wave's 139 iterations on fewer than 20 of its lanes are still walking, from the 120th fewer than 3, tools/walk_stats.py).
+struct OccState { unsigned cur; int q0, q1, q2, q3, qn; };
+
+template <bool HANDOFF, bool RESUME>
+__device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active,
+                                                      OccState& st, int minLanes, bool& suspended) {
     const char* nodes = reinterpret_cast<const char*>(s.occNodes);
 #ifdef RS_OCC_PAIR
     const unsigned endOff = (unsigned)s.occCount * 32u;      // 32-byte pair records (occlusion_bvh.cpp rs_pair_occlusion_bvh)
@@ -555,7 +563,9 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
                               fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
     unsigned cur = active ? 0u : endOff;
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
+    if (RESUME && active) { cur = st.cur; q0 = st.q0; q1 = st.q1; q2 = st.q2; q3 = st.q3; qn = st.qn; }
     bool occluded = false;
+    suspended = false;
 #if RS_OCC_PERM
     // Which of the two grid planes of an axis is the near one depends on the sign of A only (fma is monotone in q): a byte
     // permute with a per-ray selector puts {near plane, far plane} of an axis into one dword, and the six min / max of the slab
@@ -574,10 +584,17 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #endif
     for (;;) {
         // walk phase: a tight loop until some lane's leaf queue is full or every walk has ended
-        while (__any(cur != endOff)) {
+        for (;;) {
+            const unsigned long long walkers = __ballot(cur != endOff);
+            if (!walkers) break;
+            if (HANDOFF && __popcll(walkers | __ballot(qn > 0)) <= minLanes) { suspended = true; break; }
             RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
 #ifdef RS_WALK_STATS
             if (cur != endOff) mySteps++;
+#ifdef RS_WALK_STATS_TIME      // instead of the depth histogram: walking lanes and wave iterations by iteration index (buckets of 24)
+            { const unsigned long long walkers = __ballot(cur != endOff);
+              if (s.walkStats && __lane_id() == 0) { const int b = st[5] / 24 < 9 ? (int)(st[5] / 24) : 9; atomicAdd(&s.walkStats[44 + b], (unsigned long long)__popcll(walkers)); atomicAdd(&s.walkStats[54 + b], 1ull); } }
+#endif
 #endif
 #if defined(RS_OCC_PAIR) && RS_OCC_PERM
             {   // pair record: the boxes of both children of an inner node, one dependent fetch for two tests; leaves cost no step
@@ -614,7 +631,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #else
             {   // every lane, also one whose walk has ended: it reads the record past the end, an empty box linked to itself (scene.hip)
                 const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
-#ifdef RS_WALK_STATS
+#if defined(RS_WALK_STATS) && !defined(RS_WALK_STATS_TIME)
                 if (s.walkStats && s.occDepth && cur != endOff) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
 #endif
 #if RS_OCC_PERM
@@ -641,6 +658,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #endif
             if (__any(qn == kLeafQueue)) break;
         }
+        if (HANDOFF && suspended) { st.cur = cur; st.q0 = q0; st.q1 = q1; st.q2 = q2; st.q3 = q3; st.qn = qn; break; }
         if (!__any(qn > 0)) break;
         // leaf round: every lane takes its newest queued leaf (so no queue is full when the walk resumes) and
         // tests its triangles; a hit becomes a candidate, and the rest of the leaf waits for its verdict
@@ -710,6 +728,11 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #endif
 #undef RS_STAT
     return occluded;
+}
+
+__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
+    OccState st; bool suspended;
+    return walk_occlusion_tree_x<false, false>(s, ray, ctx, limit, active, st, 0, suspended);
 }
 
 // all 64 lanes of the wave must call this

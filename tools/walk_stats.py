@@ -36,7 +36,14 @@ print("  walking lanes per walk iteration %.1f, verifying lanes per verify itera
 if out[10] + out[12]:
     print("per RAY of the shadow-tree walk: %.3f occluded; node steps %.1f for an occluded ray, %.1f for an unoccluded one; triangle tests %.2f per ray" %
           (out[10] / (out[10] + out[12]), out[11] / max(out[10], 1), out[13] / max(out[12], 1), out[14] / (out[10] + out[12])))
-tot = sum(out[44:64])
+if os.environ.get("WALK_STATS_TIME"):          # a -DRS_WALK_STATS_TIME build: slots 44.. hold the walk by iteration index instead of by depth
+    print("shadow-tree walk by iteration index (buckets of 24 iterations): waves still iterating (per wave), walking lanes per iteration")
+    for b in range(10):
+        if out[54 + b]:
+            print("   iterations %3d-%-4s waves %.3f  lanes %.1f" % (b * 24, str(b * 24 + 23) if b < 9 else "...", out[54 + b] / 24 / w if b < 9 else out[54 + b] / w, out[44 + b] / out[54 + b]))
+    tot = 0
+else:
+    tot = sum(out[44:64])
 if tot:
     print("shadow-tree steps by node depth (19 = 19 and deeper), fraction and cumulative:")
     acc = 0
