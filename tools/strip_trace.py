@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""tools/strip_trace.py RANK -- runs strip RANK of the 8-way split alone for 60 frames (to be run under rocprofv3 --kernel-trace);
+"""tools/strip_trace.py RANK -- runs strip RANK of the 8-way split alone for 60 frames, to be run under the profiler with the
+interpreter itself after `--` (never this script directly: its `#!/usr/bin/env` line would be an exec hop under a preloaded profiler):
+
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d OUT -- python $REPO/tools/strip_trace.py RANK
+
 tools/strip_trace_report.py condenses the trace: per queue the busy time per frame, per kernel the mean duration."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
