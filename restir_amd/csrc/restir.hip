@@ -904,6 +904,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     static const bool aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return !(e && e[0] == '0'); }();      // measurement switch
     const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
     if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
+        // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
+        // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
         RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
     else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && aliasLds) {
         const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
