@@ -468,6 +468,12 @@ int  rs_pbo_unregister(rs_pbo* pbo);
 int  rs_save_image(const char* path, const float* devImage, int width, int height, int toneMapping);
 /* the PNG writer by itself (host only): rgb = height rows of width * 3 bytes */
 int  rs_write_png(const char* path, const unsigned char* rgb, int width, int height);
+/* saveImage(true) (src/main.cpp:138-140): the same tone-mapped, mirrored 8-bit picture through Image::saveJPG (src/image.cpp:60-74:
+ * stb_image_write's stbi_write_jpg at quality 90) -- a baseline JFIF file, 4:4:4, Annex-K tables scaled to the quality, AAN float DCT;
+ * byte-identical to the reference's file (pinned against its compiled writer).  `path` is the complete file name. */
+int  rs_save_image_jpg(const char* path, const float* devImage, int width, int height, int toneMapping);
+/* Image::saveJPG's file from bytes that are already clamped and scaled: rgb = height rows of width * 3 bytes. */
+int  rs_write_jpg(const char* path, const unsigned char* rgb, int width, int height);
 
 /* ---- EAW denoiser (src/denoiser.h:33-43,72-74) -------------------------------------------- */
 int  rs_eaw_create(int width, int height, int level, rs_eaw** f);   /* LeveledEAWFilter::create */

@@ -640,6 +640,7 @@ def ref_loaders():
     R.ref_image_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int]
     R.ref_obj_load.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     R.ref_read_lines.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    R.ref_save_jpg.argtypes = [C.c_char_p, C.c_int, C.c_int, f32p]
     return R
 
 

@@ -64,6 +64,18 @@ int ref_obj_load(const char* path, int cap, float* vertices, float* normals, flo
     return n;
 }
 
+/* Image(width, height) + setPixel for every pixel + saveJPG (src/image.cpp:8-12,36-39,60-74): writes baseFilename + ".jpg".
+ * pixels: width * height * 3 floats, row-major. */
+void ref_save_jpg(const char* baseFilename, int width, int height, const float* pixels) {
+    Image img(width, height);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const float* p = pixels + ((size_t)y * width + x) * 3;
+            img.setPixel(x, y, glm::vec3(p[0], p[1], p[2]));
+        }
+    img.saveJPG(std::string(baseFilename));
+}
+
 /* The read loop of Scene::Scene (scene.cpp:108-111): every line safeGetline returns while the stream is good, tokens
  * joined by '\t', lines by '\n'.  Returns the length written (or needed when cap is too small). */
 int ref_read_lines(const char* path, char* out, int cap) {

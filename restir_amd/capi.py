@@ -115,7 +115,7 @@ EXPORTS = [
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
-    "rs_restir_enable_timing", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_write_png", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_debug_sqrt_of_unit_floats_mismatches", "rs_debug_div_sigma_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_restir_enable_timing", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_save_image_jpg", "rs_write_png", "rs_write_jpg", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_debug_sqrt_of_unit_floats_mismatches", "rs_debug_div_sigma_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_svgf_set_params", "rs_svgf_get_params", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
@@ -197,6 +197,8 @@ def lib():
     L.rs_pbo_unregister.argtypes = [vp]
     L.rs_save_image.argtypes = [C.c_char_p, vp, ci, ci, ci]
     L.rs_write_png.argtypes = [C.c_char_p, vp, ci, ci]
+    L.rs_write_jpg.argtypes = [C.c_char_p, vp, ci, ci]
+    L.rs_save_image_jpg.argtypes = [C.c_char_p, vp, ci, ci, ci]
     L.rs_debug_sqrt_of_uniform_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
     L.rs_debug_sqrt_of_unit_floats_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
     L.rs_debug_div_sigma_mismatches.argtypes = [C.c_float, C.POINTER(C.c_ulonglong)]
@@ -315,6 +317,17 @@ def set_ris_table_pixels(pixels):
 def set_stream_plan(chain_streams=-1, small_chains=-1, shadow_on_main=-1):
     """How the overlapped mode spreads a frame's kernels over the internal streams (rs_set_stream_plan); -1 keeps a value."""
     check(lib().rs_set_stream_plan(int(chain_streams), int(small_chains), int(shadow_on_main)))
+
+
+def write_jpg(path, rgb):
+    """Image::saveJPG's file (stbi_write_jpg, quality 90) from an (H, W, 3) uint8 array."""
+    a = np.ascontiguousarray(rgb, np.uint8)
+    check(lib().rs_write_jpg(os.fsencode(path), _p(a), a.shape[1], a.shape[0]))
+
+
+def save_image_jpg(path, dev_image_ptr, width, height, tone_mapping):
+    """saveImage(true) (src/main.cpp:105-144): tone map + gamma, mirrored in x, JPEG at quality 90."""
+    check(lib().rs_save_image_jpg(os.fsencode(path), dev_image_ptr, width, height, tone_mapping))
 
 
 def save_image(path, dev_image_ptr, width, height, tone_mapping):

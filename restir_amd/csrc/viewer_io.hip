@@ -88,7 +88,11 @@ int rs_write_png(const char* path, const unsigned char* rgb, int width, int heig
 // saveImage(false) (src/main.cpp:105-144): every pixel through the tone map and the gamma curve, stored at (width - 1 - x, y), clamped
 // to [0, 1], scaled by 255 and truncated (src/image.cpp:44-50) -- the bytes sendImageToPBO produces with scale 1 (src/pathtrace.cu:41-55),
 // mirrored in x.  `path` is the complete file name (the viewer appends ".<time>.<samples>samp.png" to its image name).
-int rs_save_image(const char* path, const float* devImage, int width, int height, int toneMapping) {
+static int save_image(const char* path, const float* devImage, int width, int height, int toneMapping, bool jpg);
+int rs_save_image(const char* path, const float* devImage, int width, int height, int toneMapping) { return save_image(path, devImage, width, height, toneMapping, false); }
+// saveImage(true): the same bytes through Image::saveJPG (src/image.cpp:60-74, stbi_write_jpg at quality 90), jpeg_writer.cpp
+int rs_save_image_jpg(const char* path, const float* devImage, int width, int height, int toneMapping) { return save_image(path, devImage, width, height, toneMapping, true); }
+static int save_image(const char* path, const float* devImage, int width, int height, int toneMapping, bool jpg) {
     rs_ctx_scope scope(nullptr);
     if (!path || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_save_image: bad argument");
     const size_t n = (size_t)width * height;
@@ -107,7 +111,7 @@ int rs_save_image(const char* path, const float* devImage, int width, int height
             unsigned char* d = &rgb[((size_t)y * width + (width - 1 - x)) * 3];
             d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
         }
-    return rs_write_png(path, rgb.data(), width, height);
+    return jpg ? rs_write_jpg(path, rgb.data(), width, height) : rs_write_png(path, rgb.data(), width, height);
 }
 
 // cudaGLRegisterBufferObject(pbo) (src/preview.cpp:133): glBuffer is the GLuint of the viewer's GL_PIXEL_UNPACK_BUFFER, created in the GL

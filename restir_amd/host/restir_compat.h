@@ -235,10 +235,10 @@ inline void cudaGLRegisterBufferObject(unsigned pbo) { rsc::check(rs_pbo_registe
 inline void cudaGLMapBufferObject(void** devPtr, unsigned pbo) { rsc::check(rs_pbo_map(rsc::pbos()[pbo], devPtr, nullptr), "cudaGLMapBufferObject"); }
 inline void cudaGLUnmapBufferObject(unsigned pbo) { rsc::check(rs_pbo_unmap(rsc::pbos()[pbo]), "cudaGLUnmapBufferObject"); }
 inline void cudaGLUnregisterBufferObject(unsigned pbo) { rsc::check(rs_pbo_unregister(rsc::pbos()[pbo]), "cudaGLUnregisterBufferObject"); rsc::pbos().erase(pbo); }
-// saveImage(false) (src/main.cpp:105-144) for a device image: "<imageName>.<time>.<samples>samp.png"
-inline std::string saveImage(const std::string& imageName, const std::string& timeString, int samples, rsc::vec3* devImage, int width, int height, int toneMapping) {
-    const std::string filename = imageName + "." + timeString + "." + std::to_string(samples) + "samp.png";
-    rsc::check(rs_save_image(filename.c_str(), reinterpret_cast<const float*>(devImage), width, height, toneMapping), "saveImage");
+// saveImage(jpg) (src/main.cpp:105-144) for a device image: "<imageName>.<time>.<samples>samp.png" or ".jpg" (Image::saveJPG, quality 90)
+inline std::string saveImage(const std::string& imageName, const std::string& timeString, int samples, rsc::vec3* devImage, int width, int height, int toneMapping, bool jpg = false) {
+    const std::string filename = imageName + "." + timeString + "." + std::to_string(samples) + (jpg ? "samp.jpg" : "samp.png");
+    rsc::check((jpg ? rs_save_image_jpg : rs_save_image)(filename.c_str(), reinterpret_cast<const float*>(devImage), width, height, toneMapping), "saveImage");
     return filename;
 }
 

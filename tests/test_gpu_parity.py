@@ -1260,6 +1260,12 @@ def test_save_image_is_the_tone_mapped_frame_mirrored(hip, tmp_path):
         ref = ob.send_image_to_pbo(img, W, H, mode, 1.0)[:, :3].reshape(H, W, 3)[:, ::-1]
         diff = np.abs(ref.astype(np.int32) - got.astype(np.int32))
         assert diff.max() <= 1 and np.mean(diff > 0) <= 1e-3, mode
+        # saveImage(true): the same 8-bit picture through Image::saveJPG's writer (byte-exact against the reference's own file in
+        # tests/test_host_and_abi.py): the file of rs_save_image_jpg is rs_write_jpg of the PNG's pixels
+        hip.save_image_jpg(tmp_path / ("m%d.jpg" % mode), h.image.data_ptr(), W, H, mode)
+        hip.write_jpg(tmp_path / ("m%d_from_png.jpg" % mode), got)
+        a, b = open(tmp_path / ("m%d.jpg" % mode), "rb").read(), open(tmp_path / ("m%d_from_png.jpg" % mode), "rb").read()
+        assert a == b and a[:4] == b"\xff\xd8\xff\xe0" and a[-2:] == b"\xff\xd9"
         pbo = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")          # and exactly the library's own PBO bytes, mirrored
         hip.copy_image_to_pbo(pbo.data_ptr(), h.image.data_ptr(), W, H, mode, 1.0)
         assert np.array_equal(pbo.cpu().numpy()[:, :3].reshape(H, W, 3)[:, ::-1], got)

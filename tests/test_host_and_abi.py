@@ -203,6 +203,22 @@ def test_png_writer_round_trip(tmp_path):
     assert capi.lib().rs_write_png(b"x.png", None, 2, 2) != 0
 
 
+def test_jpg_writer_writes_the_reference_s_file(tmp_path):
+    """rs_write_jpg (restir_amd/csrc/jpeg_writer.cpp) against the bytes the REFERENCE's own Image::saveJPG wrote for the same pictures
+    (src/image.cpp:60-74 -> stbi_write_jpg at quality 90, compiled in place; tests/golden/jpeg_ref.npz by make_jpeg_golden.py):
+    40 pictures -- sizes that are and are not multiples of 8, a single pixel, flat, gradients, noise, saturated -- byte for byte."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_ref.npz"))
+    n = len(g.files) // 2
+    assert n == 40
+    for i in range(n):
+        path = tmp_path / ("p%d.jpg" % i)
+        capi.write_jpg(path, g["in_%d" % i])
+        got = np.frombuffer(open(path, "rb").read(), np.uint8)
+        assert np.array_equal(got, g["out_%d" % i]), (i, g["in_%d" % i].shape)
+    with pytest.raises(capi.RestirHipError):
+        capi.write_jpg(tmp_path / "no" / "such" / "dir.jpg", g["in_0"])
+
+
 def test_procedural_scene_budgets():
     sd = scenes.sponza_class(1, 1.0)
     assert sd.num_prims == 262144
