@@ -504,6 +504,8 @@ int  rs_svgf_destroy(rs_svgf* f);
  * (src/denoiser.cu:488).  As in the reference the filter always runs five levels. */
 int  rs_svgf_set_params(rs_svgf* f, float sigLumin, float sigNormal, float sigDepth, int level);
 int  rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level);
+/* 1 (default): the a-trous levels read their taps from an LDS tile (the reference's default sigmas only); 0: plain gathers.  Same bits. */
+int  rs_svgf_set_tiled(rs_svgf* f, int tiled);
 /* SpatioTemporalFilter::filter (src/denoiser.cu:532-564): temporal accumulation (alpha .2), variance estimate, five
  * variance-guided a-trous levels.  *devColorOut is the reference's `glm::vec3*& devColorOut`: it is swapped with the
  * filter's buffers (the level-0 result becomes the history), so the caller continues with the pointer it gets back

@@ -295,6 +295,28 @@ __global__ void __launch_bounds__(256) k_svgf_filter_variance(float* __restrict_
 // ~100 VALU instructions -- a third of the tap.  Every squaring rounds once, so the power is within 2^(NSQ-1) ulp of the exact
 // one (3.8e-6 relative for 128; CUDA's powf is specified to 4 ulp), well inside the filter's stated tolerance (tests: rtol 3e-5).
 // NSQ < 0: powf.  DMUL: sigDepth is a power of two, x / sigDepth == x * (1 / sigDepth) exactly (default 1).
+// The weight of one SVGF tap (src/denoiser.cu:176-189), shared by both forms of the kernel: wColor * wNorm * wPos with
+//   wPos   = exp(-|dp|^2 / sigDepth) + 1e-4,  wNorm = max(nP . nQ, 0)^sigNormal + 1e-4,
+//   wColor = exp(-|lumP - lumQ| / (sigLumin * sqrt(max(varFiltered[Q], 0)) + 1e-4)) + 1e-4.
+// The denominator of wColor depends on the tap's pixel only: `denomQ` and its correctly rounded reciprocal are evaluated once per
+// pixel where the kernel stages its tile (the same expressions, so the same values as evaluating them per tap), and the division
+// takes Markstein's form (div_sigma).  Exponentials as in the EAW filter (exp_neg).  Stated tolerance against the oracle: rtol 3e-5.
+template <int NSQ, bool DMUL>
+__device__ __forceinline__ float svgf_tap_weight(f3 dp, f3 normP, f3 normQ, float lumP, float lumQ, float denomQ, float rdenomQ,
+                                                 float sigDepth, float rDepth, float sigNormal) {
+    const float wPos = exp_neg(div_sigma<DMUL>(dot(dp, dp), sigDepth, rDepth)) + 1e-4f;
+    float pn = sat_dot(normP, normQ);
+    if (NSQ >= 0) {
+#pragma unroll
+        for (int k = 0; k < NSQ; k++) pn = pn * pn;
+    }
+    else pn = powf(pn, sigNormal);
+    const float wNorm = pn + 1e-4f;
+    const float wColor = exp_neg(div_sigma<false>(gabs(lumP - lumQ), denomQ, rdenomQ)) + 1e-4f;
+    return wColor * wNorm * wPos;
+}
+__device__ __forceinline__ float svgf_color_denominator(float varFiltered, float sigLumin) { return sigLumin * sqrtf(gmax(varFiltered, 0.f)) + 1e-4f; }
+
 template <int NSQ, bool DMUL>
 __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorOut, const float* __restrict__ colorIn,
                                                       float* __restrict__ varOut, const float* __restrict__ varIn,
@@ -327,17 +349,8 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
             const f3 normQ = ld3(normal + (size_t)idxQ * 3);
             const f3 colorQ = ld3(colorIn + (size_t)idxQ * 3);
             const f3 dp = posP - ld3(pos + (size_t)idxQ * 3);
-            const float wPos = expf(DMUL ? -dot(dp, dp) * rDepth : -dot(dp, dp) / sigDepth) + 1e-4f;
-            float pn = sat_dot(normP, normQ);
-            if (NSQ >= 0) {
-#pragma unroll
-                for (int k = 0; k < NSQ; k++) pn = pn * pn;
-            }
-            else pn = powf(pn, sigNormal);
-            const float wNorm = pn + 1e-4f;
-            const float denom = sigLumin * sqrtf(gmax(varFiltered[idxQ], 0.f)) + 1e-4f;
-            const float wColor = expf(-gabs(lumP - luminance(colorQ)) / denom) + 1e-4f;
-            const float w = wColor * wNorm * wPos * kGaussian5x5[i + 2][j + 2];
+            const float denomQ = svgf_color_denominator(varFiltered[idxQ], sigLumin);
+            const float w = svgf_tap_weight<NSQ, DMUL>(dp, normP, normQ, lumP, luminance(colorQ), denomQ, 1.f / denomQ, sigDepth, rDepth, sigNormal) * kGaussian5x5[i + 2][j + 2];
             const float w2 = w * w;
             sumColor = sumColor + colorQ * w;
             sumVar += varIn[idxQ] * w2;
@@ -347,6 +360,77 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
     }
     st3(colorOut + (size_t)idxP * 3, sumW < 1.1920928955078125e-7f ? colorP : sumColor / sumW);
     varOut[idxP] = sumW2 < 1.1920928955078125e-7f ? varIn[idxP] : sumVar / sumW2;
+}
+
+// The same level from the EAW filter's row-phase LDS tile (k_wavelet_tiled above): 64 x 8 pixels of one row phase, staged with
+// 2 rows of that phase above and below and 2 * STEP pixels to the left and right, 52 B per record -- colour + id, normal + position x,
+// {position y, z, variance, the colour weight's denominator} and its reciprocal.  Same arithmetic in the same order as
+// k_svgf_wavelet: same bits (test_svgf_tiled_levels_equal_plain_gathers).
+template <int STEP, int NSQ, bool DMUL>
+__global__ void __launch_bounds__(kTileThreads) k_svgf_wavelet_tiled(float* __restrict__ colorOut, const float* __restrict__ colorIn,
+                                                                    float* __restrict__ varOut, const float* __restrict__ varIn,
+                                                                    const float* __restrict__ varFiltered,
+                                                                    const int* __restrict__ primId, const float* __restrict__ normal,
+                                                                    const float* __restrict__ pos, int W, int H,
+                                                                    float sigDepth, float sigNormal, float sigLumin) {
+    constexpr int kHaloX = 2 * STEP, kRW = kTileW + 2 * kHaloX, kRH = kTileH + 4, kRN = kRW * kRH;
+    __shared__ float4 sColId[kRN];          // colour xyz, id bits
+    __shared__ float4 sNormPx[kRN];         // normal xyz, position x
+    __shared__ float4 sMisc[kRN];           // position y, z, variance, denominator of the colour weight
+    __shared__ float sRden[kRN];            // 1 / denominator
+    const int phase = blockIdx.y % STEP, group = blockIdx.y / STEP;
+    const int rowBase = group * (kTileH * STEP) + phase;
+    const int ox = blockIdx.x * kTileW - kHaloX;
+    for (int e = threadIdx.x; e < kRN; e += kTileThreads) {
+        const int lx = e % kRW, lr = e / kRW;
+        const int gx = ox + lx, gy = rowBase + (lr - 2) * STEP;
+        float4 a = make_float4(0.f, 0.f, 0.f, __int_as_float(-3)), b = make_float4(0.f, 0.f, 0.f, 0.f), c = b;      // id -3 matches no pixel
+        float r = 0.f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            const size_t q = (size_t)gy * W + gx;
+            const f3 col = ld3(colorIn + q * 3), n = ld3(normal + q * 3), p = ld3(pos + q * 3);
+            const float denom = svgf_color_denominator(varFiltered[q], sigLumin);
+            a = make_float4(col.x, col.y, col.z, __int_as_float(primId[q]));
+            b = make_float4(n.x, n.y, n.z, p.x);
+            c = make_float4(p.y, p.z, varIn[q], denom);
+            r = 1.f / denom;
+        }
+        sColId[e] = a; sNormPx[e] = b; sMisc[e] = c; sRden[e] = r;
+    }
+    __syncthreads();
+    const float rDepth = 1.f / sigDepth;
+    const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
+    const int x = blockIdx.x * kTileW + tx, y = rowBase + ty * STEP;
+    if (x >= W || y >= H) return;
+    const int idxP = y * W + x, lp = (ty + 2) * kRW + tx + kHaloX;
+    const float4 pa = sColId[lp], pb = sNormPx[lp], pc = sMisc[lp];
+    const int idP = __float_as_int(pa.w);
+    const f3 colorP = mk3(pa.x, pa.y, pa.z);
+    if (idP <= kNullPrim) { st3(colorOut + (size_t)idxP * 3, colorP); varOut[idxP] = pc.z; return; }
+    const f3 normP = mk3(pb.x, pb.y, pb.z), posP = mk3(pb.w, pc.x, pc.y);
+    const float lumP = luminance(colorP);
+    f3 sumColor = splat(0.f);
+    float sumVar = 0.f, sumW = 0.f, sumW2 = 0.f;
+#pragma unroll
+    for (int i = -2; i <= 2; i++) {
+#pragma unroll
+        for (int j = -2; j <= 2; j++) {
+            const int lq = lp + i * kRW + j * STEP;
+            const float4 qa = sColId[lq];
+            if (__float_as_int(qa.w) != idP) continue;         // also a tap outside the image (id -3)
+            const float4 qb = sNormPx[lq], qc = sMisc[lq];
+            const f3 colorQ = mk3(qa.x, qa.y, qa.z);
+            const f3 dp = posP - mk3(qb.w, qc.x, qc.y);
+            const float w = svgf_tap_weight<NSQ, DMUL>(dp, normP, mk3(qb.x, qb.y, qb.z), lumP, luminance(colorQ), qc.w, sRden[lq], sigDepth, rDepth, sigNormal) * kGaussian5x5[i + 2][j + 2];
+            const float w2 = w * w;
+            sumColor = sumColor + colorQ * w;
+            sumVar += qc.z * w2;
+            sumW += w;
+            sumW2 += w2;
+        }
+    }
+    st3(colorOut + (size_t)idxP * 3, sumW < 1.1920928955078125e-7f ? colorP : sumColor / sumW);
+    varOut[idxP] = sumW2 < 1.1920928955078125e-7f ? pc.z : sumVar / sumW2;
 }
 
 // pos0: level 0 computes the positions itself (and writes the plane): only for a full-frame call, whose level 0 visits every pixel
@@ -523,6 +607,13 @@ int rs_svgf_set_params(rs_svgf* f, float sigLumin, float sigNormal, float sigDep
     f->sigLumin = sigLumin; f->sigNormal = sigNormal; f->sigDepth = sigDepth; f->level = level;
     return 0;
 }
+// which form the a-trous levels take: 1 (default) the LDS tile, 0 the plain gathers -- same bits, for measurements and tests
+int rs_svgf_set_tiled(rs_svgf* f, int tiled) {
+    RS_SCOPE(f);
+    if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_set_tiled: null filter");
+    f->tiled = tiled != 0;
+    return 0;
+}
 int rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level) {
     RS_SCOPE(f);
     if (!f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_svgf_get_params: null filter");
@@ -599,7 +690,16 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
         hipLaunchKernelGGL(k_svgf_filter_variance, grid2, dim3(256), 0, rs_stream(), f->devFilteredVariance, f->devVariance, W, H);
 #define RS_SVGF_WAVELET(N, D) hipLaunchKernelGGL((k_svgf_wavelet<N, D>), grid2, dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
                                                 f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, lv)
-        if (f->sigNormal == 128.f) { if (depthPow2) RS_SVGF_WAVELET(7, true); else RS_SVGF_WAVELET(7, false); }
+        // the reference's defaults (sigNormal 128, sigDepth 1) from the LDS tile; edited sigmas keep the plain gathers
+        if (f->tiled && f->sigNormal == 128.f && depthPow2 && lv <= 4) {
+            const int step = 1 << lv;
+            const dim3 gridT((W + kTileW - 1) / kTileW, ((H + kTileH * step - 1) / (kTileH * step)) * step);
+#define RS_SVGF_TILED(S) hipLaunchKernelGGL((k_svgf_wavelet_tiled<S, 7, true>), gridT, dim3(kTileThreads), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
+                                            f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin)
+            if (lv == 0) RS_SVGF_TILED(1); else if (lv == 1) RS_SVGF_TILED(2); else if (lv == 2) RS_SVGF_TILED(4); else if (lv == 3) RS_SVGF_TILED(8); else RS_SVGF_TILED(16);
+#undef RS_SVGF_TILED
+        }
+        else if (f->sigNormal == 128.f) { if (depthPow2) RS_SVGF_WAVELET(7, true); else RS_SVGF_WAVELET(7, false); }
         else if (f->sigNormal == 64.f) { if (depthPow2) RS_SVGF_WAVELET(6, true); else RS_SVGF_WAVELET(6, false); }
         else if (f->sigNormal == 32.f) { if (depthPow2) RS_SVGF_WAVELET(5, true); else RS_SVGF_WAVELET(5, false); }
         else { if (depthPow2) RS_SVGF_WAVELET(-1, true); else RS_SVGF_WAVELET(-1, false); }

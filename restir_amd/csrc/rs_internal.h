@@ -338,6 +338,7 @@ struct rs_svgf {
     float* devPos = nullptr;                  // per-pixel cam.getPosition(x,y,depth), once per filter call
     bool firstTime = true;
     int frameIdx = 0;
+    bool tiled = true;                        // the a-trous levels from the row-phase LDS tile (k_svgf_wavelet_tiled); rs_svgf_set_tiled
 };
 
 rs::CamParams rs_make_cam_params(const rs_camera* cam);

@@ -733,6 +733,40 @@ def test_svgf_filter(hip):
     fh.destroy()
 
 
+def test_svgf_tiled_levels_equal_plain_gathers(hip):
+    """SpatioTemporalFilter's variance-guided a-trous levels from the row-phase LDS tile (k_svgf_wavelet_tiled) against the plain
+    gathers: the same arithmetic in the same order, so filtered image, variance and history must agree BIT FOR BIT over several
+    frames of a moving camera, on a frame size that is no multiple of the tile."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.03")
+    W, H = 157, 83
+    h = HipRenderer(hip, sd, W, H)
+    filters = [hip.SVGFFilter(W, H, 5), hip.SVGFFilter(W, H, 5)]
+    filters[1].set_tiled(False)
+
+    def grab(ptr, count):
+        t = torch.empty(count, dtype=torch.float32, device="cuda")
+        hip.hip_memcpy_d2d(t.data_ptr(), ptr, count * 4)
+        return t.cpu().numpy()
+
+    for frame in range(6):
+        h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.3))
+        h.gbuf.render(h.scene, h.cam)
+        h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 1)
+        h.looper += 1
+        outs = []
+        for f in filters:
+            img = grab(f.filter(h.image.data_ptr(), h.gbuf, h.cam), W * H * 3)
+            v = f.view()
+            outs.append((img, grab(v.devVariance, W * H), grab(v.devAccumColor[v.frameIdx], W * H * 3)))
+            f.next_frame()
+        for a, b in zip(outs[0], outs[1]):
+            assert bits_equal(a, b), (frame, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+        assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][0] - h.image.cpu().numpy().reshape(-1)).max() > 1e-4
+        h.gbuf.update(h.cam)
+
+
 def test_modulate_and_add(hip):
     import torch
     sd = get_scene("cornell")
