@@ -13,7 +13,9 @@ capi.init(0)
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 180
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(int(time.time()))
-names = ["cornell", "sponza:0.05", "bistro:0.03", "cornell_textured"]
+names = os.environ.get("RS_SCENES", "cornell,sponza:0.05,bistro:0.03,cornell_textured").split(",")
+from restir_amd import sobol
+table = sobol.sobol_table()                            # every second pass over the scenes runs the Sobol sampler branch (src/sampler.h:9-36)
 scenes = {n: get_scene(n) for n in names}
 osc = {n: oracle_scene(s) for n, s in scenes.items()}
 hsc = {n: hip_scene(capi, s) for n, s in scenes.items()}
@@ -24,7 +26,10 @@ while time.time() - t0 < budget:
     n = names[runs % len(names)]
     sd = scenes[n]
     ob.set_libm_mode(1 if n == "cornell_textured" else mode)
-    o = OracleRenderer(sd, W, H, scene=osc[n]); h = HipRenderer(capi, sd, W, H, scene=hsc[n])
+    use_sobol = (runs // len(names)) % 2 == 1
+    o = OracleRenderer(sd, W, H, scene=osc[n], sobol=table if use_sobol else None); h = HipRenderer(capi, sd, W, H, scene=hsc[n], sobol=table if use_sobol else None)
+    if not use_sobol:
+        osc[n].set_sample_sequence(None); hsc[n].set_sample_sequence(None)
     base = np.array(sd.camera_args["position"], np.float64)
     for r in (o, h):
         r.cam.rotation[0] = sd.camera_args["rotation"][0] + 0.0
@@ -35,7 +40,7 @@ while time.time() - t0 < budget:
         for i in range(3):
             r.cam.position[i] = float(base[i] + jitter[i])
         upd(r.cam)
-    o.looper = h.looper = int(rng.integers(0, 1 << 20))
+    o.looper = h.looper = int(rng.integers(0, 10000 if use_sobol else 1 << 20))
     for frame in range(3):
         a = o.frame(3); b = h.frame(3)
         ne = (a.view(np.uint32) != b.view(np.uint32)).any(axis=1)
@@ -47,7 +52,7 @@ while time.time() - t0 < budget:
         import torch
         d0 = np.zeros((W * H, 3), np.float32); i0 = np.zeros_like(d0); i1 = np.zeros_like(d0)
         d1 = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda"); j0 = torch.zeros_like(d1); j1 = torch.zeros_like(d1)
-        depth = int(rng.integers(1, 6)); lp = int(rng.integers(0, 1 << 20))
+        depth = int(rng.integers(1, 6)); lp = int(rng.integers(0, 9999 if use_sobol else 1 << 20))
         ra = ob.path_trace(o.scene, o.cam, d0, i0, 0, lp, depth); rb = capi.path_trace(h.scene, h.cam, d1.data_ptr(), j0.data_ptr(), 0, lp, depth)
         o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
         rc = o.restir.indirect(o.scene, o.cam, o.gbuf, i1, 0, lp + 1, 1, depth); rd = h.restir.indirect(h.scene, h.cam, h.gbuf, j1.data_ptr(), 0, lp + 1, 1, depth)
@@ -64,4 +69,5 @@ while time.time() - t0 < budget:
         print("... %d runs, %d pixel-frames, %d differing" % (runs, px, bad + gi_bad), flush=True)
 ob.set_libm_mode(0)
 print("multi-bounce kernels: %d pixel-images, %d with different bits" % (gi_px, gi_bad))
+print("scenes %s at %dx%d, default engine and Sobol sampler in turn;" % (",".join(names), W, H))
 print("libm mode %d;" % mode, "soak: %d runs, %d pixel-frames, %d with different bits (worst L1 %.3g) in %.0f s" % (runs, px, bad, worst, time.time() - t0))
