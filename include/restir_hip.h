@@ -402,6 +402,14 @@ int  rs_strips_frame(rs_strips* strips, rs_restir* r, const rs_scene* scene, con
  * of the driver whose rows [y0, y1) equal the full-frame rs_eaw_filter's.  Strips of at least 32 rows; call before
  * rs_gbuffer_update; the rows of devColor and of the current G-buffer planes just outside the strip are overwritten. */
 int  rs_strips_eaw_filter(rs_strips* strips, rs_eaw* f, rs_gbuffer* g, const rs_camera* cam, float* devColor, float** devResult);
+/* SpatioTemporalFilter::filter (src/denoiser.cu:532-564) on the strip: the 32 G-buffer rows beyond each edge arrive once, one row of
+ * the accumulated moments after the temporal accumulation, the 2 * step + 1 border rows of every level's input colour and of the
+ * variance before that level.  Rows [y0, y1) of the result equal the full-frame rs_svgf_filter's; *devColorOut is handed over as by
+ * rs_svgf_filter.  Strips of at least 33 rows; call before rs_gbuffer_update, then rs_svgf_next_frame.  With a moving camera the
+ * filter's history (accumulated colour and moments, 24 B/px) travels to every rank by rs_strips_exchange_svgf_history, called after
+ * the filter and before rs_svgf_next_frame. */
+int  rs_strips_svgf_filter(rs_strips* strips, rs_svgf* f, rs_gbuffer* g, const rs_camera* cam, const float* devColorIn, float** devColorOut);
+int  rs_strips_exchange_svgf_history(rs_strips* strips, rs_svgf* f);
 /* Moving camera (findTemporalNeighbor reads the reprojected pixel of the last frame, src/restir.cu:20-45, which may belong to
  * another strip): every rank's rows of the reservoirs the next temporal merge reads and of the "last" G-buffer planes travel to
  * every other rank.  Call after rs_gbuffer_update.  Not needed for a static camera (the reference's default). */

@@ -119,7 +119,7 @@ EXPORTS = [
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_svgf_set_params", "rs_svgf_get_params", "rs_svgf_set_tiled", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
-    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create_rccl_lib", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_exchange_history", "rs_strips_gather", "rs_strips_gather_begin", "rs_strips_gather_end", "rs_strips_enable_timing", "rs_strips_halo_wait_ms",
+    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create_rccl_lib", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_svgf_filter", "rs_strips_exchange_svgf_history", "rs_strips_exchange_history", "rs_strips_gather", "rs_strips_gather_begin", "rs_strips_gather_end", "rs_strips_enable_timing", "rs_strips_halo_wait_ms",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
 
@@ -239,6 +239,8 @@ def lib():
     L.rs_strips_frame.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci]
     L.rs_strips_eaw_filter.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, C.POINTER(vp)]
     L.rs_strips_exchange_history.argtypes = [vp, vp, vp]
+    L.rs_strips_svgf_filter.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, C.POINTER(vp)]
+    L.rs_strips_exchange_svgf_history.argtypes = [vp, vp]
     L.rs_strips_gather.argtypes = [vp, vp, C.c_size_t, ci]
     L.rs_strips_gather_begin.argtypes = [vp, vp, C.c_size_t, ci, ci]
     L.rs_strips_gather_end.argtypes = [vp, ci]
@@ -817,6 +819,18 @@ class Strips:
         p = C.c_void_p()
         check(lib().rs_strips_eaw_filter(self.handle, eaw.handle, gbuf.handle, C.byref(cam), dev_color_ptr, C.byref(p)))
         return p.value
+
+    def svgf_filter(self, svgf, gbuf, cam, dev_color_ptr):
+        """SpatioTemporalFilter on the strip (before GBuffer.update); `svgf` is a capi.SVGFFilter, whose out pointer is handed over as
+        by its own filter(); returns the device pointer of the filtered image (rows of this strip valid)."""
+        p = C.c_void_p(svgf.out_ptr)
+        check(lib().rs_strips_svgf_filter(self.handle, svgf.handle, gbuf.handle, C.byref(cam), dev_color_ptr, C.byref(p)))
+        svgf.out_ptr = p.value
+        return svgf.out_ptr
+
+    def exchange_svgf_history(self, svgf):
+        """Moving camera: after svgf_filter and before svgf.next_frame(), the filter's history rows travel to every other rank."""
+        check(lib().rs_strips_exchange_svgf_history(self.handle, svgf.handle))
 
     def exchange_history(self, restir, gbuf):
         """Moving camera: after GBuffer.update, every rank's history rows travel to every other rank."""

@@ -220,9 +220,9 @@ __constant__ float kGaussian3x3[3][3] = {        // src/denoiser.cu:11-15
 // `diff` (also for lastIdx = -1); the values are only used when !diff, so they are only loaded then.
 __global__ void __launch_bounds__(256) k_svgf_temporal(float* __restrict__ colorOut, const float* __restrict__ colorAccIn,
                                                        float* __restrict__ momentOut, const float* __restrict__ momentAccIn,
-                                                       const float* __restrict__ colorIn, GBufView g, int first) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= g.width * g.height) return;
+                                                       const float* __restrict__ colorIn, GBufView g, int first, int firstIdx, int lastIdx1) {
+    const int idx = firstIdx + blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= lastIdx1) return;
     const int primId = g.primId[idx];
     const int lastIdx = g.motion[idx];
     bool diff = first != 0;
@@ -250,9 +250,9 @@ __global__ void __launch_bounds__(256) k_svgf_temporal(float* __restrict__ color
 }
 
 // estimateVariance (:307-343): temporal variance after 4 accumulated frames, else the 3x3 spatial estimate
-__global__ void __launch_bounds__(256) k_svgf_variance(float* __restrict__ variance, const float* __restrict__ moment, int W, int H) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
+__global__ void __launch_bounds__(256) k_svgf_variance(float* __restrict__ variance, const float* __restrict__ moment, int W, int H, int y0, int y1) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= y1) return;
     const int idx = y * W + x;
     const f3 m = ld3(moment + (size_t)idx * 3);
     if (m.z > 3.5f) { variance[idx] = m.y - m.x * m.x; return; }
@@ -271,9 +271,9 @@ __global__ void __launch_bounds__(256) k_svgf_variance(float* __restrict__ varia
 }
 
 // filterVariance (:345-371); the reference walks qx with the OUTER loop variable (:358-359), kept for the summation order
-__global__ void __launch_bounds__(256) k_svgf_filter_variance(float* __restrict__ out, const float* __restrict__ in, int W, int H) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
+__global__ void __launch_bounds__(256) k_svgf_filter_variance(float* __restrict__ out, const float* __restrict__ in, int W, int H, int y0, int y1) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= y1) return;
     float sum = 0.f, sumW = 0.f;
 #pragma unroll
     for (int i = -1; i <= 1; i++) {
@@ -323,9 +323,9 @@ __global__ void __launch_bounds__(256) k_svgf_wavelet(float* __restrict__ colorO
                                                       const float* __restrict__ varFiltered,
                                                       const int* __restrict__ primId, const float* __restrict__ normal,
                                                       const float* __restrict__ pos, int W, int H,
-                                                      float sigDepth, float sigNormal, float sigLumin, int level) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
+                                                      float sigDepth, float sigNormal, float sigLumin, int level, int y0, int y1) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= y1) return;
     const float rDepth = 1.f / sigDepth;
     const int step = 1 << level;
     const int idxP = y * W + x;
@@ -372,14 +372,14 @@ __global__ void __launch_bounds__(kTileThreads) k_svgf_wavelet_tiled(float* __re
                                                                     const float* __restrict__ varFiltered,
                                                                     const int* __restrict__ primId, const float* __restrict__ normal,
                                                                     const float* __restrict__ pos, int W, int H,
-                                                                    float sigDepth, float sigNormal, float sigLumin) {
+                                                                    float sigDepth, float sigNormal, float sigLumin, int y0, int y1) {
     constexpr int kHaloX = 2 * STEP, kRW = kTileW + 2 * kHaloX, kRH = kTileH + 4, kRN = kRW * kRH;
     __shared__ float4 sColId[kRN];          // colour xyz, id bits
     __shared__ float4 sNormPx[kRN];         // normal xyz, position x
     __shared__ float4 sMisc[kRN];           // position y, z, variance, denominator of the colour weight
     __shared__ float sRden[kRN];            // 1 / denominator
     const int phase = blockIdx.y % STEP, group = blockIdx.y / STEP;
-    const int rowBase = group * (kTileH * STEP) + phase;
+    const int rowBase = y0 + group * (kTileH * STEP) + phase;
     const int ox = blockIdx.x * kTileW - kHaloX;
     for (int e = threadIdx.x; e < kRN; e += kTileThreads) {
         const int lx = e % kRW, lr = e / kRW;
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(kTileThreads) k_svgf_wavelet_tiled(float* __re
     const float rDepth = 1.f / sigDepth;
     const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
     const int x = blockIdx.x * kTileW + tx, y = rowBase + ty * STEP;
-    if (x >= W || y >= H) return;
+    if (x >= W || y >= y1) return;
     const int idxP = y * W + x, lp = (ty + 2) * kRW + tx + kHaloX;
     const float4 pa = sColId[lp], pb = sNormPx[lp], pc = sMisc[lp];
     const int idP = __float_as_int(pa.w);
@@ -665,37 +665,50 @@ int rs_svgf_get_view(const rs_svgf* f, rs_svgf_view* v) {
 // SpatioTemporalFilter::filter (:532-564).  *devColorOut is the reference's `glm::vec3*& devColorOut`: after level 0
 // it is swapped with devAccumColor[frameIdx], so the caller's buffer becomes the filter's history and the caller
 // continues with one of the filter's buffers; as in the reference the caller must keep using the pointer it gets back.
-int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
-    RS_SCOPE(f);
-    RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
-    if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
-    if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
-        return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: size mismatch");
-    const int W = f->width, H = f->height, n = W * H;
+// Rows [y0, y1): the whole frame for rs_svgf_filter, a strip for the strip driver (strips.hip rs_strips_svgf_filter), which
+// passes `hooks` to exchange border rows with its neighbours at the three places a strip reads beyond its rows:
+//   after the temporal accumulation   1 row of devAccumMoment[frameIdx] (the 3x3 variance estimate)
+//   before level lv                   2 * step + 1 rows of the level's input colour and of devVariance (the 3x3 variance
+//                                     pre-filter is then evaluated on rows [y0 - 2 step, y1 + 2 step) locally)
+// (the G-buffer rows and positions up to 32 rows beyond the strip are the caller's business, before the call).
+}  // extern "C"
+int rs_svgf_filter_rows(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam, int y0, int y1,
+                        const rs_svgf_row_hooks* hooks) {
+    const int W = f->width, H = f->height;
     const int fi = f->frameIdx;
-    const dim3 grid2((W + 31) / 32, (H + 7) / 8);
     const GBufView gv = gbuf_view(g);
-    hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
-                       g->depth[g->cur()], g->primId[g->cur()], f->devPos, 0, n);
+    const auto grid_rows = [&](int a, int b) { return dim3((W + 31) / 32, (b - a + 7) / 8); };
+    const auto clampRow = [&](int y) { return y < 0 ? 0 : (y > H ? H : y); };
+    const bool strip = hooks != nullptr;
+    const int reach = 2 << 4;
+    {   // positions of every row a tap can look at
+        const int a = clampRow(y0 - (strip ? reach : 0)), b = clampRow(y1 + (strip ? reach : 0));
+        hipLaunchKernelGGL(k_positions, dim3(((b - a) * W + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
+                           g->depth[g->cur()], g->primId[g->cur()], f->devPos, a * W, b * W);
+    }
     // temporalAccumulate (:506-519), estimateVariance (:521-527)
-    hipLaunchKernelGGL(k_svgf_temporal, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), f->devAccumColor[fi], f->devAccumColor[fi ^ 1],
-                       f->devAccumMoment[fi], f->devAccumMoment[fi ^ 1], devColorIn, gv, f->firstTime ? 1 : 0);
+    hipLaunchKernelGGL(k_svgf_temporal, dim3(((y1 - y0) * W + 255) / 256), dim3(256), 0, rs_stream(), f->devAccumColor[fi], f->devAccumColor[fi ^ 1],
+                       f->devAccumMoment[fi], f->devAccumMoment[fi ^ 1], devColorIn, gv, f->firstTime ? 1 : 0, y0 * W, y1 * W);
     f->firstTime = false;
-    hipLaunchKernelGGL(k_svgf_variance, grid2, dim3(256), 0, rs_stream(), f->devVariance, f->devAccumMoment[fi], W, H);
+    if (strip) RS_TRY(hooks->exchange(hooks->ctx, f->devAccumMoment[fi], 3, nullptr, 0, 1));
+    hipLaunchKernelGGL(k_svgf_variance, grid_rows(y0, y1), dim3(256), 0, rs_stream(), f->devVariance, f->devAccumMoment[fi], W, H, y0, y1);
     RS_TRY(rs_after_launch("SpatioTemporalFilter::temporalAccumulate"));
 
     int de = 0;
     const bool depthPow2 = f->sigDepth > 0.f && std::isfinite(f->sigDepth) && std::frexp(f->sigDepth, &de) == 0.5f && std::isnormal(1.f / f->sigDepth);
-    auto level = [&](float* out, const float* in, int lv) {
-        hipLaunchKernelGGL(k_svgf_filter_variance, grid2, dim3(256), 0, rs_stream(), f->devFilteredVariance, f->devVariance, W, H);
-#define RS_SVGF_WAVELET(N, D) hipLaunchKernelGGL((k_svgf_wavelet<N, D>), grid2, dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
-                                                f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, lv)
+    int err = 0;
+    auto level = [&](float* out, float* in, int lv) {
+        const int step = 1 << lv;
+        if (strip && !err) err = hooks->exchange(hooks->ctx, in, 3, f->devVariance, 1, 2 * step + 1);
+        const int va = clampRow(y0 - (strip ? 2 * step : 0)), vb = clampRow(y1 + (strip ? 2 * step : 0));
+        hipLaunchKernelGGL(k_svgf_filter_variance, grid_rows(va, vb), dim3(256), 0, rs_stream(), f->devFilteredVariance, f->devVariance, W, H, va, vb);
+#define RS_SVGF_WAVELET(N, D) hipLaunchKernelGGL((k_svgf_wavelet<N, D>), grid_rows(y0, y1), dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
+                                                f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, lv, y0, y1)
         // the reference's defaults (sigNormal 128, sigDepth 1) from the LDS tile; edited sigmas keep the plain gathers
         if (f->tiled && f->sigNormal == 128.f && depthPow2 && lv <= 4) {
-            const int step = 1 << lv;
-            const dim3 gridT((W + kTileW - 1) / kTileW, ((H + kTileH * step - 1) / (kTileH * step)) * step);
+            const dim3 gridT((W + kTileW - 1) / kTileW, ((y1 - y0 + kTileH * step - 1) / (kTileH * step)) * step);
 #define RS_SVGF_TILED(S) hipLaunchKernelGGL((k_svgf_wavelet_tiled<S, 7, true>), gridT, dim3(kTileThreads), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
-                                            f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin)
+                                            f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, y0, y1)
             if (lv == 0) RS_SVGF_TILED(1); else if (lv == 1) RS_SVGF_TILED(2); else if (lv == 2) RS_SVGF_TILED(4); else if (lv == 3) RS_SVGF_TILED(8); else RS_SVGF_TILED(16);
 #undef RS_SVGF_TILED
         }
@@ -713,7 +726,18 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
         level(f->devTempColor, *devColorOut, lv);
         float* t = f->devTempColor; f->devTempColor = *devColorOut; *devColorOut = t;
     }
+    if (err) return err;
     return rs_after_launch("SpatioTemporalFilter::filter");
+}
+extern "C" {
+
+int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam) {
+    RS_SCOPE(f);
+    RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
+    if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
+    if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: size mismatch");
+    return rs_svgf_filter_rows(f, devColorOut, devColorIn, g, cam, 0, f->height, nullptr);
 }
 
 int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {

@@ -341,6 +341,15 @@ struct rs_svgf {
     bool tiled = true;                        // the a-trous levels from the row-phase LDS tile (k_svgf_wavelet_tiled); rs_svgf_set_tiled
 };
 
+// SpatioTemporalFilter on the rows of a strip (denoiser.hip): `exchange` swaps the first / last `rows` rows of the strip's part of
+// image a (ca floats per pixel) -- and of image b when it is not null -- with the strips above and below, into the rows just outside
+struct rs_svgf_row_hooks {
+    void* ctx;
+    int (*exchange)(void* ctx, float* a, int ca, float* b, int cb, int rows);
+};
+int rs_svgf_filter_rows(rs_svgf* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam, int y0, int y1,
+                        const rs_svgf_row_hooks* hooks);
+
 rs::CamParams rs_make_cam_params(const rs_camera* cam);
 
 // occlusion_bvh.cpp

@@ -107,7 +107,47 @@ int post(rs_strips* s, const Xfer* ops, size_t n) {
     }
     return err;
 }
-int join(rs_strips* s, bool timed = false) {
+int join(rs_strips* s, bool timed);
+// the `reach` rows of the current G-buffer id / normal / depth planes beyond each edge of the strip, from the neighbouring strips
+// (what the taps of a denoiser compare against; rs_strips_eaw_filter, rs_strips_svgf_filter)
+int exchange_gbuffer_rows(rs_strips* s, rs_gbuffer* g, int reach) {
+    const rs_comm* c = s->comm;
+    const int y0 = s->y0, y1 = s->y1;
+    const bool up = c->rank > 0, down = c->rank + 1 < c->world;
+    if (!up && !down) return 0;
+    const size_t gBytes = rs_gbuffer_rows_bytes(g, reach);
+    for (int i = 0; i < 2; i++)
+        if ((i == 0 ? up : down) && !s->eawSend[i]) { RS_TRY(rs_dev_alloc(&s->eawSend[i], gBytes)); RS_TRY(rs_dev_alloc(&s->eawRecv[i], gBytes)); }
+    Xfer ops[4]; size_t n = 0;
+    if (up) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, reach, s->eawSend[0])); ops[n++] = { true, s->eawSend[0], gBytes, c->rank - 1 }; ops[n++] = { false, s->eawRecv[0], gBytes, c->rank - 1 }; }
+    if (down) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - reach, reach, s->eawSend[1])); ops[n++] = { true, s->eawSend[1], gBytes, c->rank + 1 }; ops[n++] = { false, s->eawRecv[1], gBytes, c->rank + 1 }; }
+    RS_TRY(post(s, ops, n));
+    RS_TRY(join(s, false));
+    if (up) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - reach, reach, s->eawRecv[0]));
+    if (down) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, reach, s->eawRecv[1]));
+    return 0;
+}
+// the first / last `rows` rows of the strip's part of a row-major image (and of a second one) to the strips above / below, theirs
+// into the rows just outside the strip: sent from and received into place
+int exchange_image_rows(rs_strips* s, float* a, int ca, float* b, int cb, int rows) {
+    const rs_comm* c = s->comm;
+    const int W = s->width, y0 = s->y0, y1 = s->y1;
+    const bool up = c->rank > 0, down = c->rank + 1 < c->world;
+    if (!up && !down) return 0;
+    Xfer ops[8]; size_t n = 0;
+    float* img[2] = { a, b }; const int comp[2] = { ca, cb };
+    for (int k = 0; k < 2; k++) {
+        if (!img[k]) continue;
+        const size_t row = (size_t)W * comp[k], bytes = row * rows * sizeof(float);
+        if (up) { ops[n++] = { true, img[k] + (size_t)y0 * row, bytes, c->rank - 1 }; ops[n++] = { false, img[k] + (size_t)(y0 - rows) * row, bytes, c->rank - 1 }; }
+        if (down) { ops[n++] = { true, img[k] + (size_t)(y1 - rows) * row, bytes, c->rank + 1 }; ops[n++] = { false, img[k] + (size_t)y1 * row, bytes, c->rank + 1 }; }
+    }
+    RS_TRY(post(s, ops, n));
+    return join(s, false);
+}
+int svgf_exchange_hook(void* ctx, float* a, int ca, float* b, int cb, int rows) { return exchange_image_rows((rs_strips*)ctx, a, ca, b, cb, rows); }
+
+int join(rs_strips* s, bool timed) {
     if (s->comm->t.stream_ordered) {
         RS_HIP(hipEventRecord(s->arrived, s->commStream));
         if (timed && s->timing) RS_HIP(hipEventRecord(s->waitFrom, rs_stream()));
@@ -309,18 +349,7 @@ int rs_strips_eaw_filter(rs_strips* s, rs_eaw* f, rs_gbuffer* g, const rs_camera
     const size_t image = (size_t)W * s->height * 3 * sizeof(float);
     for (int i = 0; i < 2; i++)
         if (!s->eawBuf[i]) { RS_TRY(rs_dev_alloc(&s->eawBuf[i], image / sizeof(float))); RS_HIP(hipMemsetAsync(s->eawBuf[i], 0, image, rs_stream())); }
-    const size_t gBytes = rs_gbuffer_rows_bytes(g, reach);
-    if (up || down) {
-        for (int i = 0; i < 2; i++)
-            if ((i == 0 ? up : down) && !s->eawSend[i]) { RS_TRY(rs_dev_alloc(&s->eawSend[i], gBytes)); RS_TRY(rs_dev_alloc(&s->eawRecv[i], gBytes)); }
-        Xfer ops[4]; size_t n = 0;
-        if (up) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, reach, s->eawSend[0])); ops[n++] = { true, s->eawSend[0], gBytes, c->rank - 1 }; ops[n++] = { false, s->eawRecv[0], gBytes, c->rank - 1 }; }
-        if (down) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - reach, reach, s->eawSend[1])); ops[n++] = { true, s->eawSend[1], gBytes, c->rank + 1 }; ops[n++] = { false, s->eawRecv[1], gBytes, c->rank + 1 }; }
-        RS_TRY(post(s, ops, n));
-        RS_TRY(join(s));
-        if (up) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - reach, reach, s->eawRecv[0]));
-        if (down) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, reach, s->eawRecv[1]));
-    }
+    RS_TRY(exchange_gbuffer_rows(s, g, reach));
     RS_TRY(rs_eaw_positions_rows(f, g, cam, y0 - reach > 0 ? y0 - reach : 0, y1 + reach < s->height ? y1 + reach : s->height));
     for (int level = 0; level < kLevels; level++) {
         float* in = level == 0 ? devColor : s->eawBuf[(level - 1) % 2];
@@ -332,12 +361,57 @@ int rs_strips_eaw_filter(rs_strips* s, rs_eaw* f, rs_gbuffer* g, const rs_camera
             if (up) { ops[n++] = { true, in + (size_t)y0 * W * 3, bytes, c->rank - 1 }; ops[n++] = { false, in + (size_t)(y0 - rows) * W * 3, bytes, c->rank - 1 }; }
             if (down) { ops[n++] = { true, in + (size_t)(y1 - rows) * W * 3, bytes, c->rank + 1 }; ops[n++] = { false, in + (size_t)y1 * W * 3, bytes, c->rank + 1 }; }
             RS_TRY(post(s, ops, n));
-            RS_TRY(join(s));
+            RS_TRY(join(s, false));
         }
         RS_TRY(rs_eaw_level_rows(f, out, in, g, level, y0, y1));
     }
     *devResult = s->eawBuf[(kLevels - 1) % 2];
     return 0;
+}
+
+// SpatioTemporalFilter::filter (src/denoiser.cu:532-564) on this strip's rows.  What a strip reads beyond its rows travels from the
+// neighbouring strips: the 32 G-buffer rows the taps compare against (once), one row of the accumulated moments (the 3x3 variance
+// estimate), and before every level the 2 * step + 1 border rows of that level's input colour and of the variance -- the values a
+// full-frame filter reads there, so rows [y0, y1) of the result equal the full-frame rs_svgf_filter's bit for bit.  *devColorOut is
+// handed over exactly as by rs_svgf_filter (every rank performs the same buffer swaps).  Strips of at least 33 rows; call between
+// rs_strips_frame and rs_gbuffer_update, then rs_svgf_next_frame; with a moving camera rs_strips_exchange_svgf_history in between.
+int rs_strips_svgf_filter(rs_strips* s, rs_svgf* f, rs_gbuffer* g, const rs_camera* cam, const float* devColorIn, float** devColorOut) {
+    RS_SCOPE(s);
+    if (!s || !f || !g || !cam || !devColorIn || !devColorOut || !*devColorOut) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_svgf_filter: null argument");
+    if (g->width != s->width || g->height != s->height || f->width != s->width || f->height != s->height || cam->resolution[0] != s->width || cam->resolution[1] != s->height)
+        return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_svgf_filter: size mismatch");
+    const rs_comm* c = s->comm;
+    RS_TRY(rs_gbuffer_join(g));
+    if (c->world == 1) return rs_svgf_filter_rows(f, devColorOut, devColorIn, g, cam, 0, s->height, nullptr);
+    const int reach = 2 << 4;
+    for (int r = 0; r < c->world; r++)
+        if (s->bounds[(size_t)r + 1] - s->bounds[(size_t)r] < reach + 1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_svgf_filter: strips must be at least 33 rows tall");
+    RS_TRY(exchange_gbuffer_rows(s, g, reach));
+    const rs_svgf_row_hooks hooks{ s, svgf_exchange_hook };
+    return rs_svgf_filter_rows(f, devColorOut, devColorIn, g, cam, s->y0, s->y1, &hooks);
+}
+
+// Moving camera: the temporal accumulation of the next frame reads the filter's history -- accumulated colour and moments of this
+// frame -- at the reprojected pixel (src/denoiser.cu:250-305), which may lie in another strip: every rank's rows of both planes travel
+// to every other rank, from and into place.  Call after rs_strips_svgf_filter and before rs_svgf_next_frame.
+int rs_strips_exchange_svgf_history(rs_strips* s, rs_svgf* f) {
+    RS_SCOPE(s);
+    if (!s || !f) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_exchange_svgf_history: null argument");
+    if (f->width != s->width || f->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_exchange_svgf_history: size mismatch");
+    const rs_comm* c = s->comm;
+    if (c->world == 1) return 0;
+    const size_t row = (size_t)s->width * 3;
+    float* planes[2] = { f->devAccumColor[f->frameIdx], f->devAccumMoment[f->frameIdx] };
+    std::vector<Xfer> ops;
+    for (int k = 0; k < c->world; k++) {
+        if (k == c->rank) continue;
+        for (float* p : planes) {
+            ops.push_back({ true, p + (size_t)s->y0 * row, (size_t)(s->y1 - s->y0) * row * sizeof(float), k });
+            ops.push_back({ false, p + (size_t)s->bounds[(size_t)k] * row, (size_t)(s->bounds[(size_t)k + 1] - s->bounds[(size_t)k]) * row * sizeof(float), k });
+        }
+    }
+    RS_TRY(post(s, ops.data(), ops.size()));
+    return join(s, false);
 }
 
 // Moving camera: the temporal merge of the next frame reads last-frame reservoirs and G-buffer planes at the reprojected pixel
@@ -368,7 +442,7 @@ int rs_strips_exchange_history(rs_strips* s, rs_restir* r, rs_gbuffer* g) {
         off += bytesOf(k);
     }
     RS_TRY(post(s, ops.data(), ops.size()));
-    RS_TRY(join(s));
+    RS_TRY(join(s, false));
     off = 0;
     for (int k = 0; k < c->world; k++) {
         if (k == c->rank) continue;
@@ -396,7 +470,7 @@ int rs_strips_gather(rs_strips* s, void* devImage, size_t bytesPerPixel, int roo
         if (root < 0 || root == c->rank) ops.push_back({ false, base + (size_t)s->bounds[(size_t)k] * row, (size_t)(s->bounds[(size_t)k + 1] - s->bounds[(size_t)k]) * row, k });
     }
     RS_TRY(post(s, ops.data(), ops.size()));
-    return join(s);
+    return join(s, false);
 }
 
 // The same assembly without making the library stream wait for it: _begin posts the transfers (after everything enqueued on the

@@ -987,7 +987,9 @@ def test_multi_process_strips_on_one_gpu():
     and all-gather) with two ranks sharing this GPU and gloo standing in for RCCL: tools/rehearse_strips.py compares
     the gathered strips with a full-frame render, static and orbiting camera, synchronous launches and overlapped frames,
     radiance and the EAW-filtered image (BASELINE config 5's denoiser on strips); then the same strips through the C-ABI strip
-    driver (include/restir_hip.h rs_strips_frame / _eaw_filter / _exchange_history / _gather), the form a C++ caller runs over RCCL."""
+    driver (include/restir_hip.h rs_strips_frame / _eaw_filter / _exchange_history / _gather / _gather_begin,_end), the form a C++
+    caller runs over RCCL; and SpatioTemporalFilter on the strips (rs_strips_svgf_filter / _exchange_svgf_history) against the
+    full-frame filter, five frames of a static and of an orbiting camera."""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -107,6 +107,48 @@ for moving, overlapped, denoise in ((False, False, False), (False, True, False),
               (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", ", EAW filter" if denoise else "", same, all(flags)), flush=True)
         ok = ok and same and all(flags)
     drv.destroy(); comm.destroy()
+# ---- SpatioTemporalFilter on strips (rs_strips_svgf_filter / rs_strips_exchange_svgf_history) against the full-frame filter ---------
+W2, H2 = 320, 40 * world + 8                                          # strips of at least 33 rows
+for moving, overlapped in ((False, False), (True, False), (True, True)):
+    capi.set_sync(not overlapped)
+    cam = capi.camera_update(sd.camera(W2, H2))
+    comm = GlooTransport(capi, dist, torch).comm(rank, world)
+    drv = capi.Strips(comm, W2, H2)
+    gbuf, restir, svgf = capi.GBuffer(W2, H2), capi.ReSTIR(W2, H2), capi.SVGFFilter(W2, H2, 5)
+    image = torch.zeros((W2 * H2, 3), dtype=torch.float32, device="cuda")
+    fgb, frs, fsv = (capi.GBuffer(W2, H2), capi.ReSTIR(W2, H2), capi.SVGFFilter(W2, H2, 5)) if rank == 0 else (None, None, None)
+    fimage = torch.zeros_like(image) if rank == 0 else None
+    same = True
+    for frame in range(5):
+        if moving:
+            p = orbit_position(sd.camera_args["position"], frame, radius=0.4)
+            for i in range(3):
+                cam.position[i] = float(p[i])
+            capi.camera_update(cam)
+        drv.frame(restir, scene, cam, gbuf, image.data_ptr(), 0, frame, 1)
+        res_ptr = drv.svgf_filter(svgf, gbuf, cam, image.data_ptr())
+        gbuf.update(cam)
+        if moving:
+            drv.exchange_history(restir, gbuf)
+            drv.exchange_svgf_history(svgf)
+        svgf.next_frame()
+        drv.gather(res_ptr, 12, 0)
+        capi.synchronize(); torch.cuda.synchronize()
+        if rank == 0:
+            fgb.render(scene, cam); frs.direct(scene, cam, fgb, fimage.data_ptr(), 0, frame, 1)
+            ref_ptr = fsv.filter(fimage.data_ptr(), fgb, cam)
+            fgb.update(cam); fsv.next_frame()
+            capi.synchronize()
+            a = torch.empty((W2 * H2, 3), dtype=torch.float32, device="cuda"); b = torch.empty_like(a)
+            capi.hip_memcpy_d2d(a.data_ptr(), res_ptr, W2 * H2 * 12); capi.hip_memcpy_d2d(b.data_ptr(), ref_ptr, W2 * H2 * 12)
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+    capi.set_sync(True)
+    if rank == 0:
+        print("world %d, C-ABI strip driver, SVGF filter, %s camera, %s launches: gathered strips == full-frame filter over 5 frames: %s" %
+              (world, "orbiting" if moving else "static", "overlapped" if overlapped else "synchronous", same), flush=True)
+        ok = ok and same
+    drv.destroy(); comm.destroy()
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
