@@ -901,13 +901,16 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
     // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
     // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
-    static const bool aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return !(e && e[0] == '0'); }();      // measurement switch
+    // Alone the alias-in-LDS form is a third faster (config 5: 645 -> 455 us); inside overlapped frames it is slower (1.88 -> 1.95 ms per
+    // frame: one 1024-thread block with 82 KB of LDS per CU keeps the other streams' kernels off that CU), so it is taken when the
+    // kernels run one after the other on the library stream only.  RS_RIS_ALIAS_LDS=0 / 1: never / always (measurements).
+    static const int aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return e ? std::atoi(e) : 2; }();
     const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
     if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
         // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
         // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
         RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
-    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && aliasLds) {
+    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && (aliasLds == 1 || (aliasLds == 2 && !aux))) {
         const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
         static const bool ldsAllowed = []{      // more than 64 KB of dynamic LDS is opt-in
             const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
