@@ -258,7 +258,12 @@ def main():
         scene.set_sample_sequence(table)
         sobol_num = len(table)
     cam = capi.camera_update(sd.camera(WIDTH, HEIGHT))
-    backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
+    if driver == "c" and world > 1:
+        # the strip driver enqueues its RCCL transfers on the library stream: give it a stream of the kind RCCL is always used with
+        # (an ordinary non-blocking one, as torch's own process groups use) instead of the legacy default stream
+        lib_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(lib_stream)
+    backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)          # (hands torch's current stream to the library: rs_set_stream)
     capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
     # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
     # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights

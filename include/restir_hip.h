@@ -379,7 +379,9 @@ typedef struct rs_transport {
     int stream_ordered;
 } rs_transport;
 /* ncclComm: an ncclComm_t of `world` ranks created by the caller (ncclCommInitRank); librccl.so is opened at run time, the
- * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on a stream of the strip driver */
+ * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on the library stream (rs_set_stream), between
+ * the launch that packs the border rows and the interior rows of phase B; RS_STRIPS_COMM_STREAM=1 in the environment puts them on
+ * a stream of the strip driver instead (measured slower: a fifth stream shares a hardware queue with a chain) */
 int  rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** comm);
 /* The same, naming the copy of RCCL that created ncclComm (a process can hold two: PyTorch wheels bundle their own librccl.so).
  * librcclPath NULL or "" = rs_comm_create_rccl's search: symbols the process has linked or loaded globally, else a copy already
@@ -417,9 +419,12 @@ int  rs_strips_exchange_history(rs_strips* strips, rs_restir* r, rs_gbuffer* g);
 /* Image assembly: rows [y0, y1) of every rank's devImage (full-frame sized, bytesPerPixel bytes per pixel: 12 for the radiance
  * image, 4 for the display image) arrive in the same rows on rank `root`, or on every rank for root = -1. */
 int  rs_strips_gather(rs_strips* strips, void* devImage, size_t bytesPerPixel, int root);
-/* The same without making the library stream wait: _begin posts the transfers behind what has been enqueued so far, _end makes the
- * library stream wait for them (call it before devImage is written again or read on root).  slot in [0, 4) names a gather in
- * flight; every rank begins the same gathers in the same order (all transfers of a strip driver share one stream). */
+/* The same, overlapped with the next frame: _begin records the transfers, which then travel in the next transfer group the driver
+ * posts (the border rows of the next rs_strips_frame: one RCCL group per frame) or, failing that, in a group of their own posted by
+ * _end; _end returns with the transfers ordered before whatever is enqueued on the library stream next (call it before devImage is
+ * written again or read on root).  devImage's rows must be final on the library stream when the next group is posted, i.e. enqueue
+ * their producer before rs_strips_frame.  slot in [0, 4) names a gather in flight; every rank begins the same gathers in the same
+ * order (all transfers of a strip driver share one stream). */
 int  rs_strips_gather_begin(rs_strips* strips, void* devImage, size_t bytesPerPixel, int root, int slot);
 int  rs_strips_gather_end(rs_strips* strips, int slot);
 /* Measurement: with timing enabled rs_strips_frame brackets the library stream's wait for the neighbours' border rows with two

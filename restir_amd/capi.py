@@ -766,7 +766,7 @@ class Comm:
     """rs_comm: the exchange of the strip driver.  Comm.rccl(nccl_comm_ptr, rank, world) wraps an ncclComm_t; Comm(callbacks...)
     takes host callbacks send(dev_ptr, nbytes, peer) / recv(dev_ptr, nbytes, peer) / group_begin() / group_end() (tests)."""
 
-    def __init__(self, rank, world, send, recv, group_begin=None, group_end=None):
+    def __init__(self, rank, world, send, recv, group_begin=None, group_end=None, stream_ordered=False):
         def guard(fn):
             def call(*a):
                 try:
@@ -780,7 +780,7 @@ class Comm:
                      TRANSPORT_SEND(guard(lambda ctx, p, n, peer, st: send(p, n, peer))),
                      TRANSPORT_RECV(guard(lambda ctx, p, n, peer, st: recv(p, n, peer))),
                      TRANSPORT_GROUP(guard(lambda ctx: group_end() if group_end else None)))
-        t = Transport(None, self._cbs[0], self._cbs[1], self._cbs[2], self._cbs[3], 0)
+        t = Transport(None, self._cbs[0], self._cbs[1], self._cbs[2], self._cbs[3], 1 if stream_ordered else 0)
         self.handle = C.c_void_p()
         check(lib().rs_comm_create(C.byref(t), rank, world, C.byref(self.handle)))
 

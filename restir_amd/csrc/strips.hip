@@ -19,6 +19,7 @@
 // colour rows and the assembled image travel from and into place without packing.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "rs_internal.h"
@@ -36,6 +37,8 @@ struct rs_comm {
     const char* (*pErr)(int) = nullptr;
 };
 
+struct Xfer { bool send; void* buf; size_t bytes; int peer; };
+
 struct rs_strips {
     rs_context* ctx = nullptr;
     rs_comm* comm = nullptr;
@@ -44,7 +47,17 @@ struct rs_strips {
     int y0 = 0, y1 = 0;
     size_t haloBytes = 0;                          // one edge: reservoirs + G-buffer rows
     char* sendUp = nullptr; char* recvUp = nullptr; char* sendDown = nullptr; char* recvDown = nullptr;
-    hipStream_t commStream = nullptr;              // carries the transfers: ONE stream, so that every rank issues its groups in one order
+    // Where the transfers are enqueued.  commOnMain (default): on the library stream itself, in order with the packing copies before
+    // and the unpacking copies after them -- no extra stream, no events.  The overlapped mode already keeps four streams busy (the
+    // library stream and three chains), which is the number of hardware queues: a fifth stream shares a queue with one of the chains
+    // and serialises two of the three (a 1/8 strip of 1080p through this driver with a transport that does nothing: 0.289 ms per
+    // frame with a separate stream against 0.19 without; tools/host_enqueue_strips.py, tools/strip_trace_c.py).  The price: the
+    // library stream does not run the interior rows of phase B while the rows travel -- a few microseconds of kernel on a strip.
+    // RS_STRIPS_COMM_STREAM=1: the transfers on a stream of their own, ordered by events (rounds 2's form).
+    bool commOnMain = true;
+    hipStream_t commStream = nullptr;              // carries the transfers when !commOnMain: ONE stream, so that every rank issues its groups in one order
+    std::vector<Xfer> deferred;             // rs_strips_gather_begin on the library stream: its transfers ride in the next group
+    int deferredSlots = 0;                         // bit per gather slot whose transfers are still in `deferred`
     hipEvent_t packed = nullptr, arrived = nullptr;
     static constexpr int kGatherSlots = 4;
     hipEvent_t gathered[kGatherSlots] = {};        // rs_strips_gather_begin / _end: the gather of a slot has finished
@@ -82,14 +95,67 @@ int rccl_recv(void* ctx, void* buf, size_t bytes, int peer, void* stream) {
     return e ? rccl_fail(c, e, "ncclRecv") : 0;
 }
 
-struct Xfer { bool send; void* buf; size_t bytes; int peer; };
+// Packing and unpacking the border rows of a frame: 6 planes (published reservoirs li / wi / tap, G-buffer id / normal / depth) x 2
+// edges.  As 24 hipMemcpyAsync calls per frame they cost the HOST 0.12 ms -- more than half of what a 1/8 strip's kernels last
+// (tools/host_enqueue_strips.py: 0.210 ms of host time per frame against 0.18 ms of kernels) -- so all segments of a direction go
+// through ONE launch of a copy kernel that finds its segment from a table passed by value.
+constexpr int kMaxSegs = 12;
+struct CopyTable { const char* src[kMaxSegs]; char* dst[kMaxSegs]; unsigned start[kMaxSegs + 1]; int n; };      // start: in units of `unit` bytes
+template <typename T>
+__global__ void __launch_bounds__(256) k_copy_segments(CopyTable t) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= t.start[t.n]) return;
+    int k = 0;
+    while (i >= t.start[k + 1]) k++;
+    reinterpret_cast<T*>(t.dst[k])[i - t.start[k]] = reinterpret_cast<const T*>(t.src[k])[i - t.start[k]];
+}
+struct SegList {
+    const char* a[kMaxSegs]; char* b[kMaxSegs]; size_t bytes[kMaxSegs]; int n = 0;
+    void add(const void* plane, void* packed, size_t nbytes) { a[n] = (const char*)plane; b[n] = (char*)packed; bytes[n] = nbytes; n++; }
+};
+// pack: plane -> packed buffer; unpack: packed buffer -> plane
+int copy_segments(const SegList& l, bool pack) {
+    if (l.n == 0) return 0;
+    bool wide = true;
+    for (int k = 0; k < l.n; k++) wide = wide && l.bytes[k] % 16 == 0 && ((size_t)l.a[k] % 16 == 0) && ((size_t)l.b[k] % 16 == 0);
+    const unsigned unit = wide ? 16u : 4u;
+    CopyTable t; t.n = l.n; t.start[0] = 0;
+    for (int k = 0; k < l.n; k++) {
+        t.src[k] = pack ? l.a[k] : l.b[k];
+        t.dst[k] = pack ? l.b[k] : const_cast<char*>(l.a[k]);
+        t.start[k + 1] = t.start[k] + (unsigned)(l.bytes[k] / unit);
+    }
+    const unsigned total = t.start[t.n];
+    if (total == 0) return 0;
+    if (wide) hipLaunchKernelGGL(k_copy_segments<uint4>, dim3((total + 255) / 256), dim3(256), 0, rs_stream(), t);
+    else hipLaunchKernelGGL(k_copy_segments<unsigned>, dim3((total + 255) / 256), dim3(256), 0, rs_stream(), t);
+    return rs_check_hip(hipGetLastError(), "strip border rows");
+}
+// the border rows of one edge in the packed layout of rs_restir_halo_pack followed by rs_gbuffer_rows_pack: li, wi, tap, id, normal, depth
+void halo_segments(SegList& l, rs_restir* r, rs_gbuffer* g, int y, int rows, char* packed) {
+    const size_t n = (size_t)r->width * rows, off = (size_t)y * r->width;
+    const int c = g->cur();
+    l.add(r->temp.li + off, packed, n * 16); l.add(r->temp.wi + off, packed + n * 16, n * 16); l.add(r->temp.tap + off, packed + n * 32, n * 16);
+    char* gb = packed + n * 48;
+    l.add(g->primId[c] + off, gb, n * 4); l.add(g->normal[c] + off * 3, gb + n * 4, n * 12); l.add(g->depth[c] + off, gb + n * 16, n * 4);
+}
 
 // One grouped exchange, ordered after everything enqueued on the library stream so far: on the driver's stream for a stream-ordered
 // transport (RCCL), from the host side of a finished library stream otherwise.  join() makes the library stream continue after it.
-int post(rs_strips* s, const Xfer* ops, size_t n) {
+int post(rs_strips* s, const Xfer* opsIn, size_t nIn) {
     const rs_comm* c = s->comm;
-    hipStream_t ts = s->commStream;
-    if (c->t.stream_ordered) { RS_HIP(hipEventRecord(s->packed, rs_stream())); RS_HIP(hipStreamWaitEvent(ts, s->packed, 0)); }
+    // transfers of a gather that was begun on the library stream travel in this group (one RCCL launch per frame instead of two)
+    std::vector<Xfer> merged;
+    const Xfer* ops = opsIn; size_t n = nIn;
+    if (!s->deferred.empty()) {
+        merged.assign(opsIn, opsIn + nIn);
+        merged.insert(merged.end(), s->deferred.begin(), s->deferred.end());
+        s->deferred.clear(); s->deferredSlots = 0;
+        ops = merged.data(); n = merged.size();
+    }
+    if (n == 0) return 0;
+    hipStream_t ts = s->commOnMain ? rs_stream() : s->commStream;
+    if (c->t.stream_ordered) { if (!s->commOnMain) { RS_HIP(hipEventRecord(s->packed, rs_stream())); RS_HIP(hipStreamWaitEvent(ts, s->packed, 0)); } }
     else RS_TRY(rs_synchronize());
     if (c->t.group_begin) RS_TRY(c->t.group_begin(c->t.ctx));
     // a group that was begun is always ended (an open ncclGroup would swallow every later call of this thread); the first error is reported
@@ -148,7 +214,7 @@ int exchange_image_rows(rs_strips* s, float* a, int ca, float* b, int cb, int ro
 int svgf_exchange_hook(void* ctx, float* a, int ca, float* b, int cb, int rows) { return exchange_image_rows((rs_strips*)ctx, a, ca, b, cb, rows); }
 
 int join(rs_strips* s, bool timed) {
-    if (s->comm->t.stream_ordered) {
+    if (s->comm->t.stream_ordered && !s->commOnMain) {
         RS_HIP(hipEventRecord(s->arrived, s->commStream));
         if (timed && s->timing) RS_HIP(hipEventRecord(s->waitFrom, rs_stream()));
         RS_HIP(hipStreamWaitEvent(rs_stream(), s->arrived, 0));
@@ -238,6 +304,8 @@ int rs_strips_destroy(rs_strips* s) {
     RS_SCOPE(s);
     if (!s) return 0;
     (void)rs_synchronize();
+    if (!s->deferred.empty()) (void)post(s, nullptr, 0);      // (every rank reaches this with the same deferred gathers)
+    (void)rs_synchronize();
     if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
     if (s->packed) (void)hipEventDestroy(s->packed);
     if (s->arrived) (void)hipEventDestroy(s->arrived);
@@ -274,8 +342,9 @@ int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs
     int e = 0;
     if (comm->rank > 0) { e = rs_dev_alloc(&s->sendUp, s->haloBytes); if (!e) e = rs_dev_alloc(&s->recvUp, s->haloBytes); }
     if (!e && comm->rank + 1 < comm->world) { e = rs_dev_alloc(&s->sendDown, s->haloBytes); if (!e) e = rs_dev_alloc(&s->recvDown, s->haloBytes); }
+    { const char* env = std::getenv("RS_STRIPS_COMM_STREAM"); s->commOnMain = !(env && env[0] == '1'); }
     if (!e && comm->world > 1) {
-        e = rs_check_hip(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
+        if (!s->commOnMain) e = rs_check_hip(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
         if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->packed, hipEventDisableTiming), "hipEventCreate");
         if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->arrived, hipEventDisableTiming), "hipEventCreate");
         for (hipEvent_t& ev : s->gathered) if (!e) e = rs_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
@@ -310,22 +379,33 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
         RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1));
         return rs_restir_end_frame(r);
     }
-    const size_t nr = rs_restir_halo_bytes(r, kHalo);
-    // pack the border rows (library stream)
-    if (up) { RS_TRY(rs_restir_halo_pack(r, y0, kHalo, s->sendUp)); RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, kHalo, s->sendUp + nr)); }
-    if (down) { RS_TRY(rs_restir_halo_pack(r, y1 - kHalo, kHalo, s->sendDown)); RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - kHalo, kHalo, s->sendDown + nr)); }
+    // pack the border rows (library stream): one launch for the six planes of both edges
+    RS_TRY(rs_gbuffer_join(g));
+    {
+        SegList l;
+        if (up) halo_segments(l, r, g, y0, kHalo, s->sendUp);
+        if (down) halo_segments(l, r, g, y1 - kHalo, kHalo, s->sendDown);
+        RS_TRY(copy_segments(l, true));
+    }
     // the transfers: after the packing copies
     Xfer ops[4]; size_t n = 0;
     if (up) { ops[n++] = { true, s->sendUp, s->haloBytes, c->rank - 1 }; ops[n++] = { false, s->recvUp, s->haloBytes, c->rank - 1 }; }
     if (down) { ops[n++] = { true, s->sendDown, s->haloBytes, c->rank + 1 }; ops[n++] = { false, s->recvDown, s->haloBytes, c->rank + 1 }; }
+    const bool timeMain = s->commOnMain && c->t.stream_ordered && s->timing;
+    if (timeMain) RS_HIP(hipEventRecord(s->waitFrom, rs_stream()));
     RS_TRY(post(s, ops, n));
+    if (timeMain) { RS_HIP(hipEventRecord(s->waitTo, rs_stream())); s->waitValid = true; }
     // interior rows (their taps stay inside the strip) while the border rows travel
     const int topEnd = up ? (y0 + kHalo < y1 ? y0 + kHalo : y1) : y0;
     const int botStart = down ? (y1 - kHalo > topEnd ? y1 - kHalo : topEnd) : y1;
     if (botStart > topEnd) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, topEnd, botStart));
     RS_TRY(join(s, true));
-    if (up) { RS_TRY(rs_restir_halo_unpack(r, y0 - kHalo, kHalo, s->recvUp)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - kHalo, kHalo, s->recvUp + nr)); }
-    if (down) { RS_TRY(rs_restir_halo_unpack(r, y1, kHalo, s->recvDown)); RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, kHalo, s->recvDown + nr)); }
+    {
+        SegList l;
+        if (up) halo_segments(l, r, g, y0 - kHalo, kHalo, s->recvUp);
+        if (down) halo_segments(l, r, g, y1, kHalo, s->recvDown);
+        RS_TRY(copy_segments(l, false));
+    }
     if (topEnd > y0) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, topEnd));
     if (y1 > botStart) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, botStart, y1));
     return rs_restir_end_frame(r);
@@ -492,6 +572,14 @@ int rs_strips_gather_begin(rs_strips* s, void* devImage, size_t bytesPerPixel, i
         if (root < 0 || root == k) ops.push_back({ true, base + (size_t)s->y0 * row, (size_t)(s->y1 - s->y0) * row, k });
         if (root < 0 || root == c->rank) ops.push_back({ false, base + (size_t)s->bounds[(size_t)k] * row, (size_t)(s->bounds[(size_t)k + 1] - s->bounds[(size_t)k]) * row, k });
     }
+    if (s->commOnMain && c->t.stream_ordered) {
+        // on the library stream a gather is in order with everything else anyway: its transfers wait for the next group (the next
+        // frame's border rows), or for rs_strips_gather_end if that comes first
+        s->deferred.insert(s->deferred.end(), ops.begin(), ops.end());
+        s->deferredSlots |= 1 << slot;
+        s->gatherPending[slot] = true;
+        return 0;
+    }
     RS_TRY(post(s, ops.data(), ops.size()));
     if (c->t.stream_ordered) RS_HIP(hipEventRecord(s->gathered[slot], s->commStream));
     s->gatherPending[slot] = true;
@@ -502,6 +590,10 @@ int rs_strips_gather_end(rs_strips* s, int slot) {
     if (!s || slot < 0 || slot >= rs_strips::kGatherSlots) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_gather_end: bad argument");
     if (!s->gatherPending[slot]) return 0;
     s->gatherPending[slot] = false;
+    if (s->commOnMain && s->comm->t.stream_ordered) {
+        if (s->deferredSlots & (1 << slot)) RS_TRY(post(s, nullptr, 0));      // nothing has carried them yet: a group of their own
+        return 0;                                                               // (in order on the library stream: nothing to wait for)
+    }
     if (s->comm->t.stream_ordered) RS_HIP(hipStreamWaitEvent(rs_stream(), s->gathered[slot], 0));
     return 0;
 }

@@ -1000,7 +1000,9 @@ def test_multi_process_strips_on_one_gpu():
     assert r.stdout.count("strips == full frame: True") == 10, r.stdout[-2000:]
     # ... of which four lines are the C-ABI strip driver (rs_comm / rs_strips with gloo under its transport callbacks: static and
     # orbiting camera, the EAW filter, the image assembled by rs_strips_gather), also compared with tiling.py's strips on every rank
-    assert r.stdout.count("C-ABI strip driver") == 4 and r.stdout.count("== tiling.py on every rank: True") == 4, r.stdout[-2000:]
+    assert r.stdout.count("C-ABI strip driver") == 7 and r.stdout.count("== tiling.py on every rank: True") == 4, r.stdout[-2000:]
+    # ... and three SpatioTemporalFilter on the strips (static / orbiting camera, synchronous / overlapped launches)
+    assert r.stdout.count("gathered strips == full-frame filter over 5 frames: True") == 3, r.stdout[-2000:]
 
 
 def test_scene_without_extent_renders_without_the_shadow_tree(hip):

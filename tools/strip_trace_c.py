@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""tools/strip_trace_c.py [WORLD RANK] -- one strip of an N-way split through the C-ABI strip driver (rs_strips_frame, tone map,
+rs_strips_gather_begin / _end) with a stream-ordered no-op transport, 80 frames, to be run under the profiler with the interpreter
+after `--`:   rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/strip_trace_c.py 8 3
+tools/strip_trace_report.py condenses the trace (per queue the busy time per frame, per kernel the mean duration)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from restir_amd import capi, scenes
+
+W, H = 1920, 1080
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+capi.init(0)
+sd = scenes.sponza_class(seed=1, scale=1.0)
+scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
+cam = capi.camera_update(sd.camera(W, H))
+capi.set_sync(False)
+comm = capi.Comm(rank, world, lambda p, n, peer: None, lambda p, n, peer: None, None, None, stream_ordered=True)
+drv = capi.Strips(comm, W, H)
+gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
+image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
+pbos = [torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+y0, y1 = drv.y0, drv.y1
+for n in range(80):
+    k = n % 2
+    drv.frame(restir, scene, cam, gbuf, image.data_ptr(), 0, n, 3)
+    gbuf.update(cam)
+    drv.gather_end(k)
+    capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * W * 4, image.data_ptr() + y0 * W * 12, W, y1 - y0, 2, 1.0)
+    drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)
+capi.synchronize(); torch.cuda.synchronize()
