@@ -507,7 +507,7 @@ def main():
                        "strip_driver": {"c": "librestir_hip rs_strips_frame / rs_strips_gather_begin,_end (restir_amd/csrc/strips.hip)",
                                         "py": "restir_amd/tiling.py over torch.distributed (%s)" % backend_name, "none": "none (single GPU: rs_gbuffer_render + rs_restir_direct)"}[driver],
                        "transport": ("none" if driver == "none" else "torch.distributed " + backend_name if driver == "py" else
-                                     "RCCL ncclSend / ncclRecv groups on the driver's stream (rs_comm_create_rccl_lib), ncclComm_t made by ncclCommInitRank from " + str(rccl.path)
+                                     "RCCL ncclSend / ncclRecv groups on the library stream, one group per frame (rs_comm_create_rccl_lib), ncclComm_t made by ncclCommInitRank from " + str(rccl.path)
                                      if transport == "rccl" else "host callbacks over torch.distributed gloo (rehearsal, not RCCL)"),
                        "rccl_ranks": (world if (driver == "c" and transport == "rccl") else (world if (driver == "py" and backend_name == "nccl" and world > 1) else 0)),
                        "strip_rows_per_rank": [b - a for a, b in bounds],

@@ -501,6 +501,12 @@ int  rs_eaw_get_params(const rs_eaw* f, float* sigLumin, float* sigNormal, float
  * filter call at 1080p) or gather them from memory like the levels of step 8 and 16 (0).  Same arithmetic in the same order: the
  * results are identical bit for bit (tests/test_gpu_parity.py test_eaw_tiled_levels_equal_plain_gathers). */
 int  rs_eaw_set_tiled(rs_eaw* f, int tiled);
+/* The arithmetic of a tap (waveletFilter's loop body, src/denoiser.cu:98-128).  0: every operation rounded separately in the reference's
+ * order, as a host build of the reference without contraction computes it.  1: fused multiply-adds for the three squared distances, for
+ * the exponent -(dc.dc / sigLumin + dn.dn / sigNormal + dp.dp / sigDepth) * log2(e) as one chain over coefficients -log2(e) / sigma, and
+ * for sum += colour * w -- what a contracting compiler (nvcc's default) is free to produce; 36 vector instructions per tap for 50.  The
+ * results agree to a few ulp (all sums are of non-negative terms); both stay inside the filter's stated rtol 1e-5 against the oracle. */
+int  rs_eaw_set_fused(rs_eaw* f, int fused);
 /* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
  * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
 int  rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const rs_gbuffer* g, const rs_camera* cam);
@@ -519,6 +525,10 @@ int  rs_svgf_set_params(rs_svgf* f, float sigLumin, float sigNormal, float sigDe
 int  rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, float* sigDepth, int* level);
 /* 1 (default): the a-trous levels read their taps from an LDS tile (the reference's default sigmas only); 0: plain gathers.  Same bits. */
 int  rs_svgf_set_tiled(rs_svgf* f, int tiled);
+/* The arithmetic of a tap, as rs_eaw_set_fused: fused dot products and accumulation, one multiplication per exponent (the colour
+ * weight's -log2(e) / denominator and the luminance staged once per pixel).  Acts with the reference's defaults sigNormal 128 and a
+ * power-of-two sigDepth; other sigmas keep the separately rounded operations.  Stated tolerance against the oracle as before: rtol 3e-5. */
+int  rs_svgf_set_fused(rs_svgf* f, int fused);
 /* SpatioTemporalFilter::filter (src/denoiser.cu:532-564): temporal accumulation (alpha .2), variance estimate, five
  * variance-guided a-trous levels.  *devColorOut is the reference's `glm::vec3*& devColorOut`: it is swapped with the
  * filter's buffers (the level-0 result becomes the history), so the caller continues with the pointer it gets back

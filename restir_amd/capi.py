@@ -118,7 +118,7 @@ EXPORTS = [
     "rs_restir_enable_timing", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_save_image_jpg", "rs_write_png", "rs_write_jpg", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_debug_sqrt_of_unit_floats_mismatches", "rs_debug_div_sigma_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
-    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_svgf_set_params", "rs_svgf_get_params", "rs_svgf_set_tiled", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
+    "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_eaw_set_fused", "rs_svgf_set_params", "rs_svgf_get_params", "rs_svgf_set_tiled", "rs_svgf_set_fused", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
     "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create_rccl_lib", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_svgf_filter", "rs_strips_exchange_svgf_history", "rs_strips_exchange_history", "rs_strips_gather", "rs_strips_gather_begin", "rs_strips_gather_end", "rs_strips_enable_timing", "rs_strips_halo_wait_ms",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
@@ -199,6 +199,7 @@ def lib():
     L.rs_write_png.argtypes = [C.c_char_p, vp, ci, ci]
     L.rs_write_jpg.argtypes = [C.c_char_p, vp, ci, ci]
     L.rs_svgf_set_tiled.argtypes = [vp, ci]
+    L.rs_svgf_set_fused.argtypes = [vp, ci]
     L.rs_save_image_jpg.argtypes = [C.c_char_p, vp, ci, ci, ci]
     L.rs_debug_sqrt_of_uniform_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
     L.rs_debug_sqrt_of_unit_floats_mismatches.argtypes = [C.POINTER(C.c_ulonglong)]
@@ -253,6 +254,7 @@ def lib():
     for name in ("rs_eaw_get_params", "rs_svgf_get_params"):
         getattr(L, name).argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(ci)]
     L.rs_eaw_set_tiled.argtypes = [vp, ci]
+    L.rs_eaw_set_fused.argtypes = [vp, ci]
     L.rs_eaw_destroy.argtypes = [vp]
     L.rs_eaw_filter.argtypes = [vp, C.POINTER(vp), vp, vp, C.POINTER(Camera)]
     L.rs_eaw_positions_rows.argtypes = [vp, vp, C.POINTER(Camera), ci, ci]
@@ -880,6 +882,10 @@ class EAWFilter:
         """Levels of step 1, 2, 4 from an LDS tile (default) or as plain gathers; same bits."""
         check(lib().rs_eaw_set_tiled(self.handle, int(bool(tiled))))
 
+    def set_fused(self, fused):
+        """Taps in fused arithmetic (1) or every operation rounded separately in the reference's order (0, default)."""
+        check(lib().rs_eaw_set_fused(self.handle, int(bool(fused))))
+
     def get_params(self):
         a, b, c, lv = C.c_float(), C.c_float(), C.c_float(), C.c_int()
         check(lib().rs_eaw_get_params(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(lv)))
@@ -926,6 +932,10 @@ class SVGFFilter:
     def set_tiled(self, tiled):
         """a-trous levels from the LDS tile (True, default) or as plain gathers (False): same bits."""
         check(lib().rs_svgf_set_tiled(self.handle, 1 if tiled else 0))
+
+    def set_fused(self, fused):
+        """Taps in fused arithmetic (True) or every operation rounded separately in the reference's order (False)."""
+        check(lib().rs_svgf_set_fused(self.handle, 1 if fused else 0))
 
     def next_frame(self):
         check(lib().rs_svgf_next_frame(self.handle))

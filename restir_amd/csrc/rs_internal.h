@@ -322,6 +322,7 @@ struct rs_eaw {
     float* devTempImg = nullptr;
     float* devPos = nullptr;        // per-pixel cam.getPosition(x,y,depth), computed once per filter call
     bool tiled = true;              // levels of step 1, 2, 4 from an LDS tile (k_wavelet_tiled); rs_eaw_set_tiled, RS_EAW_TILED=0
+    bool fused = true;              // taps in fused arithmetic (denoiser.hip kFusedTaps); rs_eaw_set_fused
 };
 
 // SpatioTemporalFilter (src/denoiser.h:45-70); EAWaveletFilter(width, height, 4, 128, 1) (src/denoiser.cu:488)
@@ -339,6 +340,7 @@ struct rs_svgf {
     bool firstTime = true;
     int frameIdx = 0;
     bool tiled = true;                        // the a-trous levels from the row-phase LDS tile (k_svgf_wavelet_tiled); rs_svgf_set_tiled
+    bool fused = true;                        // taps in fused arithmetic (denoiser.hip svgf_tap_weight FUSED); rs_svgf_set_fused
 };
 
 // SpatioTemporalFilter on the rows of a strip (denoiser.hip): `exchange` swaps the first / last `rows` rows of the strip's part of

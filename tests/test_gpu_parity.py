@@ -540,7 +540,11 @@ def test_copy_debug_image_to_pbo(hip, kind):
     assert diff.max() <= 1 and np.mean(diff > 0) <= 1e-4
 
 
-def test_eaw_filter(hip):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused taps (default)", "separately rounded taps"])
+def test_eaw_filter(hip, fused):
+    """LeveledEAWFilter against the oracle, stated tolerance rtol 1e-5 (the exponential is the hardware's 2^t): with the taps in fused
+    arithmetic (rs_eaw_set_fused, the default) and with every operation rounded separately in the reference's order -- measured
+    7.4e-7 and 7.1e-7 from the oracle (tools/ab_eaw_fused.py)."""
     import torch
     sd = get_scene("sponza:0.03")
     W, H = 160, 96
@@ -553,6 +557,7 @@ def test_eaw_filter(hip):
     a = o.image
     ref = ob.eaw_filter(o.gbuf, o.cam, a)
     f = hip.EAWFilter(W, H, 5)
+    f.set_fused(fused)
     out = torch.zeros_like(h.image)
     p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
     hip.synchronize()
@@ -561,6 +566,7 @@ def test_eaw_filter(hip):
     got = res.cpu().numpy()
     f.destroy()
     assert np.allclose(ref, got, rtol=1e-5, atol=1e-6), float(np.abs(ref - got).max())
+    assert float((np.abs(ref - got) / np.maximum(np.abs(ref), 1e-6)).max()) < 3e-6          # what the arithmetic actually delivers
     assert np.abs(ref - a).max() > 1e-3               # the filter did something
 
 
@@ -575,7 +581,8 @@ def test_eaw_filter_with_edited_sigmas(hip):
     o.frame(3); h.frame(3)
     f = hip.EAWFilter(W, H, 5)
     assert f.get_params() == (64.0, np.float32(0.2), 1.0, 5)
-    for sig in ((3.7, 0.35, 0.6), (8.0, 0.25, 2.0)):
+    for sig, fused in (((3.7, 0.35, 0.6), False), ((8.0, 0.25, 2.0), False), ((3.7, 0.35, 0.6), True)):
+        f.set_fused(fused)
         f.set_params(*sig, level=3)                      # the level is stored, the filter still runs five (src/denoiser.cu:463-477)
         assert f.get_params()[3] == 3
         out = torch.zeros_like(h.image)
@@ -601,7 +608,8 @@ def test_eaw_division_by_sigma_is_exact(hip, sigma):
     assert bad.value == 0, (sigma, bad.value)
 
 
-def test_eaw_tiled_levels_equal_plain_gathers(hip):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused taps (default)", "separately rounded taps"])
+def test_eaw_tiled_levels_equal_plain_gathers(hip, fused):
     """The levels of step 1, 2 and 4 read their taps from an LDS tile (k_wavelet_tiled); the claim is the plain kernel's arithmetic in
     the same order, so the filtered image must be the plain form's BIT FOR BIT -- checked directly, not through the oracle's rtol:
     the default sigmas and two edited sets (other division / multiplication instantiations), a frame size that is no multiple of
@@ -613,6 +621,7 @@ def test_eaw_tiled_levels_equal_plain_gathers(hip):
     h.frame(3); h.frame(3)
     h.gbuf.render(h.scene, h.cam)                        # the planes the filter reads are this frame's
     f = hip.EAWFilter(W, H, 5)
+    f.set_fused(fused)
 
     def filtered(tiled):
         f.set_tiled(tiled)
@@ -664,6 +673,43 @@ def test_eaw_tiled_levels_equal_plain_gathers(hip):
     f.destroy()
 
 
+def test_fused_taps_stay_within_ulps_of_the_separately_rounded_ones(hip):
+    """rs_eaw_set_fused / rs_svgf_set_fused change roundings, not the filter: on the same input the two forms of LeveledEAWFilter agree
+    to 5e-6 relative after five levels, those of SpatioTemporalFilter to 2e-5 after five frames of accumulated history."""
+    import torch
+    sd = get_scene("sponza:0.03")
+    W, H = 157, 83
+    h = HipRenderer(hip, sd, W, H)
+    h.frame(3); h.frame(3)
+    h.gbuf.render(h.scene, h.cam)
+
+    def grab(ptr, count):
+        t = torch.empty(count, dtype=torch.float32, device="cuda")
+        hip.hip_memcpy_d2d(t.data_ptr(), ptr, count * 4)
+        return t.cpu().numpy()
+
+    outs = []
+    for fused in (True, False):
+        f = hip.EAWFilter(W, H, 5)
+        f.set_fused(fused)
+        out = torch.zeros_like(h.image)
+        outs.append(grab(f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam), W * H * 3))
+        f.destroy()
+    assert not bits_equal(outs[0], outs[1])                   # the switch acts
+    assert float((np.abs(outs[0] - outs[1]) / np.maximum(np.abs(outs[1]), 1e-6)).max()) < 5e-6
+    filters = [hip.SVGFFilter(W, H, 5), hip.SVGFFilter(W, H, 5)]
+    filters[0].set_fused(True); filters[1].set_fused(False)
+    for frame in range(5):
+        res = []
+        for f in filters:
+            res.append(grab(f.filter(h.image.data_ptr(), h.gbuf, h.cam), W * H * 3))
+            f.next_frame()
+        assert float((np.abs(res[0] - res[1]) / np.maximum(np.abs(res[1]), 1e-6)).max()) < 2e-5, frame
+    assert not bits_equal(res[0], res[1])
+    for f in filters:
+        f.destroy()
+
+
 def test_eaw_row_strip_form_equals_filter(hip):
     """rs_eaw_positions_rows + rs_eaw_level_rows (the form the strip tiling drives, restir_amd/tiling.py eaw_filter) over the
     whole frame, in bands, give the image of rs_eaw_filter bit for bit."""
@@ -691,7 +737,8 @@ def test_eaw_row_strip_form_equals_filter(hip):
     f.destroy()
 
 
-def test_svgf_filter(hip):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused taps (default)", "separately rounded taps"])
+def test_svgf_filter(hip, fused):
     """SpatioTemporalFilter (denoiser.cu:136-216,250-371,479-568) on an orbiting camera: temporal accumulation through
     devMotion, spatial then (from the fifth frame on) temporal variance, five variance-guided a-trous levels, and
     the pointer hand-over of filter(); filtered image and filter state against the oracle every frame."""
@@ -703,6 +750,7 @@ def test_svgf_filter(hip):
     h = HipRenderer(hip, sd, W, H)
     fo = ob.SVGF(W, H)
     fh = hip.SVGFFilter(W, H, 5)
+    fh.set_fused(fused)
 
     def grab(ptr, count):
         t = torch.empty(count, dtype=torch.float32, device="cuda")
@@ -733,7 +781,8 @@ def test_svgf_filter(hip):
     fh.destroy()
 
 
-def test_svgf_tiled_levels_equal_plain_gathers(hip):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused taps (default)", "separately rounded taps"])
+def test_svgf_tiled_levels_equal_plain_gathers(hip, fused):
     """SpatioTemporalFilter's variance-guided a-trous levels from the row-phase LDS tile (k_svgf_wavelet_tiled) against the plain
     gathers: the same arithmetic in the same order, so filtered image, variance and history must agree BIT FOR BIT over several
     frames of a moving camera, on a frame size that is no multiple of the tile."""
@@ -744,6 +793,8 @@ def test_svgf_tiled_levels_equal_plain_gathers(hip):
     h = HipRenderer(hip, sd, W, H)
     filters = [hip.SVGFFilter(W, H, 5), hip.SVGFFilter(W, H, 5)]
     filters[1].set_tiled(False)
+    for f in filters:
+        f.set_fused(fused)
 
     def grab(ptr, count):
         t = torch.empty(count, dtype=torch.float32, device="cuda")
