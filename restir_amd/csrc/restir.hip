@@ -188,7 +188,7 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
         f4 r = rng.uniform4();
         LightSample c = sample_light_nv<ENV, AliasPtr, LightPtr>(s, alias, lights, s.numLights, pos, r);
         f3 g = c.Li * eval_bsdf(m.type, baseColor, m.metallic, m.roughness, norm, wo, c.wi) * sat_dot(norm, c.wi);
-        float weight = luminance(g / c.pdf);
+        float weight = luminance(div3_exact(g, c.pdf, c.pdf <= 0.f));             // pdf <= 0: the weight is replaced by 0 below
         if (is_nan_or_inf(weight) || c.pdf <= 0.f) weight = 0.f;
         float u = rng.uniform();
         wsum += weight;                                    // Reservoir::update (restir.h:38-44)

@@ -25,6 +25,7 @@
 #pragma once
 
 #include "rs_math.h"
+#include "rs_exact.h"
 #include "../../include/restir_hip.h"
 
 namespace rs {
@@ -1097,13 +1098,28 @@ __device__ inline bool trace_occluded(const DevScene& s, f3 x, f3 y) {
 #endif  // __HIPCC__
 
 // ---- materials (src/material.h:34-124,171-186,218-228) -----------------------------------------
-RS_HD float schlick_g(float c, float alpha) { float a = alpha * .5f; return c / (c * (1.f - a) + a); }
+// x / d, 1 / sqrt(x): on the device the short forms of rs_exact.h (the same IEEE results, fewer instructions for operands in [2^-60, 2^60))
+RS_HD float bsdf_div(float x, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return div_exact(x, d);
+#else
+    return x / d;
+#endif
+}
+RS_HD f3 bsdf_normalize(f3 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return v * rcp_exact(sqrt_exact(dot(v, v)));
+#else
+    return normalize(v);
+#endif
+}
+RS_HD float schlick_g(float c, float alpha) { float a = alpha * .5f; return bsdf_div(c, c * (1.f - a) + a); }
 RS_HD float gtr2(float c, float alpha) {
     if (c < 1e-6f) return 0.f;
     float aa = alpha * alpha;
     float den = c * c * (aa - 1.f) + 1.f;
     den = den * den * kPi;
-    return aa / den;
+    return bsdf_div(aa, den);
 }
 
 RS_HD f3 eval_bsdf(int type, f3 baseColor, float metallic, float roughness, f3 n, f3 wo, f3 wi) {
@@ -1112,7 +1128,7 @@ RS_HD f3 eval_bsdf(int type, f3 baseColor, float metallic, float roughness, f3 n
     }
     if (type == 1) {                                   // metallicWorkflowBSDF
         float alpha = roughness * roughness;
-        f3 h = normalize(wo + wi);
+        f3 h = bsdf_normalize(wo + wi);
         float cosO = dot(n, wo);
         float cosI = dot(n, wi);
         if (cosI * cosO < 1e-7f) return splat(0.f);
@@ -1121,7 +1137,7 @@ RS_HD f3 eval_bsdf(int type, f3 baseColor, float metallic, float roughness, f3 n
         float g = schlick_g(gabs(cosO), alpha) * schlick_g(gabs(cosI), alpha);
         float d = gtr2(dot(n, h), alpha);
         f3 diffuse = ((baseColor * 1.f) / kPi) * (1.f - metallic);
-        return mix(diffuse, splat(g * d / (4.f * cosI * cosO)), f);
+        return mix(diffuse, splat(bsdf_div(g * d, 4.f * cosI * cosO)), f);
     }
     return splat(0.f);                                 // Dielectric, Disney, Light
 }

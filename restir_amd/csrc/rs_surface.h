@@ -194,11 +194,11 @@ __device__ __forceinline__ LightSample sample_light_nv(const DevScene& s, AliasP
     f3 toS = sampled - pos;
     if (dot(nrm, toS) > -1e-6f) return o;          // SCENE_LIGHT_SINGLE_SIDED
     float dd = dot(toS, toS);
-    float len = sqrtf(dd);
+    float len = sqrt_exact(dd);                    // rs_exact.h: the IEEE results, fewer instructions for operands in [2^-60, 2^60)
     o.Li = mk3(d.x, d.y, d.z);
-    o.wi = toS * (1.f / len);
+    o.wi = toS * rcp_exact(len);
     o.dist = len;
-    o.pdf = d.w * dd / gabs(-dot(nrm, o.wi));
+    o.pdf = div_exact(d.w * dd, gabs(-dot(nrm, o.wi)));
     return o;
 }
 
@@ -211,9 +211,9 @@ __device__ __forceinline__ void light_sample_again(LightPtr lights, int id, floa
     const f3 v0 = mk3(a.x, a.y, a.z), v1 = mk3(b.x, b.y, b.z), v2 = mk3(c.x, c.y, c.z);
     const f3 sampled = v1 * u + v2 * v + v0 * (1.f - u - v);
     const f3 toS = sampled - pos;
-    const float len = sqrtf(dot(toS, toS));
+    const float len = sqrt_exact(dot(toS, toS));
     Li = mk3(d.x, d.y, d.z);
-    wi = toS * (1.f / len);
+    wi = toS * rcp_exact(len);
     dist = len;
 }
 
