@@ -356,9 +356,10 @@ int  rs_debug_div_sigma_mismatches(float sigma, unsigned long long* mismatches);
 /* The same for every value the Sobol sampler can return: 0 and all floats in [2^-32, 1] (2^28 + 2 of them). */
 int  rs_debug_sqrt_of_unit_floats_mismatches(unsigned long long* mismatches);
 /* Test hook for restir_amd/csrc/rs_exact.h (the short forms of 1 / d, x / d and sqrt(x) the kernels use for operands in [2^-60, 2^60)),
- * each compared with the compiler's correctly rounded operator.  op 0: the reciprocal of EVERY float in the range; op 1: the square root
+ * each compared with the compiler's correctly rounded operator.  op 0: the reciprocal of EVERY float in the range and of its negative; op 1: the square root
  * of every float in the range; op 2: the quotient x / d for the denominators 1.s * 2^expD, s in [firstSig, firstSig + countSig) (at most
- * 65 536 per call), each against ALL 2^23 numerators 1.t * 2^expX.  out3[0] = results that differ (must be 0), out3[1] = operands
+ * 65 536 per call), each against ALL 2^23 numerators 1.t * 2^expX; op 3 / 4 / 5: the same with negative numerators / a negative denominator /
+ * both.  out3[0] = results that differ (must be 0), out3[1] = operands
  * (pairs) compared, out3[2] reserved.  tools/verify_exact_division.py walks op 2 over all 2^23 denominators: every pair of significands. */
 int  rs_debug_exact_ops_mismatches(int op, unsigned firstSig, unsigned countSig, int expX, int expD, unsigned long long* out3);
 

@@ -17,7 +17,7 @@ __device__ __forceinline__ void tally(unsigned long long* out, unsigned long lon
     }
 }
 
-// op 0: 1 / d for every float d in [2^-60, 2^60)
+// op 0: 1 / d for every float d with |d| in [2^-60, 2^60)
 // op 1: sqrt(x) for every float x in [2^-60, 2^60)
 __global__ void __launch_bounds__(256) k_check_unary(int op, unsigned long long* out) {
     unsigned long long bad = 0, n = 0, badExcluded = 0;
@@ -25,7 +25,11 @@ __global__ void __launch_bounds__(256) k_check_unary(int op, unsigned long long*
     for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < span; k += (unsigned long long)gridDim.x * blockDim.x) {
         const unsigned bits = kExactLo + (unsigned)k;
         const float v = __uint_as_float(bits);
-        if (op == 0) { n++; bad += __float_as_uint(rcp_refined(v)) == __float_as_uint(1.f / v) ? 0 : 1; }
+        if (op == 0) {
+            n += 2;
+            bad += __float_as_uint(rcp_refined(v)) == __float_as_uint(1.f / v) ? 0 : 1;
+            bad += __float_as_uint(rcp_refined(-v)) == __float_as_uint(1.f / -v) ? 0 : 1;
+        }
         else { n++; bad += __float_as_uint(sqrt_refined(v)) == __float_as_uint(sqrtf(v)) ? 0 : 1; }
     }
     tally(out, bad, n, badExcluded);
@@ -33,12 +37,13 @@ __global__ void __launch_bounds__(256) k_check_unary(int op, unsigned long long*
 
 // op 2: x / d for d = 1.sd * 2^expD over the significands sd in [firstSig, firstSig + gridDim.x) -- one per block -- and x = 1.sx * 2^expX
 // over ALL 2^23 significands sx
-__global__ void __launch_bounds__(256) k_check_division(unsigned firstSig, int expX, int expD, unsigned long long* out) {
+// signs: bit 0 = negative numerators, bit 1 = negative denominator
+__global__ void __launch_bounds__(256) k_check_division(unsigned firstSig, int expX, int expD, int signs, unsigned long long* out) {
     const unsigned sd = firstSig + blockIdx.x;
-    const unsigned bd = ((unsigned)(127 + expD) << 23) | sd;
+    const unsigned bd = ((unsigned)(127 + expD) << 23) | sd | ((signs & 2) ? 0x80000000u : 0u);
     const float d = __uint_as_float(bd);
     const float y = rcp_refined(d);
-    const unsigned ex = (unsigned)(127 + expX) << 23;
+    const unsigned ex = ((unsigned)(127 + expX) << 23) | ((signs & 1) ? 0x80000000u : 0u);
     unsigned long long bad = 0, n = 0;
     for (unsigned sx = threadIdx.x; sx < (1u << 23); sx += 256) {
         const float x = __uint_as_float(ex | sx);
@@ -54,14 +59,14 @@ extern "C" {
 
 int rs_debug_exact_ops_mismatches(int op, unsigned firstSig, unsigned countSig, int expX, int expD, unsigned long long* out3) {
     rs_ctx_scope scope(nullptr);
-    if (!out3 || op < 0 || op > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_exact_ops_mismatches: bad argument");
-    if (op == 2 && (countSig == 0 || countSig > (1u << 16) || firstSig >= (1u << 23) || firstSig + countSig > (1u << 23) ||
+    if (!out3 || op < 0 || op > 5) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_exact_ops_mismatches: bad argument");
+    if (op >= 2 && (countSig == 0 || countSig > (1u << 16) || firstSig >= (1u << 23) || firstSig + countSig > (1u << 23) ||
                     expX < -60 || expX > 59 || expD < -60 || expD > 59))
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_debug_exact_ops_mismatches: significands beyond 2^23, more than 65536 per call, or an exponent outside [-60, 59]");
     unsigned long long* d = nullptr;
     RS_TRY(rs_dev_alloc(&d, 3));
     RS_HIP(hipMemsetAsync(d, 0, 24, rs_stream()));
-    if (op == 2) hipLaunchKernelGGL(k_check_division, dim3(countSig), dim3(256), 0, rs_stream(), firstSig, expX, expD, d);
+    if (op >= 2) hipLaunchKernelGGL(k_check_division, dim3(countSig), dim3(256), 0, rs_stream(), firstSig, expX, expD, op - 2, d);
     else hipLaunchKernelGGL(k_check_unary, dim3(8192), dim3(256), 0, rs_stream(), op, d);
     int err = rs_after_launch("rs_debug_exact_ops_mismatches");
     if (!err) err = rs_check_hip(hipStreamSynchronize(rs_stream()), "rs_debug_exact_ops_mismatches: synchronize");

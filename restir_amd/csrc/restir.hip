@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, in
     const f3 target = pos + wi * cl.w;
     f3 dir = target - pos;
     float dist = length(dir);
-    dir = dir / dist;
+    dir = div3_exact_signed(dir, dist);
     Ray ray; ray.o = pos + dir * 1e-5f; ray.d = dir;
     dist -= 1e-4f * 2.f;
     RayBoxCtx ctx = make_box_ctx(ray);

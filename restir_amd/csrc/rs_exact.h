@@ -19,9 +19,10 @@
 //     without its range scaling and class test; every float of the range agrees.
 // The guards are wave-uniform (__all): one scalar branch, no exec-mask region; a wave with one operand outside the range takes the
 // compiler's operator for all its lanes.  Zero, negative numbers, infinity and NaN are outside the range by construction of the test.
-#pragma once
-
-#include "rs_math.h"
+#ifndef RS_MATH_H_BODY
+#include "rs_math.h"        // which includes this file once its vector type and operators are defined (normalize / length use the forms below)
+#elif !defined(RS_EXACT_H_BODY)
+#define RS_EXACT_H_BODY
 
 namespace rs {
 
@@ -49,6 +50,10 @@ __device__ __forceinline__ float div_by_rcp(float x, float d, float y) {
     return __builtin_fmaf(rem, y, q0);
 }
 
+// the same range for |x|: the forms are sign-symmetric (round-to-nearest is, and so is the hardware's estimate: the reciprocal check runs
+// over the negative floats of the range as well)
+__device__ __forceinline__ bool exact_range_abs(unsigned bits) { return (bits & 0x7FFFFFFFu) - kExactLo < kExactHi - kExactLo; }
+
 // 1.f / d
 __device__ __forceinline__ float rcp_exact(float d) {
     const unsigned b = __float_as_uint(d);
@@ -75,6 +80,21 @@ __device__ __forceinline__ f3 div3_exact(f3 g, float d, bool unused = false) {
     return g / d;
 }
 
+// the same for operands of either sign: 1 / d per component of a direction, g / d of a difference vector
+__device__ __forceinline__ f3 rcp3_exact_signed(f3 d) {
+    if (RS_EXACT_GUARD(exact_range_abs(__float_as_uint(d.x)) && exact_range_abs(__float_as_uint(d.y)) && exact_range_abs(__float_as_uint(d.z))))
+        return mk3(rcp_refined(d.x), rcp_refined(d.y), rcp_refined(d.z));
+    return mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+}
+__device__ __forceinline__ f3 div3_exact_signed(f3 g, float d) {
+    if (RS_EXACT_GUARD(exact_range_abs(__float_as_uint(g.x)) && exact_range_abs(__float_as_uint(g.y)) && exact_range_abs(__float_as_uint(g.z)) &&
+                       exact_range_abs(__float_as_uint(d)))) {
+        const float y = rcp_refined(d);
+        return mk3(div_by_rcp(g.x, d, y), div_by_rcp(g.y, d, y), div_by_rcp(g.z, d, y));
+    }
+    return g / d;
+}
+
 __device__ __forceinline__ float sqrt_refined(float x) {
     const float s = __builtin_amdgcn_sqrtf(x);
     const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
@@ -90,3 +110,5 @@ __device__ __forceinline__ float sqrt_exact(float x) {
 }
 
 }  // namespace rs
+
+#endif  // RS_MATH_H_BODY / RS_EXACT_H_BODY

@@ -50,8 +50,17 @@ RS_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RS_HD f3 cross(f3 a, f3 b) {
     return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
+}  // namespace rs
+#define RS_MATH_H_BODY
+#include "rs_exact.h"          // device: sqrt_exact / rcp_exact -- the IEEE results, fewer instructions for operands in [2^-60, 2^60)
+namespace rs {
+#if defined(__HIP_DEVICE_COMPILE__)
+RS_HD float rsqrt_glm(float x) { return rcp_exact(sqrt_exact(x)); }     // glm::inversesqrt = 1 / sqrt(x)
+RS_HD float length(f3 v) { return sqrt_exact(dot(v, v)); }
+#else
 RS_HD float rsqrt_glm(float x) { return 1.f / sqrtf(x); }            // glm::inversesqrt
 RS_HD float length(f3 v) { return sqrtf(dot(v, v)); }
+#endif
 RS_HD f3 normalize(f3 v) { return v * rsqrt_glm(dot(v, v)); }
 RS_HD f3 mix(f3 x, f3 y, float a) { return x + (y - x) * a; }          // x + a*(y-x)
 RS_HD f3 mix(f3 x, f3 y, f3 a) { return x + a * (y - x); }

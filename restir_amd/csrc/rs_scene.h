@@ -181,7 +181,11 @@ RS_HD RayBoxCtx make_box_ctx(const Ray& r) {
     const float Eps = 1e-6f;
     RayBoxCtx c;
     c.o = r.o; c.d = r.d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    c.dinv = rcp3_exact_signed(r.d);
+#else
     c.dinv = mk3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+#endif
     c.mode = gabs(r.d.x) > 1.f - Eps ? 1 : (gabs(r.d.y) > 1.f - Eps ? 2 : (gabs(r.d.z) > 1.f - Eps ? 3 : 0));
     c.zx = gabs(r.d.x) < Eps; c.zy = gabs(r.d.y) < Eps; c.zz = gabs(r.d.z) < Eps;
     c.cull = true;
@@ -1080,7 +1084,7 @@ __device__ inline Hit trace_closest_wave(const DevScene& s, const Ray& ray, bool
 __device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool active) {
     f3 dir = y - x;
     float dist = length(dir);
-    dir = dir / dist;
+    dir = div3_exact_signed(dir, dist);
     Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
     dist -= 1e-4f * 2.f;
     return walk_dispatch_paired<true>(s, ray, dist, active).any;
@@ -1090,7 +1094,7 @@ __device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool a
 __device__ inline bool trace_occluded(const DevScene& s, f3 x, f3 y) {
     f3 dir = y - x;
     float dist = length(dir);
-    dir = dir / dist;
+    dir = div3_exact_signed(dir, dist);
     Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
     dist -= 1e-4f * 2.f;
     return walk_dispatch<true>(s, ray, dist).any;

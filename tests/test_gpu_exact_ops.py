@@ -18,7 +18,7 @@ def run(hip, op, first=0, count=1, ex=0, ed=0):
 
 def test_reciprocal_of_every_float_in_range(hip):
     bad, n, _ = run(hip, 0)
-    assert n == 0x5D800000 - 0x21800000 and bad == 0          # including the all-ones significands, the refinement's textbook exception
+    assert n == 2 * (0x5D800000 - 0x21800000) and bad == 0    # both signs; including the all-ones significands, the refinement's textbook exception
 
 
 def test_square_root_of_every_float_in_range(hip):
@@ -38,6 +38,13 @@ def test_quotient_over_all_numerators(hip, ex, ed):
         total_bad += bad; total_n += n
         assert bad == 0, (first, count, bad)
     assert total_n >= 2 ** 23 * 2000
+
+
+@pytest.mark.parametrize("op", [3, 4, 5], ids=["-x / d", "x / -d", "-x / -d"])
+def test_quotient_of_negative_operands(hip, op):
+    for first in (0, (1 << 23) - 256, 1234567, 4194304):
+        bad, n, _ = run(hip, op, first, 256, 3, -5)
+        assert bad == 0 and n == 256 << 23
 
 
 def test_the_guarded_functions_fall_back_outside_the_range(hip):
