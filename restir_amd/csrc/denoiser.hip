@@ -766,12 +766,13 @@ int rs_svgf_filter_rows(rs_svgf* f, float** devColorOut, const float* devColorIn
         // the reference's defaults (sigNormal 128, sigDepth 1) from the LDS tile; edited sigmas keep the plain gathers
         if (f->tiled && f->sigNormal == 128.f && depthPow2 && lv <= 4) {
             const dim3 gridT((W + kTileW - 1) / kTileW, ((y1 - y0 + kTileH * step - 1) / (kTileH * step)) * step);
-#define RS_SVGF_TILED(S) if (f->fused) hipLaunchKernelGGL((k_svgf_wavelet_tiled<S, 7, true, true>), gridT, dim3(kTileThreads), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
-                                            f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, y0, y1); \
-                         else hipLaunchKernelGGL((k_svgf_wavelet_tiled<S, 7, true>), gridT, dim3(kTileThreads), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
-                                            f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, y0, y1)
+#define RS_SVGF_TILED_ARGS gridT, dim3(kTileThreads), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance, \
+                           f->devFilteredVariance, gv.primId, gv.normal, f->devPos, W, H, f->sigDepth, f->sigNormal, f->sigLumin, y0, y1
+#define RS_SVGF_TILED(S) do { if (f->fused) hipLaunchKernelGGL((k_svgf_wavelet_tiled<S, 7, true, true>), RS_SVGF_TILED_ARGS); \
+                              else hipLaunchKernelGGL((k_svgf_wavelet_tiled<S, 7, true>), RS_SVGF_TILED_ARGS); } while (0)
             if (lv == 0) RS_SVGF_TILED(1); else if (lv == 1) RS_SVGF_TILED(2); else if (lv == 2) RS_SVGF_TILED(4); else if (lv == 3) RS_SVGF_TILED(8); else RS_SVGF_TILED(16);
 #undef RS_SVGF_TILED
+#undef RS_SVGF_TILED_ARGS
         }
         else if (f->sigNormal == 128.f && depthPow2 && f->fused)
             hipLaunchKernelGGL((k_svgf_wavelet<7, true, true>), grid_rows(y0, y1), dim3(256), 0, rs_stream(), out, in, f->devTempVariance, f->devVariance,
