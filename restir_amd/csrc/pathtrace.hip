@@ -28,32 +28,46 @@ __global__ void __launch_bounds__(256, RS_PT_BLOCKS) k_pt_direct(DevScene s, Cam
     f4 r = rng.uniform4();
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
     Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
+    // The shadow ray of sampleDirectLight (scene.h:427-459) is walked by the WHOLE wave through the shadow tree (trace_occluded_wave), as
+    // in gi.hip: the light sample first (sampleDirectLight tests occlusion towards the sampled point before it looks at the side or
+    // the pdf, so every sampling lane has a segment), then one cooperative walk, then the shading.
+    f3 direct = splat(0.f), norm = splat(0.f), wo = splat(0.f);
+    SurfMat m = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
+    LightSample c;
+    c.pdf = kInvalidPdf; c.Li = splat(0.f); c.wi = splat(0.f); c.dist = 0.f; c.point = h.pos; c.id = 0; c.bu = c.bv = 0.f;
+    bool nee = false;
     if (inside) {
-        f3 direct = splat(0.f);
         walks = 1;
         if (h.primId == kNullPrim) {
             if (TEX && s.envTex >= 0) direct = env_radiance(s, ray.d);          // pathtrace.cu:295-297
         }
         else {
-            f3 norm = h.norm;
-            const SurfMat m = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);    // pathtrace.cu:301
+            norm = h.norm;
+            m = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);    // pathtrace.cu:301
             if (m.type == 4) {
                 direct = m.baseColor;
             }
             else {
-                f3 wo = -ray.d;
+                wo = -ray.d;
                 const bool delta = m.type == 2;
                 if (!delta && dot(norm, wo) < 0.f) norm = -norm;
                 if (!delta) {
-                    f3 Li = splat(0.f), wi = splat(0.f);
-                    f4 rl = rng.uniform4();
-                    float pdf = (TEX && s.envTex >= 0) ? sample_light_visible<true>(s, h.pos, rl, Li, wi, walks)
-                                                       : sample_light_visible<false>(s, h.pos, rl, Li, wi, walks);
-                    if (pdf > 0.f)
-                        direct = ((Li * eval_bsdf(m.type, m.baseColor, m.metallic, m.roughness, norm, wo, wi)) * sat_dot(norm, wi)) / pdf;
+                    const f4 rl = rng.uniform4();
+                    nee = s.numLights > 0;
+                    if (nee) c = (TEX && s.envTex >= 0) ? sample_light_nv<true, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, h.pos, rl)
+                                                        : sample_light_nv<false, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, h.pos, rl);
                 }
             }
         }
+    }
+    const bool occluded = trace_occluded_wave(s, h.pos, c.point, nee);
+    if (nee) {
+        walks++;
+        const float pdf = occluded ? kInvalidPdf : c.pdf;
+        if (pdf > 0.f)
+            direct = ((c.Li * eval_bsdf(m.type, m.baseColor, m.metallic, m.roughness, norm, wo, c.wi)) * sat_dot(norm, c.wi)) / pdf;
+    }
+    if (inside) {
         float* o = directIllum + (size_t)index * 3;
         st3(o, (ld3(o) * (float)iter + direct) / (float)(iter + 1));
     }

@@ -217,18 +217,6 @@ __device__ __forceinline__ void light_sample_again(LightPtr lights, int id, floa
     dist = len;
 }
 
-// sampleDirectLight (src/scene.h:427-459): like the NoVisibility form, but with an occlusion test to
-// the sampled point before the single-sided test.
-// With an environment map the last sampler entry is sampleEnvironmentMap (:378-392): occlusion towards pos + wi * 1e6.
-template <bool ENV>
-__device__ inline float sample_light_visible(const DevScene& s, f3 pos, f4 r, f3& Li, f3& wi, int& walks) {
-    LightSample c = sample_light_nv<ENV, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
-    if (s.numLights == 0) return kInvalidPdf;
-    walks++;
-    if (trace_occluded(s, pos, c.point)) return kInvalidPdf;
-    Li = c.Li; wi = c.wi;
-    return c.pdf;
-}
 #endif  // __HIPCC__
 
 }  // namespace rs
