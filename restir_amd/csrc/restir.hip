@@ -159,7 +159,10 @@ __global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParam
 // pixel are five 64-address gathers per candidate, and the texture addresser was as busy (88 %) as the VALU.
 // Up to kRisLdsLights lights the whole table (72 B per light) is copied into LDS by a 1024-thread block --
 // two such blocks per CU keep 8 waves per SIMD -- and the gathers become ds_read_b128 / ds_read_b64.
-constexpr int kRisThreads = 1024;
+#ifndef RS_RIS_THREADS
+#define RS_RIS_THREADS 1024
+#endif
+constexpr int kRisThreads = RS_RIS_THREADS;
 constexpr int kRisLdsLights = 1024;
 constexpr int kRisAliasLdsLights = 16384;        // alias records only: 128 KB of the CU's 160 KB at most
 
