@@ -1145,6 +1145,20 @@ def test_strip_driver_binds_to_rccl():
     assert r.returncode == 0 and "strips_rccl_check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_strip_driver_ranks_as_threads_over_rccl():
+    """restir_amd/host/strips_rccl_ranks.cpp: N ranks as N host threads, thread k on GPU k with its own library context and its own
+    ncclComm_t, the per-frame calls of INTEGRATION.md, rank 0 comparing the gathered strips with its own full frame bit for bit (static and
+    orbiting camera, asynchronous launches).  Here N = 1 -- what one GPU can run (RCCL refuses two ranks on one device); on a multi-GPU node
+    the same binary without an argument uses every GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "restir_amd", "host", "strips_rccl_ranks")
+    if not os.path.exists(exe):
+        pytest.skip("restir_amd/host/strips_rccl_ranks is built only where RCCL's development files are installed (restir_amd/csrc/Makefile)")
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "strips_rccl_ranks ok (1 rank)" in r.stdout and r.stdout.count("== full frame over 4 frames: True") == 2, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_config4_4k_eight_strips_equal_full_frame(hip):
     """BASELINE config 4: the bench scene at 3840x2160 cut into 8 row strips with the 5-row reservoir halo -- the
     eight ranks are run one after the other on this GPU -- against the full-frame result, bit for bit."""
