@@ -10,12 +10,20 @@
 
 #include "rs_internal.h"
 
+#ifndef RS_WALK_WAVES
+#define RS_WALK_WAVES 8        // waves per SIMD the walk kernels are held to (A/B: -DRS_WALK_WAVES=4 -DRS_WALK_CAP)
+#endif
+#ifdef RS_WALK_CAP            // hold the kernels to exactly RS_WALK_WAVES waves per SIMD (more registers each, room for other kernels' waves)
+#define RS_WALK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RS_WALK_WAVES, RS_WALK_WAVES)))
+#else
+#define RS_WALK_WAVES_ATTR
+#endif
 using namespace rs;
 
 // TEX: the scene has texture maps or an environment map (getTexturedMaterialAndSurface, gbuffer.cu:38,59-62)
 // 8 blocks per CU: without the bound the kernel takes 100+ SGPRs and runs at 7 waves per SIMD (0.392 -> 0.370 ms at 1080p)
 template <bool TEX>
-__global__ void __launch_bounds__(256, 8) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
                                                         int y0, int y1, int tilesX) {
     // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

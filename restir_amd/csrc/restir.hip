@@ -26,6 +26,14 @@
 
 #include "rs_internal.h"
 
+#ifndef RS_WALK_WAVES
+#define RS_WALK_WAVES 8        // waves per SIMD the walk kernels are held to (A/B: -DRS_WALK_WAVES=4 -DRS_WALK_CAP)
+#endif
+#ifdef RS_WALK_CAP            // hold the kernels to exactly RS_WALK_WAVES waves per SIMD (more registers each, room for other kernels' waves)
+#define RS_WALK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RS_WALK_WAVES, RS_WALK_WAVES)))
+#else
+#define RS_WALK_WAVES_ATTR
+#endif
 using namespace rs;
 
 namespace {
@@ -98,7 +106,7 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
 }
 
 template <bool TEX, bool SOBOL>
-__global__ void __launch_bounds__(256, 8) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
@@ -130,7 +138,7 @@ constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of th
 // union: it paid both slab tests per visit and, after the round-2 walk, measured 1.29 ms per frame against 1.20 for two launches and
 // 1.193 for this form.)  Tiles are 8x4 from the G-buffer rows [gy0, gy1), blocks 32x4 pixels; the shading ray is active on rows [y0, y1).
 template <bool TEX, bool SOBOL>
-__global__ void __launch_bounds__(256, 8) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
                                                                   int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31;
     const bool shading = lane >= 32;                            // which of the pixel's two rays this lane carries
@@ -290,7 +298,7 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
 constexpr int kHandoffLanes = RS_HANDOFF_LANES, kHandoffPool = 4 * kHandoffLanes;
 struct __attribute__((aligned(16))) PooledRay { float ox, oy, oz, limit; float dx, dy, dz; unsigned cur; int q0, q1, q2, q3; int qn, index, pad0, pad1; };
 
-__global__ void __launch_bounds__(256, 8) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
     __shared__ PooledRay pool[kHandoffPool > 0 ? kHandoffPool : 1];
     __shared__ int poolCount;
     int x, y;
