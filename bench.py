@@ -29,7 +29,9 @@ One JSON line is printed by rank 0; besides the contract's fields it carries
   cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a
                 bounded sample of the same workload (rank 0, N = 1 only)
-  parity        the frames cpu_baseline rendered, rendered again by the GPU and compared bit for bit (differing_pixels, mean_l1)
+  parity        N = 1: the frames cpu_baseline rendered, rendered again by the GPU and compared bit for bit (differing_pixels, mean_l1);
+                N > 1: six frames through the strip driver from fresh reservoirs, gathered on rank 0 and compared bit for bit with rank 0's
+                own full-frame render of the same frames (`strips_parity` when BENCH_FORCE_STRIPS=1 sends N = 1 through the strip driver)
   cpu_config1   BASELINE config 1 (Cornell 256x256, 1 spp PTDirect) as a host loop on the same cores
 """
 import argparse
@@ -452,6 +454,39 @@ def main():
     backend.restir.enable_timing(False)
 
     finish_gathers()
+    # N > 1 (and BENCH_FORCE_STRIPS): the strips' image against a full frame.  Fresh reservoirs and G-buffers on every rank for the strip
+    # driver, a full-frame renderer of its own on rank 0, the same six frames (camera as in the timed region) through both; after every
+    # frame the ranks' rows of the radiance image are gathered on rank 0 (rs_strips_gather) and compared with the full frame's BIT FOR BIT.
+    strips_parity = None
+    if driver == "c":
+        capi.set_sync(True)
+        chk = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
+        ref = StripRenderer(HipBackend(capi, scene, cam, WIDTH, HEIGHT), 1, 0, HEIGHT) if rank == 0 else None
+        differing, l1_sum, frames_checked = 0, 0.0, 6
+        for f in range(frames_checked):
+            move_camera(f)
+            drv.frame(chk.restir, scene, cam, chk.gbuf, chk.image.data_ptr(), 0, f, REUSE)
+            chk.gbuf.update(cam)
+            if args.orbit and world > 1:
+                drv.exchange_history(chk.restir, chk.gbuf)
+            drv.gather(chk.image.data_ptr(), 12, 0)
+            if ref is not None:
+                ref.looper = f
+                ref.frame(REUSE, 0)
+                torch.cuda.synchronize()
+                a, b = chk.image.view(torch.int32), ref.b.image.view(torch.int32)
+                differing += int((a != b).any(dim=1).sum().item())
+                if os.environ.get("BENCH_PARITY_ROWS", "0") == "1":          # which rows differ (debugging a failed check)
+                    bad_rows = (a != b).any(dim=1).view(HEIGHT, WIDTH).any(dim=1).nonzero().flatten().tolist()
+                    print("bench.py: strips parity, frame %d: %d rows differ: %s (strip bounds %s)" % (f, len(bad_rows), bad_rows[:40], bounds), file=sys.stderr, flush=True)
+                l1_sum += float((chk.image - ref.b.image).abs().sum(dim=1).mean().item())
+        torch.cuda.synchronize()
+        capi.set_sync(False)
+        if world > 1:
+            dist.barrier()
+        strips_parity = {"frames": frames_checked, "pixels_per_frame": WIDTH * HEIGHT, "differing_pixels": differing, "mean_l1": l1_sum / frames_checked,
+                         "checker": "rank 0's own full-frame render of the same frames from fresh reservoirs (librestir_hip, which the N = 1 line pins to the "
+                                    "oracle), radiance of the gathered strips compared bit for bit"}
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device=ctl_device)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -534,6 +569,8 @@ def main():
         how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
         out["config"]["launch_choice"] = "%s (%s), chains on %d streams in turn" % (form, how, chains)
         out["config"]["calibration_frames_before_warmup"] = calibration_frames
+        if strips_parity is not None:
+            out["parity" if world > 1 else "strips_parity"] = strips_parity       # N = 1 through the strip driver keeps the oracle's `parity` below
         if world == 1 and args.cpu_frames > 0 and sobol_num is None:
             out["cpu_baseline"], oracle_images = cpu_baseline(sd, args.cpu_frames)
             out["parity"] = parity_against(capi, sd, scene, oracle_images)

@@ -628,6 +628,7 @@ def _hiprt():
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _hip.hipFree.argtypes = [C.c_void_p]
     return _hip
@@ -646,9 +647,15 @@ def hip_free(ptr):
 
 
 def hip_memcpy_d2d(dst, src, nbytes):
+    """Device-to-device copy that has finished when the call returns, ordered after everything the library has enqueued.  (hipMemcpy of
+    device memory goes through the null stream and need not block the host; a caller whose own work runs on a NON-BLOCKING stream -- torch's
+    torch.cuda.Stream() -- is not ordered with the null stream either, so the copy is waited for here.  bench.py's strips-against-full-frame
+    check found the missing wait: the gloo rehearsal transport read a staging buffer before this copy had written it.)"""
     _hiprt()
     synchronize()
     e = _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
+    if e == 0:
+        e = _hip.hipStreamSynchronize(None)
     if e != 0:
         raise RestirHipError(f"hipMemcpy failed: {e}")
 
