@@ -324,17 +324,20 @@ def main():
         # gather of frame f travels while frame f + 1 renders
         pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
 
-        def frame():
-            move_camera(state["looper"])
-            drv.frame(backend.restir, scene, cam, backend.gbuf, backend.image.data_ptr(), 0, state["looper"], REUSE)
-            backend.gbuf.update(cam)
+        def frame(bk=None, st=None, pb=None):
+            # (bk, st, pb: another set of render objects, frame counters and display buffers -- the parity check below runs this very
+            # function on fresh ones)
+            bk, st, pb = bk or backend, st or state, pb or pbos
+            move_camera(st["looper"])
+            drv.frame(bk.restir, scene, cam, bk.gbuf, bk.image.data_ptr(), 0, st["looper"], REUSE)
+            bk.gbuf.update(cam)
             if args.orbit and world > 1:
-                drv.exchange_history(backend.restir, backend.gbuf)
-            state["looper"] = state["looper"] + 1 if sobol_num is None else (state["looper"] + 1) % sobol_num
-            k = state["frame_no"] % 2; state["frame_no"] += 1
-            drv.gather_end(k)                                           # the gather that read pbos[k] two frames ago
-            capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * WIDTH * 4, backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
-            drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)
+                drv.exchange_history(bk.restir, bk.gbuf)
+            st["looper"] = st["looper"] + 1 if sobol_num is None else (st["looper"] + 1) % sobol_num
+            k = st["frame_no"] % 2; st["frame_no"] += 1
+            drv.gather_end(k)                                           # the gather that read pb[k] two frames ago
+            capi.copy_image_to_pbo(pb[k].data_ptr() + y0 * WIDTH * 4, bk.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+            drv.gather_begin(pb[k].data_ptr(), 4, 0, k)
 
         def finish_gathers():
             drv.gather_end(0); drv.gather_end(1)
@@ -454,39 +457,45 @@ def main():
     backend.restir.enable_timing(False)
 
     finish_gathers()
-    # N > 1 (and BENCH_FORCE_STRIPS): the strips' image against a full frame.  Fresh reservoirs and G-buffers on every rank for the strip
-    # driver, a full-frame renderer of its own on rank 0, the same six frames (camera as in the timed region) through both; after every
-    # frame the ranks' rows of the radiance image are gathered on rank 0 (rs_strips_gather) and compared with the full frame's BIT FOR BIT.
+    # N > 1 (and BENCH_FORCE_STRIPS): the strips' image against a full frame.  Fresh reservoirs, G-buffers and display buffers on every rank
+    # for the strip driver, a full-frame renderer of its own on rank 0, the same six frames through both -- the strips through the very
+    # frame() of the timed region, launches overlapped, the display image gathered behind the next frame.  After every frame the ranks' rows
+    # of the RADIANCE image are gathered on rank 0 as well (rs_strips_gather) and compared with the full frame's BIT FOR BIT; at the end the
+    # last two DISPLAY images (RGBA8, the asynchronous gathers) are compared with the full frame's tone-mapped ones byte for byte.
     strips_parity = None
     if driver == "c":
-        capi.set_sync(True)
         chk = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
+        chk_state = {"looper": 0, "frame_no": 0}
+        chk_pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
         ref = StripRenderer(HipBackend(capi, scene, cam, WIDTH, HEIGHT), 1, 0, HEIGHT) if rank == 0 else None
+        ref_pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if rank == 0 else None
         differing, l1_sum, frames_checked = 0, 0.0, 6
         for f in range(frames_checked):
-            move_camera(f)
-            drv.frame(chk.restir, scene, cam, chk.gbuf, chk.image.data_ptr(), 0, f, REUSE)
-            chk.gbuf.update(cam)
-            if args.orbit and world > 1:
-                drv.exchange_history(chk.restir, chk.gbuf)
+            frame(chk, chk_state, chk_pbos)
             drv.gather(chk.image.data_ptr(), 12, 0)
             if ref is not None:
                 ref.looper = f
                 ref.frame(REUSE, 0)
-                torch.cuda.synchronize()
+                capi.copy_image_to_pbo(ref_pbos[f % 2].data_ptr(), ref.b.image.data_ptr(), WIDTH, HEIGHT, TONEMAP, 1.0)
+                capi.synchronize(); torch.cuda.synchronize()
                 a, b = chk.image.view(torch.int32), ref.b.image.view(torch.int32)
                 differing += int((a != b).any(dim=1).sum().item())
+                l1_sum += float((chk.image - ref.b.image).abs().sum(dim=1).mean().item())
                 if os.environ.get("BENCH_PARITY_ROWS", "0") == "1":          # which rows differ (debugging a failed check)
                     bad_rows = (a != b).any(dim=1).view(HEIGHT, WIDTH).any(dim=1).nonzero().flatten().tolist()
                     print("bench.py: strips parity, frame %d: %d rows differ: %s (strip bounds %s)" % (f, len(bad_rows), bad_rows[:40], bounds), file=sys.stderr, flush=True)
-                l1_sum += float((chk.image - ref.b.image).abs().sum(dim=1).mean().item())
-        torch.cuda.synchronize()
-        capi.set_sync(False)
+        finish_gathers()
+        capi.synchronize(); torch.cuda.synchronize()
+        display_differing = None
+        if ref is not None:
+            display_differing = sum(int((chk_pbos[k] != ref_pbos[k]).any(dim=1).sum().item()) for k in range(2))
         if world > 1:
             dist.barrier()
         strips_parity = {"frames": frames_checked, "pixels_per_frame": WIDTH * HEIGHT, "differing_pixels": differing, "mean_l1": l1_sum / frames_checked,
+                         "display_frames": 2, "display_differing_pixels": display_differing,
                          "checker": "rank 0's own full-frame render of the same frames from fresh reservoirs (librestir_hip, which the N = 1 line pins to the "
-                                    "oracle), radiance of the gathered strips compared bit for bit"}
+                                    "oracle): radiance of the gathered strips bit for bit after every frame, the last two asynchronously gathered RGBA8 "
+                                    "display images byte for byte; launches overlapped as in the timed region"}
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device=ctl_device)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
