@@ -263,6 +263,13 @@ int  rs_bake_instance(const float* translation, const float* rotation, const flo
  * Outputs (device): primId[n], matId[n], pos[3n], norm[3n]. */
 int  rs_trace_closest(const rs_scene* scene, int n, const float* devRays,
                       int* devPrimId, int* devMatId, float* devPos, float* devNorm);
+/* The same query through the wave-level service the multi-bounce kernels use for their bounce rays (general-case rays walk the
+ * closest-hit tree of their threaded order, occlusion_bvh.cpp; same outputs, same bits). */
+int  rs_trace_closest_wave(const rs_scene* scene, int n, const float* devRays,
+                           int* devPrimId, int* devMatId, float* devPos, float* devNorm);
+/* on = 0: bounce rays walk the reference's own tree (src/scene.h:245-284 literally); 1: the closest-hit trees again (the default
+ * when the scene's tables allow them).  *was (may be NULL) receives the previous setting.  Results are identical either way. */
+int  rs_scene_set_ordered_tree(rs_scene* scene, int on, int* was);
 /* DevScene::testOcclusion (src/scene.h:286-316): n segments of 6 floats (x, y). */
 int  rs_trace_occlusion(const rs_scene* scene, int n, const float* devSegments, int* devOccluded);
 

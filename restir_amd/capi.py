@@ -110,7 +110,7 @@ class GBufferView(C.Structure):
 EXPORTS = [
     "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_stream_plan", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
-    "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_occlusion",
+    "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_closest_wave", "rs_scene_set_ordered_tree", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
@@ -169,6 +169,8 @@ def lib():
     L.rs_camera_update.argtypes = [C.POINTER(Camera)]
     L.rs_trace_closest.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.rs_trace_occlusion.argtypes = [vp, ci, vp, vp]
+    L.rs_trace_closest_wave.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    L.rs_scene_set_ordered_tree.argtypes = [vp, ci, vp]
     L.rs_gbuffer_create.argtypes = [ci, ci, C.POINTER(vp)]
     L.rs_gbuffer_destroy.argtypes = [vp]
     L.rs_gbuffer_render.argtypes = [vp, vp, C.POINTER(Camera)]
@@ -996,6 +998,24 @@ def trace_closest(scene, rays_t):
     pos = torch.empty((n, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((n, 3), dtype=torch.float32, device="cuda")
     check(lib().rs_trace_closest(scene.handle, n, rays_t.data_ptr(), prim.data_ptr(), mat.data_ptr(), pos.data_ptr(), nrm.data_ptr()))
     return prim, mat, pos, nrm
+
+
+def trace_closest_wave(scene, rays_t):
+    """As trace_closest, through the wave-level service of the multi-bounce kernels (rs_trace_closest_wave)."""
+    import torch
+    n = rays_t.shape[0]
+    prim = torch.empty(n, dtype=torch.int32, device="cuda"); mat = torch.empty(n, dtype=torch.int32, device="cuda")
+    pos = torch.empty((n, 3), dtype=torch.float32, device="cuda"); nrm = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    check(lib().rs_trace_closest_wave(scene.handle, n, rays_t.data_ptr(), prim.data_ptr(), mat.data_ptr(), pos.data_ptr(), nrm.data_ptr()))
+    return prim, mat, pos, nrm
+
+
+def set_ordered_tree(scene, on):
+    """rs_scene_set_ordered_tree; returns whether the closest-hit trees were in use before the call."""
+    import ctypes
+    was = ctypes.c_int(0)
+    check(lib().rs_scene_set_ordered_tree(scene.handle, 1 if on else 0, ctypes.byref(was)))
+    return bool(was.value)
 
 
 def trace_occlusion(scene, seg_t):

@@ -286,3 +286,82 @@ int rs_reference_chain_tables(int bvhSize, const int* order0 /* 3 ints per node 
     for (int p = 0; p < numPrims; p++) if (leafOfPrim[(size_t)p] < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_reference_chain_tables: primitive without a leaf");
     return 0;
 }
+
+// ---- closest-hit trees that keep the reference's visiting order ---------------------------------------------------------------
+// DevScene::intersect (src/scene.h:245-284) depends on the ORDER in which its threaded walk meets the triangles: a triangle is
+// accepted iff its leaf is entered (box test passes with tBox < closest AT THAT MOMENT) and it is hit closer than closest at
+// that moment -- ties and boxes whose entry distance exceeds their triangle's hit distance by rounding are settled by who comes
+// first.  A second tree can therefore only be exact if it presents the triangles in the same order.  Each threaded order k
+// (src/bvh.cpp:156-193) is the pre-order leaf sequence of one tree, and ANY binary tree whose leaves, read in walking order, are
+// that sequence visits the triangles in the reference's order.  Built here: over the leaf sequence of an order, every split
+// chosen by a surface-area sweep along the SEQUENCE (cumulative, where the reference's bucket sweep is not, src/bvh.cpp:92-100;
+// its tree costs 129 / 168 node visits per ray on the Sponza- / Bistro-class scene, this one 113 / 135 at half the bytes per
+// node, tools/models/ordered_tree_closest_hit.cpp), leaves of up to 4 consecutive triangles, boxes = exact unions of the
+// reference's leaf boxes (conservative for the relaxed slab test, see the top of this file).  The walk (rs_scene.h
+// walk_ordered_tree) then applies the reference's rule literally: enter a node iff tBox' < closest -- a skipped node has
+// tBox' >= closest and tBox' <= tLeaf of all its triangles, so the reference would not enter those leaves either -- and accept a
+// triangle hit closer than closest iff the reference's own test passes on its leaf box with tLeaf < closest and on every ancestor.
+// Orders 2a and 2a + 1 walk the same tree with the children swapped at EVERY inner node (src/bvh.cpp:186-190: the comparison is
+// xor-ed with `lesser`), so their leaf sequences are mirror images: one tree per axis, emitted in forward and in mirrored pre-order.
+// seq: the numPrims primitive ids in the order the even threaded order meets them.  Leaves: code = start * 8 + count with
+// `start` the index INTO seq of the triangle met first; the mirrored order meets a leaf's triangles at start, start - 1, ...
+int rs_build_ordered_bvh(int numPrims, const float* primBoxes, const int* seq, std::vector<BvhNode>& forward, std::vector<BvhNode>& mirrored) {
+    if (numPrims <= 0 || !primBoxes || !seq) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_build_ordered_bvh: bad argument");
+    struct Tmp { Bx box; int left, right, first, count; };
+    std::vector<Tmp> t;
+    t.reserve((size_t)numPrims);
+    struct Job { int node, first, count, depth; };
+    std::vector<Job> jobs;
+    std::vector<float> suffix((size_t)numPrims);
+    t.emplace_back(); jobs.push_back(Job{ 0, 0, numPrims, 0 });
+    while (!jobs.empty()) {
+        const Job j = jobs.back(); jobs.pop_back();
+        Bx box; box.reset();
+        for (int i = 0; i < j.count; i++) box.add(primBoxes + (size_t)seq[j.first + i] * 6), box.add(primBoxes + (size_t)seq[j.first + i] * 6 + 3);
+        int cut = -1;
+        if (j.count > 1) {
+            if (j.depth >= 64) cut = j.count / 2;        // any split of the sequence is a valid tree: a sequence that drives the sweep into a chain gets halves from here on
+            else {
+                Bx acc; acc.reset();
+                for (int i = j.count - 1; i > 0; i--) { const float* b = primBoxes + (size_t)seq[j.first + i] * 6; acc.add(b); acc.add(b + 3); suffix[(size_t)i] = acc.half_area(); }
+                acc.reset();
+                float best = FLT_MAX;
+                for (int i = 1; i < j.count; i++) {
+                    const float* b = primBoxes + (size_t)seq[j.first + i - 1] * 6; acc.add(b); acc.add(b + 3);
+                    const float c = acc.half_area() * (float)i + suffix[(size_t)i] * (float)(j.count - i);
+                    if (c < best) { best = c; cut = i; }
+                }
+                if (j.count <= kMaxLeaf && !(best * kCostTri + box.half_area() * 2.f * kCostBox < box.half_area() * (float)j.count * kCostTri)) cut = -1;
+                if (cut < 0 && j.count > kMaxLeaf) cut = j.count / 2;      // (areas that are not finite: never for boxes that passed build_occlusion_side)
+            }
+        }
+        Tmp& me = t[(size_t)j.node];
+        me.box = box; me.first = j.first; me.count = cut < 0 ? j.count : 0; me.left = me.right = -1;
+        if (cut >= 0) {
+            const int l = (int)t.size(), r = l + 1;
+            t[(size_t)j.node].left = l; t[(size_t)j.node].right = r;
+            t.emplace_back(); t.emplace_back();
+            jobs.push_back(Job{ r, j.first + cut, j.count - cut, j.depth + 1 });
+            jobs.push_back(Job{ l, j.first, cut, j.depth + 1 });
+        }
+    }
+    // the two pre-orders; next = the record after the subtree
+    std::vector<int> size(t.size(), 1);
+    for (size_t i = t.size(); i-- > 0;) if (t[i].left >= 0) size[i] = 1 + size[(size_t)t[i].left] + size[(size_t)t[i].right];     // children are created after their parent
+    for (int dir = 0; dir < 2; dir++) {
+        std::vector<BvhNode>& out = dir ? mirrored : forward;
+        out.clear(); out.reserve(t.size());
+        std::vector<int> stack; stack.push_back(0);
+        while (!stack.empty()) {
+            const int i = stack.back(); stack.pop_back();
+            const Tmp& n = t[(size_t)i];
+            BvhNode o;
+            o.bminx = n.box.lo[0]; o.bminy = n.box.lo[1]; o.bminz = n.box.lo[2]; o.bmaxx = n.box.hi[0]; o.bmaxy = n.box.hi[1]; o.bmaxz = n.box.hi[2];
+            o.primId = n.count ? (dir ? (n.first + n.count - 1) * 8 + n.count : n.first * 8 + n.count) : -1;
+            o.next = (int)out.size() + size[(size_t)i];
+            out.push_back(o);
+            if (n.left >= 0) { if (dir) { stack.push_back(n.left); stack.push_back(n.right); } else { stack.push_back(n.right); stack.push_back(n.left); } }
+        }
+    }
+    return 0;
+}

@@ -116,6 +116,8 @@ struct rs_scene {
     uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
+    uint4* dOrdNodes = nullptr;      // closest-hit trees in the reference's visiting orders (occlusion_bvh.cpp rs_build_ordered_bvh)
+    rs::TriRec* dOrdTris = nullptr;
     unsigned long long* dWalkStats = nullptr;   // -DRS_WALK_STATS builds only
     // host copies of the source arrays (rs_scene_host_desc)
     std::vector<float> hVertices, hNormals, hTexcoords, hBoxes, hLightRadiance, hLightProb;
@@ -358,4 +360,5 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam);
 int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<rs::BvhNode>& nodes, std::vector<int>& leafPrims);
 int rs_pair_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, const std::vector<unsigned>& packed, std::vector<unsigned>& out, int* count);
 int rs_quantize_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, float base[3], float scale[3], std::vector<unsigned>& out);
+int rs_build_ordered_bvh(int numPrims, const float* primBoxes, const int* seq, std::vector<rs::BvhNode>& forward, std::vector<rs::BvhNode>& mirrored);
 int rs_reference_chain_tables(int bvhSize, const int* order0, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims);

@@ -74,6 +74,12 @@ struct DevScene {
     bool axisCull;                // boxes contain their children and triangles (enables skip_far_on_axis)
     bool linksNested;             // in every threaded order the miss links nest: c in (a, link(a)) => link(c) <= link(a)
     int occCount;
+    // closest hit of incoherent rays: six trees in the reference's six visiting orders (occlusion_bvh.cpp rs_build_ordered_bvh), 16-byte
+    // records on the shadow tree's grid, order k at byte offset k * ordStride, its end record at (k + 1) * ordStride - 16;
+    // ordTris: per axis numPrims triangles in the even order's sequence (pad0 = reference leaf node, pad1 = primitive id).  Null = off.
+    const uint4*   ordNodes;
+    const TriRec*  ordTris;
+    unsigned ordStride;
     unsigned long long* walkStats;   // null unless built with -DRS_WALK_STATS (tools/walk_stats.py)
     const unsigned char* occDepth;   // depth of every occNodes record (-DRS_WALK_STATS builds only)
     int bvhSize;
@@ -740,6 +746,108 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     return walk_occlusion_tree_x<false, false>(s, ray, ctx, limit, active, st, 0, suspended);
 }
 
+// ---- closest hit of incoherent rays through the trees that keep the reference's order ---------------------------------------
+// DevScene::intersect (src/scene.h:245-284) accepts a triangle iff its leaf is entered -- the reference's box test passes on the
+// leaf (and, before it, on every ancestor) with tBox < closest AT THAT MOMENT -- and intersectTriangle hits closer than closest at
+// that moment: the result depends on the order in which the walk meets the triangles.  The tree walked here (occlusion_bvh.cpp
+// rs_build_ordered_bvh; one per threaded order) meets them in the reference's order through better boxes on the shadow tree's
+// grid, and the rule is applied literally:
+//   * a node is entered iff the relaxed test passes with tBox' < closest.  tBox' <= tLeaf of every triangle below (conservative
+//     boxes, occlusion_bvh.cpp), so a skipped node holds only leaves the reference would not enter at this `closest` or any later one;
+//   * a triangle hit closer than `closest` is a candidate; it is accepted iff the reference's own test passes along the path to
+//     its leaf with tLeaf < closest (the chain check of the shadow rays, leaf shortcut included) -- exactly when the reference
+//     reaches it.  Boxes are nested (occNested is a precondition), so tLeaf bounds the ancestors' entry distances.
+// Leaves are queued and tested in wave-wide rounds as in walk_occlusion_tree, but FIRST IN, FIRST OUT and one candidate at a
+// time, so that a lane's triangles are judged in the reference's order with the reference's `closest`; a walk that runs ahead of
+// its queue only uses a staler (larger) `closest`, i.e. enters more, never less.  Same primitive, same barycentrics, same bits as
+// walk<false, ...>; tested against it and against the oracle on the full scenes.
+// Only for general-case rays that start within the grid's reach (as the shadow walk); every lane of the wave must call it.
+__device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, bool active) {
+    WalkResult r;
+    r.closest = 3.402823466e+38f; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f; r.any = false;
+    const char* nodes = reinterpret_cast<const char*>(s.ordNodes);
+    const unsigned k = active ? (unsigned)mtbvh_order(-ray.d) : 0u;
+    const unsigned endOff = (k + 1u) * s.ordStride - 16u;
+    const TriRec* tris = s.ordTris + (size_t)(k >> 1) * (size_t)s.numPrims;
+    const int triStep = (k & 1u) ? -1 : 1;
+    // slab distance of grid plane q: q * A + B; a lane without a ray rests on the end record with distances that fail whatever the record is
+    const f3 A = active ? mk3(s.occScale.x * ctx.dinv.x, s.occScale.y * ctx.dinv.y, s.occScale.z * ctx.dinv.z) : splat(0.f);
+    const f3 B = active ? mk3((s.occBase.x - ctx.o.x) * ctx.dinv.x, (s.occBase.y - ctx.o.y) * ctx.dinv.y, (s.occBase.z - ctx.o.z) * ctx.dinv.z) : splat(-1.f);
+    const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
+                                    fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
+                              fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
+    unsigned cur = active ? k * s.ordStride : endOff;
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // FIFO of queued leaf codes, q0 the oldest
+    const unsigned selX = A.x < 0.f ? 0x01000706u : 0x07060100u;      // near / far plane of an axis by a per-ray byte permute (walk_occlusion_tree)
+    const unsigned selY = A.y < 0.f ? 0x03020504u : 0x05040302u;
+    const unsigned selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;
+    const vf2 Axy = { A.x, A.y }, Bxy = { B.x, B.y }, Azz = { A.z, A.z }, Bzz = { B.z, B.z };
+    for (;;) {
+        for (;;) {          // walk phase: until some lane's queue is full or every walk has ended
+            if (!__ballot(cur != endOff)) break;
+            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+            const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
+            const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
+            const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
+            const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
+            const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
+            const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
+            const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < r.closest);
+            const int meta = (int)n.w;
+            const bool leaf = meta < 0;
+            const bool push = pass && leaf;
+            const int code = ~meta;
+            q0 = (push && qn == 0) ? code : q0; q1 = (push && qn == 1) ? code : q1; q2 = (push && qn == 2) ? code : q2; q3 = (push && qn == 3) ? code : q3;
+            qn = push ? qn + 1 : qn;
+            cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
+            if (__any(qn == kLeafQueue)) break;
+        }
+        if (!__any(qn > 0)) break;
+        // leaf round: every lane takes its OLDEST queued leaf and judges its triangles one after the other
+        int tri = 0, cnt = 0, verify = -1;
+        if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
+        float cd = 0.f, cbx = 0.f, cby = 0.f; int cprim = kNullPrim;
+        for (;;) {
+            while (__any((cnt > 0) & (verify < 0))) {
+                if ((cnt > 0) & (verify < 0)) {
+                    const float4* p = reinterpret_cast<const float4*>(tris + tri);
+                    const float4 a = p[0], b = p[1], c = p[2];
+                    float bx, by, dist;
+                    tri += triStep; cnt--;
+                    if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < r.closest) {
+                        cd = dist; cbx = bx; cby = by; cprim = __float_as_int(b.w);
+                        verify = __float_as_int(a.w) | 0x40000000;          // reference leaf of the candidate, bit 30 = first step
+                    }
+                }
+            }
+            if (!__any(verify >= 0)) break;
+            while (__any(verify >= 0)) {
+                if (verify >= 0) {
+                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
+                    float4 lo, hi;
+                    node_unpack(rec[0], rec[1], lo, hi);
+                    const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
+                    const float t2x = (hi.x - ctx.o.x) * ctx.dinv.x, t2y = (hi.y - ctx.o.y) * ctx.dinv.y, t2z = (hi.z - ctx.o.z) * ctx.dinv.z;
+                    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
+                    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
+                    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+                    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
+                    const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
+                    const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < r.closest);
+                    // the leaf shortcut of walk_occlusion_tree: a leaf that clears the overlap conditions by 2^-18 * tRoot settles its whole path
+                    const bool first = (verify & 0x40000000) != 0;
+                    const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
+                    const int parent = __float_as_int(lo.w);
+                    const bool done = open & ((parent < 0) | (first & clear));
+                    if (done) { r.closest = cd; r.bx = cbx; r.by = cby; r.prim = cprim; }
+                    verify = (open & !done) ? parent : -1;          // closed: the reference never reaches the triangle
+                }
+            }
+        }
+    }
+    return r;
+}
+
 // all 64 lanes of the wave must call this
 template <bool ANYHIT>
 __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active) {
@@ -757,6 +865,15 @@ __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, co
         else
             r.any = __any(special) ? walk_anyhit_deferred<false>(s, ray, ctx, limit, active)
                                    : walk_anyhit_deferred<true>(s, ray, ctx, limit, active);
+        return r;
+    }
+    if (s.ordNodes) {                      // closest hit (limit = FLT_MAX) through the tree of the ray's order; the rare other rays walk the reference's
+        const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
+        WalkResult r = walk_ordered_tree(s, ray, ctx, active && !slow);
+        if (__any(slow)) {
+            const WalkResult r2 = walk_paired<false, false>(s, ray, ctx, limit, slow);
+            if (slow) r = r2;
+        }
         return r;
     }
     if (__any(special)) return walk_paired<ANYHIT, false>(s, ray, ctx, limit, active);

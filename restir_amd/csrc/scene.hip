@@ -127,6 +127,76 @@ int build_occlusion_side(rs_scene* s) {
     return 0;
 }
 
+// The closest-hit trees of the incoherent rays (occlusion_bvh.cpp rs_build_ordered_bvh, rs_scene.h walk_ordered_tree): per axis
+// one tree over the leaf sequence of the even threaded order, emitted in forward and mirrored pre-order -> six arrays of 16-byte
+// grid-box records like the shadow tree's, laid out at a common stride in ONE allocation so that a lane addresses its order by
+// k * stride; links are absolute byte offsets; the last slot of every stride is the self-linked empty record a finished walk
+// rests on, and the slots between a shorter tree's end and that record are empty inner records linked to it.  Needs the shadow
+// side (grid, chain records) and a proper hierarchy; any table whose odd orders are not the mirror images of the even ones
+// (never one from rs_build_bvh) leaves the path off, and those rays walk the reference's tree.
+int build_ordered_side(rs_scene* s) {
+    if (!s->dev.occNodes || !s->dev.occNested || !s->dev.linksNested) return 0;
+    if (std::getenv("RS_NO_ORDERED_TREE")) return 0;            // A/B switch for measurements
+    const size_t np = (size_t)s->numPrims, nn = (size_t)s->bvhSize;
+    std::vector<int> seq[3];
+    for (int a = 0; a < 3; a++) {
+        seq[a].reserve(np);
+        for (size_t i = 0; i < nn; i++) if (s->hNodes[2 * a][i * 3] >= 0) seq[a].push_back(s->hNodes[2 * a][i * 3]);
+        if (seq[a].size() != np) return 0;
+        size_t j = np;
+        for (size_t i = 0; i < nn; i++) { const int p = s->hNodes[2 * a + 1][i * 3]; if (p >= 0) { if (j == 0 || seq[a][--j] != p) return 0; } }
+        if (j != 0) return 0;
+    }
+    std::vector<float> primBoxes(np * 6);
+    for (size_t p = 0; p < np; p++) std::memcpy(&primBoxes[p * 6], &s->hBoxes[(size_t)s->hLeafOf[p] * 6], 6 * sizeof(float));
+    std::vector<unsigned> packed[6];
+    size_t maxCount = 0;
+    for (int a = 0; a < 3; a++) {
+        std::vector<BvhNode> tree[2];
+        if (int e = rs_build_ordered_bvh(s->numPrims, primBoxes.data(), seq[a].data(), tree[0], tree[1])) return e == RS_ERR_UNSUPPORTED ? 0 : e;
+        for (int m = 0; m < 2; m++) {
+            float base[3], scale[3];
+            if (int e = rs_quantize_occlusion_bvh(tree[m], base, scale, packed[2 * a + m])) return e == RS_ERR_UNSUPPORTED ? 0 : e;
+            // every tree's root box is the union of all leaf boxes, so all of them share the shadow tree's grid
+            if (std::memcmp(base, &s->dev.occBase, 12) != 0 || std::memcmp(scale, &s->dev.occScale, 12) != 0) return 0;
+            maxCount = std::max(maxCount, tree[m].size());
+        }
+    }
+    const size_t stride = (maxCount + 1) * 16;
+    if (stride * 6 >= 0x7fffffffull) return 0;                  // links are signed 32-bit byte offsets (the sign marks a leaf)
+    std::vector<unsigned> all(stride * 6 / 4);
+    for (int k = 0; k < 6; k++) {
+        const size_t count = packed[k].size() / 4, first = (size_t)k * stride, endOff = first + maxCount * 16;
+        unsigned* o = &all[first / 4];
+        std::memcpy(o, packed[k].data(), count * 16);
+        for (size_t i = 0; i < count; i++) {
+            unsigned& w = o[i * 4 + 3];
+            if ((int)w >= 0) w = (w == count * 16) ? (unsigned)endOff : (unsigned)(first + w);       // inner: miss link, relative -> absolute
+        }
+        for (size_t i = count; i <= maxCount; i++) { o[i * 4] = 0xffffffffu; o[i * 4 + 1] = 0x0000ffffu; o[i * 4 + 2] = 0u; o[i * 4 + 3] = (unsigned)endOff; }
+    }
+    // triangles in the even orders' sequence: pad0 = reference leaf node (the chain check starts there), pad1 = primitive id
+    std::vector<TriRec> rec(np * 3);
+    for (int a = 0; a < 3; a++)
+        for (size_t i = 0; i < np; i++) {
+            const size_t p = (size_t)seq[a][i];
+            const float* t = &s->hVertices[p * 9];
+            f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+            f3 e1 = v1 - v0, e2 = v2 - v0;
+            float leafBits, primBits;
+            const int prim = (int)p;
+            std::memcpy(&leafBits, &s->hLeafOf[p], 4); std::memcpy(&primBits, &prim, 4);
+            rec[(size_t)a * np + i] = TriRec{ v0.x, v0.y, v0.z, leafBits, e1.x, e1.y, e1.z, primBits, e2.x, e2.y, e2.z, 0.f };
+        }
+    RS_TRY(rs_dev_alloc(&s->dOrdNodes, all.size() / 4));
+    RS_HIP(hipMemcpy(s->dOrdNodes, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    RS_TRY(upload(&s->dOrdTris, rec));
+    s->dev.ordNodes = s->dOrdNodes;
+    s->dev.ordTris = s->dOrdTris;
+    s->dev.ordStride = (unsigned)stride;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int rs_scene_destroy(rs_scene* s) {
@@ -134,7 +204,7 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
     (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
     (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
-    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris); rs_dev_free(s->dOrdNodes); rs_dev_free(s->dOrdTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords); rs_dev_free(s->dSampleSeq);
@@ -348,6 +418,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.occBase = splat(0.f); s->dev.occScale = splat(0.f);
     s->dev.walkStats = nullptr; s->dev.occDepth = nullptr;
     s->dev.occNested = false; s->dev.occRootLo = splat(0.f); s->dev.occRootHi = splat(0.f);
+    s->dev.ordNodes = nullptr; s->dev.ordTris = nullptr; s->dev.ordStride = 0;
     // Is the box table a proper hierarchy (finite, min <= max, every box inside its parent's, every leaf box
     // around its triangle)?  Tables from rs_build_bvh are; the two shortcuts that rely on it (skip_far_on_axis and
     // the leaf shortcut of the shadow tree) are switched off for any other caller-supplied table.
@@ -392,6 +463,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.walkStats = s->dWalkStats;
 #endif
     if (int e = build_occlusion_side(s)) { rs_scene_destroy(s); return e; }
+    if (int e = build_ordered_side(s)) { rs_scene_destroy(s); return e; }
     *out = s;
     return 0;
 }
@@ -506,6 +578,42 @@ __global__ void __launch_bounds__(256) k_trace_occlusion(DevScene s, int n, cons
     const size_t j = active ? (size_t)i : 0;
     const bool o = trace_occluded_wave(s, ld3(seg + j * 6), ld3(seg + j * 6 + 3), active);
     if (active) occ[i] = o ? 1 : 0;
+}
+
+// the wave-level service the multi-bounce kernels use for their bounce rays (gi.hip): every lane of the wave takes part
+__global__ void __launch_bounds__(256) k_trace_closest_wave(DevScene s, int n, const float* __restrict__ rays,
+                                                            int* __restrict__ primId, int* __restrict__ matId,
+                                                            float* __restrict__ pos, float* __restrict__ norm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const size_t j = active ? (size_t)i : 0;
+    Ray r; r.o = ld3(rays + j * 6); r.d = ld3(rays + j * 6 + 3);
+    const Hit h = trace_closest_wave(s, r, active);
+    if (!active) return;
+    primId[i] = h.primId;
+    matId[i] = h.primId != kNullPrim ? h.matId : -1;
+    st3(pos + (size_t)i * 3, h.pos);
+    st3(norm + (size_t)i * 3, h.norm);
+}
+
+extern "C" int rs_trace_closest_wave(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {
+    RS_SCOPE(s);
+    if (!s || n < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_trace_closest_wave: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_trace_closest_wave, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), s->dev, n, devRays, devPrimId, devMatId, devPos, devNorm);
+    return rs_after_launch("rs_trace_closest_wave");
+}
+
+// 1: bounce rays take the closest-hit trees in the reference's visiting orders (the default when they could be built), 0: the
+// reference's own tree (A/B and parity tests).  Returns through *was (may be null) whether they were in use.
+extern "C" int rs_scene_set_ordered_tree(rs_scene* s, int on, int* was) {
+    RS_SCOPE(s);
+    if (!s) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_scene_set_ordered_tree: null scene");
+    if (was) *was = s->dev.ordNodes ? 1 : 0;
+    (void)rs_gbuffer_release_scene(s);
+    RS_TRY(rs_synchronize());                           // kernels in flight carry the previous DevScene by value; nothing to wait for but keep the order simple
+    s->dev.ordNodes = (on && s->dOrdNodes) ? s->dOrdNodes : nullptr;
+    return 0;
 }
 
 extern "C" int rs_trace_closest(const rs_scene* s, int n, const float* devRays, int* devPrimId, int* devMatId, float* devPos, float* devNorm) {

@@ -8,7 +8,7 @@ from restir_amd import capi, scenes
 
 W, H, DEPTH = 1920, 1080, 4
 capi.init(0)
-sd = scenes.sponza_class(seed=1, scale=1.0)
+sd = scenes.bistro_class(seed=2, scale=1.0) if "--bistro" in sys.argv else scenes.sponza_class(seed=1, scale=1.0)
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
 cam = capi.camera_update(sd.camera(W, H))
 gbuf = capi.GBuffer(W, H); restir = capi.ReSTIR(W, H)
@@ -26,7 +26,19 @@ def run(name, fn, frames=10):
     print("%-18s %.2f ms / frame, %.2f M walks / frame -> %.0f Mrays/s" % (name, dt * 1e3, rays / frames / 1e6, rays / frames / dt / 1e6))
 
 
-run("pathTraceDirect", lambda f: capi.path_trace_direct(scene, cam, d.data_ptr(), 0, f))
-run("pathTrace", lambda f: capi.path_trace(scene, cam, d.data_ptr(), i.data_ptr(), 0, f, DEPTH))
-run("pathTraceIndirect", lambda f: capi.path_trace_indirect(scene, cam, i.data_ptr(), 0, f, DEPTH))
-run("ReSTIRIndirect", lambda f: restir.indirect(scene, cam, gbuf, i.data_ptr(), 0, f, 1, DEPTH))
+def all_kernels():
+    run("pathTraceDirect", lambda f: capi.path_trace_direct(scene, cam, d.data_ptr(), 0, f))
+    run("pathTrace", lambda f: capi.path_trace(scene, cam, d.data_ptr(), i.data_ptr(), 0, f, DEPTH))
+    run("pathTraceIndirect", lambda f: capi.path_trace_indirect(scene, cam, i.data_ptr(), 0, f, DEPTH))
+    run("ReSTIRIndirect", lambda f: restir.indirect(scene, cam, gbuf, i.data_ptr(), 0, f, 1, DEPTH))
+
+
+if "--ab" in sys.argv:       # bounce rays through the closest-hit trees in the reference's orders / through the reference's own tree, interleaved on one box
+    for rep in range(2):
+        for on in (True, False):
+            capi.set_ordered_tree(scene, on)
+            print("-- bounce rays:", "closest-hit trees in the reference's orders" if on else "the reference's tree (pair-cooperative per-lane walk)")
+            all_kernels()
+    capi.set_ordered_tree(scene, True)
+else:
+    all_kernels()
