@@ -414,7 +414,13 @@ __device__ __forceinline__ WalkResult walk_paired(const DevScene& s, const Ray& 
     const bool odd = (__lane_id() & 1u) != 0;
     const unsigned halfOff = odd ? 16u : 0u;
     unsigned cur = active ? first : endOff;            // endOff is a readable record (next order / padding)
+#ifdef RS_WALK_STATS
+    unsigned long long pst[4] = { 1, 0, 0, 0 };
+#endif
     while (__any(cur != endOff)) {
+#ifdef RS_WALK_STATS
+        pst[1]++; pst[2] += __popcll(__ballot(cur != endOff));
+#endif
         const unsigned partner = (unsigned)dpp_swap1((int)cur);
         const float4 r1 = ld16(base, (odd ? partner : cur) + halfOff);      // even lane's node, split over the pair
         const float4 r2 = ld16(base, (odd ? cur : partner) + halfOff);      // odd lane's node
@@ -444,6 +450,9 @@ __device__ __forceinline__ WalkResult walk_paired(const DevScene& s, const Ray& 
             }
         }
     }
+#ifdef RS_WALK_STATS
+    if (s.walkStats && __lane_id() == 0 && !ANYHIT) for (int i = 0; i < 3; i++) atomicAdd(&s.walkStats[80 + i], pst[i]);
+#endif
     return r;
 }
 
@@ -587,9 +596,9 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
     const vf2 Axy = { A.x, A.y }, Bxy = { B.x, B.y }, Azz = { A.z, A.z }, Bzz = { B.z, B.z };
 #endif
 #ifdef RS_WALK_STATS
-    unsigned long long st[10] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long wst[10] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int mySteps = 0, myTris = 0;         // of this lane's ray
-#define RS_STAT(i, v) st[i] += (v)
+#define RS_STAT(i, v) wst[i] += (v)
 #else
 #define RS_STAT(i, v)
 #endif
@@ -604,7 +613,7 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
             if (cur != endOff) mySteps++;
 #ifdef RS_WALK_STATS_TIME      // instead of the depth histogram: walking lanes and wave iterations by iteration index (buckets of 24)
             { const unsigned long long walkers = __ballot(cur != endOff);
-              if (s.walkStats && __lane_id() == 0) { const int b = st[5] / 24 < 9 ? (int)(st[5] / 24) : 9; atomicAdd(&s.walkStats[44 + b], (unsigned long long)__popcll(walkers)); atomicAdd(&s.walkStats[54 + b], 1ull); } }
+              if (s.walkStats && __lane_id() == 0) { const int b = wst[5] / 24 < 9 ? (int)(wst[5] / 24) : 9; atomicAdd(&s.walkStats[44 + b], (unsigned long long)__popcll(walkers)); atomicAdd(&s.walkStats[54 + b], 1ull); } }
 #endif
 #endif
 #if defined(RS_OCC_PAIR) && RS_OCC_PERM
@@ -692,7 +701,7 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
                     myTris++;
 #endif
                     if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit)
-                        verify = __float_as_int(a.w) | 0x40000000;          // reference leaf of the candidate, bit 30 = first step
+                        verify = __float_as_int(a.w);          // reference leaf of the candidate
                 }
             }
             if (!__any(verify >= 0)) break;
@@ -700,7 +709,7 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
             while (__any(verify >= 0)) {
                 RS_STAT(4, 1); RS_STAT(7, __popcll(__ballot(verify >= 0)));
                 if (verify >= 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
+                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + verify);
                     float4 lo, hi;
                     node_unpack(rec[0], rec[1], lo, hi);
                     // the general case of AABB::intersect (box_hit_general), spelled out for the margins below
@@ -719,11 +728,12 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
                     // differences can only grow towards the root; evaluated in float they are off by less than
                     // 2^-20 * tRoot (four roundings of values below 4 * tRoot, tRoot = largest |slab distance| of
                     // the root box, which bounds every ancestor's).  A leaf that clears them by 2^-18 * tRoot
-                    // therefore settles the whole path; otherwise the ancestors are tested one by one.
-                    const bool first = (verify & 0x40000000) != 0;
+                    // therefore settles the whole path; otherwise the ancestors are tested one by one -- and the same
+                    // argument holds from ANY node of the path upwards, so the first ancestor that clears them ends
+                    // the walk (thin leaf boxes in a long scene: a Bistro-class chain took 30 steps to the root).
                     const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
                     const int parent = __float_as_int(lo.w);
-                    const bool done = open & ((parent < 0) | (first & clear & s.occNested));
+                    const bool done = open & ((parent < 0) | (clear & s.occNested));
                     if (done) { occluded = true; cur = endOff; qn = 0; cnt = 0; }
                     verify = (open & !done) ? parent : -1;          // closed: the reference never reaches the triangle
                 }
@@ -731,7 +741,7 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
         }
     }
 #ifdef RS_WALK_STATS
-    if (s.walkStats && __lane_id() == 0) for (int i = 0; i < 10; i++) atomicAdd(&s.walkStats[i], st[i]);
+    if (s.walkStats && __lane_id() == 0) for (int i = 0; i < 10; i++) atomicAdd(&s.walkStats[i], wst[i]);
     if (s.walkStats && active) {        // per ray: [10] occluded rays, [11] their steps, [12] unoccluded rays, [13] their steps, [14] triangle tests of all
         atomicAdd(&s.walkStats[occluded ? 10 : 12], 1ull); atomicAdd(&s.walkStats[occluded ? 11 : 13], (unsigned long long)mySteps);
         atomicAdd(&s.walkStats[14], (unsigned long long)myTris);
@@ -762,6 +772,9 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 // its queue only uses a staler (larger) `closest`, i.e. enters more, never less.  Same primitive, same barycentrics, same bits as
 // walk<false, ...>; tested against it and against the oracle on the full scenes.
 // Only for general-case rays that start within the grid's reach (as the shadow walk); every lane of the wave must call it.
+#ifndef RS_ORD_QUEUE
+#define RS_ORD_QUEUE 4          // leaves a lane may queue before the wave runs a leaf round (1..4)
+#endif
 __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, bool active) {
     WalkResult r;
     r.closest = 3.402823466e+38f; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f; r.any = false;
@@ -782,9 +795,20 @@ __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const
     const unsigned selY = A.y < 0.f ? 0x03020504u : 0x05040302u;
     const unsigned selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;
     const vf2 Axy = { A.x, A.y }, Bxy = { B.x, B.y }, Azz = { A.z, A.z }, Bzz = { B.z, B.z };
+#ifdef RS_WALK_STATS
+    unsigned long long st[12] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int mySteps = 0;
+#define RS_OSTAT(i, v) st[i] += (v)
+#else
+#define RS_OSTAT(i, v)
+#endif
     for (;;) {
         for (;;) {          // walk phase: until some lane's queue is full or every walk has ended
             if (!__ballot(cur != endOff)) break;
+            RS_OSTAT(1, 1); RS_OSTAT(2, __popcll(__ballot(cur != endOff)));
+#ifdef RS_WALK_STATS
+            if (cur != endOff) mySteps++;
+#endif
             const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
             const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
             const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
@@ -800,15 +824,22 @@ __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const
             q0 = (push && qn == 0) ? code : q0; q1 = (push && qn == 1) ? code : q1; q2 = (push && qn == 2) ? code : q2; q3 = (push && qn == 3) ? code : q3;
             qn = push ? qn + 1 : qn;
             cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
-            if (__any(qn == kLeafQueue)) break;
+            if (__any(qn == RS_ORD_QUEUE)) break;
         }
         if (!__any(qn > 0)) break;
+#ifdef RS_ORD_DRAIN
+        while (__any(qn > 0)) {
+#else
+        {
+#endif
         // leaf round: every lane takes its OLDEST queued leaf and judges its triangles one after the other
+        RS_OSTAT(3, 1);
         int tri = 0, cnt = 0, verify = -1;
         if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
         float cd = 0.f, cbx = 0.f, cby = 0.f; int cprim = kNullPrim;
         for (;;) {
             while (__any((cnt > 0) & (verify < 0))) {
+                RS_OSTAT(4, 1); RS_OSTAT(5, __popcll(__ballot((cnt > 0) & (verify < 0))));
                 if ((cnt > 0) & (verify < 0)) {
                     const float4* p = reinterpret_cast<const float4*>(tris + tri);
                     const float4 a = p[0], b = p[1], c = p[2];
@@ -816,14 +847,15 @@ __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const
                     tri += triStep; cnt--;
                     if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < r.closest) {
                         cd = dist; cbx = bx; cby = by; cprim = __float_as_int(b.w);
-                        verify = __float_as_int(a.w) | 0x40000000;          // reference leaf of the candidate, bit 30 = first step
+                        verify = __float_as_int(a.w);          // reference leaf of the candidate
                     }
                 }
             }
             if (!__any(verify >= 0)) break;
             while (__any(verify >= 0)) {
+                RS_OSTAT(6, 1); RS_OSTAT(7, __popcll(__ballot(verify >= 0)));
                 if (verify >= 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + (verify & 0x3fffffff));
+                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + verify);
                     float4 lo, hi;
                     node_unpack(rec[0], rec[1], lo, hi);
                     const float t1x = (lo.x - ctx.o.x) * ctx.dinv.x, t1y = (lo.y - ctx.o.y) * ctx.dinv.y, t1z = (lo.z - ctx.o.z) * ctx.dinv.z;
@@ -835,16 +867,21 @@ __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const
                     const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
                     const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < r.closest);
                     // the leaf shortcut of walk_occlusion_tree: a leaf that clears the overlap conditions by 2^-18 * tRoot settles its whole path
-                    const bool first = (verify & 0x40000000) != 0;
                     const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
                     const int parent = __float_as_int(lo.w);
-                    const bool done = open & ((parent < 0) | (first & clear));
+                    const bool done = open & ((parent < 0) | clear);
                     if (done) { r.closest = cd; r.bx = cbx; r.by = cby; r.prim = cprim; }
                     verify = (open & !done) ? parent : -1;          // closed: the reference never reaches the triangle
                 }
             }
         }
+        }
     }
+#ifdef RS_WALK_STATS
+    if (s.walkStats && __lane_id() == 0) for (int i = 0; i < 8; i++) atomicAdd(&s.walkStats[64 + i], st[i]);
+    if (s.walkStats && active) { atomicAdd(&s.walkStats[72], 1ull); atomicAdd(&s.walkStats[73], (unsigned long long)mySteps); }
+#endif
+#undef RS_OSTAT
     return r;
 }
 

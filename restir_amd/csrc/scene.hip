@@ -458,8 +458,8 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
         s->dev.linksNested = nested;
     }
 #ifdef RS_WALK_STATS
-    if (int e = rs_dev_alloc(&s->dWalkStats, 64)) { rs_scene_destroy(s); return e; }
-    (void)hipMemset(s->dWalkStats, 0, 64 * sizeof(unsigned long long));
+    if (int e = rs_dev_alloc(&s->dWalkStats, 96)) { rs_scene_destroy(s); return e; }
+    (void)hipMemset(s->dWalkStats, 0, 96 * sizeof(unsigned long long));
     s->dev.walkStats = s->dWalkStats;
 #endif
     if (int e = build_occlusion_side(s)) { rs_scene_destroy(s); return e; }
@@ -475,6 +475,14 @@ extern "C" int rs_debug_walk_stats(rs_scene* s, unsigned long long* out64, int r
     RS_HIP(hipDeviceSynchronize());
     RS_HIP(hipMemcpy(out64, s->dWalkStats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) RS_HIP(hipMemset(s->dWalkStats, 0, 64 * sizeof(unsigned long long)));
+    return 0;
+}
+// slots 64..95: the closest-hit walk of the bounce rays (rs_scene.h walk_ordered_tree; tools/bench_closest_wave.py)
+extern "C" int rs_debug_walk_stats_ordered(rs_scene* s, unsigned long long* out32, int reset) {
+    RS_SCOPE(s);
+    RS_HIP(hipDeviceSynchronize());
+    RS_HIP(hipMemcpy(out32, s->dWalkStats + 64, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) RS_HIP(hipMemset(s->dWalkStats + 64, 0, 32 * sizeof(unsigned long long)));
     return 0;
 }
 #endif

@@ -55,3 +55,20 @@ for rep in range(2):
     ms = timed(lambda: capi.trace_occlusion(scene, seg))
     print("shadow segments (second tree):                            %.3f ms = %.3f ms per million" % (ms, ms / seg.shape[0] * 1e6))
 capi.set_ordered_tree(scene, True)
+
+if os.environ.get("WALK_STATS"):        # a -DRS_WALK_STATS build (tools/build_variant.sh stats -DRS_WALK_STATS; RESTIR_HIP_LIB=restir_amd/librestir_stats.so)
+    import ctypes as C
+    L = capi.lib(); out = (C.c_ulonglong * 32)()
+    L.rs_debug_walk_stats_ordered.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert L.rs_debug_walk_stats_ordered(scene.handle, out, 1) == 0
+    capi.trace_closest_wave(scene, b)
+    assert L.rs_debug_walk_stats_ordered(scene.handle, out, 1) == 0
+    w = out[0]
+    print("closest-hit trees, per wave (%d waves): walk iterations %.1f with %.1f lanes walking; leaf rounds %.1f; triangle iterations %.1f with %.1f lanes; verify iterations %.1f with %.1f lanes"
+          % (w, out[1] / w, out[2] / max(out[1], 1), out[3] / w, out[4] / w, out[5] / max(out[4], 1), out[6] / w, out[7] / max(out[6], 1)))
+    print("per ray: %.1f node steps" % (out[9] / max(out[8], 1)))
+    capi.set_ordered_tree(scene, False)
+    capi.trace_closest_wave(scene, b)
+    assert L.rs_debug_walk_stats_ordered(scene.handle, out, 1) == 0
+    capi.set_ordered_tree(scene, True)
+    print("the reference's tree, per wave (%d waves): iterations %.1f with %.1f lanes walking = %.1f node steps per ray" % (out[16], out[17] / out[16], out[18] / max(out[17], 1), out[18] / b.shape[0]))
