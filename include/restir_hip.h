@@ -27,6 +27,7 @@ extern "C" {
 
 #define RS_ERR_INVALID_ARGUMENT 10001
 #define RS_ERR_UNSUPPORTED      10002   /* e.g. an image or mesh format the scene-file reader does not decode */
+#define RS_ERR_INTERNAL         10003   /* a self-check of the library failed (rs_ordered_bvh_host_check) */
 
 /* src/material.h:258-267 -- identical 44-byte layout */
 typedef struct rs_material {
@@ -270,6 +271,11 @@ int  rs_trace_closest_wave(const rs_scene* scene, int n, const float* devRays,
 /* on = 0: bounce rays walk the reference's own tree (src/scene.h:245-284 literally); 1: the closest-hit trees again (the default
  * when the scene's tables allow them).  *was (may be NULL) receives the previous setting.  Results are identical either way. */
 int  rs_scene_set_ordered_tree(rs_scene* scene, int on, int* was);
+/* Host only (no device call): builds the closest-hit trees of the bounce rays from a reference table (rs_build_bvh's outputs) and
+ * verifies what their walk relies on: the leaves list the triangles in the order the threaded orders of src/bvh.cpp:156-193 meet
+ * them, boxes contain what is below them, miss links nest.  nodeCounts[3] / maxDepth[3] (may be NULL): per axis. */
+int  rs_ordered_bvh_host_check(int numPrims, int bvhSize, const float* boundingBoxes, const int* const bvhNodes[6],
+                               int* nodeCounts, int* maxDepth);
 /* DevScene::testOcclusion (src/scene.h:286-316): n segments of 6 floats (x, y). */
 int  rs_trace_occlusion(const rs_scene* scene, int n, const float* devSegments, int* devOccluded);
 

@@ -110,7 +110,7 @@ class GBufferView(C.Structure):
 EXPORTS = [
     "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_stream_plan", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
-    "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_closest_wave", "rs_scene_set_ordered_tree", "rs_trace_occlusion",
+    "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_closest_wave", "rs_scene_set_ordered_tree", "rs_ordered_bvh_host_check", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
@@ -371,6 +371,18 @@ def build_bvh(vertices):
     check(lib().rs_build_bvh(n, _p(v), _p(boxes), C.byref(arr), C.byref(got)))
     assert got.value == size
     return boxes, nodes
+
+
+def ordered_bvh_host_check(boxes, nodes):
+    """rs_ordered_bvh_host_check on rs_build_bvh's outputs; returns (error code, node counts per axis, depth per axis)."""
+    boxes = np.ascontiguousarray(boxes, np.float32); nodes = [np.ascontiguousarray(nodes[k], np.int32) for k in range(6)]
+    size = boxes.shape[0]
+    arr = (C.c_void_p * 6)(*[nodes[i].ctypes.data for i in range(6)])
+    counts = (C.c_int * 3)(); depth = (C.c_int * 3)()
+    fn = lib().rs_ordered_bvh_host_check
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p * 6), C.POINTER(C.c_int * 3), C.POINTER(C.c_int * 3)]
+    e = fn((size + 1) // 2, size, _p(boxes), C.byref(arr), C.byref(counts), C.byref(depth))
+    return e, list(counts), list(depth)
 
 
 def build_alias_table(values):

@@ -365,3 +365,66 @@ int rs_build_ordered_bvh(int numPrims, const float* primBoxes, const int* seq, s
     }
     return 0;
 }
+
+// Host-only check of the above for the CPU test suite: from a reference table (boxes by original node id, six threaded orders)
+// derives the leaf sequences, requires the odd orders to mirror the even ones, builds the three trees and verifies what the walk
+// relies on -- read in walking order the leaves of the forward / mirrored tree list the triangles exactly as order 2a / 2a + 1
+// meets them, every box contains the reference leaf boxes below it, every miss link is the end of its subtree.
+// nodeCounts[3], maxDepth[3]: per axis.  Returns 0, RS_ERR_UNSUPPORTED when the orders do not mirror, or RS_ERR_INTERNAL on a broken tree.
+extern "C" int rs_ordered_bvh_host_check(int numPrims, int bvhSize, const float* boundingBoxes, const int* const bvhNodes[6], int* nodeCounts, int* maxDepth) {
+    if (numPrims <= 0 || bvhSize != 2 * numPrims - 1 || !boundingBoxes || !bvhNodes) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_ordered_bvh_host_check: bad argument");
+    std::vector<int> parent, leafOf;
+    if (int e = rs_reference_chain_tables(bvhSize, bvhNodes[0], parent, leafOf, numPrims)) return e;
+    const size_t np = (size_t)numPrims;
+    std::vector<float> pb(np * 6);
+    for (size_t p = 0; p < np; p++) std::memcpy(&pb[p * 6], boundingBoxes + (size_t)leafOf[p] * 6, 24);
+    for (int a = 0; a < 3; a++) {
+        std::vector<int> seq, rev;
+        for (int i = 0; i < bvhSize; i++) { if (bvhNodes[2 * a][(size_t)i * 3] >= 0) seq.push_back(bvhNodes[2 * a][(size_t)i * 3]); if (bvhNodes[2 * a + 1][(size_t)i * 3] >= 0) rev.push_back(bvhNodes[2 * a + 1][(size_t)i * 3]); }
+        if (seq.size() != np || rev.size() != np) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_ordered_bvh_host_check: an order does not list every primitive once");
+        for (size_t i = 0; i < np; i++) if (seq[i] != rev[np - 1 - i]) return rs_fail(RS_ERR_UNSUPPORTED, "rs_ordered_bvh_host_check: the odd order is not the mirror image of the even one");
+        std::vector<BvhNode> tree[2];
+        if (int e = rs_build_ordered_bvh(numPrims, pb.data(), seq.data(), tree[0], tree[1])) return e;
+        if (tree[0].size() != tree[1].size()) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: forward and mirrored trees differ in size");
+        for (int m = 0; m < 2; m++) {
+            const std::vector<BvhNode>& t = tree[m];
+            size_t met = 0;                         // triangles met so far, in walking order
+            std::vector<int> ends;                  // open subtrees (their end indices)
+            int depth = 0;
+            for (size_t i = 0; i < t.size(); i++) {
+                while (!ends.empty() && ends.back() <= (int)i) ends.pop_back();
+                if (t[i].next <= (int)i || t[i].next > (int)t.size() || (!ends.empty() && t[i].next > ends.back())) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: miss link is not the end of a nested subtree");
+                if (t[i].primId >= 0) {
+                    if (t[i].next != (int)i + 1) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: leaf with a subtree");
+                    const int start = t[i].primId >> 3, count = t[i].primId & 7;
+                    if (count < 1 || count > kMaxLeaf) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: leaf size");
+                    for (int j = 0; j < count; j++) {
+                        const int at = m ? start - j : start + j;           // index into the even order's sequence
+                        const size_t expect = m ? np - 1 - met : met;
+                        if (at < 0 || (size_t)at != expect) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: the leaves do not list the triangles in the reference's order");
+                        const float* b = &pb[(size_t)seq[(size_t)at] * 6];
+                        // the leaf's box and every open ancestor's contain the reference leaf box
+                        const BvhNode& n = t[i];
+                        if (!(n.bminx <= b[0] && n.bminy <= b[1] && n.bminz <= b[2] && n.bmaxx >= b[3] && n.bmaxy >= b[4] && n.bmaxz >= b[5])) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: a leaf box does not contain its triangle's reference box");
+                        met++;
+                    }
+                }
+                else {
+                    if ((size_t)i + 1 >= t.size()) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: inner node without children");
+                    const BvhNode& n = t[i];
+                    const BvhNode& c1 = t[i + 1];
+                    const BvhNode& c2 = t[(size_t)c1.next < t.size() ? (size_t)c1.next : i + 1];
+                    for (const BvhNode* c : { &c1, &c2 })
+                        if (!(n.bminx <= c->bminx && n.bminy <= c->bminy && n.bminz <= c->bminz && n.bmaxx >= c->bmaxx && n.bmaxy >= c->bmaxy && n.bmaxz >= c->bmaxz)) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: a box does not contain its child's");
+                    if (c2.next != n.next) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: the second child does not end where its parent ends");
+                }
+                ends.push_back(t[i].next);
+                depth = std::max(depth, (int)ends.size());
+            }
+            if (met != np) return rs_fail(RS_ERR_INTERNAL, "rs_ordered_bvh_host_check: not every triangle is in a leaf");
+            if (maxDepth && m == 0) maxDepth[a] = depth;
+        }
+        if (nodeCounts) nodeCounts[a] = (int)tree[0].size();
+    }
+    return 0;
+}

@@ -225,3 +225,24 @@ def test_procedural_scene_budgets():
     assert int((sd.materials["type"][sd.material_ids] == LIGHT).sum()) == 1024
     b = scenes.bistro_class(2, 0.01)
     assert b.num_prims > 10000 and int((b.materials["type"][b.material_ids] == LIGHT).sum()) == 2 * max(8, round(5120 * 0.01))
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza:0.05", "bistro:0.02"])
+def test_closest_hit_trees_keep_the_reference_order(name):
+    """Host side of the bounce rays' closest-hit trees (occlusion_bvh.cpp rs_build_ordered_bvh): read in walking order their
+    leaves list the triangles exactly as the threaded orders of src/bvh.cpp:156-193 meet them (forward tree = order 2a, mirrored
+    tree = order 2a + 1), boxes contain what is below them, miss links nest -- checked by the library's own host routine on
+    rs_build_bvh's tables; and a table whose odd order is not the mirror image of the even one is refused."""
+    from restir_amd import capi
+    from tests.common import get_scene
+    sd = get_scene(name)
+    boxes, nodes = capi.build_bvh(sd.vertices)
+    e, counts, depth = capi.ordered_bvh_host_check(boxes, nodes)
+    assert e == 0, capi.lib().rs_last_error().decode()
+    n = sd.vertices.size // 9
+    for c, d in zip(counts, depth):
+        assert n / 4 <= c < 2 * n            # leaves of 1..4 triangles
+        assert d <= 64 + int(np.log2(n)) + 2
+    bad = nodes.copy(); bad[1] = bad[0]
+    e, _, _ = capi.ordered_bvh_host_check(boxes, bad)
+    assert e == 10002                        # RS_ERR_UNSUPPORTED
