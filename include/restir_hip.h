@@ -183,6 +183,12 @@ int  rs_set_ris_table_pixels(int pixels);
  * No entry point waits on the host in overlapped mode: the measurement of rs_set_side_stream's mode 4 polls its last time stamp
  * (hipEventQuery at the frame ends) and frames take two launches until it has arrived. */
 int  rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain);
+/* Closest-hit kernels (GBuffer::render, the primary rays of ReSTIRDirect): a tile whose packet walk visited at least `threshold`
+ * nodes the last time the same launch ran is traced by four waves of 16 rays instead of one of 64 -- a launch that runs alone lasts
+ * as long as its longest chain of node fetches; results do not depend on the grouping.  Applies where launches run one after the
+ * other (synchronous mode, per-pass timing); 0 = off; negative = |threshold| for every launch, also with the frames overlapped
+ * (measured slower there); default 768 (RS_TILE_SPLIT). */
+int  rs_set_tile_split(int threshold);
 int  rs_synchronize(void);
 
 /* ---- host scene build: replaces Scene::buildDevData (src/scene.cpp:159-215) ----------- */

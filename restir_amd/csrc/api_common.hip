@@ -1,4 +1,5 @@
 // api_common.hip -- library state (device, stream, sync mode, last error) of librestir_hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,7 +63,13 @@ hipStream_t rs_aux_stream(int i) {
         c->auxMode = (e && e[0] == '0') ? 0 : 1;
     }
     if (c->sync || !c->auxMode || i < 0 || i >= rs_context::kAux) return nullptr;
-    if (!c->aux[i] && hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess) { c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
+    if (!c->aux[i]) {
+        // measurement switch RS_AUX_PRIORITY="p0,p1,p2": HIP stream priority of each auxiliary stream (0 = default; negative = higher)
+        int prio = 0;
+        if (const char* e = std::getenv("RS_AUX_PRIORITY")) { int p[3] = { 0, 0, 0 }; if (std::sscanf(e, "%d,%d,%d", &p[0], &p[1], &p[2]) >= 1) prio = p[i]; }
+        const hipError_t err = prio ? hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+        if (err != hipSuccess) { c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
+    }
     return c->aux[i];
 }
 // In asynchronous mode GBuffer::render can be deferred and launched by ReSTIRDirect together with its primary rays (the two rays
@@ -127,7 +134,50 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam) {
     return c;
 }
 
+// ---- tile-split hints ---------------------------------------------------------------------------------------------------------
+int rs_tile_split_threshold() {
+    rs_context* c = rs_ctx();
+    if (!c->tileSplitSet) { const char* e = std::getenv("RS_TILE_SPLIT"); c->tileSplit = e ? std::atoi(e) : 768; c->tileSplitSet = true; }
+    return c->tileSplit;
+}
+void rs_tile_split_free(rs_tile_split* t) {
+    rs_dev_free(t->base);
+    t->bytes = 0; t->key = -1; t->rot = 0;
+}
+int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, bool serial, hipStream_t st, rs::TileSplit* ts, int* helperBlocks) {
+    *ts = rs::TileSplit{ nullptr, 0, 0 };
+    *helperBlocks = 0;
+    int threshold = rs_tile_split_threshold();
+    if (threshold == 0 || numTiles <= 0 || (threshold > 0 && !serial)) return 0;
+    if (threshold < 0) threshold = -threshold;      // negative: for every launch, also next to other kernels (tests, measurements)
+    const int capacity = std::min(rs_tile_split::kCapacity, std::max(64, regularBlocks / 2));
+    key = key * 1048573 + threshold;
+    const size_t hintInts = 2 + (size_t)capacity, flagOffset = (8 + 3 * hintInts) * sizeof(int), flagStride = ((size_t)numTiles + 15) & ~(size_t)15;
+    const size_t bytes = flagOffset + 3 * flagStride;
+    if (t->bytes < bytes) {                         // (hipFree waits for the device: nothing in flight reads the old arrays)
+        rs_tile_split_free(t);
+        unsigned char* p = nullptr;
+        RS_TRY(rs_dev_alloc(&p, bytes));
+        t->base = reinterpret_cast<int*>(p); t->bytes = bytes;
+    }
+    if (t->key != key) {                            // another geometry: no hints
+        RS_HIP(hipMemsetAsync(t->base, 0, bytes, st));
+        hipLaunchKernelGGL(rs::k_tile_split_init, dim3(1), dim3(1), 0, st, t->base, capacity, threshold, numTiles, (int)flagOffset, (int)flagStride);
+        t->key = key; t->rot = 0;
+    }
+    ts->base = t->base; ts->rot = t->rot; ts->helperBlocks = capacity;
+    *helperBlocks = capacity;
+    t->rot = (t->rot + 1) % 3;
+    return 0;
+}
+
 extern "C" {
+
+int rs_set_tile_split(int threshold) {
+    rs_ctx()->tileSplit = threshold; rs_ctx()->tileSplitSet = true;
+    return 0;
+}
+
 
 const char* rs_last_error(void) {
     std::lock_guard<std::mutex> lock(g_errMutex);

@@ -24,19 +24,20 @@ using namespace rs;
 // 8 blocks per CU: without the bound the kernel takes 100+ SGPRs and runs at 7 waves per SIMD (0.392 -> 0.370 ms at 1080p)
 template <bool TEX>
 __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
-                                                        int y0, int y1, int tilesX) {
-    // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
-    const int x = bx * 32 + wave * 8 + (lane & 7);
-    const int y = y0 + by * 8 + (lane >> 3);
-    const bool inside = x < cam.width && y < y1;
+                                                        int y0, int y1, int tilesX, TileSplit ts) {
+    // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels (a tile that was heavy last time: four waves of 4x4, rs_tilesplit.h)
+    int x, py, tile;
+    bool mine, helper;
+    if (!tile_split_map<8, 8>(ts, tilesX, threadIdx.x & 63, x, py, mine, tile, helper)) return;
+    const int y = y0 + py;
+    const bool inside = mine && x < cam.width && y < y1;
     const int idx = y * cam.width + x;
 
     Ray ray = camera_center_ray(cam, x, y);
-    Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
-    if (!inside) return;
-    gbuffer_store<TEX>(s, cam, lastCam, g, idx, ray, h);
+    unsigned unionNodes;
+    Hit h = trace_closest_packet(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
+    if (inside) gbuffer_store<TEX>(s, cam, lastCam, g, idx, ray, h);
+    tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
 }
 
 namespace {
@@ -54,16 +55,19 @@ void deferred_unregister(const rs_gbuffer* g) {
     g_deferred.erase(std::remove(g_deferred.begin(), g_deferred.end(), g), g_deferred.end());
 }
 
-void launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, const rs_camera* lastCam, int y0, int y1, hipStream_t st) {
+int launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* cam, const rs_camera* lastCam, int y0, int y1, hipStream_t st) {
     const int c = g->cur();
     GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
+    TileSplit ts; int helpers = 0;
+    RS_TRY(rs_tile_split_prepare(&g->split[st == rs_stream() ? 0 : 1], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0)), st, &ts, &helpers));
     if (scene->textured)
-        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, st,
-                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX);
+        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st,
+                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX, ts);
     else
-        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, st,
-                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX);
+        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st,
+                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX, ts);
+    return 0;
 }
 
 // launches a deferred render on the auxiliary stream
@@ -74,7 +78,7 @@ int flush_deferred(const rs_gbuffer* g) {
     hipStream_t aux = rs_aux_stream(0);
     if (aux) RS_TRY(rs_gbuffer_order_before_render(g, aux));
     else aux = rs_stream();                                 // (the mode was switched in between: plain launch on the library stream)
-    launch_render(g, g->deferred.scene, &g->deferred.cam, &g->deferred.lastCam, g->deferred.y0, g->deferred.y1, aux);
+    RS_TRY(launch_render(g, g->deferred.scene, &g->deferred.cam, &g->deferred.lastCam, g->deferred.y0, g->deferred.y1, aux));
     RS_TRY(rs_check_hip(hipGetLastError(), "renderGBuffer"));
     if (aux != rs_stream()) { RS_HIP(hipEventRecord(g->doneEv, aux)); g->pending = true; }
     return 0;
@@ -136,6 +140,7 @@ int rs_gbuffer_destroy(rs_gbuffer* g) {
     }
     if (g->forkEv) (void)hipEventDestroy(g->forkEv);
     if (g->doneEv) (void)hipEventDestroy(g->doneEv);
+    for (auto& t : g->split) rs_tile_split_free(&t);
     delete g;
     return 0;
 }
@@ -196,7 +201,7 @@ int rs_gbuffer_render_rows(rs_gbuffer* g, const rs_scene* scene, const rs_camera
         return 0;
     }
     RS_TRY(rs_gbuffer_join(g));                             // an earlier render of this frame may still be on the auxiliary stream
-    launch_render(g, scene, cam, &g->lastCamera, y0, y1, rs_stream());
+    RS_TRY(launch_render(g, scene, cam, &g->lastCamera, y0, y1, rs_stream()));
     g->renderedSinceUpdate = true;
     return rs_after_launch("renderGBuffer");
 }

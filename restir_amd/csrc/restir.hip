@@ -107,16 +107,19 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
 
 template <bool TEX, bool SOBOL>
 __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
-                                                 int y0, int y1, int tilesX, unsigned long long* rayCount) {
-    int x, y;
-    pixel_of_lane(tilesX, y0, x, y);
-    const bool inside = x < cam.width && y < y1;
+                                                 int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
+    int x, py, tile;
+    bool mine, helper;
+    if (!tile_split_map<8, 8>(ts, tilesX, threadIdx.x & 63, x, py, mine, tile, helper)) return;     // (a helper block without a tile)
+    const int y = y0 + py;
+    const bool inside = mine && x < cam.width && y < y1;
     int shaded = 0;
     const int index = y * cam.width + x;
     SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);     // restir.cu:127
     f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
-    Hit h = trace_closest_packet(s, ray, inside);       // all 64 lanes take part in the wave's walk
+    unsigned unionNodes;
+    Hit h = trace_closest_packet(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
     if (inside) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
@@ -124,6 +127,7 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_prima
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
         if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
     }
+    tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
 }
 
 // GBuffer::render and the primary rays of ReSTIRDirect in one launch (asynchronous mode, when the render of this frame is
@@ -139,17 +143,20 @@ constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of th
 // 1.193 for this form.)  Tiles are 8x4 from the G-buffer rows [gy0, gy1), blocks 32x4 pixels; the shading ray is active on rows [y0, y1).
 template <bool TEX, bool SOBOL>
 __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
-                                                                  int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31;
+                                                                  int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
+    const int lane = threadIdx.x & 63;
     const bool shading = lane >= 32;                            // which of the pixel's two rays this lane carries
-    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
-    const int x = bx * 32 + wave * 8 + (l & 7), y = gy0 + by * 4 + (l >> 3);
-    const bool inside = x < cam.width && (shading ? (y >= y0 && y < y1) : y < gy1);
+    int x, py, tile;
+    bool mine, helper;
+    if (!tile_split_map<8, 4>(ts, tilesX, lane & 31, x, py, mine, tile, helper)) return;
+    const int y = gy0 + py;
+    const bool inside = mine && x < cam.width && (shading ? (y >= y0 && y < y1) : y < gy1);
     const int index = y * cam.width + x;
     SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);
     const f4 r = rng.uniform4();
     const Ray ray = shading ? camera_sample(cam, x, y, r.x, r.y) : camera_center_ray(cam, x, y);
-    const Hit h = trace_closest_packet(s, ray, inside);
+    unsigned unionNodes;
+    const Hit h = trace_closest_packet(s, ray, inside, &unionNodes);
     int shaded = 0;
     if (inside) {
         if (shading) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
@@ -160,6 +167,7 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuff
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
         if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
     }
+    tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
 }
 
 // ---- phase A.2: RIS over the light table ----------------------------------------------------------
@@ -761,6 +769,7 @@ int rs_restir_free(rs_restir* r) {
         rs_dev_free(f.posKind); rs_dev_free(f.norm); rs_dev_free(f.wo); rs_dev_free(f.rngMat); rs_dev_free(f.candLi); rs_dev_free(f.candWi);
     }
     rs_dev_free(r->dRayCount);
+    for (auto& perStream : r->split) for (auto& t : perStream) rs_tile_split_free(&t);
     rs_dev_free(r->indResv[0]); rs_dev_free(r->indResv[1]);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
@@ -878,6 +887,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     r->lastFused = fuse ? 1 : 0;
     r->lastChains = !aux ? 0 : three ? rs_restir::kSmallChains : parityStreams ? rs_restir::kChains : 1;
     const hipStream_t st = aux ? aux : rs_stream();
+    const int splitSlot = !aux ? 0 : 1 + (three ? kThreeStreams[r->smallChain] : parityStreams ? 1 + r->chain : 1);     // the hints of the stream this launch goes to (rs_tilesplit.h)
+    const int splitCall = r->phaseACalls < 2 ? r->phaseACalls : 2;
     if (aux) {
         if (r->phaseACalls > 0) {
             RS_HIP(hipEventRecord(r->auxFork, rs_stream()));
@@ -901,12 +912,17 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         const GBufWrite gw{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
         const int gTilesY = (d.y1 - d.y0 + 3) / 4;                // 8x4-pixel tiles: two rays per pixel fill the wave
         const CamParams lp = rs_make_cam_params(&d.lastCam);
-        RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
+        TileSplit ts; int helpers = 0;
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, !aux, st, &ts, &helpers));
+        RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
         g->pending = true;
     }
-    else
-        RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+    else {
+        TileSplit ts; int helpers = 0;
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, !aux, st, &ts, &helpers));
+        RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
+    }
     mark(r, 1);
     const int npx = (y1 - y0) * W;
     // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "rs_scene.h"
+#include "rs_tilesplit.h"
 
 // ---- contexts ----------------------------------------------------------------------------------
 // What used to be process-wide settings: the device, the stream the library enqueues on, synchronous / asynchronous
@@ -32,6 +33,7 @@ struct rs_context {
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
     int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
+    int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): from the environment (RS_TILE_SPLIT) or 768; 0 off; negative: |value|, also for launches that overlap others
 };
 rs_context* rs_ctx();                                   // the context this thread's library code runs under right now
 struct rs_ctx_scope {                                   // entry points: run under the context of the object they were handed
@@ -88,6 +90,23 @@ static inline void rs_dev_free(T*& p) {
 // The Sobol branch indexes its table by the caller's looper (State::looper, kept below SobolSampleNum by the reference's
 // `(looper + 1) % SobolSampleNum`, restir.cu:441-445): a looper outside the table is refused instead of read.
 int rs_check_looper(const struct rs_scene* scene, int looper, const char* what);
+
+// ---- tile-split hints (rs_tilesplit.h) -------------------------------------------------------------
+// One per launch site and stream: the lists / flags the last launch of that geometry on that stream left for the next one.
+struct rs_tile_split {
+    static constexpr int kCapacity = 4096;
+    int* base = nullptr;                             // header + three hints + three flag arrays (layout: rs_tilesplit.h)
+    size_t bytes = 0;
+    int rot = 0;                                     // the hint the next launch reads
+    long long key = -1;                              // the launch geometry (and threshold) the hints belong to
+};
+// fills *ts for a launch of `regularBlocks` blocks of four tiles each on stream st (all zero when the feature is off) and
+// returns through *helperBlocks how many blocks the grid gets in front of them.  serial: the kernel runs with nothing next to it
+// (synchronous mode, per-pass timing) -- only then does a launch last as long as its longest chain; with the frames overlapped
+// the other frames' kernels fill in around a long tile, and splitting measured 2.5 % SLOWER (extra waves, extra blocks).
+int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, bool serial, hipStream_t st, rs::TileSplit* ts, int* helperBlocks);
+void rs_tile_split_free(rs_tile_split* t);
+int rs_tile_split_threshold();                      // of the current context
 
 // ---- scene -------------------------------------------------------------------------------------
 struct rs_scene {
@@ -166,6 +185,7 @@ struct rs_gbuffer {
         int y0 = 0, y1 = 0;
     };
     mutable Deferred deferred;
+    mutable rs_tile_split split[2];          // k_render_gbuffer on the library stream / on the auxiliary stream
     int cur() const { return ring; }
     int prev() const { return (ring + kSets - 1) % kSets; }
     // albedo / motion are single planes in the reference: they show the most recent render, also after update()
@@ -309,6 +329,7 @@ struct rs_restir {
     bool tuneCounted = false;        // this frame had a launch the choice applies to
     hipEvent_t tuneEv[3] = { nullptr, nullptr, nullptr };
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
+    rs_tile_split split[1 + rs_context::kAux][3];   // primary-ray launches: per stream (library, auxiliary 0..2) and per call within a frame (strips: interior rows, border rows)
     int raySlot = 0;
     // timing
     int timing = 0;                  // 0 off, 1 every pass on the library stream, 2 the spatial pass only, launches as in the overlapped mode

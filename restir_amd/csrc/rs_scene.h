@@ -347,8 +347,10 @@ __device__ __forceinline__ void load_tri(const TriRec* tris, int prim, f3& v0, f
 
 struct WalkResult {
     float closest; int prim; float bx, by; bool any;
+    unsigned nodes;            // packet walks: nodes the WAVE visited (the union of its lanes' walks), wave-uniform
 #ifdef RS_WALK_STATS
     unsigned steps, nearSteps, enteredSteps, leafSteps, clearSteps;   // clearSteps: entered without evaluating the overlap part
+    unsigned myVisits;                                                // nodes this lane's own walk visited (packet walks)
 #endif
 };
 
@@ -1042,8 +1044,9 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
     float4 ra = *reinterpret_cast<const float4*>(base), rb = *reinterpret_cast<const float4*>(base + 16);      // uniform addresses -> scalar loads
     const float margin = overlap_margin(ctx.o, ctx.dinv, ra, rb);        // the first record is the root
     while (c != end) {
+        r.nodes++;
 #ifdef RS_WALK_STATS
-        r.steps++;
+        r.steps++; if (myNext == c) r.myVisits++;
 #endif
         const int prim = __float_as_int(rb.z);
         const unsigned nxt = (unsigned)__float_as_int(rb.w), cNext = c + 1u;
@@ -1108,6 +1111,7 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
     float4 lo, hi;
     node_unpack(np0[0], np0[1], lo, hi);
     while (c != end) {
+        r.nodes++;
 #ifdef RS_WALK_STATS
         r.steps++;
 #endif
@@ -1157,9 +1161,10 @@ __device__ __forceinline__ void packet_walk_fast_dispatch(int neg, const DevScen
 }
 
 // closest hit for a wave of coherent rays; lanes with active == false carry no ray
-__device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bool active) {
+// unionNodes (may be null): the number of nodes the wave visited, the length of its chain of dependent fetches (tile splitting, rs_tilesplit.h)
+__device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bool active, unsigned* unionNodes = nullptr) {
     WalkResult w;
-    w.closest = 3.402823466e+38f; w.prim = kNullPrim; w.bx = 0.f; w.by = 0.f; w.any = false;
+    w.closest = 3.402823466e+38f; w.prim = kNullPrim; w.bx = 0.f; w.by = 0.f; w.any = false; w.nodes = 0;
     RayBoxCtx ctx = make_box_ctx(ray);
     ctx.cull = s.axisCull;
     const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
@@ -1167,7 +1172,7 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
     const int order = mtbvh_order(-ray.d);
     unsigned long long todo = __ballot(active);
 #ifdef RS_WALK_STATS
-    w.steps = w.nearSteps = w.enteredSteps = w.leafSteps = w.clearSteps = 0;
+    w.steps = w.nearSteps = w.enteredSteps = w.leafSteps = w.clearSteps = 0; w.myVisits = 0;
     unsigned norders = 0;
 #endif
     while (todo) {                                            // one pass per threaded order present in the wave
@@ -1194,7 +1199,16 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
         atomicAdd(&s.walkStats[23], (unsigned long long)w.leafSteps); atomicAdd(&s.walkStats[15], (unsigned long long)w.clearSteps);
         atomicAdd(&s.walkStats[24 + (w.steps ? 31 - __clz((int)w.steps) : 0)], 1ull);
     }
+    {   // is a heavy tile heavy because its rays diverge (large union) or because single rays visit that many nodes?
+        unsigned mv = w.myVisits;
+        for (int off = 32; off > 0; off >>= 1) mv = max(mv, (unsigned)__shfl_xor((int)mv, off));
+        if (s.walkStats && __lane_id() == 0) {
+            atomicAdd(&s.walkStats[87], (unsigned long long)mv);
+            if (w.steps >= 1024u) { atomicAdd(&s.walkStats[84], 1ull); atomicAdd(&s.walkStats[85], (unsigned long long)w.steps); atomicAdd(&s.walkStats[86], (unsigned long long)mv); }
+        }
+    }
 #endif
+    if (unionNodes) *unionNodes = w.nodes;
     Hit h;
     h.primId = w.prim;
     h.matId = 0;

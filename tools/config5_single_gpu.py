@@ -27,4 +27,13 @@ b.restir.enable_timing(True); capi.set_side_stream(0)
 for f in range(40+N,45+N):
     b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); b.end_frame()
 torch.cuda.synchronize()
-print("config 5 on one GPU: %.2f ms/frame incl. EAW (frames overlapped); pass ms on one stream %s; finite %s" % (dt*1e3, b.restir.pass_times(), bool(torch.isfinite(b.image).all())))
+passes = b.restir.pass_times()
+# the reference's mode: a synchronisation after every call
+b.restir.enable_timing(False); capi.set_side_stream(4); capi.set_sync(True)
+for f in range(45+N,50+N):
+    b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); eaw.filter(out.data_ptr(), b.image.data_ptr(), b.gbuf, cam); b.end_frame()
+torch.cuda.synchronize(); t=time.time()
+for f in range(50+N,60+N):
+    b.gbuffer_render(0,H); b.phase_a(f,3,0,H); b.phase_b(0,3,0,H); eaw.filter(out.data_ptr(), b.image.data_ptr(), b.gbuf, cam); b.end_frame()
+torch.cuda.synchronize(); ds=(time.time()-t)/10
+print("config 5 on one GPU: %.2f ms/frame incl. EAW (frames overlapped), %.2f ms synchronous; pass ms on one stream %s; finite %s" % (dt*1e3, ds*1e3, passes, bool(torch.isfinite(b.image).all())))

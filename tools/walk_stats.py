@@ -21,6 +21,9 @@ out = (C.c_ulonglong * 64)()
 L = capi.lib()
 L.rs_debug_walk_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 assert L.rs_debug_walk_stats(scene.handle, out, 1) == 0
+if hasattr(L, "rs_debug_walk_stats_ordered"):
+    L.rs_debug_walk_stats_ordered.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert L.rs_debug_walk_stats_ordered(scene.handle, (C.c_ulonglong * 32)(), 1) == 0
 frames = 4
 for _ in range(frames):
     strips.frame(3, 0)
@@ -56,3 +59,12 @@ print("closest-hit packet walks (G-buffer + primary), per wave: union nodes mean
 print("  of the union nodes: some lane passes the distance part %.1f, some lane enters %.1f, of which leaves %.1f (fast form only)" % (out[21] / pw, out[22] / pw, out[23] / pw))
 print("  nodes at which every lane that passed the distance part clears the overlap part by 2^-19 * tRoot: %.1f" % (out[15] / pw))
 print("  histogram of union nodes per wave (log2 buckets):", " ".join("%d:%d" % (1 << b, out[24 + b]) for b in range(20) if out[24 + b]))
+
+try:
+    o2 = (C.c_ulonglong * 32)()
+    assert L.rs_debug_walk_stats_ordered(scene.handle, o2, 0) == 0
+    if o2[23]:
+        print("  the slowest ray of a wave visits %.1f nodes on average (fast form only); waves with >= 1024 union nodes: %d, union %.0f, slowest ray %.0f nodes" %
+              (o2[23] / pw, o2[20], o2[21] / max(o2[20], 1), o2[22] / max(o2[20], 1)))
+except AttributeError:
+    pass
