@@ -142,7 +142,7 @@ int rs_tile_split_threshold() {
 }
 void rs_tile_split_free(rs_tile_split* t) {
     rs_dev_free(t->base);
-    t->bytes = 0; t->key = -1; t->rot = 0;
+    t->bytes = 0; t->key = -1; t->rot = 0; t->numTiles = t->capacity = 0;
 }
 int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, bool serial, hipStream_t st, rs::TileSplit* ts, int* helperBlocks) {
     *ts = rs::TileSplit{ nullptr, 0, 0 };
@@ -160,10 +160,10 @@ int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int reg
         RS_TRY(rs_dev_alloc(&p, bytes));
         t->base = reinterpret_cast<int*>(p); t->bytes = bytes;
     }
-    if (t->key != key) {                            // another geometry: no hints
+    if (t->key != key || t->numTiles != numTiles || t->capacity != capacity) {      // another geometry: no hints
         RS_HIP(hipMemsetAsync(t->base, 0, bytes, st));
         hipLaunchKernelGGL(rs::k_tile_split_init, dim3(1), dim3(1), 0, st, t->base, capacity, threshold, numTiles, (int)flagOffset, (int)flagStride);
-        t->key = key; t->rot = 0;
+        t->key = key; t->rot = 0; t->numTiles = numTiles; t->capacity = capacity;
     }
     ts->base = t->base; ts->rot = t->rot; ts->helperBlocks = capacity;
     *helperBlocks = capacity;

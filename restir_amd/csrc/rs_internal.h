@@ -99,6 +99,7 @@ struct rs_tile_split {
     size_t bytes = 0;
     int rot = 0;                                     // the hint the next launch reads
     long long key = -1;                              // the launch geometry (and threshold) the hints belong to
+    int numTiles = 0, capacity = 0;                  // ... and what the device header says (a changed value re-initialises the hints whatever the key)
 };
 // fills *ts for a launch of `regularBlocks` blocks of four tiles each on stream st (all zero when the feature is off) and
 // returns through *helperBlocks how many blocks the grid gets in front of them.  serial: the kernel runs with nothing next to it
