@@ -22,9 +22,9 @@ using namespace rs;
 
 // TEX: the scene has texture maps or an environment map (getTexturedMaterialAndSurface, gbuffer.cu:38,59-62)
 // 8 blocks per CU: without the bound the kernel takes 100+ SGPRs and runs at 7 waves per SIMD (0.392 -> 0.370 ms at 1080p)
-template <bool TEX>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g,
-                                                        int y0, int y1, int tilesX, TileSplit ts) {
+template <bool TEX, bool SPLIT>
+__device__ __forceinline__ void render_gbuffer_body(const DevScene& s, const CamParams& cam, const CamParams& lastCam, const GBufWrite& g,
+                                                    int y0, int y1, int tilesX, const TileSplit& ts) {
     // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels (a tile that was heavy last time: four waves of 4x4, rs_tilesplit.h)
     int x, py, tile;
     bool mine, helper;
@@ -34,10 +34,19 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_rende
     const int idx = y * cam.width + x;
 
     Ray ray = camera_center_ray(cam, x, y);
-    unsigned unionNodes;
-    Hit h = trace_closest_packet(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
+    unsigned unionNodes = 0;
+    Hit h = trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
     if (inside) gbuffer_store<TEX>(s, cam, lastCam, g, idx, ray, h);
-    tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
+    if (SPLIT) tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
+}
+
+template <bool TEX>
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX) {
+    render_gbuffer_body<TEX, false>(s, cam, lastCam, g, y0, y1, tilesX, TileSplit{ nullptr, 0, 0 });
+}
+template <bool TEX>
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX, TileSplit ts) {
+    render_gbuffer_body<TEX, true>(s, cam, lastCam, g, y0, y1, tilesX, ts);
 }
 
 namespace {
@@ -61,12 +70,13 @@ int launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* c
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
     TileSplit ts; int helpers = 0;
     RS_TRY(rs_tile_split_prepare(&g->split[st == rs_stream() ? 0 : 1], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0)), st, &ts, &helpers));
-    if (scene->textured)
-        hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st,
-                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX, ts);
-    else
-        hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st,
-                           scene->dev, rs_make_cam_params(cam), rs_make_cam_params(lastCam), w, y0, y1, tilesX, ts);
+    const CamParams cp = rs_make_cam_params(cam), lp = rs_make_cam_params(lastCam);
+    if (ts.base) {
+        if (scene->textured) hipLaunchKernelGGL(k_render_gbuffer_split<true>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX, ts);
+        else hipLaunchKernelGGL(k_render_gbuffer_split<false>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX, ts);
+    }
+    else if (scene->textured) hipLaunchKernelGGL(k_render_gbuffer<true>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX);
+    else hipLaunchKernelGGL(k_render_gbuffer<false>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX);
     return 0;
 }
 

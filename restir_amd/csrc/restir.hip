@@ -105,9 +105,10 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
     return shaded;
 }
 
-template <bool TEX, bool SOBOL>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
-                                                 int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
+// SPLIT: the launch splits its heavy tiles (rs_tilesplit.h) and counts the nodes of every walk for it; the plain kernel carries none of that
+template <bool TEX, bool SOBOL, bool SPLIT>
+__device__ __forceinline__ void primary_body(const DevScene& s, const CamParams& cam, const SurfPlanes& sp, int looper,
+                                             int y0, int y1, int tilesX, unsigned long long* rayCount, const TileSplit& ts) {
     int x, py, tile;
     bool mine, helper;
     if (!tile_split_map<8, 8>(ts, tilesX, threadIdx.x & 63, x, py, mine, tile, helper)) return;     // (a helper block without a tile)
@@ -118,8 +119,8 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_prima
     SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);     // restir.cu:127
     f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
-    unsigned unionNodes;
-    Hit h = trace_closest_packet(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
+    unsigned unionNodes = 0;
+    Hit h = trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
     if (inside) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
@@ -127,7 +128,18 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_prima
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
         if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
     }
-    tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
+    if (SPLIT) tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
+}
+
+template <bool TEX, bool SOBOL>
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+                                                 int y0, int y1, int tilesX, unsigned long long* rayCount) {
+    primary_body<TEX, SOBOL, false>(s, cam, sp, looper, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
+}
+template <bool TEX, bool SOBOL>
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary_split(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+                                                 int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
+    primary_body<TEX, SOBOL, true>(s, cam, sp, looper, y0, y1, tilesX, rayCount, ts);
 }
 
 // GBuffer::render and the primary rays of ReSTIRDirect in one launch (asynchronous mode, when the render of this frame is
@@ -141,9 +153,9 @@ constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of th
 // the single walk's cost per visit.  (Round 1's form walked both rays in one lane, one after the other at every node of an 8x8 tile's
 // union: it paid both slab tests per visit and, after the round-2 walk, measured 1.29 ms per frame against 1.20 for two launches and
 // 1.193 for this form.)  Tiles are 8x4 from the G-buffer rows [gy0, gy1), blocks 32x4 pixels; the shading ray is active on rows [y0, y1).
-template <bool TEX, bool SOBOL>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
-                                                                  int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
+template <bool TEX, bool SOBOL, bool SPLIT>
+__device__ __forceinline__ void gbuffer_primary_body(const DevScene& s, const CamParams& cam, const CamParams& lastCam, const GBufWrite& g, const SurfPlanes& sp, int looper,
+                                                     int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, const TileSplit& ts) {
     const int lane = threadIdx.x & 63;
     const bool shading = lane >= 32;                            // which of the pixel's two rays this lane carries
     int x, py, tile;
@@ -155,8 +167,8 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuff
     SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);
     const f4 r = rng.uniform4();
     const Ray ray = shading ? camera_sample(cam, x, y, r.x, r.y) : camera_center_ray(cam, x, y);
-    unsigned unionNodes;
-    const Hit h = trace_closest_packet(s, ray, inside, &unionNodes);
+    unsigned unionNodes = 0;
+    const Hit h = trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);
     int shaded = 0;
     if (inside) {
         if (shading) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
@@ -167,7 +179,18 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuff
         unsigned long long c = (unsigned long long)__popcll(ballotIn) + (unsigned long long)__popcll(ballotSh);
         if (c) atomicAdd(rayCount + (blockIdx.x % kRaySub) * kRayStride, c);
     }
-    tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
+    if (SPLIT) tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
+}
+
+template <bool TEX, bool SOBOL>
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+                                                                  int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
+    gbuffer_primary_body<TEX, SOBOL, false>(s, cam, lastCam, g, sp, looper, gy0, gy1, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
+}
+template <bool TEX, bool SOBOL>
+__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+                                                                  int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
+    gbuffer_primary_body<TEX, SOBOL, true>(s, cam, lastCam, g, sp, looper, gy0, gy1, y0, y1, tilesX, rayCount, ts);
 }
 
 // ---- phase A.2: RIS over the light table ----------------------------------------------------------
@@ -914,14 +937,16 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         const CamParams lp = rs_make_cam_params(&d.lastCam);
         TileSplit ts; int helpers = 0;
         RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, !aux, st, &ts, &helpers));
-        RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
+        if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
+        else RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
         g->pending = true;
     }
     else {
         TileSplit ts; int helpers = 0;
         RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, !aux, st, &ts, &helpers));
-        RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
+        if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
+        else RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     }
     mark(r, 1);
     const int npx = (y1 - y0) * W;

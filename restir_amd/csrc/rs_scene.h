@@ -1034,7 +1034,7 @@ __device__ __forceinline__ bool slab_overlap_part(const SlabT& t, bool near) {
     return dx + dy > (ok ? fy - nx : __builtin_inff());
 }
 
-template <int NEG>
+template <int NEG, bool COUNT>
 __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, bool mine, const Ray& ray, const RayBoxCtx& ctx, WalkResult& r) {
     const char* __restrict__ base = reinterpret_cast<const char*>(s.nodesAll + (size_t)order * (size_t)s.bvhSize);
     const unsigned end = (unsigned)s.bvhSize;
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
     float4 ra = *reinterpret_cast<const float4*>(base), rb = *reinterpret_cast<const float4*>(base + 16);      // uniform addresses -> scalar loads
     const float margin = overlap_margin(ctx.o, ctx.dinv, ra, rb);        // the first record is the root
     while (c != end) {
-        r.nodes++;
+        if (COUNT) r.nodes++;                                 // (a scalar instruction per node: only for launches that split their heavy tiles)
 #ifdef RS_WALK_STATS
         r.steps++; if (myNext == c) r.myVisits++;
 #endif
@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void packet_walk_fast(const DevScene& s, int order, b
     }
 }
 
-template <bool GENERAL>
+template <bool GENERAL, bool COUNT>
 __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, bool mine, const Ray& ray,
                                                   const RayBoxCtx& ctx, WalkResult& r) {
     const BvhNode* __restrict__ nodes = s.nodesAll + (size_t)order * (size_t)s.bvhSize;
@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
     float4 lo, hi;
     node_unpack(np0[0], np0[1], lo, hi);
     while (c != end) {
-        r.nodes++;
+        if (COUNT) r.nodes++;
 #ifdef RS_WALK_STATS
         r.steps++;
 #endif
@@ -1147,21 +1147,23 @@ __device__ __forceinline__ void packet_walk_order(const DevScene& s, int order, 
 }
 
 // the bits of `neg`: a direction component is negative in the lanes that take part (the same in all of them)
+template <bool COUNT>
 __device__ __forceinline__ void packet_walk_fast_dispatch(int neg, const DevScene& s, int order, bool mine, const Ray& ray, const RayBoxCtx& ctx, WalkResult& r) {
     switch (neg) {
-        case 0: packet_walk_fast<0>(s, order, mine, ray, ctx, r); break;
-        case 1: packet_walk_fast<1>(s, order, mine, ray, ctx, r); break;
-        case 2: packet_walk_fast<2>(s, order, mine, ray, ctx, r); break;
-        case 3: packet_walk_fast<3>(s, order, mine, ray, ctx, r); break;
-        case 4: packet_walk_fast<4>(s, order, mine, ray, ctx, r); break;
-        case 5: packet_walk_fast<5>(s, order, mine, ray, ctx, r); break;
-        case 6: packet_walk_fast<6>(s, order, mine, ray, ctx, r); break;
-        default: packet_walk_fast<7>(s, order, mine, ray, ctx, r); break;
+        case 0: packet_walk_fast<0, COUNT>(s, order, mine, ray, ctx, r); break;
+        case 1: packet_walk_fast<1, COUNT>(s, order, mine, ray, ctx, r); break;
+        case 2: packet_walk_fast<2, COUNT>(s, order, mine, ray, ctx, r); break;
+        case 3: packet_walk_fast<3, COUNT>(s, order, mine, ray, ctx, r); break;
+        case 4: packet_walk_fast<4, COUNT>(s, order, mine, ray, ctx, r); break;
+        case 5: packet_walk_fast<5, COUNT>(s, order, mine, ray, ctx, r); break;
+        case 6: packet_walk_fast<6, COUNT>(s, order, mine, ray, ctx, r); break;
+        default: packet_walk_fast<7, COUNT>(s, order, mine, ray, ctx, r); break;
     }
 }
 
 // closest hit for a wave of coherent rays; lanes with active == false carry no ray
 // unionNodes (may be null): the number of nodes the wave visited, the length of its chain of dependent fetches (tile splitting, rs_tilesplit.h)
+template <bool COUNT = false>
 __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bool active, unsigned* unionNodes = nullptr) {
     WalkResult w;
     w.closest = 3.402823466e+38f; w.prim = kNullPrim; w.bx = 0.f; w.by = 0.f; w.any = false; w.nodes = 0;
@@ -1186,9 +1188,9 @@ __device__ inline Hit trace_closest_packet(const DevScene& s, const Ray& ray, bo
         todo &= ~mm;
         const unsigned long long sx = __ballot(mine && ray.d.x < 0.f), sy = __ballot(mine && ray.d.y < 0.f), sz = __ballot(mine && ray.d.z < 0.f);
         const bool uniformSigns = (sx == 0 || sx == mm) && (sy == 0 || sy == mm) && (sz == 0 || sz == mm);
-        if (anySpecial) packet_walk_order<false>(s, k, mine, ray, ctx, w);
-        else if (uniformSigns && s.axisCull && s.linksNested) packet_walk_fast_dispatch((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0), s, k, mine, ray, ctx, w);
-        else packet_walk_order<true>(s, k, mine, ray, ctx, w);
+        if (anySpecial) packet_walk_order<false, COUNT>(s, k, mine, ray, ctx, w);
+        else if (uniformSigns && s.axisCull && s.linksNested) packet_walk_fast_dispatch<COUNT>((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0), s, k, mine, ray, ctx, w);
+        else packet_walk_order<true, COUNT>(s, k, mine, ray, ctx, w);
     }
 #ifdef RS_WALK_STATS
     if (s.walkStats && __lane_id() == 0) {
