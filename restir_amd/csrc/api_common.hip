@@ -56,6 +56,14 @@ bool rs_sync_enabled() { return rs_ctx()->sync; }
 // that order them (rs_gbuffer, rs_restir).
 // The auxiliary stream i of the current context, or nullptr when launches are synchronous (rs_set_sync(1): nothing to overlap)
 // or the feature is off (rs_set_side_stream(0) / RS_SIDE_STREAM=0).
+hipStream_t rs_aux_stream_any(int i) {
+    rs_context* c = rs_ctx();
+    const bool sync = c->sync;
+    c->sync = false;
+    const hipStream_t st = rs_aux_stream(i);
+    c->sync = sync;
+    return st;
+}
 hipStream_t rs_aux_stream(int i) {
     rs_context* c = rs_ctx();
     if (c->auxMode < 0) {

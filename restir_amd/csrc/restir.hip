@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, Res
                                                   int first, int reuse, int n0, int n1, unsigned long long* rayWork, unsigned long long* rayDone) {
     // this call's BVH-walk counters are complete (the launch is ordered after the chain that counted): publish them and leave the
     // working slot zero for its next user, so that the chain itself needs no clearing launch
-    if (blockIdx.x == 0 && threadIdx.x < kRaySub) {
+    // (rayDone null: an earlier band of a frame that is launched in bands -- the last band's launch publishes for all of them)
+    if (rayDone && blockIdx.x == 0 && threadIdx.x < kRaySub) {
         const int k = threadIdx.x * kRayStride;
         rayDone[k] = rayWork[k];
         rayWork[k] = 0;
@@ -797,6 +798,7 @@ int rs_restir_free(rs_restir* r) {
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->tuneEv) if (e) (void)hipEventDestroy(e);
+    for (auto& e : r->bandEv) if (e) (void)hipEventDestroy(e);
     if (r->auxFork) (void)hipEventDestroy(r->auxFork);
     if (r->auxDone) (void)hipEventDestroy(r->auxDone);
     delete r;
@@ -861,6 +863,37 @@ int rs_restir_enable_timing(rs_restir* r, int enable) {
 }  // extern "C"
 
 namespace {
+// RIS over the light table for rows [y0, y1) on stream st; alone: nothing runs next to it (picks the alias-in-LDS form for large tables)
+int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y1, int looper, bool sobol, hipStream_t st, bool alone) {
+    const int npx = (y1 - y0) * W;
+    // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
+    // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
+    // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
+    // Alone the alias-in-LDS form is a third faster (config 5: 645 -> 455 us); inside overlapped frames it is slower (1.88 -> 1.95 ms per
+    // frame: one 1024-thread block with 82 KB of LDS per CU keeps the other streams' kernels off that CU), so it is taken when the
+    // kernels run one after the other on the library stream only.  RS_RIS_ALIAS_LDS=0 / 1: never / always (measurements).
+    static const int aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return e ? std::atoi(e) : 2; }();
+    const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
+    if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
+        // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
+        // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
+        RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
+    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && (aliasLds == 1 || (aliasLds == 2 && alone))) {
+        const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
+        static const bool ldsAllowed = []{      // more than 64 KB of dynamic LDS is opt-in
+            const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
+            const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
+            (void)hipGetLastError();
+            return a && b; }();
+        (void)ldsAllowed;
+        if (sobol) hipLaunchKernelGGL(k_ris_alias_lds<true>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
+        else hipLaunchKernelGGL(k_ris_alias_lds<false>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
+    }
+    else                               // the environment map is one more light (scene.h:400-403)
+        RS_LAUNCH2(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), st, scene->dev, sp, W, y0, y1, looper);
+    return 0;
+}
+
 // `last`: the call ends with rs_after_launch (which synchronises in synchronous mode); ReSTIRDirect passes false for its two
 // inner calls and synchronises once at its end
 int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, int looper, int reuse, int y0, int y1, bool last) {
@@ -950,31 +983,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     }
     mark(r, 1);
     const int npx = (y1 - y0) * W;
-    // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
-    // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
-    // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
-    // Alone the alias-in-LDS form is a third faster (config 5: 645 -> 455 us); inside overlapped frames it is slower (1.88 -> 1.95 ms per
-    // frame: one 1024-thread block with 82 KB of LDS per CU keeps the other streams' kernels off that CU), so it is taken when the
-    // kernels run one after the other on the library stream only.  RS_RIS_ALIAS_LDS=0 / 1: never / always (measurements).
-    static const int aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return e ? std::atoi(e) : 2; }();
-    const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
-    if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
-        // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
-        // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
-        RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
-    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && (aliasLds == 1 || (aliasLds == 2 && !aux))) {
-        const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
-        static const bool ldsAllowed = []{      // more than 64 KB of dynamic LDS is opt-in
-            const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
-            const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
-            (void)hipGetLastError();
-            return a && b; }();
-        (void)ldsAllowed;
-        if (sobol) hipLaunchKernelGGL(k_ris_alias_lds<true>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
-        else hipLaunchKernelGGL(k_ris_alias_lds<false>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
-    }
-    else                               // the environment map is one more light (scene.h:400-403)
-        RS_LAUNCH2(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), st, scene->dev, sp, W, y0, y1, looper);
+    RS_TRY(launch_ris(scene, sp, W, y0, y1, looper, sobol, st, !aux));
     mark(r, 2);
     // The shadow rays of a launch that fills the chip several times over go to the library stream, behind the previous frame's
     // spatial pass: every stream then has slack against the frame period and three or four kernels are in flight at any time,
@@ -1080,10 +1089,75 @@ int rs_restir_end_frame(rs_restir* r) {
     return 0;
 }
 
+// ReSTIRDirect of a synchronous caller (the reference's mode: every call returns with its work done) as a software pipeline over
+// bands of rows.  Alone on the chip the three kernels of the chain are bound by different things -- the primary rays and the shadow
+// rays by memory latency (65 % / 55 % of their issue slots idle), RIS by instruction issue -- and a synchronous frame pays their
+// SUM (0.28 + 0.29 + 0.39 ms at 1080p).  Nothing but rows links them, so the frame is cut into kSyncBands bands and the kernels
+// go to three internal streams by KIND: primary rays of band b, b + 1, ... on one, RIS on the second (band b after its primary
+// rays), shadow rays on the third, the streaming temporal merge on the library stream -- band b + 1's latency-bound walk runs under
+// band b's RIS and band b - 1's shadow rays.  The same kernels on the same rows, so the same bits; the call still returns with
+// everything done.  MEASURED SLOWER (tools/bench_sync_frame.py, profiles/r03_ab_sync_bands.log): a synchronous 1080p frame 1.404 ms with
+// one launch per kernel, 1.57 / 1.56 / 1.63 ms with 2 / 3 / 4 bands; Bistro-class 2.54 -> 3.64 / 4.30 ms -- a band's walk kernel is a
+// single round of waves that lasts as long as its slowest tile, every band pays that tail, and what the stages hide of each other
+// is less than that.  Kept behind RS_SYNC_BANDS=2..4 (default 1: off).
+int direct_banded(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, float* devDirectIllum, int iter, int looper, int reuse, int bands) {
+    RS_TRY(rs_check_looper(scene, looper, "ReSTIRDirect"));
+    if (!devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: null radiance buffer");
+    const bool sobol = scene->dev.sampleSeq != nullptr;
+    const int W = r->width, H = r->height;
+    hipStream_t stP = rs_aux_stream_any(0), stR = rs_aux_stream_any(1), stS = rs_aux_stream_any(2), lib = rs_stream();
+    for (auto& e : r->bandEv) if (!e) RS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    r->looper = looper;
+    r->raySlot = (r->raySlot + 1) % kRaySlots;                  // ONE counter slot for all bands; the last band's temporal launch publishes it
+    unsigned long long* rayCounter = r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride;
+    unsigned long long* rayDone = rayCounter + (size_t)kRaySlots * kRaySub * kRayStride;
+    const SurfPlanes sp = surf_of(r);
+    const CamParams cp = rs_make_cam_params(cam);
+    const int tilesX = (W + 31) / 32;
+    RS_TRY(rs_gbuffer_join(g));                                 // (a render that a caller switched to asynchronous mode in between left pending)
+    // everything the caller enqueued on the library stream so far comes first
+    RS_HIP(hipEventRecord(r->bandEv[0], lib));
+    RS_HIP(hipStreamWaitEvent(stP, r->bandEv[0], 0));
+    r->phaseACalls++;
+    r->lastFused = 0; r->lastChains = 0;
+    const int rowsPer = (((H + bands - 1) / bands) + 7) & ~7;
+    int b = 0;
+    for (int y0 = 0; y0 < H; y0 += rowsPer, b++) {
+        const int y1 = y0 + rowsPer < H ? y0 + rowsPer : H;
+        const bool lastBand = y1 == H;
+        const int tilesY = (y1 - y0 + 7) / 8, npx = (y1 - y0) * W;
+        hipEvent_t evP = r->bandEv[1 + 3 * b], evR = r->bandEv[2 + 3 * b], evS = r->bandEv[3 + 3 * b];
+        RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), stP, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+        RS_HIP(hipEventRecord(evP, stP));
+        RS_HIP(hipStreamWaitEvent(stR, evP, 0));
+        RS_TRY(launch_ris(scene, sp, W, y0, y1, looper, sobol, stR, false));
+        RS_HIP(hipEventRecord(evR, stR));
+        RS_HIP(hipStreamWaitEvent(stS, evR, 0));
+        hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, stS, scene->dev, sp, W, y0, y1, tilesX);
+        RS_HIP(hipEventRecord(evS, stS));
+        RS_HIP(hipStreamWaitEvent(lib, evS, 0));
+        RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), lib, sp, gbuf_view(g),
+                   r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter,
+                   lastBand ? rayDone : (unsigned long long*)nullptr);
+    }
+    RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (bands)"));
+    RS_TRY(phase_b_impl(r, scene, cam, g, devDirectIllum, iter, reuse, 0, H, false));
+    RS_TRY(rs_restir_end_frame(r));
+    return rs_after_launch("ReSTIR Direct");                   // the library stream has waited for every band's chain
+}
+
 int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                      float* devDirectIllum, int iter, int looper, int reuse) {
     RS_SCOPE(r);
     RS_TRY(check_frame_args(r, scene, cam, g));
+    {
+        static const int bandsEnv = []{ const char* e = std::getenv("RS_SYNC_BANDS"); return e ? std::atoi(e) : 1; }();      // measured slower than one launch per kernel: off unless asked for
+        const int bands = bandsEnv < 1 ? 1 : bandsEnv > rs_restir::kSyncBands ? rs_restir::kSyncBands : bandsEnv;
+        // worth it from about a quarter of a million pixels per band on (RIS then still runs its LDS form)
+        if (bands > 1 && rs_sync_enabled() && r->timing == 0 && !g->deferred.valid && (long long)r->width * r->height >= (long long)bands * rs_ris_global_below() &&
+            rs_aux_stream_any(0) && rs_aux_stream_any(1) && rs_aux_stream_any(2))
+            return direct_banded(r, scene, cam, g, devDirectIllum, iter, looper, reuse, bands);
+    }
     // one synchronisation for the whole call (synchronous mode); the library's mode itself is not touched, so the two phases
     // stay on the library stream in synchronous mode and use the auxiliary streams in asynchronous mode only
     RS_TRY(phase_a_impl(r, scene, cam, g, looper, reuse, 0, r->height, false));

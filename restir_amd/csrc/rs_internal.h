@@ -54,6 +54,7 @@ int rs_after_launch(const char* what);
 // auxiliary streams of the asynchronous mode (api_common.hip): 0 = GBuffer::render, 1 + k = primary rays + RIS + shadow rays of every
 // kChains-th frame; nullptr = not in use
 hipStream_t rs_aux_stream(int i);
+hipStream_t rs_aux_stream_any(int i);                  // the same stream whatever the launch mode (null only when the side streams are switched off)
 int rs_aux_synchronize();
 
 #define RS_TRY(expr)                                       \
@@ -298,6 +299,8 @@ struct rs_restir {
     // takes the fused launch (render + primary rays, k_gbuffer_primary), after which nothing runs on the render's stream, and
     // gives that stream to a third chain (kSmallChains; restir.hip phase_a_impl): 8 strips of 1080p 5.96x -> 6.5x.
     static constexpr int kChains = 2, kSmallChains = 3, kSurfSets = RS_SURF_SETS;
+    static constexpr int kSyncBands = 4;              // a synchronous ReSTIRDirect as a pipeline over at most this many bands of rows (restir.hip direct_banded)
+    hipEvent_t bandEv[1 + 3 * kSyncBands] = {};
     int width = 0, height = 0;
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
