@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per launch from the PMC passes of tools/profile.sh on this same command (FETCH_SIZE x 2 + WRITE_SIZE,
 # the gfx950 correction of MI355X_MICROARCH.md), condensed by tools/summarize_profile.py; counters cannot be read
 # from inside the process, so `roofline.traffic` quotes the committed summary (null if it is absent).
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final_hbm_counters.json")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final2_hbm_counters.json")
 
 
 def pmc_traffic(kernel):
@@ -66,7 +66,7 @@ def pmc_traffic(kernel):
         return None, None
 
 
-OVERLAPPED_STATS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final_kernel_stats_overlapped.csv")
+OVERLAPPED_STATS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final2_kernel_stats_overlapped.csv")
 
 
 def overlapped_kernel_us(kernel):
