@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""tools/strip_trace_report.py KERNEL_TRACE_CSV -- timeline summary of tools/strip_trace.py: the last 30 frames (by k_spatial_shade
-launches); per kernel mean duration and per queue the busy fraction of the span."""
+"""tools/strip_trace_report.py KERNEL_TRACE_CSV -- timeline summary of tools/strip_trace.py: the last 30 frames (by k_send_image_to_pbo
+launches, one per frame; the spatial pass runs up to three times per frame: interior rows and the two border bands); per kernel mean
+duration and per queue the busy fraction of the span."""
 import csv, re, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -9,7 +10,7 @@ def short(n):
     return m.group(1) if m else n[:30]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows]
 ev.sort()
-sp = [e for e in ev if e[2] == "k_spatial_shade"]
+sp = [e for e in ev if e[2] == "k_send_image_to_pbo"]
 t0, t1 = sp[-31][1], sp[-1][1]
 sel = [e for e in ev if e[0] >= t0 and e[1] <= t1]
 span = (t1 - t0) / 30
