@@ -600,11 +600,12 @@ __device__ __forceinline__ Staged fetch_staged_global(const GBufView& g, const T
 
 // The per-pixel body of phase B (restir.cu:196-230).  STAGED: neighbour records come from the LDS tile
 // `stage` (origin sox, soy); otherwise from global memory.
-template <bool STAGED, bool SOBOL>
+// RING: the staged rows are a ring -- row r of the window [soy, soy + kBStageH) lies at slot (r + ringOff) mod kBStageH (k_spatial_shade_roll)
+template <bool STAGED, bool SOBOL, bool RING = false>
 __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlanes& sp, const GBufView& g, const ResvPlanes& own,
                                               const TempPlanes& temp, const Staged* stage, int sox, int soy,
                                               float* __restrict__ directIllum, int iter, int looper, bool spatial,
-                                              int x, int y, int index, uint2 rm, f3 albedo, f3 prev) {
+                                              int x, int y, int index, uint2 rm, f3 albedo, f3 prev, int ringOff = 0) {
     const int W = g.width, H = g.height;
     const int mk = (int)rm.y;
     const int kind = mk_kind(mk);
@@ -621,7 +622,9 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
         // own reservoir = what phase A published (post-temporal, validity-checked)
         float W0; int M0; int src = index;
         if (spatial) {
-            const Staged c = STAGED ? stage[(y - soy) * kBStageW + (x - sox)] : fetch_staged_global(g, temp, index);
+            int cy = y - soy;
+            if (RING) { cy += ringOff; cy -= cy >= kBStageH ? kBStageH : 0; }
+            const Staged c = STAGED ? stage[cy * kBStageW + (x - sox)] : fetch_staged_global(g, temp, index);
             W0 = c.tap.x; M0 = __float_as_int(c.tap.y);
             const int idC = __float_as_int(c.tap.z);
             const float dC = c.tap.w;
@@ -638,7 +641,9 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
                 const bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & !((px == x) & (py == y));
                 Staged q;
                 if (STAGED) {       // taps reach x-4..x+5, y-4..y+5: always inside the staged halo; the clamp keeps garbage in bounds
-                    const int lx = iclamp(px - sox, 0, kBStageW - 1), ly = iclamp(py - soy, 0, kBStageH - 1);
+                    const int lx = iclamp(px - sox, 0, kBStageW - 1);
+                    int ly = iclamp(py - soy, 0, kBStageH - 1);
+                    if (RING) { ly += ringOff; ly -= ly >= kBStageH ? kBStageH : 0; }
                     q = stage[ly * kBStageW + lx];
                 }
                 else q = fetch_staged_global(g, temp, iclamp(py, 0, H - 1) * W + iclamp(px, 0, W - 1));
@@ -739,6 +744,62 @@ __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevSce
     }
     if (!inside) return;
     spatial_pixel<true, SOBOL>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, looper, spatial, x, y, index, rm, albedo, prev);
+}
+
+// The same pass with a ROLLING window: a block takes kRollTiles tiles of one column of tiles, top to bottom, and keeps the staged
+// rows in a ring -- moving down one tile replaces kBTileH of the kBStageH rows and keeps the 2 * kHalo that the two tiles share.
+// Staged records per pixel: (26 + 5 * 16) * 42 / (6 * 512) = 1.45 instead of 26 * 42 / 512 = 2.13 -- the vertical halo, which is
+// most of what the pass re-reads, is read once per block instead of once per tile.  Same per-pixel code (spatial_pixel), same bits.
+#ifndef RS_K4_ROLL_TILES
+#define RS_K4_ROLL_TILES 6
+#endif
+constexpr int kRollTiles = RS_K4_ROLL_TILES;
+template <bool SOBOL>
+__global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade_roll(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
+                                                                  float* __restrict__ directIllum, int iter, int looper, int reuse,
+                                                                  int y0, int y1, int tilesX, int numBlocks) {
+    __shared__ Staged stage[kBStageN];
+    int blk = blockIdx.x;                                    // XCD-aware order as in k_spatial_shade: each XCD a contiguous run of blocks
+    {
+        const int q = numBlocks / 8, rem = numBlocks % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+        blk = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+    }
+    const int ox = (blk % tilesX) * kBTileW, oySeg = y0 + (blk / tilesX) * (kBTileH * kRollTiles);
+    const int W = g.width, H = g.height;
+    const int tx = threadIdx.x % kBTileW, ty = threadIdx.x / kBTileW;
+    const int x = ox + tx;
+    int ringOff = 0;                                         // slot of the window's first row
+    for (int j = 0; j < kRollTiles; j++) {
+        const int oy = oySeg + j * kBTileH;
+        if (oy >= y1) break;                                 // (block-uniform)
+        const int y = oy + ty;
+        const bool inside = x < W && y < y1;
+        const int index = inside ? y * W + x : 0;
+        uint2 rm = make_uint2(0u, 0u);
+        f3 albedo = splat(0.f), prev = splat(0.f);
+        if (inside) {
+            const unsigned long long rmBits = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sp.rngMat + index));
+            rm = make_uint2((unsigned)rmBits, (unsigned)(rmBits >> 32));
+            albedo = ld3_stream(g.albedo + (size_t)index * 3);
+            prev = ld3_stream(directIllum + (size_t)index * 3);
+        }
+        // window rows [oy - kHalo, oy - kHalo + kBStageH); the first tile stages all of them, the next ones the kBTileH new rows at the bottom
+        const int firstNew = j == 0 ? 0 : kBStageH - kBTileH, count = (kBStageH - firstNew) * kBStageW;
+        for (int e = threadIdx.x; e < count; e += kBThreads) {
+            const int wr = firstNew + e / kBStageW;          // row within the window
+            const int sx = ox - kHalo + (e % kBStageW), sy = oy - kHalo + wr;
+            Staged v;
+            v.tap = make_float4(0.f, 0.f, __int_as_float(-3), 0.f);     // id -3 matches nothing
+            v.nx = v.ny = v.nz = v.pad = 0.f;
+            if (sx >= 0 && sx < W && sy >= 0 && sy < H) v = fetch_staged_global(g, temp, sy * W + sx);
+            int slot = wr + ringOff; slot -= slot >= kBStageH ? kBStageH : 0;
+            stage[slot * kBStageW + (e % kBStageW)] = v;
+        }
+        __syncthreads();
+        if (inside) spatial_pixel<true, SOBOL, true>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, looper, true, x, y, index, rm, albedo, prev, ringOff);
+        __syncthreads();                                     // every tap of this tile has been read before the next tile's rows replace the oldest ones
+        ringOff += kBTileH; ringOff -= ringOff >= kBStageH ? kBStageH : 0;
+    }
 }
 
 }  // namespace
@@ -1016,6 +1077,18 @@ int phase_b_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
     RS_TRY(rs_gbuffer_join(g));
+    // The rolling window (k_spatial_shade_roll: the vertical halo read once per block of kRollTiles tiles) is a measured negative:
+    // 1.45-1.72 staged records per pixel instead of 2.13, bit-exact, and 54-63 us against 48 (profiles/r03_ab_spatial_rolling_window.log)
+    // -- a block's tiles run one after the other, every one a load phase, a barrier, a compute phase, a barrier, where independent
+    // tiles overlap each other's phases.  RS_K4_ROLL=1: always, 2: for passes over at least 2 * kRollTiles rows of tiles; default 0.
+    static const int rollEnv = []{ const char* e = std::getenv("RS_K4_ROLL"); return e ? std::atoi(e) : 0; }();
+    const bool roll = (reuse & 2) != 0 && (rollEnv == 1 || (rollEnv == 2 && tilesY >= 2 * kRollTiles));
+    if (roll) {
+        const int segs = (tilesY + kRollTiles - 1) / kRollTiles, numBlocks = tilesX * segs;
+        RS_LAUNCH1(k_spatial_shade_roll, scene->dev.sampleSeq != nullptr, dim3(numBlocks), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
+                   r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numBlocks);
+    }
+    else
     RS_LAUNCH1(k_spatial_shade, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
                r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);
