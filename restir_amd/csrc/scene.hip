@@ -157,6 +157,7 @@ int build_ordered_side(rs_scene* s) {
         bool sameGrid[3] = { true, true, true };
         size_t counts[3] = { 0, 0, 0 };
         auto work = [&](int a) {
+          try {                                              // (an exception must not leave a host thread: the build's vectors can run out of memory)
             std::vector<BvhNode> tree[2];
             if ((err[a] = rs_build_ordered_bvh(s->numPrims, primBoxes.data(), seq[a].data(), tree[0], tree[1])) != 0) return;
             for (int m = 0; m < 2; m++) {
@@ -166,6 +167,7 @@ int build_ordered_side(rs_scene* s) {
                 if (std::memcmp(base, &s->dev.occBase, 12) != 0 || std::memcmp(scale, &s->dev.occScale, 12) != 0) sameGrid[a] = false;
                 counts[a] = std::max(counts[a], tree[m].size());
             }
+          } catch (...) { err[a] = RS_ERR_UNSUPPORTED; }     // the scene then renders without these trees (the reference walk)
         };
         std::thread t1(work, 1), t2(work, 2);
         work(0);
