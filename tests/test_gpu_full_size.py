@@ -223,3 +223,18 @@ def test_svgf_full_size(hip, exact_libm):
         o.gbuf.update(o.cam); h.gbuf.update(h.cam)
     assert np.abs(ref - o.image).max() > 1e-3
     fh.destroy()
+
+
+@pytest.mark.parametrize("name", ["sponza:1.0", "bistro:1.0"])
+def test_path_trace_direct_full_size(hip, exact_libm, name):
+    """PTDirectKernel (src/pathtrace.cu:279-328) at 1920x1080 on the full scenes, two accumulated frames: image and ray count bit for bit."""
+    sd = get_scene(name)
+    W, H = 1920, 1080
+    o = OracleRenderer(sd, W, H)
+    h = HipRenderer(hip, sd, W, H)
+    for frame in range(2):
+        a = o.frame(0, use_reservoir=False, iteration=frame)
+        b = h.frame(0, use_reservoir=False, iteration=frame)
+        assert o.rays == h.rays, (frame, o.rays, h.rays)
+        assert bits_equal(a, b), (frame, radiance_stats(a, b))
+    assert a.max() > 0
