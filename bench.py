@@ -1,37 +1,48 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on its config: Mrays/s and ms/frame of the ReSTIR-DI per-frame
-sequence (runCuda, src/main.cpp:146-185: GBuffer::render -> ReSTIRDirect -> copyImageToPBO ->
-GBuffer::update) at 1920x1080, 32 candidates, spatiotemporal reuse, on the procedural Sponza-class
-scene (262 144 triangles, 1 024 emissive; BASELINE config 3).
+"""bench.py -- BASELINE.json's metric: Mrays/s and ms/frame of the ReSTIR-DI per-frame sequence (runCuda,
+src/main.cpp:146-185: GBuffer::render -> ReSTIRDirect -> [LeveledEAWFilter] -> copyImageToPBO -> GBuffer::update), 32 candidates,
+spatiotemporal reuse, on the procedural scenes of BASELINE.json's configs.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config 3|4|5]
 
-A step = one frame.  A ray = one BVH walk (intersect or testOcclusion call): 1 G-buffer ray + 1
-shading ray per pixel + 1 shadow ray per shaded pixel; counted by the kernels.
+  --config 3 (default, the headline)  Sponza-class scene (262 144 triangles, 1 024 emissive), 1920x1080
+  --config 4                          the same scene at 3840x2160 (the config BASELINE defines on 8 GPUs)
+  --config 5                          Bistro-class scene (2.83 M triangles, 10 240 emissive), 1920x1080, + the 5-level EAW filter
 
-N > 1: the 1920x1080 framebuffer is cut into N row strips (strong scaling: the total work is fixed).
-Every rank renders its strip, exchanges 5 border rows of published reservoirs and of the G-buffer id / normal / depth planes
-with its strip neighbours over RCCL point-to-point between phase A and phase B, tone-maps its strip, and the RGBA8 strips are
-gathered on rank 0 (asynchronously: the gather of one frame overlaps the next frame's kernels; the last gathers are waited for
-before the clock stops) -- all inside the timed region.  The frames go through the PRODUCT's strip driver, the C ABI of
-restir_amd/csrc/strips.hip (rs_strips_frame / rs_strips_gather_begin / _end over rs_comm_create_rccl_lib), on an ncclComm_t this
-script creates the way a C++ caller does (ncclGetUniqueId on rank 0, the id broadcast, ncclCommInitRank; restir_amd/rccl.py);
-torch.distributed (gloo) is the control plane only: the id broadcast, barriers, the reduction of the timings.
+A step = one frame.  A ray = one BVH walk (intersect or testOcclusion call): 1 G-buffer ray + 1 shading ray per pixel + 1 shadow ray
+per shaded pixel; counted by the kernels.
+
+N > 1: the framebuffer is cut into N row strips (strong scaling: the total work is fixed).  `python bench.py --gpus N` starts its N
+rank processes itself (fresh children through torch.distributed.run, before this process has made any GPU call) and relays rank 0's
+JSON line; started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  Every rank renders its strip, exchanges
+5 border rows of published reservoirs and of the G-buffer id / normal / depth planes with its strip neighbours over RCCL
+point-to-point between phase A and phase B, [filters its strip, exchanging the border rows of every level,] tone-maps its strip, and
+the RGBA8 strips are gathered on rank 0 (asynchronously: the gather of one frame overlaps the next frame's kernels; the last gathers
+are waited for before the clock stops) -- all inside the timed region.  The frames go through the PRODUCT's strip driver, the C ABI
+of restir_amd/csrc/strips.hip (rs_strips_frame / rs_strips_eaw_filter / rs_strips_gather_begin / _end over rs_comm_create_rccl_lib),
+on an ncclComm_t this script creates the way a C++ caller does (ncclGetUniqueId on rank 0, the id broadcast, ncclCommInitRank;
+restir_amd/rccl.py); torch.distributed (gloo) is the control plane only: the id broadcast, barriers, the reduction of the timings.
   BENCH_STRIP_DRIVER=py      the Python form of the same schedule (restir_amd/tiling.py over torch.distributed) for cross-checks
   BENCH_STRIP_TRANSPORT=gloo the C driver over host callbacks + gloo: rehearsal on a one-GPU box (with BENCH_DEVICE=0 every rank
                              uses the same card; RCCL refuses two ranks on one device)
   BENCH_FORCE_STRIPS=1       N = 1 through the strip driver and a one-rank ncclComm as well
+  BENCH_WATCHDOG=seconds     every rank (and the launcher) ends itself after that long (default 900 with N > 1)
 
 One JSON line is printed by rank 0; besides the contract's fields it carries
-  roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its
-                HIP-event duration (events recorded on the stream the kernel is launched on),
-                against the 8 TB/s HBM3E peak; `traffic` is filled from profiles/ PMC runs when known
+  roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its HIP-event duration (events
+                recorded on the stream the kernel is launched on), against the 8 TB/s HBM3E peak; `traffic` is filled from
+                profiles/ PMC runs when known
+  roofline_eaw  config 5: the five a-trous level kernels, 44 B/px and level
+  per_rank      N > 1: every rank's rows, ms per step, wait for the halo rows, per-pass times
   cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
-  cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a
-                bounded sample of the same workload (rank 0, N = 1 only)
-  parity        N = 1: the frames cpu_baseline rendered, rendered again by the GPU and compared bit for bit (differing_pixels, mean_l1);
+  cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a bounded sample of the same workload
+                (rank 0, N = 1 only)
+  parity        N = 1: the frames cpu_baseline rendered, rendered again by the GPU and compared bit for bit (differing_pixels, mean_l1)
+                with the oracle's cos / sin correctly rounded (the mode the product is exact in);
                 N > 1: six frames through the strip driver from fresh reservoirs, gathered on rank 0 and compared bit for bit with rank 0's
                 own full-frame render of the same frames (`strips_parity` when BENCH_FORCE_STRIPS=1 sends N = 1 through the strip driver)
+  parity_glibc  N = 1: the same GPU frames against the oracle in the mode the compiled reference pins (glibc's cosf / sinf): mean
+                per-pixel L1, fraction of pixels beyond 1e-3, differing pixels -- the tolerance north_star states
   cpu_config1   BASELINE config 1 (Cornell 256x256, 1 spp PTDirect) as a host loop on the same cores
 """
 import argparse
@@ -44,44 +55,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT = 1920, 1080
 REUSE = 3                      # ReservoirReuse::Spatiotemporal
 TONEMAP = 2                    # ToneMapping::ACES (Settings default, src/common.cpp:4)
 ALGO_BYTES_PER_PIXEL = 92      # spatial-reuse pass
+EAW_BYTES_PER_PIXEL_LEVEL = 44 # (12 colour + 20 id/normal/depth) read + 12 written per pixel and level
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per launch from the PMC passes of tools/profile.sh on this same command (FETCH_SIZE x 2 + WRITE_SIZE,
-# the gfx950 correction of MI355X_MICROARCH.md), condensed by tools/summarize_profile.py; counters cannot be read
-# from inside the process, so `roofline.traffic` quotes the committed summary (null if it is absent).
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final2_hbm_counters.json")
+
+CONFIGS = {
+    3: dict(width=1920, height=1080, scene="sponza", denoise=False, cpu_frames=3,
+            workload="BASELINE config 3: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 1920x1080, 32 RIS candidates, "
+                     "spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update"),
+    4: dict(width=3840, height=2160, scene="sponza", denoise=False, cpu_frames=1,
+            workload="BASELINE config 4: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 3840x2160, 32 RIS candidates, "
+                     "spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update"),
+    5: dict(width=1920, height=1080, scene="bistro", denoise=True, cpu_frames=2,
+            workload="BASELINE config 5: procedural Bistro-class seed 2 (2830336 triangles, 10240 emissive), 1920x1080, 32 RIS candidates, "
+                     "spatiotemporal ReSTIR-DI + LeveledEAWFilter (5 levels); frame = GBuffer::render + ReSTIRDirect + LeveledEAWFilter::filter + "
+                     "copyImageToPBO + GBuffer::update"),
+}
 
 
-def pmc_traffic(kernel):
-    """(bytes per launch, the kernel's average duration in that profile): the duration lets a reader see whether the committed
-    summary still describes the kernel that ran here."""
+def profile_file(config, suffix):
+    """The committed rocprofv3 summary of this command for `config` (newest round first; None if there is none)."""
+    for name in ("r04_config%d_%s" % (config, suffix),) + (("r03_final2_%s" % suffix,) if config == 3 else ()):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def pmc_traffic(config, kernel):
+    """(HBM bytes per launch, the kernel's average duration in that profile, file): FETCH_SIZE x 2 + WRITE_SIZE (the gfx950 correction of
+    MI355X_MICROARCH.md) from the separate --pmc passes of tools/profile.sh on this same command, condensed by
+    tools/summarize_profile.py.  Counters cannot be read from inside the process, so `roofline.traffic` quotes the committed summary
+    (null if it is absent); the duration lets a reader see whether the summary still describes the kernel that ran here."""
+    p = profile_file(config, "hbm_counters.json")
     try:
-        with open(PMC_SUMMARY) as fh:
+        with open(p) as fh:
             k = json.load(fh)["kernels"][kernel]
-            return float(k["hbm_bytes_per_launch"]), (float(k["average_ns"]) / 1e3 if k.get("average_ns") else None)
-    except (OSError, KeyError, ValueError):
-        return None, None
+            return float(k["hbm_bytes_per_launch"]), (float(k["average_ns"]) / 1e3 if k.get("average_ns") else None), p
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None, p
 
 
-OVERLAPPED_STATS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final2_kernel_stats_overlapped.csv")
-
-
-def overlapped_kernel_us(kernel):
+def overlapped_kernel_us(config, kernel):
     """Average duration of a kernel in the committed rocprofv3 kernel trace of this command with the frames overlapped."""
+    p = profile_file(config, "kernel_stats_overlapped.csv")
     try:
         import csv
-        with open(OVERLAPPED_STATS) as fh:
+        with open(p) as fh:
             rows = [r for r in csv.reader(fh) if r and not r[0].startswith("#")]
         head = rows[0]
         for r in rows[1:]:
             if r[0] == kernel:
-                return float(r[head.index("average_ns")]) / 1e3
-    except (OSError, ValueError, IndexError):
+                return float(r[head.index("average_ns")]) / 1e3, p
+    except (OSError, ValueError, IndexError, TypeError):
         pass
-    return None
+    return None, p
 
 
 def host_threads():
@@ -96,46 +126,160 @@ def host_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(sd, frames):
-    """The oracle on the host cores: `frames` full 1920x1080 spatiotemporal frames (bounded sample).  Also returns the images of
-    all frames it rendered (the untimed first one included): the checker's side of the `parity` field."""
+# ---- the launcher: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE -------------------------------------------------------------
+
+def launch_ranks(n, argv, script=None, watchdog=960.0, out=None, err=None):
+    """Start the n rank processes of one node as fresh children -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> script argv...`, the command the driver itself uses -- from a process that has made
+    no GPU call (nothing is re-exec'd).  Relays the ranks' stderr as it comes, keeps its tail, and prints the one JSON line rank 0
+    wrote on stdout.  Returns the exit code: the children's if they failed, 124 if they were still running after `watchdog` seconds
+    (their process group -- the one started here -- is killed), 1 if they ended cleanly without a JSON line."""
+    import collections
+    import signal
+    import socket
+    import subprocess
+    import threading
+    out = out or sys.stdout
+    err = err or sys.stderr
+    script = script or os.path.abspath(__file__)
+    with socket.socket() as s:                              # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=err, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    tail = collections.deque(maxlen=60)
+    lines = []
+
+    def pump_err():
+        for line in p.stderr:
+            tail.append(line)
+            err.write(line); err.flush()
+
+    def pump_out():
+        for line in p.stdout:
+            lines.append(line)
+
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    try:
+        rc = p.wait(timeout=watchdog)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the ranks did not finish within %.0f s: killing their process group" % watchdog, file=err, flush=True)
+        try:
+            os.killpg(p.pid, signal.SIGKILL)               # the session started above: the launcher and its ranks, nothing else
+        except ProcessLookupError:
+            pass
+        p.wait()
+        rc = 124
+    for t in threads:
+        t.join(timeout=10)
+    result = None
+    for line in lines:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            try:
+                json.loads(s)
+                result = s
+                continue
+            except ValueError:
+                pass
+        if s:
+            err.write("[ranks stdout] " + line)
+    if rc == 0 and result is None:
+        print("bench.py: the ranks ended with rc 0 but printed no JSON line", file=err, flush=True)
+        rc = 1
+    if rc != 0:
+        print("bench.py: the ranks ended with rc %d; last lines of their stderr:\n%s" % (rc, "".join(list(tail)[-25:])), file=err, flush=True)
+    if result is not None:
+        out.write(result + "\n"); out.flush()
+    return rc
+
+
+# ---- the checker's side (after the timed region; rank 0, N = 1) ---------------------------------------------------------------------------
+
+def oracle_frames(cfg, sd, frames, libm_mode, timed):
+    """`frames` + 1 frames of the workload on the oracle (looper 0.., static camera, fresh reservoirs): the images a GPU run of the same
+    frames is compared with; with `timed`, the cpu_baseline record (the first frame untimed: thread-pool start-up, page faults)."""
+    import numpy as np
+    W, H = cfg["width"], cfg["height"]
     threads = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(threads)          # read by libgomp when liboracle.so is loaded
     from oracle import binding as ob
     from tests.common import OracleRenderer
-    ob.set_libm_mode(1)                                   # cos / sin of the spatial taps correctly rounded: the mode the product is exact in (DESIGN.md 2)
-    o = OracleRenderer(sd, WIDTH, HEIGHT)
-    images = [o.frame(REUSE).copy()]                      # untimed: thread-pool start-up, page faults
-    rays = 0
-    dt = 0.0
-    for _ in range(frames):
-        t0 = time.perf_counter()
-        o.frame(REUSE)
-        dt += time.perf_counter() - t0
-        rays += o.rays + WIDTH * HEIGHT
-        images.append(o.image.copy())
-    ob.set_libm_mode(0)
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "ms_per_frame": dt / frames * 1e3,
-            "sample": f"{frames} frames of the same workload (1920x1080 spatiotemporal, Sponza-class 262144 tris), OpenMP over rows"}, images
+    ob.set_libm_mode(libm_mode)
+    try:
+        o = OracleRenderer(sd, W, H)
+        images, filtered = [], []
+        rays, dt = 0, 0.0
+        for f in range(frames + 1):
+            t0 = time.perf_counter()
+            o.gbuf.render(o.scene, o.cam)
+            o.rays = o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, o.looper, REUSE)
+            if cfg["denoise"]:
+                filtered.append(ob.eaw_filter(o.gbuf, o.cam, o.image).copy())
+            o.gbuf.update(o.cam)
+            o.looper += 1
+            if f > 0:
+                dt += time.perf_counter() - t0
+                rays += o.rays + W * H
+            images.append(o.image.copy())
+    finally:
+        ob.set_libm_mode(0)
+    rec = None
+    if timed and frames > 0:
+        rec = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "ms_per_frame": dt / frames * 1e3,
+               "sample": f"{frames} frames of the same workload ({W}x{H} spatiotemporal, {cfg['scene']}-class scene"
+                         + (", 5-level EAW filter" if cfg["denoise"] else "") + "), OpenMP over rows"}
+    return rec, images, filtered
 
 
-def parity_against(capi, sd, scene, oracle_images):
-    """The frames cpu_baseline rendered (looper 0, 1, ...: static camera, spatiotemporal reuse) once more on the GPU, from fresh
-    reservoirs, in the reference's synchronous mode, compared pixel by pixel: the checker's verdict on the workload that was timed."""
-    import numpy as np
+def gpu_frames(capi, cfg, sd, scene, count):
+    """The checker's frames once more on the GPU, from fresh reservoirs, in the reference's synchronous mode (host copies)."""
+    import torch
     from tests.common import HipRenderer
+    W, H = cfg["width"], cfg["height"]
     capi.set_sync(True)
-    h = HipRenderer(capi, sd, WIDTH, HEIGHT, scene=scene)
-    differing, l1 = 0, 0.0
-    for ref in oracle_images:
-        got = h.frame(REUSE)
-        differing += int(np.count_nonzero((ref.view(np.uint32) != got.view(np.uint32)).any(axis=1)))
-        l1 += float(np.abs(ref.astype(np.float64) - got.astype(np.float64)).sum(axis=1).mean())
+    h = HipRenderer(capi, sd, W, H, scene=scene)
+    eaw = capi.EAWFilter(W, H, 5) if cfg["denoise"] else None
+    out = torch.zeros_like(h.image) if eaw else None
+    images, filtered = [], []
+    for f in range(count):
+        h.gbuf.render(h.scene, h.cam)
+        h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, f, REUSE)
+        if eaw:
+            p = eaw.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+            capi.synchronize()
+            res = torch.empty_like(h.image)
+            capi.hip_memcpy_d2d(res.data_ptr(), p, res.numel() * 4)
+            filtered.append(res.cpu().numpy())
+        h.gbuf.update(h.cam)
+        images.append(h.image.cpu().numpy())
+    if eaw:
+        eaw.destroy()
     capi.set_sync(False)
-    return {"frames": len(oracle_images), "pixels_per_frame": WIDTH * HEIGHT, "differing_pixels": differing, "mean_l1": l1 / len(oracle_images),
-            "checker": "oracle/restir_oracle.c (libm mode: correctly rounded), frames looper 0.. of the benchmark workload from fresh reservoirs, "
-                       "radiance compared bit for bit"}
+    return images, filtered
+
+
+def compare_frames(cfg, ref_images, got_images, ref_filtered, got_filtered, checker):
+    import numpy as np
+    differing, l1, flips, worst = 0, 0.0, 0.0, 0.0
+    for ref, got in zip(ref_images, got_images):
+        d = np.abs(ref.astype(np.float64) - got.astype(np.float64)).sum(axis=1)
+        differing += int(np.count_nonzero((ref.view(np.uint32) != got.view(np.uint32)).any(axis=1)))
+        l1 += float(d.mean()); flips += float(np.mean(d > 1e-3)); worst = max(worst, float(d.max()))
+    n = len(ref_images)
+    rec = {"frames": n, "pixels_per_frame": cfg["width"] * cfg["height"], "differing_pixels": differing, "mean_l1": l1 / n,
+           "fraction_beyond_1e-3": flips / n, "max_l1": worst, "checker": checker}
+    if ref_filtered:
+        # the filter's exponentials are the hardware's: stated tolerance rtol 1e-5 (tests/test_gpu_parity.py test_eaw_filter)
+        err = max(float(np.max(np.abs(a.astype(np.float64) - b) / (1e-6 + 1e-5 * np.abs(a.astype(np.float64))))) for a, b in zip(ref_filtered, got_filtered))
+        rec["eaw_error_over_tolerance"] = err              # <= 1 : within atol 1e-6 + rtol 1e-5 everywhere
+    return rec
 
 
 def cpu_config1(threads, seconds=3.0):
@@ -163,12 +307,11 @@ def cpu_config1(threads, seconds=3.0):
             "sample": f"{frames} frames of Cornell box 256x256, 1 spp pathTraceDirect (primary + one shadow ray per shaded pixel), host loop only"}
 
 
-def cpu_reference_loop(sd, threads):
+def cpu_reference_loop(cfg, sd, threads):
     """The baseline north_star names: a host-side loop over the reference's own intersections.h / bvh.h -- DevScene::intersect's
     traversal around the reference's compiled AABB::intersect / intersectTriangle on the reference builder's tree
     (oracle/_ref/libref_subset.so, prebuilt in the build container; oracle/ref_subset.cpp).  Closest hits of the benchmark view's
-    camera rays (one jittered ray per pixel of the 1920x1080 frame), repeated for about five seconds.  None when the library
-    is not there."""
+    camera rays (one jittered ray per pixel of the frame), repeated for about five seconds.  None when the library is not there."""
     import ctypes as C
     import numpy as np
     os.environ["OMP_NUM_THREADS"] = str(threads)
@@ -176,7 +319,7 @@ def cpu_reference_loop(sd, threads):
     R = ob.ref_subset()
     if R is None:
         return None
-    w, h = WIDTH, HEIGHT
+    w, h = cfg["width"], cfg["height"]
     cam = ob.camera_update(sd.camera(w, h))
     rng = np.random.default_rng(1)
     ys, xs = np.mgrid[0:h, 0:w]
@@ -204,9 +347,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json config (3 = the headline)")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames timed for cpu_baseline (0 = skip; default depends on the config)")
     ap.add_argument("--orbit", action="store_true", help="orbit the camera (runCuda animateCamera) instead of the static default")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    WIDTH, HEIGHT, DENOISE = cfg["width"], cfg["height"], cfg["denoise"]
+    if args.cpu_frames is None:
+        args.cpu_frames = cfg["cpu_frames"]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's own form of the command: this process becomes the launcher (no GPU call has been made, and none will be)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], watchdog=float(os.environ.get("BENCH_WATCHDOG", "900")) + 60.0))
+
     # A rank that waits for a peer that will never answer would hang the whole job: with N > 1 every rank ends itself (Python
     # stacks of all threads on stderr) if the run takes longer than BENCH_WATCHDOG seconds (default 900; N = 1: only when set).
     watchdog = os.environ.get("BENCH_WATCHDOG", "900" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
@@ -222,7 +375,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run, one rank per GPU")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (plain `python bench.py --gpus N` starts the ranks itself)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no fallback"
     # which strip driver runs the frames: "c" = rs_strips_* of librestir_hip (the product; default for N > 1), "py" = restir_amd/tiling.py,
     # "none" = the plain single-GPU calls (default for N = 1)
@@ -249,7 +402,7 @@ def main():
     from restir_amd.tiling import HipBackend, StripRenderer, calibrate_bounds, strip_bounds
     capi.init(device)
 
-    sd = scenes.sponza_class(seed=1, scale=1.0)
+    sd = scenes.sponza_class(seed=1, scale=1.0) if cfg["scene"] == "sponza" else scenes.bistro_class(seed=2, scale=1.0)
     scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
     # BENCH_SOBOL=1: the reference built with SAMPLER_USE_SOBOL true (src/sampler.h:9-36) -- the 10 000 x 200 table of
     # restir_amd/sobol.py on the scene, looper wrapped at 10 000; the default (and the headline) is the default engine
@@ -267,11 +420,12 @@ def main():
         torch.cuda.set_stream(lib_stream)
     backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)          # (hands torch's current stream to the library: rs_set_stream)
     capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
+    min_rows = 32 if DENOISE else 8        # the EAW levels on strips reach 32 rows (rs_strips_eaw_filter)
     # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
     # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights
     bounds = None
     if world > 1 and os.environ.get("BENCH_EVEN_STRIPS", "0") != "1":
-        bounds = calibrate_bounds(backend, world, rank, HEIGHT, dist, torch.cuda.synchronize, reuse=REUSE)
+        bounds = calibrate_bounds(backend, world, rank, HEIGHT, dist, torch.cuda.synchronize, reuse=REUSE, denoise=DENOISE, min_rows=min_rows)
         torch.cuda.synchronize()
         backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)          # fresh reservoirs and G-buffer for the measured run
     if bounds is None:
@@ -285,6 +439,9 @@ def main():
             for i in range(3):
                 cam.position[i] = float(p[i])
             capi.camera_update(cam)
+
+    def next_looper(looper):
+        return looper + 1 if sobol_num is None else (looper + 1) % sobol_num
 
     rccl = None
     fallback = None
@@ -323,6 +480,7 @@ def main():
         # the display image, full-frame sized on every rank (rs_strips_gather addresses rows in place); two of them, so that the
         # gather of frame f travels while frame f + 1 renders
         pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        eaw = capi.EAWFilter(WIDTH, HEIGHT, 5) if DENOISE else None
 
         def frame(bk=None, st=None, pb=None):
             # (bk, st, pb: another set of render objects, frame counters and display buffers -- the parity check below runs this very
@@ -330,13 +488,17 @@ def main():
             bk, st, pb = bk or backend, st or state, pb or pbos
             move_camera(st["looper"])
             drv.frame(bk.restir, scene, cam, bk.gbuf, bk.image.data_ptr(), 0, st["looper"], REUSE)
+            shown = bk.image.data_ptr()
+            if DENOISE:
+                shown = drv.eaw_filter(eaw, bk.gbuf, cam, bk.image.data_ptr())      # rows [y0, y1) of the driver's result buffer
+            st["shown"] = shown
             bk.gbuf.update(cam)
             if args.orbit and world > 1:
                 drv.exchange_history(bk.restir, bk.gbuf)
-            st["looper"] = st["looper"] + 1 if sobol_num is None else (st["looper"] + 1) % sobol_num
+            st["looper"] = next_looper(st["looper"])
             k = st["frame_no"] % 2; st["frame_no"] += 1
             drv.gather_end(k)                                           # the gather that read pb[k] two frames ago
-            capi.copy_image_to_pbo(pb[k].data_ptr() + y0 * WIDTH * 4, bk.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+            capi.copy_image_to_pbo(pb[k].data_ptr() + y0 * WIDTH * 4, shown + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
             drv.gather_begin(pb[k].data_ptr(), 4, 0, k)
 
         def finish_gathers():
@@ -354,16 +516,28 @@ def main():
         pbos = [torch.zeros((strips.max_rows * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
         gather_outs = [[torch.empty_like(pbos[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in pbos]
         pending = [None] * len(pbos)
+        eaw = capi.EAWFilter(WIDTH, HEIGHT, 5) if (DENOISE and world == 1) else None
+        eaw_out = torch.zeros_like(backend.image) if eaw else None
 
         def frame():
             move_camera(strips.looper)
-            strips.frame(REUSE, 0)             # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), GBuffer::update
+            if eaw is not None:                # N = 1 with the filter: the plain calls, LeveledEAWFilter::filter as one call (rs_eaw_filter)
+                backend.gbuffer_render(0, HEIGHT)
+                backend.phase_a(strips.looper, REUSE, 0, HEIGHT)
+                backend.phase_b(0, REUSE, 0, HEIGHT)
+                shown = eaw.filter(eaw_out.data_ptr(), backend.image.data_ptr(), backend.gbuf, cam)
+                backend.end_frame()
+                strips.looper += 1
+            else:
+                strips.frame(REUSE, 0, denoise=DENOISE)    # GBuffer::render, ReSTIRDirect (phase A, halo, phase B), [filter], GBuffer::update
+                shown = (strips.filtered if DENOISE else backend.image).data_ptr()
+            state["shown"] = shown
             if sobol_num is not None:
                 strips.looper %= sobol_num
             k = state["frame_no"] % len(pbos); state["frame_no"] += 1
             if pending[k] is not None:
                 pending[k].wait(); pending[k] = None
-            capi.copy_image_to_pbo(pbos[k].data_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
+            capi.copy_image_to_pbo(pbos[k].data_ptr(), shown + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0)
             if world > 1:
                 pending[k] = dist.gather(pbos[k], gather_outs[k], dst=0, async_op=True)
 
@@ -402,6 +576,7 @@ def main():
         frame()
     barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     timed_form = backend.restir.last_launch()             # (fused, chains) of the timed frames' launches: read before any other mode runs
     counted = min(args.steps, 1024)
     # G-buffer rays: only the strip's own rows count (the +-5 halo rows a strip re-renders are overhead, not throughput)
@@ -420,9 +595,6 @@ def main():
     capi.set_sync(False)
     barrier()
 
-    # per-pass times of a few extra (untimed) frames, HIP events on the library's stream; the G-buffer render is kept on
-    # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
-    # primary-ray and RIS kernels from the library's second stream)
     # how long this rank's library stream sat waiting for the neighbours' border rows (the part of the exchange the interior rows
     # of phase B did not hide), frames overlapped as in the timed region, read after each frame
     halo_wait = []
@@ -436,6 +608,9 @@ def main():
         drv.enable_timing(False)
         barrier()
 
+    # per-pass times of a few extra (untimed) frames, HIP events on the library's stream; the G-buffer render is kept on
+    # that stream for these frames so that every pass is timed alone (in the timed region above it overlaps the
+    # primary-ray and RIS kernels from the library's second stream)
     capi.set_side_stream(0)
     backend.restir.enable_timing(True)
     spatial_ms, pass_ms = [], np.zeros(4)
@@ -445,7 +620,7 @@ def main():
         ms = backend.restir.pass_times()
         spatial_ms.append(ms[3]); pass_ms += np.array(ms)
     pass_ms /= len(spatial_ms)
-    # the two passes outside ReSTIRDirect (the library enqueues on the null stream, which is torch's current stream here)
+    # the passes outside ReSTIRDirect (the library enqueues on the stream it was handed, which is torch's current stream here)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     gb_ms, pbo_ms = [], []
     for _ in range(10):
@@ -453,6 +628,29 @@ def main():
         ev[2].record(); capi.copy_image_to_pbo(pbo_ptr(), backend.image.data_ptr() + y0 * WIDTH * 12, WIDTH, rows, TONEMAP, 1.0); ev[3].record()
         torch.cuda.synchronize()
         gb_ms.append(ev[0].elapsed_time(ev[1])); pbo_ms.append(ev[2].elapsed_time(ev[3]))
+    # config 5: the filter's position pass and its five levels, each alone (rs_eaw_positions_rows / rs_eaw_level_rows on this rank's rows;
+    # the rows outside the strip hold what the last frame's exchange left there -- same work, the values do not matter here)
+    eaw_level_ms = None
+    if DENOISE:
+        f = capi.EAWFilter(WIDTH, HEIGHT, 5)
+        bufs = [torch.zeros_like(backend.image), torch.zeros_like(backend.image)]
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        acc = np.zeros(6)
+        reps = 10
+        for _ in range(reps + 2):
+            evs[0].record()
+            f.positions_rows(backend.gbuf, cam, max(0, y0 - 32), min(HEIGHT, y1 + 32))
+            evs[1].record()
+            for level in range(5):
+                src = backend.image if level == 0 else bufs[(level - 1) % 2]
+                f.level_rows(bufs[level % 2].data_ptr(), src.data_ptr(), backend.gbuf, level, y0, y1)
+                evs[level + 2].record()
+            torch.cuda.synchronize()
+            if _ >= 2:
+                acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(6)])
+        eaw_level_ms = (acc / reps).tolist()
+        f.destroy()
+        del bufs
     capi.set_side_stream(4)
     backend.restir.enable_timing(False)
 
@@ -460,8 +658,9 @@ def main():
     # N > 1 (and BENCH_FORCE_STRIPS): the strips' image against a full frame.  Fresh reservoirs, G-buffers and display buffers on every rank
     # for the strip driver, a full-frame renderer of its own on rank 0, the same six frames through both -- the strips through the very
     # frame() of the timed region, launches overlapped, the display image gathered behind the next frame.  After every frame the ranks' rows
-    # of the RADIANCE image are gathered on rank 0 as well (rs_strips_gather) and compared with the full frame's BIT FOR BIT; at the end the
-    # last two DISPLAY images (RGBA8, the asynchronous gathers) are compared with the full frame's tone-mapped ones byte for byte.
+    # of the RADIANCE image (config 5: of the FILTERED image) are gathered on rank 0 as well (rs_strips_gather) and compared with the full
+    # frame's BIT FOR BIT; at the end the last two DISPLAY images (RGBA8, the asynchronous gathers) are compared with the full frame's
+    # tone-mapped ones byte for byte.
     strips_parity = None
     if driver == "c":
         chk = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
@@ -469,18 +668,22 @@ def main():
         chk_pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
         ref = StripRenderer(HipBackend(capi, scene, cam, WIDTH, HEIGHT), 1, 0, HEIGHT) if rank == 0 else None
         ref_pbos = [torch.zeros((HEIGHT * WIDTH, 4), dtype=torch.uint8, device="cuda") for _ in range(2)] if rank == 0 else None
+        gathered = torch.zeros_like(chk.image)
         differing, l1_sum, frames_checked = 0, 0.0, 6
         for f in range(frames_checked):
             frame(chk, chk_state, chk_pbos)
-            drv.gather(chk.image.data_ptr(), 12, 0)
+            # the strip's rows of what was shown, copied into a buffer of our own (the driver's filter result buffer is the driver's)
+            capi.hip_memcpy_d2d(gathered.data_ptr() + y0 * WIDTH * 12, chk_state["shown"] + y0 * WIDTH * 12, rows * WIDTH * 12)
+            drv.gather(gathered.data_ptr(), 12, 0)
             if ref is not None:
                 ref.looper = f
-                ref.frame(REUSE, 0)
-                capi.copy_image_to_pbo(ref_pbos[f % 2].data_ptr(), ref.b.image.data_ptr(), WIDTH, HEIGHT, TONEMAP, 1.0)
+                ref.frame(REUSE, 0, denoise=DENOISE)
+                ref_img = ref.filtered if DENOISE else ref.b.image
+                capi.copy_image_to_pbo(ref_pbos[f % 2].data_ptr(), ref_img.data_ptr(), WIDTH, HEIGHT, TONEMAP, 1.0)
                 capi.synchronize(); torch.cuda.synchronize()
-                a, b = chk.image.view(torch.int32), ref.b.image.view(torch.int32)
+                a, b = gathered.view(torch.int32), ref_img.view(torch.int32)
                 differing += int((a != b).any(dim=1).sum().item())
-                l1_sum += float((chk.image - ref.b.image).abs().sum(dim=1).mean().item())
+                l1_sum += float((gathered - ref_img).abs().sum(dim=1).mean().item())
                 if os.environ.get("BENCH_PARITY_ROWS", "0") == "1":          # which rows differ (debugging a failed check)
                     bad_rows = (a != b).any(dim=1).view(HEIGHT, WIDTH).any(dim=1).nonzero().flatten().tolist()
                     print("bench.py: strips parity, frame %d: %d rows differ: %s (strip bounds %s)" % (f, len(bad_rows), bad_rows[:40], bounds), file=sys.stderr, flush=True)
@@ -494,8 +697,22 @@ def main():
         strips_parity = {"frames": frames_checked, "pixels_per_frame": WIDTH * HEIGHT, "differing_pixels": differing, "mean_l1": l1_sum / frames_checked,
                          "display_frames": 2, "display_differing_pixels": display_differing,
                          "checker": "rank 0's own full-frame render of the same frames from fresh reservoirs (librestir_hip, which the N = 1 line pins to the "
-                                    "oracle): radiance of the gathered strips bit for bit after every frame, the last two asynchronously gathered RGBA8 "
-                                    "display images byte for byte; launches overlapped as in the timed region"}
+                                    "oracle): " + ("filtered image" if DENOISE else "radiance") + " of the gathered strips bit for bit after every frame, the last two "
+                                    "asynchronously gathered RGBA8 display images byte for byte; launches overlapped as in the timed region"}
+
+    # what every rank saw, for the reader of a multi-GPU line: the slowest rank decides the frame time
+    mine = {"rank": rank, "device": device, "rows": rows, "ms_per_step": own_elapsed / args.steps * 1e3,
+            "ms_per_frame_synchronous": float(np.median(sync_ms[2:])),
+            "halo_wait_ms": (float(np.median(halo_wait)) if halo_wait else None),
+            "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]),
+                        "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3]),
+                        **({"eaw_positions": eaw_level_ms[0], "eaw_levels": eaw_level_ms[1:]} if eaw_level_ms else {})},
+            "rays_per_frame": local_rays / args.steps}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     t = torch.tensor([elapsed, float(local_rays)], dtype=torch.float64, device=ctl_device)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -520,11 +737,12 @@ def main():
 
     if rank == 0:
         spatial_us = float(np.median(spatial_ms)) * 1e3
-        overlapped_us = overlapped_kernel_us("k_spatial_shade")
+        overlapped_us, overlapped_src = overlapped_kernel_us(args.config, "k_spatial_shade")
+        traffic, traffic_us, traffic_src = pmc_traffic(args.config, "k_spatial_shade")
         algo_bytes = ALGO_BYTES_PER_PIXEL * WIDTH * rows
         achieved = algo_bytes / (spatial_us * 1e-6) / 1e9
         out = {
-            "metric": "Mrays/s (1920x1080 ReSTIR-DI, 32 candidates, spatiotemporal reuse)",
+            "metric": "Mrays/s (%dx%d ReSTIR-DI, 32 candidates, spatiotemporal reuse%s)" % (WIDTH, HEIGHT, " + 5-level EAW filter" if DENOISE else ""),
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -537,8 +755,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: procedural Sponza-class seed 1 (262144 triangles, 1024 emissive), 1920x1080, "
-                                   "32 RIS candidates, spatiotemporal ReSTIR-DI; frame = GBuffer::render + ReSTIRDirect + copyImageToPBO + GBuffer::update",
+            "config": {"workload": cfg["workload"],
+                       "baseline_config": args.config,
                        "camera": "orbit" if args.orbit else "static",
                        "sampler": "default engine (thrust minstd_rand, SAMPLER_USE_SOBOL false: the reference's default)" if sobol_num is None else
                                   "Sobol (src/sampler.h:9-36) over the build's own %d x 200 table" % sobol_num,
@@ -547,9 +765,11 @@ def main():
                                    "ms_per_frame_synchronous is one frame alone with a synchronisation after every call, the reference's mode",
                        "tiling": (f"{world} row strips of " + "/".join(str(b - a) for a, b in bounds) + " rows (" +
                                   ("equal heights" if os.environ.get("BENCH_EVEN_STRIPS", "0") == "1" else "cost-balanced by measurement") + "), "
-                                  "5 border rows of reservoirs + G-buffer id / normal / depth point-to-point (68 B/px), RGBA8 gather to rank 0") if world > 1 else "none",
-                       "strip_driver": {"c": "librestir_hip rs_strips_frame / rs_strips_gather_begin,_end (restir_amd/csrc/strips.hip)",
-                                        "py": "restir_amd/tiling.py over torch.distributed (%s)" % backend_name, "none": "none (single GPU: rs_gbuffer_render + rs_restir_direct)"}[driver],
+                                  "5 border rows of reservoirs + G-buffer id / normal / depth point-to-point (68 B/px)" +
+                                  (", 32 G-buffer rows + 2 << level colour rows per EAW level" if DENOISE else "") + ", RGBA8 gather to rank 0") if world > 1 else "none",
+                       "strip_driver": {"c": "librestir_hip rs_strips_frame / " + ("rs_strips_eaw_filter / " if DENOISE else "") + "rs_strips_gather_begin,_end (restir_amd/csrc/strips.hip)",
+                                        "py": "restir_amd/tiling.py over torch.distributed (%s)" % backend_name,
+                                        "none": "none (single GPU: rs_gbuffer_render + rs_restir_direct" + (" + rs_eaw_filter)" if DENOISE else ")")}[driver],
                        "transport": ("none" if driver == "none" else "torch.distributed " + backend_name if driver == "py" else
                                      "RCCL ncclSend / ncclRecv groups on the library stream, one group per frame (rs_comm_create_rccl_lib), ncclComm_t made by ncclCommInitRank from " + str(rccl.path)
                                      if transport == "rccl" else "host callbacks over torch.distributed gloo (rehearsal, not RCCL)"),
@@ -559,20 +779,31 @@ def main():
                        "halo_wait_ms_rank0": (float(np.median(halo_wait)) if halo_wait else None),
                        "rays_per_frame": total_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_spatial_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_spatial_shade")[0] if world == 1 else None,
-                         "traffic_source": "profiles/" + os.path.basename(PMC_SUMMARY) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
-                                           "the kernel lasted %s us there)" % pmc_traffic("k_spatial_shade")[1],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic if world == 1 else None,
+                         "traffic_source": (("profiles/" + os.path.basename(traffic_src) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                             "the kernel lasted %s us there)" % traffic_us) if traffic_src else None),
                          "algorithmic_bytes": algo_bytes, "kernel_us": spatial_us,
                          # the same kernel inside the timed region's mode shares the CUs with the kernels of the other frames: its duration
                          # there comes from the committed kernel trace of this command with the frames overlapped (events would need the
                          # host to wait inside the frames, which drains the overlap they are meant to observe)
                          "kernel_us_in_overlapped_frame": overlapped_us,
                          "frac_in_overlapped_frame": (algo_bytes / (overlapped_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (overlapped_us and world == 1) else None,
-                         "overlapped_source": "profiles/" + os.path.basename(OVERLAPPED_STATS),
+                         "overlapped_source": ("profiles/" + os.path.basename(overlapped_src)) if overlapped_src else None,
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},
-            "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]), "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3])},
+            "pass_ms": mine["pass_ms"],
         }
+        if eaw_level_ms:
+            eaw_us = sum(eaw_level_ms[1:]) * 1e3
+            eaw_bytes = EAW_BYTES_PER_PIXEL_LEVEL * WIDTH * rows * 5
+            out["roofline_eaw"] = {"bound": "hbm", "kernel": "k_wavelet_tiled (the five a-trous levels, steps 1..16)", "achieved": eaw_bytes / (eaw_us * 1e-6) / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eaw_bytes / (eaw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": pmc_traffic(args.config, "k_wavelet_tiled")[0] if world == 1 else None,
+                                   "algorithmic_bytes": eaw_bytes, "kernel_us": eaw_us, "level_us": [x * 1e3 for x in eaw_level_ms[1:]],
+                                   "positions_us": eaw_level_ms[0] * 1e3,
+                                   "note": "44 B per pixel and level (SURVEY.md 8d); `traffic` = mean HBM bytes of ONE level launch from the committed counters"}
+        if world > 1:
+            out["per_rank"] = per_rank
         fused, chains = timed_form                            # what the timed frames launched, as the library reported it then
         form = "one fused launch" if fused == 1 else "two launches"
         how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
@@ -581,10 +812,22 @@ def main():
         if strips_parity is not None:
             out["parity" if world > 1 else "strips_parity"] = strips_parity       # N = 1 through the strip driver keeps the oracle's `parity` below
         if world == 1 and args.cpu_frames > 0 and sobol_num is None:
-            out["cpu_baseline"], oracle_images = cpu_baseline(sd, args.cpu_frames)
-            out["parity"] = parity_against(capi, sd, scene, oracle_images)
+            n = args.cpu_frames
+            out["cpu_baseline"], exact_images, exact_filtered = oracle_frames(cfg, sd, n, 1, True)
+            got_images, got_filtered = gpu_frames(capi, cfg, sd, scene, n + 1)
+            out["parity"] = compare_frames(cfg, exact_images, got_images, exact_filtered, got_filtered,
+                                           "oracle/restir_oracle.c (libm mode: correctly rounded), frames looper 0.. of the benchmark workload from fresh "
+                                           "reservoirs, radiance compared bit for bit" + ("; the filtered image within rtol 1e-5" if DENOISE else ""))
+            del exact_images, exact_filtered
+            _, glibc_images, glibc_filtered = oracle_frames(cfg, sd, n, 0, False)
+            out["parity_glibc"] = compare_frames(cfg, glibc_images, got_images, glibc_filtered, got_filtered,
+                                                 "oracle/restir_oracle.c in the mode the compiled reference pins (glibc cosf / sinf in the spatial taps, "
+                                                 "src/restir.cu:47-56, src/mathUtil.h:128-132): stated tolerance mean per-pixel L1 < 1e-4 and at most 1e-3 of the "
+                                                 "pixels beyond 1e-3")
+            out["parity_glibc"]["within_tolerance"] = bool(out["parity_glibc"]["mean_l1"] < 1e-4 and out["parity_glibc"]["fraction_beyond_1e-3"] <= 1e-3)
+            del glibc_images, glibc_filtered, got_images, got_filtered
             out["cpu_config1"] = cpu_config1(out["cpu_baseline"]["cores"])
-            ref_loop = cpu_reference_loop(sd, out["cpu_baseline"]["cores"])
+            ref_loop = cpu_reference_loop(cfg, sd, out["cpu_baseline"]["cores"])
             if ref_loop is not None:
                 out["cpu_reference_loop"] = ref_loop
         print(json.dumps(out), flush=True)

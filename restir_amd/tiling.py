@@ -219,11 +219,14 @@ class StripRenderer:
         self.looper += 1
 
 
-def calibrate_bounds(backend, world, rank, height, dist, synchronize, reuse=3, rounds=3, frames=8):
+def calibrate_bounds(backend, world, rank, height, dist, synchronize, reuse=3, rounds=3, frames=8, denoise=False, min_rows=8):
     """Cost-balanced strip bounds from measurement: every rank times its own strip's kernels alone (no halo exchange, so a
     slow neighbour does not leak into the number), the times are all-gathered, `rebalance_bounds` moves the boundaries, and the
     loop repeats.  Rows around the horizon of a scene cost several times what sky or floor rows cost, and the slowest strip
     sets the frame time.  All ranks compute the same bounds (pure function of the gathered times).
+
+    denoise: the frames include LeveledEAWFilter on the strip (its cost per row is uniform, which flattens the balance);
+    min_rows: the shortest strip allowed (32 with the filter, whose levels reach 32 rows into the neighbours).
 
     `synchronize()` waits for the backend's device work (a no-op for a CPU backend).  The frames rendered here leave
     reservoir and G-buffer contents behind that a fresh run would not have (stale slots are visible to the spatial pass, Q1):
@@ -237,17 +240,18 @@ def calibrate_bounds(backend, world, rank, height, dist, synchronize, reuse=3, r
     for _ in range(rounds):
         s = StripRenderer(backend, world, rank, height, bounds=bounds)
         s.start_halo_exchange = lambda: ([], [], [])            # the strip's own kernels only
+        s._exchange_rows = lambda rows, get, put: None
         for _ in range(2):
-            s.frame(reuse, 0)
+            s.frame(reuse, 0, denoise=denoise)
         synchronize()
         t0 = time.perf_counter()
         for _ in range(frames):
-            s.frame(reuse, 0)
+            s.frame(reuse, 0, denoise=denoise)
         synchronize()
         mine = torch.tensor([(time.perf_counter() - t0) / frames], dtype=torch.float64, device=device)
         out = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(out, mine)
-        bounds = rebalance_bounds(bounds, [float(t[0]) for t in out], height)
+        bounds = rebalance_bounds(bounds, [float(t[0]) for t in out], height, min_rows=min_rows)
     return bounds
 
 
