@@ -163,23 +163,22 @@ int  rs_set_sync(int sync);
  * be deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal:
  * faster or slower by a few percent depending on the scene and the launch size, so by default
  * every rs_restir measures the frame period both ways once per scene (frames 2..13) and keeps the faster.
- *   0 = everything on the library stream (also RS_SIDE_STREAM=0)
- *   1 = overlapped frames, the render always its own launch (also RS_FUSE_GBUFFER=0)
- *   2 = overlapped frames, the render always deferred for launches of at least three rounds of the chip's wave slots (RS_FUSE_GBUFFER=1)
+ *   0 = everything on the library stream (RS_SIDE_STREAM=0 in the environment pre-sets this: the profiling scripts use it)
+ *   1 = overlapped frames, the render always its own launch
+ *   2 = overlapped frames, the render always deferred for launches of at least three rounds of the chip's wave slots
  *   3 = like 2 for launches of any size
  *   4 = overlapped frames, measured choice (the default) */
 int  rs_set_side_stream(int enable);
 /* The RIS pass keeps the light table (up to 1 024 lights) in LDS, one copy per 1 024-thread block; a launch of fewer than `pixels`
  * pixels reads it from global memory in 256-thread blocks instead, which spread evenly over the CUs (default 384 Ki pixels, i.e.
- * about 1.5 of the large blocks per CU; also RS_RIS_GLOBAL_BELOW).  Same results either way; 0 = always LDS. */
+ * about 1.5 of the large blocks per CU).  Same results either way; 0 = always LDS. */
 int  rs_set_ris_table_pixels(int pixels);
 /* How the overlapped mode spreads a frame's kernels over the internal streams (a setting of the current context; every argument
  * -1 = keep).  chainStreams 1 / 2: the primary-ray -> RIS -> shadow-ray chains of all frames on one stream, or of alternating frames on
  * two (default 2).  smallChains 0 / 1: a launch below three rounds of the chip's wave slots (a strip) takes the fused render and rotates
  * its chains over three streams (default 1).  shadowOnMain 0 / 1 / 2: the shadow rays never / always / for launches of at least three
  * rounds of wave slots (default 2) on the library stream.  Results are identical in every setting (tools/soak_async.py); the defaults
- * are what measured fastest.  Until this is called the context takes its defaults from the environment
- * variables RS_PARITY_STREAMS (0: one chain stream), RS_SMALL_CHAINS, RS_SHADOW_ON_MAIN, read once per context -- tuning runs only.
+ * are what measured fastest.
  * No entry point waits on the host in overlapped mode: the measurement of rs_set_side_stream's mode 4 polls its last time stamp
  * (hipEventQuery at the frame ends) and frames take two launches until it has arrived. */
 int  rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain);
@@ -187,7 +186,7 @@ int  rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain);
  * nodes the last time the same launch ran is traced by four waves of 16 rays instead of one of 64 -- a launch that runs alone lasts
  * as long as its longest chain of node fetches; results do not depend on the grouping.  Applies where launches run one after the
  * other (synchronous mode, per-pass timing); 0 = off; negative = |threshold| for every launch, also with the frames overlapped
- * (measured slower there); default 768 (RS_TILE_SPLIT). */
+ * (measured slower there); default 768. */
 int  rs_set_tile_split(int threshold);
 int  rs_synchronize(void);
 
@@ -406,8 +405,9 @@ typedef struct rs_transport {
 } rs_transport;
 /* ncclComm: an ncclComm_t of `world` ranks created by the caller (ncclCommInitRank); librccl.so is opened at run time, the
  * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on the library stream (rs_set_stream), between
- * the launch that packs the border rows and the interior rows of phase B; RS_STRIPS_COMM_STREAM=1 in the environment puts them on
- * a stream of the strip driver instead (measured slower: a fifth stream shares a hardware queue with a chain) */
+ * the launch that packs the border rows and the interior rows of phase B; rs_strips_set_comm_stream(strips, 1) puts them on
+ * a stream of the strip driver instead (measured slower with a transport that moves nothing: a fifth stream shares a hardware queue
+ * with a chain) */
 int  rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** comm);
 /* The same, naming the copy of RCCL that created ncclComm (a process can hold two: PyTorch wheels bundle their own librccl.so).
  * librcclPath NULL or "" = rs_comm_create_rccl's search: symbols the process has linked or loaded globally, else a copy already
@@ -421,6 +421,10 @@ int  rs_comm_self_exchange(rs_comm* comm, const void* devSend, void* devRecv, si
 int  rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs_strips** strips);
 int  rs_strips_destroy(rs_strips* strips);
 int  rs_strips_rows(const rs_strips* strips, int* y0, int* y1);
+/* Stream-ordered transports (RCCL): 0 (default) = the transfers are enqueued on the library stream, in order with the packing and
+ * unpacking copies; 1 = on a stream of the driver, ordered by events, so that the interior rows of phase B run while the border rows
+ * travel.  Same results.  Call between frames with no gather in flight. */
+int  rs_strips_set_comm_stream(rs_strips* strips, int ownStream);
 /* GBuffer::render + ReSTIRDirect of this rank's rows; GBuffer::update stays with the caller, as in runCuda.  Afterwards rows
  * [y0, y1) of devDirectIllum hold the frame's radiance. */
 int  rs_strips_frame(rs_strips* strips, rs_restir* r, const rs_scene* scene, const rs_camera* cam, rs_gbuffer* g,
@@ -531,7 +535,9 @@ int  rs_eaw_set_tiled(rs_eaw* f, int tiled);
  * order, as a host build of the reference without contraction computes it.  1: fused multiply-adds for the three squared distances, for
  * the exponent -(dc.dc / sigLumin + dn.dn / sigNormal + dp.dp / sigDepth) * log2(e) as one chain over coefficients -log2(e) / sigma, and
  * for sum += colour * w -- what a contracting compiler (nvcc's default) is free to produce; 36 vector instructions per tap for 50.  The
- * results agree to a few ulp (all sums are of non-negative terms); both stay inside the filter's stated rtol 1e-5 against the oracle. */
+ * results agree to a few ulp (all sums are of non-negative terms); both stay inside the filter's stated rtol 1e-5 against the oracle.
+ * DEFAULT 1 (a deviation from the reference's operation order that the parity contract states: the filters are compared within rtol,
+ * never bit for bit); a caller that wants the reference's order sets 0. */
 int  rs_eaw_set_fused(rs_eaw* f, int fused);
 /* LeveledEAWFilter::filter (src/denoiser.cu:463-477): *devColorOut is in/out exactly like the
  * reference's `glm::vec3*& devColorOut` (it is swapped with the filter's internal buffer). */
@@ -553,7 +559,8 @@ int  rs_svgf_get_params(const rs_svgf* f, float* sigLumin, float* sigNormal, flo
 int  rs_svgf_set_tiled(rs_svgf* f, int tiled);
 /* The arithmetic of a tap, as rs_eaw_set_fused: fused dot products and accumulation, one multiplication per exponent (the colour
  * weight's -log2(e) / denominator and the luminance staged once per pixel).  Acts with the reference's defaults sigNormal 128 and a
- * power-of-two sigDepth; other sigmas keep the separately rounded operations.  Stated tolerance against the oracle as before: rtol 3e-5. */
+ * power-of-two sigDepth; other sigmas keep the separately rounded operations.  Stated tolerance against the oracle as before: rtol 3e-5.
+ * DEFAULT 1, as rs_eaw_set_fused. */
 int  rs_svgf_set_fused(rs_svgf* f, int fused);
 /* SpatioTemporalFilter::filter (src/denoiser.cu:532-564): temporal accumulation (alpha .2), variance estimate, five
  * variance-guided a-trous levels.  *devColorOut is the reference's `glm::vec3*& devColorOut`: it is swapped with the

@@ -67,15 +67,15 @@ hipStream_t rs_aux_stream_any(int i) {
 hipStream_t rs_aux_stream(int i) {
     rs_context* c = rs_ctx();
     if (c->auxMode < 0) {
+        // RS_SIDE_STREAM=0 pre-sets rs_set_side_stream(0) for a process that cannot call it: the profiling scripts in tools/ time every
+        // kernel alone on one stream under rocprofv3
         const char* e = std::getenv("RS_SIDE_STREAM");
         c->auxMode = (e && e[0] == '0') ? 0 : 1;
     }
     if (c->sync || !c->auxMode || i < 0 || i >= rs_context::kAux) return nullptr;
     if (!c->aux[i]) {
-        // measurement switch RS_AUX_PRIORITY="p0,p1,p2": HIP stream priority of each auxiliary stream (0 = default; negative = higher)
-        int prio = 0;
-        if (const char* e = std::getenv("RS_AUX_PRIORITY")) { int p[3] = { 0, 0, 0 }; if (std::sscanf(e, "%d,%d,%d", &p[0], &p[1], &p[2]) >= 1) prio = p[i]; }
-        const hipError_t err = prio ? hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+        // (stream priorities were A/B'd in round 3 and changed nothing: EXPERIMENTS.md)
+        const hipError_t err = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         if (err != hipSuccess) { c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
     }
     return c->aux[i];
@@ -83,31 +83,24 @@ hipStream_t rs_aux_stream(int i) {
 // In asynchronous mode GBuffer::render can be deferred and launched by ReSTIRDirect together with its primary rays (the two rays
 // of a pixel in one packet walk).  That saves walk work on a full frame, but the slowest tile of the launch takes longer, which
 // costs on scenes whose closest-hit kernels are tails of a few long tiles: by default every rs_restir measures the
-// frame period both ways once and keeps the faster (restir.hip).  RS_FUSE_GBUFFER=0 / 1 force it off / on.
+// frame period both ways once and keeps the faster (restir.hip); rs_set_side_stream(1) / (2) force it off / on.
 // 0 never, 1 always (launches of at least three rounds of wave slots), 2 always (any size), 3 decided per rs_restir by measuring
 int rs_fuse_mode() {
     rs_context* c = rs_ctx();
-    if (c->fuseMode < 0) {
-        const char* e = std::getenv("RS_FUSE_GBUFFER");
-        c->fuseMode = !e ? 3 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : 3;
-    }
+    if (c->fuseMode < 0) c->fuseMode = 3;
     return c->fuseMode;
 }
 bool rs_fuse_enabled() { return rs_fuse_mode() != 0; }
 const rs_context* rs_stream_plan() {
     rs_context* c = rs_ctx();
-    if (c->chainStreams < 0) { const char* e = std::getenv("RS_PARITY_STREAMS"); c->chainStreams = (e && e[0] == '0') ? 1 : 2; }
-    if (c->smallChains < 0) { const char* e = std::getenv("RS_SMALL_CHAINS"); c->smallChains = (e && e[0] == '0') ? 0 : 1; }
-    if (c->shadowOnMain < 0) { const char* e = std::getenv("RS_SHADOW_ON_MAIN"); const int v = e ? std::atoi(e) : 2; c->shadowOnMain = (v >= 0 && v <= 2) ? v : 2; }
+    if (c->chainStreams < 0) c->chainStreams = 2;          // the defaults of rs_set_stream_plan
+    if (c->smallChains < 0) c->smallChains = 1;
+    if (c->shadowOnMain < 0) c->shadowOnMain = 2;
     return c;
 }
 int rs_ris_global_below() {
     rs_context* c = rs_ctx();
-    if (c->risGlobalBelow < 0) {
-        const char* e = std::getenv("RS_RIS_GLOBAL_BELOW");
-        c->risGlobalBelow = e ? std::atoi(e) : 384 * 1024;
-        if (c->risGlobalBelow < 0) c->risGlobalBelow = 0;
-    }
+    if (c->risGlobalBelow < 0) c->risGlobalBelow = 384 * 1024;
     return c->risGlobalBelow;
 }
 int rs_aux_synchronize() {
@@ -145,7 +138,7 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam) {
 // ---- tile-split hints ---------------------------------------------------------------------------------------------------------
 int rs_tile_split_threshold() {
     rs_context* c = rs_ctx();
-    if (!c->tileSplitSet) { const char* e = std::getenv("RS_TILE_SPLIT"); c->tileSplit = e ? std::atoi(e) : 768; c->tileSplitSet = true; }
+    if (!c->tileSplitSet) { c->tileSplit = 768; c->tileSplitSet = true; }
     return c->tileSplit;
 }
 void rs_tile_split_free(rs_tile_split* t) {
@@ -251,7 +244,6 @@ int rs_set_side_stream(int enable) {
 //   smallChains   0 / 1: a launch below three rounds of wave slots (a strip) fuses the render with the primary rays and rotates
 //                 its chains over three streams (default 1)
 //   shadowOnMain  0 never / 1 always / 2 for launches that fill the chip three times over (default): the shadow rays on the library stream
-// Defaults come from RS_PARITY_STREAMS, RS_SMALL_CHAINS, RS_SHADOW_ON_MAIN when set (tuning runs), read once per context.
 int rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain) {
     rs_context* c = rs_ctx();
     if (chainStreams > 2 || smallChains > 1 || shadowOnMain > 2 || chainStreams == 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_stream_plan: value out of range");

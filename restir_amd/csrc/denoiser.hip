@@ -479,8 +479,7 @@ int wavelet_level(const rs_eaw* f, float* out, const float* in, const rs_gbuffer
     const int mul = fused ? kFusedTaps : (pow2(f->sigLumin) ? 1 : 0) | (pow2(f->sigNormal) ? 2 : 0) | (pow2(f->sigDepth) ? 4 : 0);
     const auto coef = [](float sigma) { return (float)(-1.44269504088896340736 / (double)sigma); };
     const float aDepth = fused ? coef(f->sigDepth) : f->sigDepth, aNormal = fused ? coef(f->sigNormal) : f->sigNormal, aLumin = fused ? coef(f->sigLumin) : f->sigLumin;
-    static const bool tiledEnv = []{ const char* e = std::getenv("RS_EAW_TILED"); return !(e && e[0] == '0'); }();     // measurement switch
-    const bool tiled = tiledEnv && f->tiled && level <= 4;
+    const bool tiled = f->tiled && level <= 4;
     const int c = g->cur();
     if (tiled) {
         const int step = 1 << level;
@@ -570,7 +569,7 @@ int rs_eaw_set_tiled(rs_eaw* f, int tiled) {
     f->tiled = tiled != 0;
     return 0;
 }
-// the arithmetic of a tap: 0 (default) every operation rounded separately, in the reference's order; 1 fused multiply-adds for the squared
+// the arithmetic of a tap: 0 every operation rounded separately, in the reference's order; 1 (DEFAULT) fused multiply-adds for the squared
 // distances, the exponent and the accumulation (kFusedTaps above): same taps, same weights to < 2e-6 relative, 0.7 x the instructions
 int rs_eaw_set_fused(rs_eaw* f, int fused) {
     RS_SCOPE(f);
@@ -595,8 +594,7 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
     const int n = f->width * f->height;
-    static const bool tiledEnv = []{ const char* e = std::getenv("RS_EAW_TILED"); return !(e && e[0] == '0'); }();
-    const bool fusedPositions = tiledEnv && f->tiled;           // the tiled level 0 computes the positions while it stages its tile
+    const bool fusedPositions = f->tiled;           // the tiled level 0 computes the positions while it stages its tile
     if (!fusedPositions) {
         hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
                            g->depth[g->cur()], g->primId[g->cur()], f->devPos, 0, n);

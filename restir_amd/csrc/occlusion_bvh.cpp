@@ -201,59 +201,6 @@ int rs_quantize_occlusion_bvh(const std::vector<BvhNode>& nodes, float base[3], 
     return 0;
 }
 
-// ---- 32-byte pair records (measurement build -DRS_OCC_PAIR) ------------------------------------------------------------------------
-// One record per INNER node X holding the grid boxes of BOTH children A and B: a step of the walk tests two boxes with one
-// dependent fetch, leaves never cost a step of their own (their box is tested at the parent), so a ray takes about half the
-// steps.  Records in pre-order of the inner nodes: A's record, if A is inner, follows X's directly.
-//   dwords 0-2 box of A, 3-5 box of B (as in the 16-byte records), 6 = w6, 7 = skip(X) * 32 | type
-//   type 0 (A, B inner): w6 = byte offset of B's record          type 1 (A leaf, B inner; B's record follows): w6 = leaf word
-//   type 2 (A inner, B leaf): w6 = leaf word                      type 3 (both leaves): w6 = leaf word of both
-//   leaf word = first triangle | count of A << 24 | count of B << 28 (the triangles of two sibling leaves are contiguous)
-// skip(X) = the record to go on with when X's subtree is done = the first inner node at or after nodes[X].next in pre-order.
-int rs_pair_occlusion_bvh(const std::vector<BvhNode>& nodes, const std::vector<unsigned>& packed, std::vector<unsigned>& out, int* count) {
-    const int n = (int)nodes.size();
-    std::vector<int> innerIdx((size_t)n, -1), innerAtOrAfter((size_t)n + 1, 0);
-    int ni = 0;
-    for (int i = 0; i < n; i++) if (nodes[(size_t)i].primId < 0) innerIdx[(size_t)i] = ni++;
-    innerAtOrAfter[(size_t)n] = ni;
-    for (int i = n - 1; i >= 0; i--) innerAtOrAfter[(size_t)i] = innerIdx[(size_t)i] >= 0 ? innerIdx[(size_t)i] : innerAtOrAfter[(size_t)i + 1];
-    const unsigned emptyBox[3] = { 0xffffffffu, 0x0000ffffu, 0u };      // lo = 65535 > hi = 0 on every axis
-    auto leafWord = [&](int a, int b) {                                  // a, b: leaf node ids or -1
-        const int codeA = a >= 0 ? nodes[(size_t)a].primId : -1, codeB = b >= 0 ? nodes[(size_t)b].primId : -1;
-        const int first = codeA >= 0 ? codeA >> 3 : codeB >> 3, cA = codeA >= 0 ? codeA & 7 : 0, cB = codeB >= 0 ? codeB & 7 : 0;
-        if (codeA >= 0 && codeB >= 0 && (codeB >> 3) != first + cA) return 0xffffffffu;          // not contiguous: cannot happen with this builder
-        if (first >= (1 << 24)) return 0xffffffffu;
-        return (unsigned)first | ((unsigned)cA << 24) | ((unsigned)cB << 28);
-    };
-    if (ni == 0) {                                                       // the root is a leaf: one record, child B empty
-        out.assign(8, 0u);
-        for (int k = 0; k < 3; k++) { out[(size_t)k] = packed[(size_t)k]; out[3 + (size_t)k] = emptyBox[k]; }
-        out[6] = leafWord(0, -1); out[7] = 1u * 32u | 3u;
-        ni = 1;
-    }
-    else {
-        out.assign((size_t)ni * 8, 0u);
-        for (int x = 0; x < n; x++) {
-            if (innerIdx[(size_t)x] < 0) continue;
-            const int a = x + 1, b = nodes[(size_t)a].next;
-            unsigned* o = &out[(size_t)innerIdx[(size_t)x] * 8];
-            for (int k = 0; k < 3; k++) { o[k] = packed[(size_t)a * 4 + (size_t)k]; o[3 + k] = packed[(size_t)b * 4 + (size_t)k]; }
-            const bool la = nodes[(size_t)a].primId >= 0, lb = nodes[(size_t)b].primId >= 0;
-            const unsigned skip = (unsigned)innerAtOrAfter[(size_t)nodes[(size_t)x].next] * 32u;
-            const unsigned type = la ? (lb ? 3u : 1u) : (lb ? 2u : 0u);
-            o[6] = type == 0 ? (unsigned)innerIdx[(size_t)b] * 32u : leafWord(la ? a : -1, lb ? b : -1);
-            if (type != 0 && o[6] == 0xffffffffu) return rs_fail(RS_ERR_UNSUPPORTED, "rs_pair_occlusion_bvh: leaf word does not fit");
-            o[7] = skip | type;
-        }
-    }
-    // sentinel past the end: two empty boxes, both "leaves" without triangles, linked to itself
-    for (int k = 0; k < 3; k++) out.push_back(emptyBox[k]);
-    for (int k = 0; k < 3; k++) out.push_back(emptyBox[k]);
-    out.push_back(0u); out.push_back((unsigned)ni * 32u | 3u);
-    *count = ni;
-    return 0;
-}
-
 // parent of every reference node (indexed by the ORIGINAL pre-order id = MTBVHNode::boundingBoxId) and
 // the leaf node of every primitive, derived from one threaded order (src/bvh.cpp:156-193: order 0).
 int rs_reference_chain_tables(int bvhSize, const int* order0 /* 3 ints per node */, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims) {

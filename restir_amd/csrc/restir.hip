@@ -314,24 +314,9 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
 // the library stream, the only chain that links consecutive frames, is the streaming half: temporal merge, validity check, publish.
 // (As one kernel the pass lasted as long as its slowest wave's walk, 0.2 ms on a 1/8 strip however few rows it has.)
 // 8 blocks per CU = 8 waves per SIMD.
-// Stragglers (measurement build -DRS_HANDOFF_LANES=16; off by default).  A wave walks until its slowest ray is done: 139 iterations
-// for a mean of 74 per ray, and from the 72nd iteration on fewer than 20 of its 64 lanes still walk, from the 120th fewer than 3
-// (tools/walk_stats.py, -DRS_WALK_STATS_TIME).  With the hand-off a wave leaves the walk as soon as no more than kHandoffLanes of
-// its rays have anything left to do and puts those -- ray, range, position in the tree, queued leaves, pixel -- into a pool in LDS;
-// after the block's four waves have done so, ONE wave picks the pool up (at most 4 x 16 = 64 rays) and finishes them.  The same
-// steps per ray, the same result (36 GPU tests), a quarter fewer wave iterations per block -- and no gain: shadow + temporal
-// 457 -> 455 us alone, the overlapped frame 1.083 -> 1.097 ms (profiles/r03_ab_shadow_straggler_handoff.log).  What the pass is bound
-// by is the number of per-LANE fetches (each a look-up of its own in the CU's L1: 74 + 15 per ray), which the hand-off leaves as it
-// is; the wave iterations it removes are the nearly empty ones, which cost issue slots the pass has to spare.
-#ifndef RS_HANDOFF_LANES
-#define RS_HANDOFF_LANES 0
-#endif
-constexpr int kHandoffLanes = RS_HANDOFF_LANES, kHandoffPool = 4 * kHandoffLanes;
-struct __attribute__((aligned(16))) PooledRay { float ox, oy, oz, limit; float dx, dy, dz; unsigned cur; int q0, q1, q2, q3; int qn, index, pad0, pad1; };
-
+// (A hand-off of each wave's last rays to one wave per block was built and measured in round 3 -- same results, a quarter fewer wave
+// iterations, no gain: the pass is bound by per-lane L1 look-ups; EXPERIMENTS.md, commit 933552f.)
 __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
-    __shared__ PooledRay pool[kHandoffPool > 0 ? kHandoffPool : 1];
-    __shared__ int poolCount;
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
     const bool inside = x < width && y < y1;
@@ -341,64 +326,9 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_shado
     float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
     if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
     const f3 pos = mk3(pm.x, pm.y, pm.z), wi = mk3(cw.x, cw.y, cw.z);
-    if (kHandoffLanes == 0 || !s.occNodes) {
-        // every lane of the wave takes part in the cooperative any-hit walk
-        const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded);
-        if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
-        return;
-    }
-    if (threadIdx.x == 0) poolCount = 0;
-    __syncthreads();
-    // testOcclusion's segment (scene.h:286-299), as trace_occluded_wave sets it up
-    const f3 target = pos + wi * cl.w;
-    f3 dir = target - pos;
-    float dist = length(dir);
-    dir = div3_exact_signed(dir, dist);
-    Ray ray; ray.o = pos + dir * 1e-5f; ray.d = dir;
-    dist -= 1e-4f * 2.f;
-    RayBoxCtx ctx = make_box_ctx(ray);
-    ctx.cull = s.axisCull;
-    const bool special = shaded && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
-    const bool slow = shaded && (special || !occlusion_tree_usable(s, ray.o));
-    const bool fast = shaded && !slow;
-    OccState st;
-    bool suspended;
-    bool occluded = walk_occlusion_tree_x<true, false>(s, ray, ctx, dist, fast, st, kHandoffLanes, suspended);
-#ifdef RS_OCC_PAIR
-    const unsigned endOff = (unsigned)s.occCount * 32u;
-#else
-    const unsigned endOff = (unsigned)s.occCount * 16u;
-#endif
-    const bool pending = suspended && fast && !occluded && (st.cur != endOff || st.qn > 0);
-    if (__any(slow)) occluded = walk_anyhit_deferred<false>(s, ray, ctx, dist, slow) || occluded;      // special-case / far-origin rays: the reference walk
-    if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;
-    {
-        const unsigned long long mask = __ballot(pending);
-        if (mask) {
-            int base = 0;
-            if ((threadIdx.x & 63) == 0) base = atomicAdd(&poolCount, __popcll(mask));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (pending) {
-                const int slot = base + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
-                PooledRay r;
-                r.ox = ray.o.x; r.oy = ray.o.y; r.oz = ray.o.z; r.limit = dist; r.dx = ray.d.x; r.dy = ray.d.y; r.dz = ray.d.z; r.cur = st.cur;
-                r.q0 = st.q0; r.q1 = st.q1; r.q2 = st.q2; r.q3 = st.q3; r.qn = st.qn; r.index = index; r.pad0 = r.pad1 = 0;
-                pool[slot] = r;
-            }
-        }
-    }
-    __syncthreads();
-    const int pooled = poolCount;
-    if ((int)(threadIdx.x & ~63u) >= pooled) return;                    // (at most one wave with kHandoffLanes = 16)
-    const bool mine = (int)threadIdx.x < pooled;
-    const PooledRay r = pool[mine ? threadIdx.x : 0];
-    Ray ray2; ray2.o = mk3(r.ox, r.oy, r.oz); ray2.d = mk3(r.dx, r.dy, r.dz);
-    RayBoxCtx ctx2 = make_box_ctx(ray2);
-    ctx2.cull = s.axisCull;
-    OccState st2; st2.cur = r.cur; st2.q0 = r.q0; st2.q1 = r.q1; st2.q2 = r.q2; st2.q3 = r.q3; st2.qn = r.qn;
-    bool susp2;
-    const bool occ2 = walk_occlusion_tree_x<false, true>(s, ray2, ctx2, r.limit, mine, st2, 0, susp2);
-    if (mine && occ2) reinterpret_cast<float*>(sp.candWi + r.index)[3] = 0.f;
+    // every lane of the wave takes part in the cooperative any-hit walk
+    const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded);
+    if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
 }
 
 template <bool SOBOL>
@@ -406,8 +336,7 @@ __global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, Res
                                                   int first, int reuse, int n0, int n1, unsigned long long* rayWork, unsigned long long* rayDone) {
     // this call's BVH-walk counters are complete (the launch is ordered after the chain that counted): publish them and leave the
     // working slot zero for its next user, so that the chain itself needs no clearing launch
-    // (rayDone null: an earlier band of a frame that is launched in bands -- the last band's launch publishes for all of them)
-    if (rayDone && blockIdx.x == 0 && threadIdx.x < kRaySub) {
+    if (blockIdx.x == 0 && threadIdx.x < kRaySub) {
         const int k = threadIdx.x * kRayStride;
         rayDone[k] = rayWork[k];
         rayWork[k] = 0;
@@ -600,12 +529,11 @@ __device__ __forceinline__ Staged fetch_staged_global(const GBufView& g, const T
 
 // The per-pixel body of phase B (restir.cu:196-230).  STAGED: neighbour records come from the LDS tile
 // `stage` (origin sox, soy); otherwise from global memory.
-// RING: the staged rows are a ring -- row r of the window [soy, soy + kBStageH) lies at slot (r + ringOff) mod kBStageH (k_spatial_shade_roll)
-template <bool STAGED, bool SOBOL, bool RING = false>
+template <bool STAGED, bool SOBOL>
 __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlanes& sp, const GBufView& g, const ResvPlanes& own,
                                               const TempPlanes& temp, const Staged* stage, int sox, int soy,
                                               float* __restrict__ directIllum, int iter, int looper, bool spatial,
-                                              int x, int y, int index, uint2 rm, f3 albedo, f3 prev, int ringOff = 0) {
+                                              int x, int y, int index, uint2 rm, f3 albedo, f3 prev) {
     const int W = g.width, H = g.height;
     const int mk = (int)rm.y;
     const int kind = mk_kind(mk);
@@ -622,8 +550,7 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
         // own reservoir = what phase A published (post-temporal, validity-checked)
         float W0; int M0; int src = index;
         if (spatial) {
-            int cy = y - soy;
-            if (RING) { cy += ringOff; cy -= cy >= kBStageH ? kBStageH : 0; }
+            const int cy = y - soy;
             const Staged c = STAGED ? stage[cy * kBStageW + (x - sox)] : fetch_staged_global(g, temp, index);
             W0 = c.tap.x; M0 = __float_as_int(c.tap.y);
             const int idC = __float_as_int(c.tap.z);
@@ -642,8 +569,7 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
                 Staged q;
                 if (STAGED) {       // taps reach x-4..x+5, y-4..y+5: always inside the staged halo; the clamp keeps garbage in bounds
                     const int lx = iclamp(px - sox, 0, kBStageW - 1);
-                    int ly = iclamp(py - soy, 0, kBStageH - 1);
-                    if (RING) { ly += ringOff; ly -= ly >= kBStageH ? kBStageH : 0; }
+                    const int ly = iclamp(py - soy, 0, kBStageH - 1);
                     q = stage[ly * kBStageW + lx];
                 }
                 else q = fetch_staged_global(g, temp, iclamp(py, 0, H - 1) * W + iclamp(px, 0, W - 1));
@@ -746,61 +672,8 @@ __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevSce
     spatial_pixel<true, SOBOL>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, looper, spatial, x, y, index, rm, albedo, prev);
 }
 
-// The same pass with a ROLLING window: a block takes kRollTiles tiles of one column of tiles, top to bottom, and keeps the staged
-// rows in a ring -- moving down one tile replaces kBTileH of the kBStageH rows and keeps the 2 * kHalo that the two tiles share.
-// Staged records per pixel: (26 + 5 * 16) * 42 / (6 * 512) = 1.45 instead of 26 * 42 / 512 = 2.13 -- the vertical halo, which is
-// most of what the pass re-reads, is read once per block instead of once per tile.  Same per-pixel code (spatial_pixel), same bits.
-#ifndef RS_K4_ROLL_TILES
-#define RS_K4_ROLL_TILES 6
-#endif
-constexpr int kRollTiles = RS_K4_ROLL_TILES;
-template <bool SOBOL>
-__global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade_roll(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
-                                                                  float* __restrict__ directIllum, int iter, int looper, int reuse,
-                                                                  int y0, int y1, int tilesX, int numBlocks) {
-    __shared__ Staged stage[kBStageN];
-    int blk = blockIdx.x;                                    // XCD-aware order as in k_spatial_shade: each XCD a contiguous run of blocks
-    {
-        const int q = numBlocks / 8, rem = numBlocks % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-        blk = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
-    }
-    const int ox = (blk % tilesX) * kBTileW, oySeg = y0 + (blk / tilesX) * (kBTileH * kRollTiles);
-    const int W = g.width, H = g.height;
-    const int tx = threadIdx.x % kBTileW, ty = threadIdx.x / kBTileW;
-    const int x = ox + tx;
-    int ringOff = 0;                                         // slot of the window's first row
-    for (int j = 0; j < kRollTiles; j++) {
-        const int oy = oySeg + j * kBTileH;
-        if (oy >= y1) break;                                 // (block-uniform)
-        const int y = oy + ty;
-        const bool inside = x < W && y < y1;
-        const int index = inside ? y * W + x : 0;
-        uint2 rm = make_uint2(0u, 0u);
-        f3 albedo = splat(0.f), prev = splat(0.f);
-        if (inside) {
-            const unsigned long long rmBits = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(sp.rngMat + index));
-            rm = make_uint2((unsigned)rmBits, (unsigned)(rmBits >> 32));
-            albedo = ld3_stream(g.albedo + (size_t)index * 3);
-            prev = ld3_stream(directIllum + (size_t)index * 3);
-        }
-        // window rows [oy - kHalo, oy - kHalo + kBStageH); the first tile stages all of them, the next ones the kBTileH new rows at the bottom
-        const int firstNew = j == 0 ? 0 : kBStageH - kBTileH, count = (kBStageH - firstNew) * kBStageW;
-        for (int e = threadIdx.x; e < count; e += kBThreads) {
-            const int wr = firstNew + e / kBStageW;          // row within the window
-            const int sx = ox - kHalo + (e % kBStageW), sy = oy - kHalo + wr;
-            Staged v;
-            v.tap = make_float4(0.f, 0.f, __int_as_float(-3), 0.f);     // id -3 matches nothing
-            v.nx = v.ny = v.nz = v.pad = 0.f;
-            if (sx >= 0 && sx < W && sy >= 0 && sy < H) v = fetch_staged_global(g, temp, sy * W + sx);
-            int slot = wr + ringOff; slot -= slot >= kBStageH ? kBStageH : 0;
-            stage[slot * kBStageW + (e % kBStageW)] = v;
-        }
-        __syncthreads();
-        if (inside) spatial_pixel<true, SOBOL, true>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, looper, true, x, y, index, rm, albedo, prev, ringOff);
-        __syncthreads();                                     // every tap of this tile has been read before the next tile's rows replace the oldest ones
-        ringOff += kBTileH; ringOff -= ringOff >= kBStageH ? kBStageH : 0;
-    }
-}
+// (A rolling-window form of this pass -- a block walks a column of tiles and keeps the shared halo rows in a ring, 1.45 staged records
+// per pixel instead of 2.13 -- was built and measured in round 3: bit-exact and slower, 54-63 us against 48; EXPERIMENTS.md, commit da6e82f.)
 
 }  // namespace
 
@@ -859,7 +732,6 @@ int rs_restir_free(rs_restir* r) {
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->tuneEv) if (e) (void)hipEventDestroy(e);
-    for (auto& e : r->bandEv) if (e) (void)hipEventDestroy(e);
     if (r->auxFork) (void)hipEventDestroy(r->auxFork);
     if (r->auxDone) (void)hipEventDestroy(r->auxDone);
     delete r;
@@ -932,14 +804,13 @@ int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y
     // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
     // Alone the alias-in-LDS form is a third faster (config 5: 645 -> 455 us); inside overlapped frames it is slower (1.88 -> 1.95 ms per
     // frame: one 1024-thread block with 82 KB of LDS per CU keeps the other streams' kernels off that CU), so it is taken when the
-    // kernels run one after the other on the library stream only.  RS_RIS_ALIAS_LDS=0 / 1: never / always (measurements).
-    static const int aliasLds = []{ const char* e = std::getenv("RS_RIS_ALIAS_LDS"); return e ? std::atoi(e) : 2; }();
-    const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels / RS_RIS_GLOBAL_BELOW say otherwise
+    // kernels run one after the other on the library stream only (`alone`; A/B in profiles/r03_ab_config5_ris_alias_lds.log).
+    const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels says otherwise
     if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
         // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
         // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
         RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
-    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && (aliasLds == 1 || (aliasLds == 2 && alone))) {
+    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && alone) {
         const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
         static const bool ldsAllowed = []{      // more than 64 KB of dynamic LDS is opt-in
             const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
@@ -1077,18 +948,6 @@ int phase_b_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
     RS_TRY(rs_gbuffer_join(g));
-    // The rolling window (k_spatial_shade_roll: the vertical halo read once per block of kRollTiles tiles) is a measured negative:
-    // 1.45-1.72 staged records per pixel instead of 2.13, bit-exact, and 54-63 us against 48 (profiles/r03_ab_spatial_rolling_window.log)
-    // -- a block's tiles run one after the other, every one a load phase, a barrier, a compute phase, a barrier, where independent
-    // tiles overlap each other's phases.  RS_K4_ROLL=1: always, 2: for passes over at least 2 * kRollTiles rows of tiles; default 0.
-    static const int rollEnv = []{ const char* e = std::getenv("RS_K4_ROLL"); return e ? std::atoi(e) : 0; }();
-    const bool roll = (reuse & 2) != 0 && (rollEnv == 1 || (rollEnv == 2 && tilesY >= 2 * kRollTiles));
-    if (roll) {
-        const int segs = (tilesY + kRollTiles - 1) / kRollTiles, numBlocks = tilesX * segs;
-        RS_LAUNCH1(k_spatial_shade_roll, scene->dev.sampleSeq != nullptr, dim3(numBlocks), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
-                   r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numBlocks);
-    }
-    else
     RS_LAUNCH1(k_spatial_shade, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
                r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);
@@ -1162,75 +1021,13 @@ int rs_restir_end_frame(rs_restir* r) {
     return 0;
 }
 
-// ReSTIRDirect of a synchronous caller (the reference's mode: every call returns with its work done) as a software pipeline over
-// bands of rows.  Alone on the chip the three kernels of the chain are bound by different things -- the primary rays and the shadow
-// rays by memory latency (65 % / 55 % of their issue slots idle), RIS by instruction issue -- and a synchronous frame pays their
-// SUM (0.28 + 0.29 + 0.39 ms at 1080p).  Nothing but rows links them, so the frame is cut into kSyncBands bands and the kernels
-// go to three internal streams by KIND: primary rays of band b, b + 1, ... on one, RIS on the second (band b after its primary
-// rays), shadow rays on the third, the streaming temporal merge on the library stream -- band b + 1's latency-bound walk runs under
-// band b's RIS and band b - 1's shadow rays.  The same kernels on the same rows, so the same bits; the call still returns with
-// everything done.  MEASURED SLOWER (tools/bench_sync_frame.py, profiles/r03_ab_sync_bands.log): a synchronous 1080p frame 1.404 ms with
-// one launch per kernel, 1.57 / 1.56 / 1.63 ms with 2 / 3 / 4 bands; Bistro-class 2.54 -> 3.64 / 4.30 ms -- a band's walk kernel is a
-// single round of waves that lasts as long as its slowest tile, every band pays that tail, and what the stages hide of each other
-// is less than that.  Kept behind RS_SYNC_BANDS=2..4 (default 1: off).
-int direct_banded(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g, float* devDirectIllum, int iter, int looper, int reuse, int bands) {
-    RS_TRY(rs_check_looper(scene, looper, "ReSTIRDirect"));
-    if (!devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "ReSTIRDirect: null radiance buffer");
-    const bool sobol = scene->dev.sampleSeq != nullptr;
-    const int W = r->width, H = r->height;
-    hipStream_t stP = rs_aux_stream_any(0), stR = rs_aux_stream_any(1), stS = rs_aux_stream_any(2), lib = rs_stream();
-    for (auto& e : r->bandEv) if (!e) RS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    r->looper = looper;
-    r->raySlot = (r->raySlot + 1) % kRaySlots;                  // ONE counter slot for all bands; the last band's temporal launch publishes it
-    unsigned long long* rayCounter = r->dRayCount + (size_t)r->raySlot * kRaySub * kRayStride;
-    unsigned long long* rayDone = rayCounter + (size_t)kRaySlots * kRaySub * kRayStride;
-    const SurfPlanes sp = surf_of(r);
-    const CamParams cp = rs_make_cam_params(cam);
-    const int tilesX = (W + 31) / 32;
-    RS_TRY(rs_gbuffer_join(g));                                 // (a render that a caller switched to asynchronous mode in between left pending)
-    // everything the caller enqueued on the library stream so far comes first
-    RS_HIP(hipEventRecord(r->bandEv[0], lib));
-    RS_HIP(hipStreamWaitEvent(stP, r->bandEv[0], 0));
-    r->phaseACalls++;
-    r->lastFused = 0; r->lastChains = 0;
-    const int rowsPer = (((H + bands - 1) / bands) + 7) & ~7;
-    int b = 0;
-    for (int y0 = 0; y0 < H; y0 += rowsPer, b++) {
-        const int y1 = y0 + rowsPer < H ? y0 + rowsPer : H;
-        const bool lastBand = y1 == H;
-        const int tilesY = (y1 - y0 + 7) / 8, npx = (y1 - y0) * W;
-        hipEvent_t evP = r->bandEv[1 + 3 * b], evR = r->bandEv[2 + 3 * b], evS = r->bandEv[3 + 3 * b];
-        RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), stP, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
-        RS_HIP(hipEventRecord(evP, stP));
-        RS_HIP(hipStreamWaitEvent(stR, evP, 0));
-        RS_TRY(launch_ris(scene, sp, W, y0, y1, looper, sobol, stR, false));
-        RS_HIP(hipEventRecord(evR, stR));
-        RS_HIP(hipStreamWaitEvent(stS, evR, 0));
-        hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, stS, scene->dev, sp, W, y0, y1, tilesX);
-        RS_HIP(hipEventRecord(evS, stS));
-        RS_HIP(hipStreamWaitEvent(lib, evS, 0));
-        RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), lib, sp, gbuf_view(g),
-                   r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter,
-                   lastBand ? rayDone : (unsigned long long*)nullptr);
-    }
-    RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (bands)"));
-    RS_TRY(phase_b_impl(r, scene, cam, g, devDirectIllum, iter, reuse, 0, H, false));
-    RS_TRY(rs_restir_end_frame(r));
-    return rs_after_launch("ReSTIR Direct");                   // the library stream has waited for every band's chain
-}
+// (A synchronous ReSTIRDirect as a software pipeline over bands of rows -- primary rays / RIS / shadow rays of consecutive bands on three
+// streams -- was built and measured in round 3: bit-exact and slower, 1.40 -> 1.56-1.63 ms; EXPERIMENTS.md, commit 9bc6c62.)
 
 int rs_restir_direct(rs_restir* r, const rs_scene* scene, const rs_camera* cam, const rs_gbuffer* g,
                      float* devDirectIllum, int iter, int looper, int reuse) {
     RS_SCOPE(r);
     RS_TRY(check_frame_args(r, scene, cam, g));
-    {
-        static const int bandsEnv = []{ const char* e = std::getenv("RS_SYNC_BANDS"); return e ? std::atoi(e) : 1; }();      // measured slower than one launch per kernel: off unless asked for
-        const int bands = bandsEnv < 1 ? 1 : bandsEnv > rs_restir::kSyncBands ? rs_restir::kSyncBands : bandsEnv;
-        // worth it from about a quarter of a million pixels per band on (RIS then still runs its LDS form)
-        if (bands > 1 && rs_sync_enabled() && r->timing == 0 && !g->deferred.valid && (long long)r->width * r->height >= (long long)bands * rs_ris_global_below() &&
-            rs_aux_stream_any(0) && rs_aux_stream_any(1) && rs_aux_stream_any(2))
-            return direct_banded(r, scene, cam, g, devDirectIllum, iter, looper, reuse, bands);
-    }
     // one synchronisation for the whole call (synchronous mode); the library's mode itself is not touched, so the two phases
     // stay on the library stream in synchronous mode and use the auxiliary streams in asynchronous mode only
     RS_TRY(phase_a_impl(r, scene, cam, g, looper, reuse, 0, r->height, false));

@@ -299,8 +299,6 @@ struct rs_restir {
     // takes the fused launch (render + primary rays, k_gbuffer_primary), after which nothing runs on the render's stream, and
     // gives that stream to a third chain (kSmallChains; restir.hip phase_a_impl): 8 strips of 1080p 5.96x -> 6.5x.
     static constexpr int kChains = 2, kSmallChains = 3, kSurfSets = RS_SURF_SETS;
-    static constexpr int kSyncBands = 4;              // a synchronous ReSTIRDirect as a pipeline over at most this many bands of rows (restir.hip direct_banded)
-    hipEvent_t bandEv[1 + 3 * kSyncBands] = {};
     int width = 0, height = 0;
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
@@ -383,7 +381,6 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam);
 
 // occlusion_bvh.cpp
 int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<rs::BvhNode>& nodes, std::vector<int>& leafPrims);
-int rs_pair_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, const std::vector<unsigned>& packed, std::vector<unsigned>& out, int* count);
 int rs_quantize_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, float base[3], float scale[3], std::vector<unsigned>& out);
 int rs_build_ordered_bvh(int numPrims, const float* primBoxes, const int* seq, std::vector<rs::BvhNode>& forward, std::vector<rs::BvhNode>& mirrored);
 int rs_reference_chain_tables(int bvhSize, const int* order0, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims);

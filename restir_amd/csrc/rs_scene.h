@@ -94,9 +94,6 @@ struct DevScene {
 constexpr int kSobolGuard = 4096;
 
 typedef float vf2 __attribute__((ext_vector_type(2)));     // operands of the packed FP32 instructions (v_pk_add / mul / fma_f32)
-#ifndef RS_OCC_PERM
-#define RS_OCC_PERM 1
-#endif
 
 struct Ray { f3 o, d; };
 
@@ -557,21 +554,9 @@ __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
            gabs(o.z - s.occBase.z) <= reach * s.occScale.z;
 }
 
-// What a lane's walk consists of between two steps: where it is and the leaves it has queued.  HANDOFF: the walk returns
-// (*suspended = true, the states in `st`) as soon as no more than minLanes lanes of the wave have anything left to do, so that the
-// caller can finish those rays elsewhere (k_shadow pools the stragglers of a block's four waves into one wave: from the 72nd of a
-// wave's 139 iterations on fewer than 20 of its lanes are still walking, from the 120th fewer than 3, tools/walk_stats.py).
-struct OccState { unsigned cur; int q0, q1, q2, q3, qn; };
-
-template <bool HANDOFF, bool RESUME>
-__device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active,
-                                                      OccState& st, int minLanes, bool& suspended) {
+__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
     const char* nodes = reinterpret_cast<const char*>(s.occNodes);
-#ifdef RS_OCC_PAIR
-    const unsigned endOff = (unsigned)s.occCount * 32u;      // 32-byte pair records (occlusion_bvh.cpp rs_pair_occlusion_bvh)
-#else
     const unsigned endOff = (unsigned)s.occCount * 16u;
-#endif
     // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
     // A lane that enters without a ray of its own (outside the frame, a special-case or far-origin ray that takes the reference walk)
     // is parked on the sentinel record past the end for the whole walk; it evaluates that record like every other lane, so its
@@ -585,10 +570,7 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
                               fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
     unsigned cur = active ? 0u : endOff;
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
-    if (RESUME && active) { cur = st.cur; q0 = st.q0; q1 = st.q1; q2 = st.q2; q3 = st.q3; qn = st.qn; }
     bool occluded = false;
-    suspended = false;
-#if RS_OCC_PERM
     // Which of the two grid planes of an axis is the near one depends on the sign of A only (fma is monotone in q): a byte
     // permute with a per-ray selector puts {near plane, far plane} of an axis into one dword, and the six min / max of the slab
     // test are gone.  Node dwords: x = lo.x | lo.y << 16, y = lo.z | hi.x << 16, z = hi.y | hi.z << 16.
@@ -596,7 +578,6 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
     const unsigned selY = A.y < 0.f ? 0x03020504u : 0x05040302u;      // v_perm_b32(n.z, n.x)
     const unsigned selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;      // v_perm_b32(n.z, n.y)
     const vf2 Axy = { A.x, A.y }, Bxy = { B.x, B.y }, Azz = { A.z, A.z }, Bzz = { B.z, B.z };
-#endif
 #ifdef RS_WALK_STATS
     unsigned long long wst[10] = { 1, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int mySteps = 0, myTris = 0;         // of this lane's ray
@@ -609,7 +590,6 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
         for (;;) {
             const unsigned long long walkers = __ballot(cur != endOff);
             if (!walkers) break;
-            if (HANDOFF && __popcll(walkers | __ballot(qn > 0)) <= minLanes) { suspended = true; break; }
             RS_STAT(1, 1); RS_STAT(5, 1); RS_STAT(6, __popcll(__ballot(cur != endOff)));
 #ifdef RS_WALK_STATS
             if (cur != endOff) mySteps++;
@@ -618,45 +598,11 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
               if (s.walkStats && __lane_id() == 0) { const int b = wst[5] / 24 < 9 ? (int)(wst[5] / 24) : 9; atomicAdd(&s.walkStats[44 + b], (unsigned long long)__popcll(walkers)); atomicAdd(&s.walkStats[54 + b], 1ull); } }
 #endif
 #endif
-#if defined(RS_OCC_PAIR) && RS_OCC_PERM
-            {   // pair record: the boxes of both children of an inner node, one dependent fetch for two tests; leaves cost no step
-                const uint4 n0 = *reinterpret_cast<const uint4*>(nodes + cur), n1 = *reinterpret_cast<const uint4*>(nodes + cur + 16);
-                bool passA, passB;
-                {
-                    const unsigned px = __builtin_amdgcn_perm(n0.y, n0.x, selX), py = __builtin_amdgcn_perm(n0.z, n0.x, selY), pz = __builtin_amdgcn_perm(n0.z, n0.y, selZ);
-                    const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
-                    const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
-                    const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
-                    const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x), tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
-                    passA = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
-                }
-                {
-                    const unsigned px = __builtin_amdgcn_perm(n1.x, n0.w, selX), py = __builtin_amdgcn_perm(n1.y, n0.w, selY), pz = __builtin_amdgcn_perm(n1.y, n1.x, selZ);
-                    const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
-                    const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
-                    const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
-                    const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x), tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
-                    passB = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
-                }
-                const unsigned w6 = n1.z, w7 = n1.w;
-                const bool leafA = (w7 & 1u) != 0, leafB = (w7 & 2u) != 0;
-                const unsigned skip = w7 & ~31u;
-                const bool hitLeafA = passA && leafA, hitLeafB = passB && leafB;
-                const bool push = hitLeafA || hitLeafB;
-                const unsigned cA = (w6 >> 24) & 15u, cB = w6 >> 28;
-                const int code = (int)((((w6 & 0xffffffu) + (hitLeafA ? 0u : cA)) << 4) | ((hitLeafA ? cA : 0u) + (hitLeafB ? cB : 0u)));
-                q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? code : q0; qn = push ? qn + 1 : qn;
-                const bool goA = passA && !leafA, goB = passB && !leafB;
-                const unsigned toB = leafA ? cur + 32u : w6;           // B's record follows X's directly when A is a leaf
-                cur = goA ? cur + 32u : (goB ? toB : skip);
-            }
-#else
             {   // every lane, also one whose walk has ended: it reads the record past the end, an empty box linked to itself (scene.hip)
                 const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
 #if defined(RS_WALK_STATS) && !defined(RS_WALK_STATS_TIME)
                 if (s.walkStats && s.occDepth && cur != endOff) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
 #endif
-#if RS_OCC_PERM
                 const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
                 const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
                 const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
@@ -664,33 +610,20 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
                 const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
                 const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
                 const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
-#else
-                const float t1x = fmaf((float)(n.x & 0xffffu), A.x, B.x), t1y = fmaf((float)(n.x >> 16), A.y, B.y), t1z = fmaf((float)(n.y & 0xffffu), A.z, B.z);
-                const float t2x = fmaf((float)(n.y >> 16), A.x, B.x), t2y = fmaf((float)(n.z & 0xffffu), A.y, B.y), t2z = fmaf((float)(n.z >> 16), A.z, B.z);
-                const float tMin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                const float tMax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                const bool pass = (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
-#endif
                 const int meta = (int)n.w;
                 const bool leaf = meta < 0;
                 const bool push = pass && leaf;
                 q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn = push ? qn + 1 : qn;
                 cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
             }
-#endif
             if (__any(qn == kLeafQueue)) break;
         }
-        if (HANDOFF && suspended) { st.cur = cur; st.q0 = q0; st.q1 = q1; st.q2 = q2; st.q3 = q3; st.qn = qn; break; }
         if (!__any(qn > 0)) break;
         // leaf round: every lane takes its newest queued leaf (so no queue is full when the walk resumes) and
         // tests its triangles; a hit becomes a candidate, and the rest of the leaf waits for its verdict
         RS_STAT(2, 1);
         int tri = 0, cnt = 0, verify = -1;
-#ifdef RS_OCC_PAIR
-        if (qn > 0) { tri = q0 >> 4; cnt = q0 & 15; q0 = q1; q1 = q2; q2 = q3; qn--; }      // up to 8 triangles: two sibling leaves in one entry
-#else
         if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
-#endif
         for (;;) {
             while (__any((cnt > 0) & (verify < 0))) {
                 RS_STAT(3, 1); RS_STAT(9, __popcll(__ballot((cnt > 0) & (verify < 0))));
@@ -751,11 +684,6 @@ __device__ __forceinline__ bool walk_occlusion_tree_x(const DevScene& s, const R
 #endif
 #undef RS_STAT
     return occluded;
-}
-
-__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
-    OccState st; bool suspended;
-    return walk_occlusion_tree_x<false, false>(s, ray, ctx, limit, active, st, 0, suspended);
 }
 
 // ---- closest hit of incoherent rays through the trees that keep the reference's order ---------------------------------------
@@ -829,11 +757,7 @@ __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const
             if (__any(qn == RS_ORD_QUEUE)) break;
         }
         if (!__any(qn > 0)) break;
-#ifdef RS_ORD_DRAIN
-        while (__any(qn > 0)) {
-#else
         {
-#endif
         // leaf round: every lane takes its OLDEST queued leaf and judges its triangles one after the other
         RS_OSTAT(3, 1);
         int tri = 0, cnt = 0, verify = -1;

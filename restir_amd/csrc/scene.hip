@@ -82,17 +82,9 @@ int build_occlusion_side(rs_scene* s) {
     s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
     // one record past the end: an empty box (lo = 65535 > hi = 0 on every axis fails the slab test for either sign of the direction)
     // whose link is its own offset -- a lane whose walk has ended stays there, so the walk loop needs no "has this lane ended" region
-#ifdef RS_OCC_PAIR
-    std::vector<unsigned> pairs;
-    int pairCount = 0;
-    if (int e = rs_pair_occlusion_bvh(nodes, packed, pairs, &pairCount)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
-    RS_TRY(rs_dev_alloc(&s->dOccNodes, pairs.size() / 4));
-    RS_HIP(hipMemcpy(s->dOccNodes, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
-#else
     packed.push_back(0xffffffffu); packed.push_back(0x0000ffffu); packed.push_back(0u); packed.push_back((unsigned)(no * 16));
     RS_TRY(rs_dev_alloc(&s->dOccNodes, no + 1));
     RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), (no + 1) * 16, hipMemcpyHostToDevice));
-#endif
     RS_TRY(upload(&s->dOccChain, chain));
     RS_TRY(upload(&s->dOccTris, rec));
 #ifdef RS_WALK_STATS
@@ -118,11 +110,7 @@ int build_occlusion_side(rs_scene* s) {
     s->dev.occNodes = s->dOccNodes;
     s->dev.occChain = s->dOccChain;
     s->dev.occTris = s->dOccTris;
-#ifdef RS_OCC_PAIR
-    s->dev.occCount = pairCount;
-#else
     s->dev.occCount = (int)no;
-#endif
     s->dev.occBase = mk3(base[0], base[1], base[2]);
     s->dev.occScale = mk3(scale[0], scale[1], scale[2]);
     return 0;

@@ -53,7 +53,7 @@ struct rs_strips {
     // and serialises two of the three (a 1/8 strip of 1080p through this driver with a transport that does nothing: 0.289 ms per
     // frame with a separate stream against 0.19 without; tools/host_enqueue_strips.py, tools/strip_trace_c.py).  The price: the
     // library stream does not run the interior rows of phase B while the rows travel -- a few microseconds of kernel on a strip.
-    // RS_STRIPS_COMM_STREAM=1: the transfers on a stream of their own, ordered by events (rounds 2's form).
+    // rs_strips_set_comm_stream(s, 1): the transfers on a stream of their own, ordered by events (round 2's form).
     bool commOnMain = true;
     hipStream_t commStream = nullptr;              // carries the transfers when !commOnMain: ONE stream, so that every rank issues its groups in one order
     std::vector<Xfer> deferred;             // rs_strips_gather_begin on the library stream: its transfers ride in the next group
@@ -342,9 +342,7 @@ int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs
     int e = 0;
     if (comm->rank > 0) { e = rs_dev_alloc(&s->sendUp, s->haloBytes); if (!e) e = rs_dev_alloc(&s->recvUp, s->haloBytes); }
     if (!e && comm->rank + 1 < comm->world) { e = rs_dev_alloc(&s->sendDown, s->haloBytes); if (!e) e = rs_dev_alloc(&s->recvDown, s->haloBytes); }
-    { const char* env = std::getenv("RS_STRIPS_COMM_STREAM"); s->commOnMain = !(env && env[0] == '1'); }
     if (!e && comm->world > 1) {
-        if (!s->commOnMain) e = rs_check_hip(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
         if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->packed, hipEventDisableTiming), "hipEventCreate");
         if (!e) e = rs_check_hip(hipEventCreateWithFlags(&s->arrived, hipEventDisableTiming), "hipEventCreate");
         for (hipEvent_t& ev : s->gathered) if (!e) e = rs_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
@@ -353,6 +351,20 @@ int rs_strips_create(rs_comm* comm, int width, int height, const int* bounds, rs
     }
     if (e) { rs_strips_destroy(s); return e; }
     *out = s;
+    return 0;
+}
+
+// Where the transfers of a stream-ordered transport are enqueued: 0 (default) on the library stream itself, 1 on a stream of the
+// driver ordered against the library stream by events (the interior rows of phase B then run while the border rows travel, at the
+// price of a fifth stream).  Between frames only: no gather may be in flight.
+int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
+    RS_SCOPE(s);
+    if (!s) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_set_comm_stream: null");
+    for (bool pending : s->gatherPending) if (pending) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_set_comm_stream: a gather is in flight");
+    RS_TRY(rs_synchronize());
+    if (s->commStream) RS_HIP(hipStreamSynchronize(s->commStream));
+    if (ownStream && !s->commStream && s->comm->world > 1) RS_HIP(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking));
+    s->commOnMain = !(ownStream && s->commStream);
     return 0;
 }
 

@@ -1159,6 +1159,22 @@ def test_strip_driver_ranks_as_threads_over_rccl():
     assert r.returncode == 0 and "strips_rccl_ranks ok (1 rank)" in r.stdout and r.stdout.count("== full frame over 4 frames: True") == 2, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_strip_driver_stream_ordered_ranks_on_one_gpu():
+    """restir_amd/host/strips_loopback_ranks.cpp: three ranks as three host threads on THIS GPU, each with its own library context and
+    stream, over an in-process transport with RCCL's contract (send / recv only enqueued on the given stream, grouped, matched in order per
+    pair) that really moves the data -- the stream-ordered path of the strip driver, which RCCL itself can only run with one rank per
+    device: border rows, the display gather DEFERRED into the next frame's group (transfers on the library stream) or on the driver's own
+    stream, history exchange, EAW level rows.  bench.py's per-frame calls; every frame's gathered radiance / filtered image and every
+    frame's asynchronously gathered display image equal rank 0's own full frame, static and orbiting camera: 8 modes x 6 frames."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "restir_amd", "host", "strips_loopback_ranks")
+    assert os.path.exists(exe), "restir_amd/host/strips_loopback_ranks is built by restir_amd/csrc/Makefile"
+    r = subprocess.run([exe, "3", "200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "strips_loopback_ranks ok (3 ranks)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("== full frame over 6 frames: True") == 8, r.stdout[-3000:]
+
+
 def test_config4_4k_eight_strips_equal_full_frame(hip):
     """BASELINE config 4: the bench scene at 3840x2160 cut into 8 row strips with the 5-row reservoir halo -- the
     eight ranks are run one after the other on this GPU -- against the full-frame result, bit for bit."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/bench_sync_frame.py [--bistro] -- one frame of the reference's runCuda() in the reference's own mode, a synchronisation after every
 call (rs_set_sync(1), the library's default): GBuffer::render, ReSTIRDirect (rs_restir_direct), copyImageToPBO, GBuffer::update at 1080p.
-RS_SYNC_BANDS=1 launches ReSTIRDirect's kernels one after the other, the default as a pipeline over bands of rows (restir.hip direct_banded)."""
+TILE_SPLIT=<threshold> in the environment is handed to rs_set_tile_split (0 = off; default 768)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,8 @@ gbuf = capi.GBuffer(W, H); restir = capi.ReSTIR(W, H)
 image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
 pbo = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")
 capi.set_sync(True)
+if "TILE_SPLIT" in os.environ:
+    capi.set_tile_split(int(os.environ["TILE_SPLIT"]))
 
 
 def frame(f):
@@ -33,5 +35,5 @@ N = 50
 for f in range(20, 20 + N):
     frame(f)
 torch.cuda.synchronize()
-print("synchronous frame (render + ReSTIRDirect + tone map + update): %.3f ms; RS_SYNC_BANDS=%s RS_TILE_SPLIT=%s" %
-      ((time.perf_counter() - t0) / N * 1e3, os.environ.get("RS_SYNC_BANDS", "default"), os.environ.get("RS_TILE_SPLIT", "default")))
+print("synchronous frame (render + ReSTIRDirect + tone map + update): %.3f ms; tile split %s" %
+      ((time.perf_counter() - t0) / N * 1e3, os.environ.get("TILE_SPLIT", "default")))

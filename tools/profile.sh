@@ -1,13 +1,14 @@
 #!/bin/bash
-# tools_profile.sh TAG -- on the GPU box: kernel trace + HBM counters of the bench command.
+# tools/profile.sh TAG [CONFIG] -- on the GPU box: kernel trace + HBM counters of the bench command (CONFIG = bench.py --config, default 3).
 # Separate rocprofv3 passes for FETCH_SIZE and WRITE_SIZE (TCC slots), counters never combined with sys/hip traces.
 set -e -o pipefail
 TAG=${1:-r01}
+CONFIG=${2:-3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --cpu-frames 0"
+CMD="python $R/bench.py --config $CONFIG --steps 20 --warmup 3 --cpu-frames 0"
 # per-kernel durations with every kernel on one stream (what bench.py's roofline / pass_ms section measures: kernels that
 # share the CUs with another frame's kernels last longer without doing more work) ...
 RS_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
