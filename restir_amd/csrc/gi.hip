@@ -264,7 +264,572 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     if (lane == 0 && walks) atomicAdd(rayCount + (blockIdx.x % 64) * 8, (unsigned long long)walks);
 }
 
+// ---- the wavefront form: one launch per stage and bounce over queues of live paths -----------------------------------------------------
+// k_path above keeps a path in one lane from the camera to its end: after the first bounce a wave's lanes die one by one (31 of 64 walk
+// on average), every lane carries the whole path state across both walks (110-140 VGPRs wanted, capped at 72 with scratch), and the rays
+// of a wave start anywhere and go anywhere.  Here a path's state lives in memory (SoA planes indexed by queue slot) between the stages
+//     primary   camera ray (packet walk), first hit                                   -> hit queue of depth 1
+//     per depth d = 1 .. maxDepth:
+//       shade    light sample + BSDF sample of every path in the hit queue              -> shadow queue, ray queue (one bucket per threaded order)
+//       shadow   any-hit walk of every shadow segment; the visible ones add their contribution to the pixel's sum
+//       extend   closest-hit walk of every bounce ray, the hit's own contribution (emissive surface, environment) -> hit queue of depth d + 1
+//     finish    per pixel: the tail of the three kernels (accumulate; ReSTIR: reservoir update, temporal merge, shade)
+// so that every wave of a walk kernel starts with 64 rays (queues are compacted with a ballot + one atomic per wave), the bounce rays of a
+// wave share one threaded order (getMTBVHId, src/scene.h:101-119: six buckets) and the walk kernels carry nothing but the ray across the walk.
+// Per path the draws, their order and every arithmetic expression are those of path_loop; the per-pixel sums receive their terms in the
+// path's own order (shadow of depth d before extend of depth d on one stream), so the images, reservoirs and ray counts are bit-identical.
+struct GiQueues {
+    int n;                                             // capacity of every queue = pixels
+    int* counters;                                     // ctr(q, depth, k): 0 hit-queue entries, 1 shadow-queue entries, 2..7 ray-queue entries per order
+    // hit queue: a path at a surface that will be shaded
+    int* hPixel; uint32_t* hRng; int* hPtr;
+    float4 *hPos, *hNorm, *hWo, *hMatA, *hMatB;       // pos | thr.x, norm | thr.y, wo | thr.z, baseColor | type, metallic roughness ior 0
+    // ray queue, slot = order * n + i
+    int* rPixel; uint32_t* rRng; int* rPtr;
+    float4 *rPos, *rDir, *rThr;                        // surface point | pdf of the sample, direction | sample is specular, throughput
+    float4* rHit;                                      // what the walk found: bx, by, primitive, distance (k_wf_walk -> k_wf_extend<.., false>)
+    int* slow;                                         // ray slots the streaming walk leaves to the general walk (special-case / far-origin rays)
+    // shadow queue
+    float4 *sX, *sY; float2* sAdd;                     // surface point | pixel and flags, light point | add.x, add.y add.z
+    // per pixel: the sums, and what ReSTIRIndirect keeps of a path (restir.cu:273-281,316-321)
+    float4 *accD, *accI;
+    float4 *pWo, *pMatA, *pMatB, *pXv, *pNv, *pXs, *pNs;       // primWo | primSamplePdf, primMaterial (pMatB.w: primSampleDelta), ...
+    uint32_t* endRng; int* endPtr;                     // the sampler as the path left it (the reservoir update draws from it)
+};
+constexpr int kFlagAdd = 1 << 29, kFlagDirect = 1 << 30, kPixelMask = kFlagAdd - 1;
+// Every counter has a 128-byte line of its own, and a block adds to it ONCE (block_append): with one atomic per wave and the seven counters
+// of a depth in one line, the shade stage spent 2.3 ms per bounce in 230 000 serialised atomics (profiles/r04_gi_wavefront_first.log).
+constexpr int kCtrStride = 32;
+__device__ __forceinline__ int* ctr(const GiQueues& q, int depth, int k) { return q.counters + (depth * 8 + k) * kCtrStride; }
+
+template <bool SOBOL> __device__ __forceinline__ void rng_save(const SamplerT<SOBOL>& r, uint32_t* word, int* ptr, int i);
+template <> __device__ __forceinline__ void rng_save<false>(const SamplerT<false>& r, uint32_t* word, int*, int i) { word[i] = r.x; }
+template <> __device__ __forceinline__ void rng_save<true>(const SamplerT<true>& r, uint32_t* word, int* ptr, int i) { word[i] = r.scramble; ptr[i] = r.ptr; }
+template <bool SOBOL> __device__ __forceinline__ SamplerT<SOBOL> rng_load(const uint32_t* table, const uint32_t* word, const int* ptr, int i);
+template <> __device__ __forceinline__ SamplerT<false> rng_load<false>(const uint32_t*, const uint32_t* word, const int*, int i) { SamplerT<false> r; r.x = word[i]; return r; }
+template <> __device__ __forceinline__ SamplerT<true> rng_load<true>(const uint32_t* table, const uint32_t* word, const int* ptr, int i) {
+    SamplerT<true> r; r.data = table; r.scramble = word[i]; r.ptr = ptr[i]; return r;
+}
+
+// Slot of this thread in queue `which` (0 .. NQ-1; -1: nothing to append) out of NQ queues the BLOCK appends to: ballots inside the waves,
+// the waves' counts through LDS, one atomic per queue and block.  Every thread of the block must call it (it synchronises the block).
+template <int NQ, int WAVES>
+__device__ __forceinline__ int block_append(int which, int* const counter[NQ], int (&lds)[WAVES + 1][NQ]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank = 0, mine = 0;
+    for (int k = 0; k < NQ; k++) {
+        const unsigned long long m = __ballot(which == k);
+        if (which == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == k) mine = __popcll(m);
+    }
+    __syncthreads();                                   // (the previous use of `lds` is over)
+    if (lane < NQ) lds[wave][lane] = mine;
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        int total = 0;
+        for (int w = 0; w < WAVES; w++) { const int c = lds[w][threadIdx.x]; lds[w][threadIdx.x] = total; total += c; }
+        lds[WAVES][threadIdx.x] = total ? atomicAdd(counter[threadIdx.x], total) : 0;
+    }
+    __syncthreads();
+    return which >= 0 ? lds[WAVES][which] + lds[wave][which] + rank : 0;
+}
+
+template <int MODE, bool TEX, bool SOBOL>
+__global__ void __launch_bounds__(256) k_wf_primary(DevScene s, CamParams cam, GiQueues q, int looper, int tilesX) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const int x = bx * 32 + wave * 8 + (lane & 7);
+    const int y = by * 8 + (lane >> 3);
+    const bool inside = x < cam.width && y < cam.height;
+    const int index = y * cam.width + x;
+    SamplerT<SOBOL> rng = SamplerT<SOBOL>::seeded(s.sampleSeq, looper, index, 0);     // pathtrace.cu:170,339, restir.cu:256
+    const f4 r = rng.uniform4();
+    const Ray ray = camera_sample(cam, x, y, r.x, r.y);
+    const Hit h = trace_closest_packet(s, ray, inside);                // all 64 lanes take part in the wave's walk
+    // primary hit (pathtrace.cu:172-190 / 343-350, restir.cu:259-270)
+    bool alive = false;
+    f3 direct = splat(0.f), norm = h.norm;
+    SurfMat material = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
+    if (inside) {
+        if (h.primId == kNullPrim) {
+            if (MODE == kModePT) direct = splat(1.f);                                  // pathtrace.cu:175-178
+        }
+        else {
+            material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+            if (MODE == kModePT) material.baseColor = splat(1.f);                      // DENOISER_DEMODULATE (:181-185)
+            if (material.type == 4) {
+                if (MODE == kModePT) direct = splat(1.f);                              // :187-190
+            }
+            else alive = true;
+        }
+        if (MODE == kModePT) q.accD[index] = make_float4(direct.x, direct.y, direct.z, 0.f);
+        q.accI[index] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == kModeReSTIR) {
+            const SurfMat pm = alive ? material : SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
+            q.pWo[index] = make_float4(-ray.d.x, -ray.d.y, -ray.d.z, 0.f);
+            q.pMatA[index] = make_float4(pm.baseColor.x, pm.baseColor.y, pm.baseColor.z, __int_as_float(pm.type));
+            q.pMatB[index] = make_float4(pm.metallic, pm.roughness, pm.ior, 0.f);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            q.pXv[index] = z; q.pNv[index] = z; q.pXs[index] = z; q.pNs[index] = z;
+            if (!alive) rng_save<SOBOL>(rng, q.endRng, q.endPtr, index);
+        }
+    }
+    __shared__ int lds[4 + 1][1];
+    int* const counters[1] = { ctr(q, 1, 0) };
+    const int slot = block_append<1, 4>(alive ? 0 : -1, counters, lds);
+    if (alive) {
+        q.hPixel[slot] = index;
+        rng_save<SOBOL>(rng, q.hRng, q.hPtr, slot);
+        q.hPos[slot] = make_float4(h.pos.x, h.pos.y, h.pos.z, 1.f);                   // throughput (1, 1, 1)
+        q.hNorm[slot] = make_float4(norm.x, norm.y, norm.z, 1.f);
+        q.hWo[slot] = make_float4(-ray.d.x, -ray.d.y, -ray.d.z, 1.f);
+        q.hMatA[slot] = make_float4(material.baseColor.x, material.baseColor.y, material.baseColor.z, __int_as_float(material.type));
+        q.hMatB[slot] = make_float4(material.metallic, material.roughness, material.ior, 0.f);
+    }
+}
+
+// light sample and BSDF sample of every path in the hit queue of `depth` (the first half of path_loop's body)
+constexpr int kShadeThreads = 1024;
+template <int MODE, bool TEX, bool SOBOL>
+__global__ void __launch_bounds__(kShadeThreads) k_wf_shade(DevScene s, GiQueues q, int depth) {
+    const int count = *ctr(q, depth, 0);
+    if ((int)(blockIdx.x * (unsigned)kShadeThreads) >= count) return;
+    const int i = blockIdx.x * kShadeThreads + threadIdx.x;
+    bool alive = i < count;
+    const int j = alive ? i : 0;
+    const int pixel = q.hPixel[j];
+    SamplerT<SOBOL> rng = rng_load<SOBOL>(s.sampleSeq, q.hRng, q.hPtr, j);
+    const float4 a0 = q.hPos[j], a1 = q.hNorm[j], a2 = q.hWo[j], m0 = q.hMatA[j], m1 = q.hMatB[j];
+    const f3 pos = mk3(a0.x, a0.y, a0.z), wo = mk3(a2.x, a2.y, a2.z);
+    f3 norm = mk3(a1.x, a1.y, a1.z), throughput = mk3(a0.w, a1.w, a2.w);
+    const SurfMat material = SurfMat{ __float_as_int(m0.w), mk3(m0.x, m0.y, m0.z), m1.x, m1.y, m1.z };
+    const bool env = TEX && s.envTex >= 0;
+    const bool deltaBSDF = material.type == 2;
+    if (alive && material.type != 2 && dot(norm, wo) < 0.f) norm = -norm;
+
+    // next-event estimation (pathtrace.cu:203-213 / 365-376, restir.cu:291-302): the light sample here, the occlusion test in k_wf_shadow
+    const bool nee = alive && !deltaBSDF && (MODE == kModePT || depth > 1) && s.numLights > 0;
+    LightSample c;
+    c.pdf = kInvalidPdf; c.Li = splat(0.f); c.wi = splat(0.f); c.dist = 0.f; c.point = pos; c.id = 0;
+    if (alive && !deltaBSDF && (MODE == kModePT || depth > 1)) {
+        const f4 r = rng.uniform4();                                            // drawn even without lights (sample4D is an argument)
+        if (nee) c = env ? sample_light_nv<true, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r)
+                         : sample_light_nv<false, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
+    }
+    f3 add = splat(0.f);
+    const bool contributes = nee && c.pdf > 0.f;                                // (visible: lightPdf = c.pdf)
+    if (contributes) {
+        const float bsdfPdf = material_pdf(material, norm, wo, c.wi);
+        add = ((((throughput * material_bsdf(material, norm, wo, c.wi)) * c.Li) * sat_dot(norm, c.wi)) / c.pdf) * power_heuristic(c.pdf, bsdfPdf);
+    }
+
+    BsdfSample sample;
+    sample.dir = splat(0.f); sample.bsdf = splat(0.f); sample.pdf = 0.f; sample.type = kBsInvalid;
+    bool deltaSample = false;
+    const bool was = alive;
+    if (alive) {
+        const f3 r3 = mk3(rng.uniform(), rng.uniform(), rng.uniform());        // sample3D
+        sample = material_sample(material, norm, wo, r3);
+        if (sample.type == kBsInvalid) alive = false;
+        else if (sample.pdf < 1e-8f) alive = false;
+    }
+    if (alive) {
+        deltaSample = (sample.type & kBsSpecular) != 0;
+        if (MODE != kModeReSTIR || depth > 1)                                   // restir.cu:315-325
+            throughput = throughput * ((sample.bsdf / sample.pdf) * (deltaSample ? 1.f : abs_dot(norm, sample.dir)));
+        else {
+            float4 w = q.pWo[pixel]; w.w = sample.pdf; q.pWo[pixel] = w;       // primSamplePdf
+            float4 b = q.pMatB[pixel]; b.w = deltaSample ? 1.f : 0.f; q.pMatB[pixel] = b;
+            q.pXv[pixel] = make_float4(pos.x, pos.y, pos.z, 0.f); q.pNv[pixel] = make_float4(norm.x, norm.y, norm.z, 0.f);
+        }
+    }
+    if (MODE == kModeReSTIR && was && !alive) rng_save<SOBOL>(rng, q.endRng, q.endPtr, pixel);
+    // the shadow segment into the shadow queue, the bounce ray into the bucket of its threaded order (what walk_ordered_tree derives from
+    // the direction): queue 0 and queues 1..6 of one block-level append
+    __shared__ int lds[kShadeThreads / 64 + 1][7];
+    int* const counters[7] = { ctr(q, depth, 1), ctr(q, depth, 2), ctr(q, depth, 3), ctr(q, depth, 4), ctr(q, depth, 5), ctr(q, depth, 6), ctr(q, depth, 7) };
+    const int order = alive ? mtbvh_order(-sample.dir) : -1;
+    // (two appends per thread: the ranks of the shadow queue and of the ray buckets are computed in two passes over one table)
+    const int sSlot = block_append<7, kShadeThreads / 64>(nee ? 0 : -1, counters, lds);
+    if (nee) {
+        const int flags = pixel | (contributes ? kFlagAdd : 0) | ((MODE == kModePT && depth == 1) ? kFlagDirect : 0);
+        q.sX[sSlot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(flags));
+        q.sY[sSlot] = make_float4(c.point.x, c.point.y, c.point.z, add.x);
+        q.sAdd[sSlot] = make_float2(add.y, add.z);
+    }
+    const int rSlot = block_append<7, kShadeThreads / 64>(order >= 0 ? 1 + order : -1, counters, lds);
+    if (order >= 0) {
+        const int slot = order * q.n + rSlot;
+        q.rPixel[slot] = pixel;
+        rng_save<SOBOL>(rng, q.rRng, q.rPtr, slot);
+        q.rPos[slot] = make_float4(pos.x, pos.y, pos.z, sample.pdf);
+        q.rDir[slot] = make_float4(sample.dir.x, sample.dir.y, sample.dir.z, deltaSample ? 1.f : 0.f);
+        q.rThr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.f);
+    }
+}
+
+// any-hit walk of every shadow segment of `depth`; a visible one adds its contribution to its pixel's sum
+__global__ void __launch_bounds__(256) k_wf_shadow(DevScene s, GiQueues q, int depth) {
+    const int count = *ctr(q, depth, 1);
+    if ((int)(blockIdx.x * 256u) >= count) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < count;
+    const int j = active ? i : 0;
+    const float4 x = q.sX[j], y = q.sY[j];
+    const bool occluded = trace_occluded_wave(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), active);
+    const int flags = __float_as_int(x.w);
+    if (active && !occluded && (flags & kFlagAdd)) {
+        const float2 yz = q.sAdd[j];
+        float4* acc = ((flags & kFlagDirect) ? q.accD : q.accI) + (flags & kPixelMask);
+        float4 v = *acc;
+        v.x += y.w; v.y += yz.x; v.z += yz.y;
+        *acc = v;
+    }
+}
+
+// ---- the streaming closest-hit walk ------------------------------------------------------------------------------------------------
+// walk_ordered_tree (rs_scene.h) for a QUEUE of rays: a wave owns a run of consecutive rays of one order's bucket and REPLACES the
+// rays that have finished -- a wave of the plain walk iterates until its slowest ray is done, 224 iterations for a mean of 108 steps per
+// ray (tools/walk_stats.py), so more than half of its lane-iterations are idle.  Whenever at least kRefillAt lanes have nothing left to do,
+// they store what they found (rHit) and take the next rays of the wave's share.  Per ray: the same nodes, the same leaves in the same
+// order, the same arithmetic as walk_ordered_tree (the interleaving of walk steps and leaf rounds differs, which that walk's argument --
+// a stale `closest` only enters more -- already allows), so the same primitive and barycentrics; tested against the oracle like the rest.
+// Rays that take one of AABB::intersect's special cases or start outside the grid's reach go to the `slow` list (k_wf_walk_slow).
+// The grid is the chip's capacity of resident waves (kWalkWavesPerSimd per SIMD), every block a share of one bucket proportional to the
+// bucket's size: one round of waves, each of which streams through its share.
+constexpr int kRefillAt = 16, kWalkWavesPerSimd = 6;
+__global__ void __launch_bounds__(256, kWalkWavesPerSimd) k_wf_walk(DevScene s, GiQueues q, int depth) {
+    int k = 0, first = 0, blockEnd = 0;
+    {
+        int c[6], total = 0;
+        for (int i = 0; i < 6; i++) { c[i] = *ctr(q, depth, 2 + i); total += c[i]; }
+        if (total == 0) return;
+        int b = blockIdx.x;
+        for (k = 0; k < 6; k++) {
+            const int blocks = c[k] ? 1 + (int)((long long)c[k] * (long long)((int)gridDim.x - 6) / total) : 0;
+            if (b < blocks) {
+                const int share = (c[k] + blocks - 1) / blocks;
+                first = b * share; blockEnd = min(c[k], first + share);
+                break;
+            }
+            b -= blocks;
+        }
+        if (k == 6 || first >= blockEnd) return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waveShare = (blockEnd - first + 3) >> 2;
+    int next = first + wave * waveShare;                              // wave-uniform: the next ray of this wave's share
+    const int waveEnd = min(blockEnd, next + waveShare);
+    if (next >= waveEnd) return;
+    const char* nodes = reinterpret_cast<const char*>(s.ordNodes);
+    const unsigned startOff = (unsigned)k * s.ordStride, endOff = ((unsigned)k + 1u) * s.ordStride - 16u;
+    const TriRec* tris = s.ordTris + (size_t)(k >> 1) * (size_t)s.numPrims;
+    const int triStep = (k & 1) ? -1 : 1;
+    // per lane: the ray and its walk (idle: cur == endOff, qn == 0, slot < 0)
+    f3 o = splat(0.f), d = splat(0.f), dinv = splat(0.f);
+    vf2 Axy = { 0.f, 0.f }, Bxy = { -1.f, -1.f }, Azz = { 0.f, 0.f }, Bzz = { -1.f, -1.f };
+    float tRoot = 0.f, closest = 3.402823466e+38f, hbx = 0.f, hby = 0.f;
+    unsigned selX = 0x07060100u, selY = 0x05040302u, selZ = 0x07060100u, cur = endOff;
+    int prim = kNullPrim, q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0, slot = -1;
+    for (;;) {
+        // ---- refill point
+        {
+            const bool idle = (cur == endOff) & (qn == 0);
+            const unsigned long long idleMask = __ballot(idle);
+            const int nIdle = __popcll(idleMask);
+            if (nIdle == 64 || (nIdle >= kRefillAt && next < waveEnd)) {
+                if (idle && slot >= 0) {
+                    q.rHit[slot] = make_float4(hbx, hby, __int_as_float(prim), closest);
+                    slot = -1;
+                    Axy = vf2{ 0.f, 0.f }; Bxy = vf2{ -1.f, -1.f }; Azz = Axy; Bzz = Bxy;      // rests on the end record, whose test then fails whatever it holds
+                }
+                if (next >= waveEnd) { if (nIdle == 64) break; }
+                else {
+                    const int idx = next + __popcll(idleMask & ((1ull << lane) - 1ull));
+                    const bool take = idle && idx < waveEnd;
+                    next = min(waveEnd, next + nIdle);
+                    if (take) {
+                        const int j = k * q.n + idx;
+                        const float4 a0 = q.rPos[j], a1 = q.rDir[j];
+                        d = mk3(a1.x, a1.y, a1.z); o = mk3(a0.x, a0.y, a0.z) + d * 1e-5f;         // makeOffsetedRay
+                        Ray ray; ray.o = o; ray.d = d;
+                        const RayBoxCtx ctx = make_box_ctx(ray);
+                        const bool special = ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(d.x == d.x);
+                        if (special || !occlusion_tree_usable(s, o)) q.slow[atomicAdd(ctr(q, depth, 0) + 1, 1)] = j;      // (the word after the hit-queue counter of this depth, which is no longer read)
+                        else {
+                            dinv = ctx.dinv;
+                            const f3 A = mk3(s.occScale.x * dinv.x, s.occScale.y * dinv.y, s.occScale.z * dinv.z);
+                            const f3 B = mk3((s.occBase.x - o.x) * dinv.x, (s.occBase.y - o.y) * dinv.y, (s.occBase.z - o.z) * dinv.z);
+                            tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - o.x) * dinv.x), gabs((s.occRootHi.x - o.x) * dinv.x)),
+                                                fmaxf(gabs((s.occRootLo.y - o.y) * dinv.y), gabs((s.occRootHi.y - o.y) * dinv.y))),
+                                          fmaxf(gabs((s.occRootLo.z - o.z) * dinv.z), gabs((s.occRootHi.z - o.z) * dinv.z)));
+                            selX = A.x < 0.f ? 0x01000706u : 0x07060100u; selY = A.y < 0.f ? 0x03020504u : 0x05040302u; selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;
+                            Axy = vf2{ A.x, A.y }; Bxy = vf2{ B.x, B.y }; Azz = vf2{ A.z, A.z }; Bzz = vf2{ B.z, B.z };
+                            closest = 3.402823466e+38f; prim = kNullPrim; hbx = 0.f; hby = 0.f;
+                            cur = startOff; slot = j;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- walk phase: until some lane's queue is full, every walk has ended, or enough lanes are idle to be refilled
+        for (;;) {
+            const unsigned long long walkers = __ballot(cur != endOff);
+            if (!walkers) break;
+            if (next < waveEnd && __popcll(__ballot((cur == endOff) & (qn == 0))) >= kRefillAt) break;
+            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+            const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
+            const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
+            const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
+            const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
+            const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
+            const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
+            const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < closest);
+            const int meta = (int)n.w;
+            const bool leaf = meta < 0;
+            const bool push = pass && leaf;
+            const int code = ~meta;
+            q0 = (push && qn == 0) ? code : q0; q1 = (push && qn == 1) ? code : q1; q2 = (push && qn == 2) ? code : q2; q3 = (push && qn == 3) ? code : q3;
+            qn = push ? qn + 1 : qn;
+            cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
+            if (__any(qn == RS_ORD_QUEUE)) break;
+        }
+        if (!__any(qn > 0)) continue;
+        // ---- leaf round: every lane takes its OLDEST queued leaf and judges its triangles one after the other (walk_ordered_tree)
+        int tri = 0, cnt = 0, verify = -1;
+        if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
+        float cd = 0.f, cbx = 0.f, cby = 0.f; int cprim = kNullPrim;
+        for (;;) {
+            while (__any((cnt > 0) & (verify < 0))) {
+                if ((cnt > 0) & (verify < 0)) {
+                    const float4* p = reinterpret_cast<const float4*>(tris + tri);
+                    const float4 a = p[0], b = p[1], c = p[2];
+                    float bx, by, dist;
+                    tri += triStep; cnt--;
+                    if (tri_hit(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < closest) {
+                        cd = dist; cbx = bx; cby = by; cprim = __float_as_int(b.w);
+                        verify = __float_as_int(a.w);          // reference leaf of the candidate
+                    }
+                }
+            }
+            if (!__any(verify >= 0)) break;
+            while (__any(verify >= 0)) {
+                if (verify >= 0) {
+                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + verify);
+                    float4 lo, hi;
+                    node_unpack(rec[0], rec[1], lo, hi);
+                    const float t1x = (lo.x - o.x) * dinv.x, t1y = (lo.y - o.y) * dinv.y, t1z = (lo.z - o.z) * dinv.z;
+                    const float t2x = (hi.x - o.x) * dinv.x, t2y = (hi.y - o.y) * dinv.y, t2z = (hi.z - o.z) * dinv.z;
+                    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
+                    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
+                    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
+                    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
+                    const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
+                    const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < closest);
+                    const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
+                    const int parent = __float_as_int(lo.w);
+                    const bool done = open & ((parent < 0) | clear);
+                    if (done) { closest = cd; hbx = cbx; hby = cby; prim = cprim; }
+                    verify = (open & !done) ? parent : -1;
+                }
+            }
+        }
+    }
+}
+// the rays the streaming walk left out: the general wave-level walk (trace_closest_wave takes every case), a few waves over the list
+__global__ void __launch_bounds__(256) k_wf_walk_slow(DevScene s, GiQueues q, int depth) {
+    const int count = ctr(q, depth, 0)[1];
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), waves = gridDim.x * 4;
+    for (int base = wave * 64; base < count; base += waves * 64) {
+        const bool active = base + lane < count;
+        const int j = q.slow[active ? base + lane : 0];
+        const float4 a0 = q.rPos[j], a1 = q.rDir[j];
+        Ray ray; ray.d = mk3(a1.x, a1.y, a1.z); ray.o = mk3(a0.x, a0.y, a0.z) + ray.d * 1e-5f;
+        const WalkResult w = walk_dispatch_paired<false>(s, ray, 3.402823466e+38f, active);
+        if (active) q.rHit[j] = make_float4(w.bx, w.by, __int_as_float(w.prim), w.closest);
+    }
+}
+
+// closest-hit walk of every bounce ray of `depth` and the hit's own contribution (the second half of path_loop's body)
+// WALK false: the walk has been done by k_wf_walk / k_wf_walk_slow (rHit); true: the plain wave-level walk here (no closest-hit trees)
+template <int MODE, bool TEX, bool SOBOL, bool WALK>
+__global__ void __launch_bounds__(256) k_wf_extend(DevScene s, GiQueues q, int depth, int maxDepth) {
+    // blocks in bucket order: bucket k takes ceil(count_k / 256) blocks
+    int k = 0, first = 0, count = 0;
+    {
+        int b = blockIdx.x;
+        for (k = 0; k < 6; k++) {
+            count = *ctr(q, depth, 2 + k);
+            const int blocks = (count + 255) >> 8;
+            if (b < blocks) { first = b * 256; break; }
+            b -= blocks;
+        }
+        if (k == 6) return;
+    }
+    const int i = first + threadIdx.x;
+    bool alive = i < count;
+    const int j = k * q.n + (alive ? i : 0);
+    const float4 a0 = q.rPos[j], a1 = q.rDir[j];
+    const f3 curPos = mk3(a0.x, a0.y, a0.z);
+    Ray ray; ray.d = mk3(a1.x, a1.y, a1.z); ray.o = curPos + ray.d * 1e-5f;   // makeOffsetedRay
+    Hit h;
+    if (WALK) h = trace_closest_wave(s, ray, alive);
+    else {
+        const float4 f = q.rHit[j];
+        h.primId = alive ? __float_as_int(f.z) : kNullPrim;
+        h.matId = 0; h.pos = splat(0.f); h.norm = splat(0.f); h.bx = f.x; h.by = f.y;
+        if (h.primId != kNullPrim) {           // getIntersecGeomInfo (scene.h:135-151), as trace_closest_wave
+            const float* v = s.vertices + (size_t)h.primId * 9;
+            const float* n = s.normals + (size_t)h.primId * 9;
+            const float wgt = 1.f - h.bx - h.by;
+            h.pos = ld3(v + 3) * h.bx + ld3(v + 6) * h.by + ld3(v) * wgt;
+            h.norm = normalize(ld3(n + 3) * h.bx + ld3(n + 6) * h.by + ld3(n) * wgt);
+            h.matId = s.materialIds[h.primId];
+        }
+    }
+    const bool mine = alive;                                                    // this lane carries a ray
+    const float samplePdf = a0.w;
+    const bool deltaSample = a1.w != 0.f;
+    const int pixel = q.rPixel[j];
+    const float4 a2 = q.rThr[j];
+    const f3 throughput = mk3(a2.x, a2.y, a2.z);
+    const bool env = TEX && s.envTex >= 0;
+    f3 pos = curPos, norm = splat(0.f);
+    SurfMat material = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
+    if (!mine) {}
+    else if (h.primId == kNullPrim) {
+        if (env) {
+            const f3 radiance = env_radiance(s, ray.d) * throughput;
+            const float weight = deltaSample ? 1.f : power_heuristic(samplePdf, environment_map_pdf(s, ray.d));
+            float4 v = q.accI[pixel];
+            v.x += radiance.x * weight; v.y += radiance.y * weight; v.z += radiance.z * weight;
+            q.accI[pixel] = v;
+        }
+        alive = false;
+    }
+    else {
+        pos = h.pos; norm = h.norm;
+        material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+        if (material.type == 4) {
+            if (!(dot(norm, ray.d) < 0.f)) {                                    // SCENE_LIGHT_SINGLE_SIDED: the back side ends the path silently
+                const f3 radiance = material.baseColor;
+                const bool unweighted = deltaSample || (MODE == kModeReSTIR && depth == 1);      // restir.cu:353
+                const float weight = unweighted ? 1.f : power_heuristic(samplePdf,
+                    (luminance(radiance) * s.sumLightPowerInv * primitive_area(s, h.primId)) * dot(curPos - pos, curPos - pos) /
+                        abs_dot(norm, normalize(curPos - pos)));                 // Math::pdfAreaToSolidAngle (mathUtil.h:182-185)
+                const f3 add = (radiance * throughput) * weight;
+                float4 v = q.accI[pixel];
+                v.x += add.x; v.y += add.y; v.z += add.z;
+                q.accI[pixel] = v;
+                if (MODE == kModeReSTIR && depth == 1) { q.pXs[pixel] = make_float4(pos.x, pos.y, pos.z, 0.f); q.pNs[pixel] = make_float4(norm.x, norm.y, norm.z, 0.f); }
+            }
+            alive = false;
+        }
+        else if (MODE == kModeReSTIR && depth == 1) { q.pXs[pixel] = make_float4(pos.x, pos.y, pos.z, 0.f); q.pNs[pixel] = make_float4(norm.x, norm.y, norm.z, 0.f); }
+    }
+    const bool goesOn = alive && depth < maxDepth;
+    if (MODE == kModeReSTIR && mine && !goesOn) { q.endRng[pixel] = q.rRng[j]; if (SOBOL) q.endPtr[pixel] = q.rPtr[j]; }
+    __shared__ int lds[4 + 1][1];
+    int* const counters[1] = { ctr(q, depth + 1, 0) };
+    const int slot = block_append<1, 4>(goesOn ? 0 : -1, counters, lds);
+    if (goesOn) {
+        q.hPixel[slot] = pixel;
+        q.hRng[slot] = q.rRng[j]; if (SOBOL) q.hPtr[slot] = q.rPtr[j];
+        q.hPos[slot] = make_float4(pos.x, pos.y, pos.z, throughput.x);
+        q.hNorm[slot] = make_float4(norm.x, norm.y, norm.z, throughput.y);
+        q.hWo[slot] = make_float4(-ray.d.x, -ray.d.y, -ray.d.z, throughput.z);
+        q.hMatA[slot] = make_float4(material.baseColor.x, material.baseColor.y, material.baseColor.z, __int_as_float(material.type));
+        q.hMatB[slot] = make_float4(material.metallic, material.roughness, material.ior, 0.f);
+    }
+}
+
+
+// per pixel: what follows the path loop in the three kernels
+template <int MODE, bool SOBOL>
+__global__ void __launch_bounds__(256) k_wf_finish(DevScene s, GiQueues q, float* __restrict__ directIllum, float* __restrict__ indirectIllum,
+                                                   rs_indirect_reservoir* __restrict__ resvOut, const rs_indirect_reservoir* __restrict__ resvIn,
+                                                   GBufView g, int iter, int maxDepth, int first, int reuse, int pixels, unsigned long long* rayCount) {
+    const int index = blockIdx.x * 256 + threadIdx.x;
+    if (index == 0) {      // BVH walks for the Mrays/s metric: one camera ray per pixel, every shadow segment, every bounce ray
+        unsigned long long walks = (unsigned long long)pixels;
+        for (int d = 1; d <= maxDepth; d++) for (int k = 1; k < 8; k++) walks += (unsigned long long)*ctr(q, d, k);
+        rayCount[0] = walks;
+    }
+    if (index >= pixels) return;
+    const float4 ai = q.accI[index];
+    f3 ind = mk3(ai.x, ai.y, ai.z);
+    if (MODE == kModePT) {
+        const float4 ad = q.accD[index];
+        f3 dir = mk3(ad.x, ad.y, ad.z);
+        if (any_nan_or_inf(dir)) dir = splat(0.f);
+        if (any_nan_or_inf(ind)) ind = splat(0.f);
+        accumulate(directIllum, index, hdr_to_ldr(dir), iter);                          // Math::HDRToLDR (:273-276)
+        accumulate(indirectIllum, index, hdr_to_ldr(ind), iter);
+    }
+    else if (MODE == kModePTIndirect) {
+        if (any_nan_or_inf(ind)) ind = splat(0.f);
+        accumulate(indirectIllum, index, ind, iter);
+    }
+    else {
+        // WriteSample (restir.cu:372-416)
+        SamplerT<SOBOL> rng = rng_load<SOBOL>(s.sampleSeq, q.endRng, q.endPtr, index);
+        const float4 w0 = q.pWo[index], m0 = q.pMatA[index], m1 = q.pMatB[index], xv = q.pXv[index], nv = q.pNv[index], xs = q.pXs[index], ns = q.pNs[index];
+        const f3 primWo = mk3(w0.x, w0.y, w0.z);
+        const float primSamplePdf = w0.w;
+        const bool primSampleDelta = m1.w != 0.f;
+        const SurfMat primMaterial = SurfMat{ __float_as_int(m0.w), mk3(m0.x, m0.y, m0.z), m1.x, m1.y, m1.z };
+        IndResv smp; smp.Lo = ind; smp.xv = mk3(xv.x, xv.y, xv.z); smp.nv = mk3(nv.x, nv.y, nv.z); smp.xs = mk3(xs.x, xs.y, xs.z); smp.ns = mk3(ns.x, ns.y, ns.z); smp.M = 0; smp.W = 0.f;
+        IndResv rv; rv.Lo = rv.xv = rv.nv = rv.xs = rv.ns = splat(0.f); rv.M = 0; rv.W = 0.f;
+        float sampleWeight = 0.f;
+        if (!(luminance(smp.Lo) < 1e-8f)) {                                         // !indirectSample.invalid()
+            sampleWeight = luminance(smp.Lo / primSamplePdf);                       // toScalar(pHatIndirect / primSamplePdf), pHat = Lo
+            if ((sampleWeight != sampleWeight) || sampleWeight < 0.f) sampleWeight = 0.f;
+        }
+        {
+            const float u = rng.uniform();                                          // Reservoir::update
+            rv.W += sampleWeight; rv.M++;
+            if (u * rv.W < sampleWeight) { rv.Lo = smp.Lo; rv.xv = smp.xv; rv.nv = smp.nv; rv.xs = smp.xs; rv.ns = smp.ns; }
+        }
+        if (!first && (reuse & 1)) {                                                // findTemporalNeighbor (restir.cu:20-45)
+            const int primId = g.primId[index];
+            const int lastIdx = g.motion[index];
+            bool diff = false;
+            if (lastIdx < 0) diff = true;
+            else if (primId <= kNullPrim) diff = true;
+            else if (g.lastPrimId[lastIdx] != primId) diff = true;
+            else {
+                const f3 n = ld3(g.normal + (size_t)index * 3), ln = ld3(g.lastNormal + (size_t)lastIdx * 3);
+                const float depth = g.depth[index], pdepth = g.lastDepth[lastIdx];
+                if (abs_dot(n, ln) < .9f || gabs(pdepth - depth) > depth * .1f) diff = true;
+            }
+            IndResv t; t.Lo = t.xv = t.nv = t.xs = t.ns = splat(0.f); t.M = 0; t.W = 0.f;
+            if (!diff) t = ind_load(resvIn + lastIdx);
+            if (!ind_invalid(t.W)) {
+                const float u = rng.uniform();                                      // Reservoir::merge (restir.h:61-68)
+                rv.W += t.W; rv.M += t.M;
+                if (u * rv.W < t.W) { rv.Lo = t.Lo; rv.xv = t.xv; rv.nv = t.nv; rv.xs = t.xs; rv.ns = t.ns; }
+            }
+        }
+        f3 indirect = splat(0.f);
+        if (rv.M > 20) { rv.W *= (float)20 / (float)rv.M; rv.M = 20; }            // clamp<20>() (restir.h:79-86)
+        if (!ind_invalid(rv.W)) {
+            const f3 primWi = normalize(rv.xs - rv.xv);
+            indirect = ((rv.Lo / luminance(rv.Lo)) * rv.W) / (float)rv.M;
+            indirect = indirect * (material_bsdf(primMaterial, rv.nv, primWo, primWi) * (primSampleDelta ? 1.f : sat_dot(rv.nv, primWi)));
+        }
+        if (any_nan_or_inf(indirect)) indirect = splat(0.f);
+        ind_store(resvOut + index, rv);
+        accumulate(indirectIllum, index, indirect, iter);
+    }
+}
+
 unsigned long long* g_giRayCount = nullptr;     // 64 partial counters, 64 B apart
+int g_pathForm = 1;        // 0: one kernel per path (k_path); 1: the wavefront form
+
+}  // namespace
+// measurement switch while both forms exist (tools/bench_gi.py --ab-form)
+extern "C" int rs_debug_set_path_form(int form) { g_pathForm = form; return 0; }
+namespace {
 
 int gi_counters() {
     if (!g_giRayCount) RS_TRY(rs_dev_alloc(&g_giRayCount, 64 * 8));
@@ -281,6 +846,107 @@ int gi_read_rays(unsigned long long* rays) {
     return 0;
 }
 
+}  // namespace
+
+// the queues of the wavefront form: one set per context, sized for the largest frame it has traced
+struct rs_gi_scratch {
+    GiQueues q{};
+    size_t pixels = 0;
+    int depths = 0;
+    bool restir = false, sobol = false, direct = false;
+    std::vector<void*> owned;
+};
+void rs_gi_scratch_free(rs_context* c) {
+    if (!c || !c->gi) return;
+    for (void* p : c->gi->owned) (void)hipFree(p);
+    delete c->gi;
+    c->gi = nullptr;
+}
+
+namespace {
+
+template <typename T> int gi_plane(rs_gi_scratch* g, T** p, size_t count) {
+    RS_TRY(rs_dev_alloc(p, count));
+    g->owned.push_back((void*)*p);
+    return 0;
+}
+int gi_scratch(size_t pixels, int maxDepth, bool restir, bool sobol, bool direct, GiQueues* out) {
+    rs_context* c = rs_ctx();
+    rs_gi_scratch* g = c->gi;
+    if (g && (g->pixels < pixels || g->depths < maxDepth + 2 || (restir && !g->restir) || (sobol && !g->sobol) || (direct && !g->direct))) {
+        RS_TRY(rs_synchronize());
+        restir = restir || g->restir; sobol = sobol || g->sobol; direct = direct || g->direct;
+        if (pixels < g->pixels) pixels = g->pixels;
+        if (maxDepth + 2 < g->depths) maxDepth = g->depths - 2;
+        rs_gi_scratch_free(c);
+        g = nullptr;
+    }
+    if (!g) {
+        g = c->gi = new rs_gi_scratch();
+        GiQueues& q = g->q;
+        const size_t n = pixels;
+        q.n = (int)n;
+        g->pixels = n; g->depths = maxDepth + 2; g->restir = restir; g->sobol = sobol; g->direct = direct;
+        RS_TRY(gi_plane(g, &q.counters, (size_t)g->depths * 8 * kCtrStride));
+        RS_TRY(gi_plane(g, &q.hPixel, n)); RS_TRY(gi_plane(g, &q.hRng, n));
+        RS_TRY(gi_plane(g, &q.hPos, n)); RS_TRY(gi_plane(g, &q.hNorm, n)); RS_TRY(gi_plane(g, &q.hWo, n)); RS_TRY(gi_plane(g, &q.hMatA, n)); RS_TRY(gi_plane(g, &q.hMatB, n));
+        RS_TRY(gi_plane(g, &q.rPixel, 6 * n)); RS_TRY(gi_plane(g, &q.rRng, 6 * n));
+        RS_TRY(gi_plane(g, &q.rPos, 6 * n)); RS_TRY(gi_plane(g, &q.rDir, 6 * n)); RS_TRY(gi_plane(g, &q.rThr, 6 * n));
+        RS_TRY(gi_plane(g, &q.rHit, 6 * n)); RS_TRY(gi_plane(g, &q.slow, n));
+        RS_TRY(gi_plane(g, &q.sX, n)); RS_TRY(gi_plane(g, &q.sY, n)); RS_TRY(gi_plane(g, &q.sAdd, n));
+        RS_TRY(gi_plane(g, &q.accI, n));
+        if (direct) RS_TRY(gi_plane(g, &q.accD, n));
+        if (sobol) { RS_TRY(gi_plane(g, &q.hPtr, n)); RS_TRY(gi_plane(g, &q.rPtr, 6 * n)); }
+        if (restir) {
+            RS_TRY(gi_plane(g, &q.pWo, n)); RS_TRY(gi_plane(g, &q.pMatA, n)); RS_TRY(gi_plane(g, &q.pMatB, n)); RS_TRY(gi_plane(g, &q.pXv, n));
+            RS_TRY(gi_plane(g, &q.pNv, n)); RS_TRY(gi_plane(g, &q.pXs, n)); RS_TRY(gi_plane(g, &q.pNs, n)); RS_TRY(gi_plane(g, &q.endRng, n));
+            if (sobol) RS_TRY(gi_plane(g, &q.endPtr, n));
+        }
+    }
+    *out = g->q;
+    return 0;
+}
+
+
+template <int MODE, bool TEX, bool SOBOL>
+int launch_wavefront_t(const rs_scene* scene, const CamParams& cp, const GiQueues& q, float* direct, float* indirect, rs_indirect_reservoir* out,
+                       const rs_indirect_reservoir* in, const GBufView& g, int looper, int iter, int maxDepth, int first, int reuse) {
+    const int W = cp.width, H = cp.height, n = W * H;
+    const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
+    hipStream_t st = rs_stream();
+    RS_HIP(hipMemsetAsync(q.counters, 0, sizeof(int) * 8 * kCtrStride * (size_t)(maxDepth + 2), st));
+    hipLaunchKernelGGL((k_wf_primary<MODE, TEX, SOBOL>), dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, q, looper, tilesX);
+    const int blocks = (n + 255) / 256;
+    static const int cus = []{ int dev = 0, v = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+    const int walkBlocks = min(cus * kWalkWavesPerSimd, (n + 255) / 256 + 6);     // resident capacity: 4 SIMDs x kWalkWavesPerSimd waves = kWalkWavesPerSimd blocks per CU
+    for (int depth = 1; depth <= maxDepth; depth++) {
+        hipLaunchKernelGGL((k_wf_shade<MODE, TEX, SOBOL>), dim3((n + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, st, scene->dev, q, depth);
+        if (MODE == kModePT || depth > 1) hipLaunchKernelGGL(k_wf_shadow, dim3(blocks), dim3(256), 0, st, scene->dev, q, depth);
+        if (scene->dev.ordNodes) {
+            hipLaunchKernelGGL(k_wf_walk, dim3(walkBlocks), dim3(256), 0, st, scene->dev, q, depth);
+            hipLaunchKernelGGL(k_wf_walk_slow, dim3(256), dim3(256), 0, st, scene->dev, q, depth);
+            hipLaunchKernelGGL((k_wf_extend<MODE, TEX, SOBOL, false>), dim3(blocks + 6), dim3(256), 0, st, scene->dev, q, depth, maxDepth);
+        }
+        else hipLaunchKernelGGL((k_wf_extend<MODE, TEX, SOBOL, true>), dim3(blocks + 6), dim3(256), 0, st, scene->dev, q, depth, maxDepth);
+    }
+    hipLaunchKernelGGL((k_wf_finish<MODE, SOBOL>), dim3(blocks), dim3(256), 0, st, scene->dev, q, direct, indirect, out, in, g, iter, maxDepth, first, reuse, n, g_giRayCount);
+    return rs_check_hip(hipGetLastError(), "pathTrace (wavefront)");
+}
+
+template <int MODE>
+int launch_wavefront(const rs_scene* scene, const rs_camera* cam, float* direct, float* indirect, rs_indirect_reservoir* out,
+                     const rs_indirect_reservoir* in, const GBufView& g, int looper, int iter, int maxDepth, int first, int reuse) {
+    const CamParams cp = rs_make_cam_params(cam);
+    const bool sobol = scene->dev.sampleSeq != nullptr;
+    GiQueues q;
+    RS_TRY(gi_scratch((size_t)cp.width * cp.height, maxDepth, MODE == kModeReSTIR, sobol, MODE == kModePT, &q));
+#define RS_WF_ARGS scene, cp, q, direct, indirect, out, in, g, looper, iter, maxDepth, first, reuse
+    if (scene->textured) return sobol ? launch_wavefront_t<MODE, true, true>(RS_WF_ARGS) : launch_wavefront_t<MODE, true, false>(RS_WF_ARGS);
+    return sobol ? launch_wavefront_t<MODE, false, true>(RS_WF_ARGS) : launch_wavefront_t<MODE, false, false>(RS_WF_ARGS);
+#undef RS_WF_ARGS
+}
+
+
 template <int MODE>
 int launch_path(const rs_scene* scene, const rs_camera* cam, float* direct, float* indirect, rs_indirect_reservoir* out,
                 const rs_indirect_reservoir* in, const GBufView& g, int looper, int iter, int maxDepth, int first, int reuse) {
@@ -294,6 +960,7 @@ int launch_path(const rs_scene* scene, const rs_camera* cam, float* direct, floa
         RS_TRY(rs_check_looper(scene, looper, "pathTrace / ReSTIRIndirect"));
         if (6 + 7LL * maxDepth > kSobolSampleDim + kSobolGuard) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTrace / ReSTIRIndirect: trace depth too large for the Sobol table's guard");
     }
+    if (g_pathForm == 1 && maxDepth >= 1) return launch_wavefront<MODE>(scene, cam, direct, indirect, out, in, g, looper, iter, maxDepth, first, reuse);
     const dim3 grid(tilesX * tilesY), block(256);
 #define RS_PATH_ARGS scene->dev, cp, direct, indirect, out, in, g, looper, iter, maxDepth, first, reuse, tilesX, g_giRayCount
     if (scene->textured) { if (sobol) hipLaunchKernelGGL((k_path<MODE, true, true>), grid, block, 0, rs_stream(), RS_PATH_ARGS);
