@@ -65,7 +65,8 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
             if (nee) c = env ? sample_light_nv<true, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r)
                              : sample_light_nv<false, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
         }
-        const bool occluded = trace_occluded_wave(s, pos, c.point, nee);
+        // (a sample without a valid pdf contributes nothing either way: counted as the reference's testOcclusion call, not walked)
+        const bool occluded = trace_occluded_wave(s, pos, c.point, nee && c.pdf > 0.f);
         if (nee) {
             st.walks++;
             const float lightPdf = occluded ? kInvalidPdf : c.pdf;
@@ -287,8 +288,6 @@ struct GiQueues {
     // ray queue, slot = order * n + i
     int* rPixel; uint32_t* rRng; int* rPtr;
     float4 *rPos, *rDir, *rThr;                        // surface point | pdf of the sample, direction | sample is specular, throughput
-    float4* rHit;                                      // what the walk found: bx, by, primitive, distance (k_wf_walk -> k_wf_extend<.., false>)
-    int* slow;                                         // ray slots the streaming walk leaves to the general walk (special-case / far-origin rays)
     // shadow queue
     float4 *sX, *sY; float2* sAdd;                     // surface point | pixel and flags, light point | add.x, add.y add.z
     // per pixel: the sums, and what ReSTIRIndirect keeps of a path (restir.cu:273-281,316-321)
@@ -446,18 +445,21 @@ __global__ void __launch_bounds__(kShadeThreads) k_wf_shade(DevScene s, GiQueues
     if (MODE == kModeReSTIR && was && !alive) rng_save<SOBOL>(rng, q.endRng, q.endPtr, pixel);
     // the shadow segment into the shadow queue, the bounce ray into the bucket of its threaded order (what walk_ordered_tree derives from
     // the direction): queue 0 and queues 1..6 of one block-level append
-    __shared__ int lds[kShadeThreads / 64 + 1][7];
-    int* const counters[7] = { ctr(q, depth, 1), ctr(q, depth, 2), ctr(q, depth, 3), ctr(q, depth, 4), ctr(q, depth, 5), ctr(q, depth, 6), ctr(q, depth, 7) };
+    __shared__ int lds[kShadeThreads / 64 + 1][8];
+    int* const counters[8] = { ctr(q, depth, 1), ctr(q, depth, 2), ctr(q, depth, 3), ctr(q, depth, 4), ctr(q, depth, 5), ctr(q, depth, 6), ctr(q, depth, 7),
+                               ctr(q, depth, 1) + 16 };       // the last one: shadow segments counted, not walked
     const int order = alive ? mtbvh_order(-sample.dir) : -1;
     // (two appends per thread: the ranks of the shadow queue and of the ray buckets are computed in two passes over one table)
-    const int sSlot = block_append<7, kShadeThreads / 64>(nee ? 0 : -1, counters, lds);
-    if (nee) {
-        const int flags = pixel | (contributes ? kFlagAdd : 0) | ((MODE == kModePT && depth == 1) ? kFlagDirect : 0);
+    // A light sample with no valid pdf (the light faces away: scene.h:448-452) contributes nothing whether its segment is occluded or not
+    // (sampleDirectLight returns InvalidPdf either way): it is counted as the reference's testOcclusion call that it is, and not walked.
+    const int sSlot = block_append<8, kShadeThreads / 64>(contributes ? 0 : (nee ? 7 : -1), counters, lds);
+    if (contributes) {
+        const int flags = pixel | kFlagAdd | ((MODE == kModePT && depth == 1) ? kFlagDirect : 0);
         q.sX[sSlot] = make_float4(pos.x, pos.y, pos.z, __int_as_float(flags));
         q.sY[sSlot] = make_float4(c.point.x, c.point.y, c.point.z, add.x);
         q.sAdd[sSlot] = make_float2(add.y, add.z);
     }
-    const int rSlot = block_append<7, kShadeThreads / 64>(order >= 0 ? 1 + order : -1, counters, lds);
+    const int rSlot = block_append<8, kShadeThreads / 64>(order >= 0 ? 1 + order : -1, counters, lds);
     if (order >= 0) {
         const int slot = order * q.n + rSlot;
         q.rPixel[slot] = pixel;
@@ -476,7 +478,9 @@ __global__ void __launch_bounds__(256) k_wf_shadow(DevScene s, GiQueues q, int d
     const bool active = i < count;
     const int j = active ? i : 0;
     const float4 x = q.sX[j], y = q.sY[j];
-    const bool occluded = trace_occluded_wave(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), active);
+    __shared__ uint4 top[RS_OCC_LDS ? kOccTopMax : 1];
+    const uint4* ldsTop = stage_occ_top(s, top);
+    const bool occluded = trace_occluded_wave(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), active, ldsTop);
     const int flags = __float_as_int(x.w);
     if (active && !occluded && (flags & kFlagAdd)) {
         const float2 yz = q.sAdd[j];
@@ -487,172 +491,12 @@ __global__ void __launch_bounds__(256) k_wf_shadow(DevScene s, GiQueues q, int d
     }
 }
 
-// ---- the streaming closest-hit walk ------------------------------------------------------------------------------------------------
-// walk_ordered_tree (rs_scene.h) for a QUEUE of rays: a wave owns a run of consecutive rays of one order's bucket and REPLACES the
-// rays that have finished -- a wave of the plain walk iterates until its slowest ray is done, 224 iterations for a mean of 108 steps per
-// ray (tools/walk_stats.py), so more than half of its lane-iterations are idle.  Whenever at least kRefillAt lanes have nothing left to do,
-// they store what they found (rHit) and take the next rays of the wave's share.  Per ray: the same nodes, the same leaves in the same
-// order, the same arithmetic as walk_ordered_tree (the interleaving of walk steps and leaf rounds differs, which that walk's argument --
-// a stale `closest` only enters more -- already allows), so the same primitive and barycentrics; tested against the oracle like the rest.
-// Rays that take one of AABB::intersect's special cases or start outside the grid's reach go to the `slow` list (k_wf_walk_slow).
-// The grid is the chip's capacity of resident waves (kWalkWavesPerSimd per SIMD), every block a share of one bucket proportional to the
-// bucket's size: one round of waves, each of which streams through its share.
-constexpr int kRefillAt = 16, kWalkWavesPerSimd = 6;
-__global__ void __launch_bounds__(256, kWalkWavesPerSimd) k_wf_walk(DevScene s, GiQueues q, int depth) {
-    int k = 0, first = 0, blockEnd = 0;
-    {
-        int c[6], total = 0;
-        for (int i = 0; i < 6; i++) { c[i] = *ctr(q, depth, 2 + i); total += c[i]; }
-        if (total == 0) return;
-        int b = blockIdx.x;
-        for (k = 0; k < 6; k++) {
-            const int blocks = c[k] ? 1 + (int)((long long)c[k] * (long long)((int)gridDim.x - 6) / total) : 0;
-            if (b < blocks) {
-                const int share = (c[k] + blocks - 1) / blocks;
-                first = b * share; blockEnd = min(c[k], first + share);
-                break;
-            }
-            b -= blocks;
-        }
-        if (k == 6 || first >= blockEnd) return;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int waveShare = (blockEnd - first + 3) >> 2;
-    int next = first + wave * waveShare;                              // wave-uniform: the next ray of this wave's share
-    const int waveEnd = min(blockEnd, next + waveShare);
-    if (next >= waveEnd) return;
-    const char* nodes = reinterpret_cast<const char*>(s.ordNodes);
-    const unsigned startOff = (unsigned)k * s.ordStride, endOff = ((unsigned)k + 1u) * s.ordStride - 16u;
-    const TriRec* tris = s.ordTris + (size_t)(k >> 1) * (size_t)s.numPrims;
-    const int triStep = (k & 1) ? -1 : 1;
-    // per lane: the ray and its walk (idle: cur == endOff, qn == 0, slot < 0)
-    f3 o = splat(0.f), d = splat(0.f), dinv = splat(0.f);
-    vf2 Axy = { 0.f, 0.f }, Bxy = { -1.f, -1.f }, Azz = { 0.f, 0.f }, Bzz = { -1.f, -1.f };
-    float tRoot = 0.f, closest = 3.402823466e+38f, hbx = 0.f, hby = 0.f;
-    unsigned selX = 0x07060100u, selY = 0x05040302u, selZ = 0x07060100u, cur = endOff;
-    int prim = kNullPrim, q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0, slot = -1;
-    for (;;) {
-        // ---- refill point
-        {
-            const bool idle = (cur == endOff) & (qn == 0);
-            const unsigned long long idleMask = __ballot(idle);
-            const int nIdle = __popcll(idleMask);
-            if (nIdle == 64 || (nIdle >= kRefillAt && next < waveEnd)) {
-                if (idle && slot >= 0) {
-                    q.rHit[slot] = make_float4(hbx, hby, __int_as_float(prim), closest);
-                    slot = -1;
-                    Axy = vf2{ 0.f, 0.f }; Bxy = vf2{ -1.f, -1.f }; Azz = Axy; Bzz = Bxy;      // rests on the end record, whose test then fails whatever it holds
-                }
-                if (next >= waveEnd) { if (nIdle == 64) break; }
-                else {
-                    const int idx = next + __popcll(idleMask & ((1ull << lane) - 1ull));
-                    const bool take = idle && idx < waveEnd;
-                    next = min(waveEnd, next + nIdle);
-                    if (take) {
-                        const int j = k * q.n + idx;
-                        const float4 a0 = q.rPos[j], a1 = q.rDir[j];
-                        d = mk3(a1.x, a1.y, a1.z); o = mk3(a0.x, a0.y, a0.z) + d * 1e-5f;         // makeOffsetedRay
-                        Ray ray; ray.o = o; ray.d = d;
-                        const RayBoxCtx ctx = make_box_ctx(ray);
-                        const bool special = ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(d.x == d.x);
-                        if (special || !occlusion_tree_usable(s, o)) q.slow[atomicAdd(ctr(q, depth, 0) + 1, 1)] = j;      // (the word after the hit-queue counter of this depth, which is no longer read)
-                        else {
-                            dinv = ctx.dinv;
-                            const f3 A = mk3(s.occScale.x * dinv.x, s.occScale.y * dinv.y, s.occScale.z * dinv.z);
-                            const f3 B = mk3((s.occBase.x - o.x) * dinv.x, (s.occBase.y - o.y) * dinv.y, (s.occBase.z - o.z) * dinv.z);
-                            tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - o.x) * dinv.x), gabs((s.occRootHi.x - o.x) * dinv.x)),
-                                                fmaxf(gabs((s.occRootLo.y - o.y) * dinv.y), gabs((s.occRootHi.y - o.y) * dinv.y))),
-                                          fmaxf(gabs((s.occRootLo.z - o.z) * dinv.z), gabs((s.occRootHi.z - o.z) * dinv.z)));
-                            selX = A.x < 0.f ? 0x01000706u : 0x07060100u; selY = A.y < 0.f ? 0x03020504u : 0x05040302u; selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;
-                            Axy = vf2{ A.x, A.y }; Bxy = vf2{ B.x, B.y }; Azz = vf2{ A.z, A.z }; Bzz = vf2{ B.z, B.z };
-                            closest = 3.402823466e+38f; prim = kNullPrim; hbx = 0.f; hby = 0.f;
-                            cur = startOff; slot = j;
-                        }
-                    }
-                }
-            }
-        }
-        // ---- walk phase: until some lane's queue is full, every walk has ended, or enough lanes are idle to be refilled
-        for (;;) {
-            const unsigned long long walkers = __ballot(cur != endOff);
-            if (!walkers) break;
-            if (next < waveEnd && __popcll(__ballot((cur == endOff) & (qn == 0))) >= kRefillAt) break;
-            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
-            const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
-            const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
-            const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
-            const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
-            const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
-            const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
-            const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < closest);
-            const int meta = (int)n.w;
-            const bool leaf = meta < 0;
-            const bool push = pass && leaf;
-            const int code = ~meta;
-            q0 = (push && qn == 0) ? code : q0; q1 = (push && qn == 1) ? code : q1; q2 = (push && qn == 2) ? code : q2; q3 = (push && qn == 3) ? code : q3;
-            qn = push ? qn + 1 : qn;
-            cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
-            if (__any(qn == RS_ORD_QUEUE)) break;
-        }
-        if (!__any(qn > 0)) continue;
-        // ---- leaf round: every lane takes its OLDEST queued leaf and judges its triangles one after the other (walk_ordered_tree)
-        int tri = 0, cnt = 0, verify = -1;
-        if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
-        float cd = 0.f, cbx = 0.f, cby = 0.f; int cprim = kNullPrim;
-        for (;;) {
-            while (__any((cnt > 0) & (verify < 0))) {
-                if ((cnt > 0) & (verify < 0)) {
-                    const float4* p = reinterpret_cast<const float4*>(tris + tri);
-                    const float4 a = p[0], b = p[1], c = p[2];
-                    float bx, by, dist;
-                    tri += triStep; cnt--;
-                    if (tri_hit(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < closest) {
-                        cd = dist; cbx = bx; cby = by; cprim = __float_as_int(b.w);
-                        verify = __float_as_int(a.w);          // reference leaf of the candidate
-                    }
-                }
-            }
-            if (!__any(verify >= 0)) break;
-            while (__any(verify >= 0)) {
-                if (verify >= 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + verify);
-                    float4 lo, hi;
-                    node_unpack(rec[0], rec[1], lo, hi);
-                    const float t1x = (lo.x - o.x) * dinv.x, t1y = (lo.y - o.y) * dinv.y, t1z = (lo.z - o.z) * dinv.z;
-                    const float t2x = (hi.x - o.x) * dinv.x, t2y = (hi.y - o.y) * dinv.y, t2z = (hi.z - o.z) * dinv.z;
-                    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
-                    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
-                    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
-                    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
-                    const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
-                    const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < closest);
-                    const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
-                    const int parent = __float_as_int(lo.w);
-                    const bool done = open & ((parent < 0) | clear);
-                    if (done) { closest = cd; hbx = cbx; hby = cby; prim = cprim; }
-                    verify = (open & !done) ? parent : -1;
-                }
-            }
-        }
-    }
-}
-// the rays the streaming walk left out: the general wave-level walk (trace_closest_wave takes every case), a few waves over the list
-__global__ void __launch_bounds__(256) k_wf_walk_slow(DevScene s, GiQueues q, int depth) {
-    const int count = ctr(q, depth, 0)[1];
-    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), waves = gridDim.x * 4;
-    for (int base = wave * 64; base < count; base += waves * 64) {
-        const bool active = base + lane < count;
-        const int j = q.slow[active ? base + lane : 0];
-        const float4 a0 = q.rPos[j], a1 = q.rDir[j];
-        Ray ray; ray.d = mk3(a1.x, a1.y, a1.z); ray.o = mk3(a0.x, a0.y, a0.z) + ray.d * 1e-5f;
-        const WalkResult w = walk_dispatch_paired<false>(s, ray, 3.402823466e+38f, active);
-        if (active) q.rHit[j] = make_float4(w.bx, w.by, __int_as_float(w.prim), w.closest);
-    }
-}
-
+// (A streaming form of the closest-hit walk -- a resident grid of waves that replace finished rays from their share of the queue, 87 % of
+// the lanes walking instead of 48 % -- was built and measured: bit-exact and slower, 1.35 ms against 1.25 per bounce.  The walk is bound by
+// the CU's vector-memory path, ~2 cycles per distinct 128-byte line and 155 line accesses per ray, busy 80-85 % either way; idle lanes
+// cost it nothing.  EXPERIMENTS.md, commit d0141a4, profiles/r04_gi_wavefront_streaming_walk_counters.txt.)
 // closest-hit walk of every bounce ray of `depth` and the hit's own contribution (the second half of path_loop's body)
-// WALK false: the walk has been done by k_wf_walk / k_wf_walk_slow (rHit); true: the plain wave-level walk here (no closest-hit trees)
-template <int MODE, bool TEX, bool SOBOL, bool WALK>
+template <int MODE, bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256) k_wf_extend(DevScene s, GiQueues q, int depth, int maxDepth) {
     // blocks in bucket order: bucket k takes ceil(count_k / 256) blocks
     int k = 0, first = 0, count = 0;
@@ -672,21 +516,7 @@ __global__ void __launch_bounds__(256) k_wf_extend(DevScene s, GiQueues q, int d
     const float4 a0 = q.rPos[j], a1 = q.rDir[j];
     const f3 curPos = mk3(a0.x, a0.y, a0.z);
     Ray ray; ray.d = mk3(a1.x, a1.y, a1.z); ray.o = curPos + ray.d * 1e-5f;   // makeOffsetedRay
-    Hit h;
-    if (WALK) h = trace_closest_wave(s, ray, alive);
-    else {
-        const float4 f = q.rHit[j];
-        h.primId = alive ? __float_as_int(f.z) : kNullPrim;
-        h.matId = 0; h.pos = splat(0.f); h.norm = splat(0.f); h.bx = f.x; h.by = f.y;
-        if (h.primId != kNullPrim) {           // getIntersecGeomInfo (scene.h:135-151), as trace_closest_wave
-            const float* v = s.vertices + (size_t)h.primId * 9;
-            const float* n = s.normals + (size_t)h.primId * 9;
-            const float wgt = 1.f - h.bx - h.by;
-            h.pos = ld3(v + 3) * h.bx + ld3(v + 6) * h.by + ld3(v) * wgt;
-            h.norm = normalize(ld3(n + 3) * h.bx + ld3(n + 6) * h.by + ld3(n) * wgt);
-            h.matId = s.materialIds[h.primId];
-        }
-    }
+    const Hit h = trace_closest_wave(s, ray, alive);
     const bool mine = alive;                                                    // this lane carries a ray
     const float samplePdf = a0.w;
     const bool deltaSample = a1.w != 0.f;
@@ -752,7 +582,10 @@ __global__ void __launch_bounds__(256) k_wf_finish(DevScene s, GiQueues q, float
     const int index = blockIdx.x * 256 + threadIdx.x;
     if (index == 0) {      // BVH walks for the Mrays/s metric: one camera ray per pixel, every shadow segment, every bounce ray
         unsigned long long walks = (unsigned long long)pixels;
-        for (int d = 1; d <= maxDepth; d++) for (int k = 1; k < 8; k++) walks += (unsigned long long)*ctr(q, d, k);
+        for (int d = 1; d <= maxDepth; d++) {
+            for (int k = 1; k < 8; k++) walks += (unsigned long long)*ctr(q, d, k);
+            walks += (unsigned long long)ctr(q, d, 1)[16];                                         // shadow segments counted, not walked
+        }
         rayCount[0] = walks;
     }
     if (index >= pixels) return;
@@ -892,7 +725,6 @@ int gi_scratch(size_t pixels, int maxDepth, bool restir, bool sobol, bool direct
         RS_TRY(gi_plane(g, &q.hPos, n)); RS_TRY(gi_plane(g, &q.hNorm, n)); RS_TRY(gi_plane(g, &q.hWo, n)); RS_TRY(gi_plane(g, &q.hMatA, n)); RS_TRY(gi_plane(g, &q.hMatB, n));
         RS_TRY(gi_plane(g, &q.rPixel, 6 * n)); RS_TRY(gi_plane(g, &q.rRng, 6 * n));
         RS_TRY(gi_plane(g, &q.rPos, 6 * n)); RS_TRY(gi_plane(g, &q.rDir, 6 * n)); RS_TRY(gi_plane(g, &q.rThr, 6 * n));
-        RS_TRY(gi_plane(g, &q.rHit, 6 * n)); RS_TRY(gi_plane(g, &q.slow, n));
         RS_TRY(gi_plane(g, &q.sX, n)); RS_TRY(gi_plane(g, &q.sY, n)); RS_TRY(gi_plane(g, &q.sAdd, n));
         RS_TRY(gi_plane(g, &q.accI, n));
         if (direct) RS_TRY(gi_plane(g, &q.accD, n));
@@ -917,17 +749,10 @@ int launch_wavefront_t(const rs_scene* scene, const CamParams& cp, const GiQueue
     RS_HIP(hipMemsetAsync(q.counters, 0, sizeof(int) * 8 * kCtrStride * (size_t)(maxDepth + 2), st));
     hipLaunchKernelGGL((k_wf_primary<MODE, TEX, SOBOL>), dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, q, looper, tilesX);
     const int blocks = (n + 255) / 256;
-    static const int cus = []{ int dev = 0, v = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
-    const int walkBlocks = min(cus * kWalkWavesPerSimd, (n + 255) / 256 + 6);     // resident capacity: 4 SIMDs x kWalkWavesPerSimd waves = kWalkWavesPerSimd blocks per CU
     for (int depth = 1; depth <= maxDepth; depth++) {
         hipLaunchKernelGGL((k_wf_shade<MODE, TEX, SOBOL>), dim3((n + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, st, scene->dev, q, depth);
         if (MODE == kModePT || depth > 1) hipLaunchKernelGGL(k_wf_shadow, dim3(blocks), dim3(256), 0, st, scene->dev, q, depth);
-        if (scene->dev.ordNodes) {
-            hipLaunchKernelGGL(k_wf_walk, dim3(walkBlocks), dim3(256), 0, st, scene->dev, q, depth);
-            hipLaunchKernelGGL(k_wf_walk_slow, dim3(256), dim3(256), 0, st, scene->dev, q, depth);
-            hipLaunchKernelGGL((k_wf_extend<MODE, TEX, SOBOL, false>), dim3(blocks + 6), dim3(256), 0, st, scene->dev, q, depth, maxDepth);
-        }
-        else hipLaunchKernelGGL((k_wf_extend<MODE, TEX, SOBOL, true>), dim3(blocks + 6), dim3(256), 0, st, scene->dev, q, depth, maxDepth);
+        hipLaunchKernelGGL((k_wf_extend<MODE, TEX, SOBOL>), dim3(blocks + 6), dim3(256), 0, st, scene->dev, q, depth, maxDepth);
     }
     hipLaunchKernelGGL((k_wf_finish<MODE, SOBOL>), dim3(blocks), dim3(256), 0, st, scene->dev, q, direct, indirect, out, in, g, iter, maxDepth, first, reuse, n, g_giRayCount);
     return rs_check_hip(hipGetLastError(), "pathTrace (wavefront)");

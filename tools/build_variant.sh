@@ -12,5 +12,5 @@ else
   cp $R/restir_amd/csrc/*.hip $R/restir_amd/csrc/*.cpp $R/restir_amd/csrc/*.h $R/restir_amd/csrc/Makefile $B/restir_amd/csrc/
   cp $R/include/*.h $B/include/
 fi
-make -C $B/restir_amd/csrc -j8 EXTRA="$EXTRA" OUT=$R/restir_amd/librestir_$NAME.so VIEWER= RCCLCHK= RCCLRANKS= >/dev/null
+make -C $B/restir_amd/csrc -j8 EXTRA="$EXTRA" OUT=$R/restir_amd/librestir_$NAME.so VIEWER= RCCLCHK= RCCLRANKS= LOOPBACK= >/dev/null
 ls -la $R/restir_amd/librestir_$NAME.so
