@@ -478,9 +478,7 @@ __global__ void __launch_bounds__(256) k_wf_shadow(DevScene s, GiQueues q, int d
     const bool active = i < count;
     const int j = active ? i : 0;
     const float4 x = q.sX[j], y = q.sY[j];
-    __shared__ uint4 top[RS_OCC_LDS ? kOccTopMax : 1];
-    const uint4* ldsTop = stage_occ_top(s, top);
-    const bool occluded = trace_occluded_wave(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), active, ldsTop);
+    const bool occluded = trace_occluded_wave(s, mk3(x.x, x.y, x.z), mk3(y.x, y.y, y.z), active);
     const int flags = __float_as_int(x.w);
     if (active && !occluded && (flags & kFlagAdd)) {
         const float2 yz = q.sAdd[j];

@@ -201,69 +201,6 @@ int rs_quantize_occlusion_bvh(const std::vector<BvhNode>& nodes, float base[3], 
     return 0;
 }
 
-// ---- the top levels of a packed tree as a table of their own ---------------------------------------------------------------------------
-// A walk step costs the CU's vector-memory path about two cycles per distinct 128-byte line that the wave's lanes touch, and that path is
-// what bounds the incoherent walks (80-85 % busy, profiles/r04_gi_wavefront_streaming_walk_counters.txt); 54 % of a shadow ray's steps visit
-// the 1 023 nodes of the tree's ten top levels (profiles/r03_walk_stats_sponza.log).  This cuts a packed pre-order tree (16-byte records,
-// rs_quantize_occlusion_bvh) into
-//   top   the nodes of depth < levels in their pre-order sequence -- small enough for LDS, which a kernel may stage it in --
-//   rest  every other node, pre-order,
-// such that the walk's step stays what it is -- entered or leaf: the next record, else the record's link -- in both tables: a link is a
-// byte offset whose bit 0 says "in top".  Where the pre-order successor of a record lies in the other table an EMPTY inner record (the box
-// of the end record: fails the test whatever the ray) is inserted whose link leads there: after every inner node of depth levels - 1
-// (to its left child in rest), after the last node of such a node's subtree (to the subtree's successor) and at the end of top.  A walk
-// visits exactly the nodes it visited in the one array, in the same order, plus those empty records.
-int rs_split_top_levels(const std::vector<BvhNode>& nodes, const std::vector<unsigned>& packed, int levels,
-                        std::vector<unsigned>& top, std::vector<unsigned>& rest) {
-    const size_t n = nodes.size();
-    if (n == 0 || packed.size() < n * 4 || levels < 1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_split_top_levels: bad argument");
-    std::vector<int> depth(n);
-    {
-        std::vector<int> ends;                  // spans nest: a stack of span ends
-        for (size_t i = 0; i < n; i++) {
-            while (!ends.empty() && ends.back() <= (int)i) ends.pop_back();
-            depth[i] = (int)ends.size();
-            ends.push_back(nodes[i].primId >= 0 ? (int)i + 1 : nodes[i].next);
-        }
-    }
-    const auto inner = [&](size_t i) { return nodes[i].primId < 0; };
-    const auto boundary = [&](size_t i) { return depth[i] == levels - 1 && inner(i); };
-    // pass 1: where every node goes
-    std::vector<unsigned> index(n);            // record index in its table
-    std::vector<unsigned char> inTop(n);
-    unsigned topCount = 0, restCount = 0;
-    for (size_t i = 0; i < n;) {
-        inTop[i] = 1; index[i] = topCount++;
-        if (!boundary(i)) { i++; continue; }
-        topCount++;                                                  // the empty record that leads to the left child
-        const size_t e = (size_t)nodes[i].next;
-        if (e <= i + 1 || e > n) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_split_top_levels: not a pre-order tree");
-        for (size_t j = i + 1; j < e; j++) { inTop[j] = 0; index[j] = restCount++; }
-        restCount++;                                                 // the empty record that leads to the subtree's successor
-        i = e;
-    }
-    const unsigned topEnd = topCount++;                              // the empty record at the end of top
-    const unsigned restEndOff = restCount * 16u;                     // the self-linked end record a finished walk rests on
-    if ((size_t)restCount * 16u >= 0x7fffffffull) return rs_fail(RS_ERR_UNSUPPORTED, "rs_split_top_levels: tree too large");
-    const auto link = [&](size_t j) -> unsigned { return j >= n ? restEndOff : (inTop[j] ? (index[j] * 16u) | 1u : index[j] * 16u); };
-    const auto empty = [](unsigned* o, unsigned to) { o[0] = 0xffffffffu; o[1] = 0x0000ffffu; o[2] = 0u; o[3] = to; };
-    top.assign((size_t)topCount * 4, 0u);
-    rest.assign((size_t)(restCount + 1) * 4, 0u);
-    for (size_t i = 0; i < n; i++) {
-        unsigned* o = inTop[i] ? &top[(size_t)index[i] * 4] : &rest[(size_t)index[i] * 4];
-        std::memcpy(o, &packed[i * 4], 16);
-        if (inner(i)) o[3] = link((size_t)nodes[i].next);            // (a leaf keeps its code: its successor is the next record)
-        if (inTop[i] && boundary(i)) {
-            empty(&top[(size_t)(index[i] + 1) * 4], link(i + 1));
-            const size_t e = (size_t)nodes[i].next;
-            empty(&rest[(size_t)(index[e - 1] + 1) * 4], link(e));
-        }
-    }
-    empty(&top[(size_t)topEnd * 4], restEndOff);
-    empty(&rest[(size_t)restCount * 4], restEndOff);
-    return 0;
-}
-
 // parent of every reference node (indexed by the ORIGINAL pre-order id = MTBVHNode::boundingBoxId) and
 // the leaf node of every primitive, derived from one threaded order (src/bvh.cpp:156-193: order 0).
 int rs_reference_chain_tables(int bvhSize, const int* order0 /* 3 ints per node */, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims) {

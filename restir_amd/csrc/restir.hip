@@ -326,10 +326,10 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_shado
     float4 cl = make_float4(0.f, 0.f, 0.f, 0.f), cw = cl;
     if (shaded) { cl = sp.candLi[index]; cw = sp.candWi[index]; }
     const f3 pos = mk3(pm.x, pm.y, pm.z), wi = mk3(cw.x, cw.y, cw.z);
-    // every lane of the wave takes part in the cooperative any-hit walk; the tree's top levels come from the block's LDS
-    __shared__ uint4 top[RS_OCC_LDS ? kOccTopMax : 1];
-    const uint4* ldsTop = stage_occ_top(s, top);
-    const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded, ldsTop);
+    // every lane of the wave takes part in the cooperative any-hit walk
+    // (the tree's top levels as an LDS-resident table -- 54 % of a ray's node steps -- were built and measured in round 4: bit-exact and
+    // slower, 0.478 -> 0.528 ms; EXPERIMENTS.md, commit 6f00700)
+    const bool occluded = trace_occluded_wave(s, pos, pos + wi * cl.w, shaded);
     if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
 }
 

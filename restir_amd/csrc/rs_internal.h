@@ -136,8 +136,7 @@ struct rs_scene {
     int envMapTexId = -1;
     bool textured = false;                        // any material map or an environment map: kernels take the textured variant
     uint32_t* dSampleSeq = nullptr;  // the Sobol table (rs_scene_set_sample_sequence); null: the default thrust engine
-    uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp): the records below its top levels
-    uint4* dOccTop = nullptr;        //                                        its top levels (rs_split_top_levels)
+    uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
     uint4* dOrdNodes = nullptr;      // closest-hit trees in the reference's visiting orders (occlusion_bvh.cpp rs_build_ordered_bvh)
@@ -385,6 +384,5 @@ rs::CamParams rs_make_cam_params(const rs_camera* cam);
 // occlusion_bvh.cpp
 int rs_build_occlusion_bvh(int numPrims, const float* primBoxes, std::vector<rs::BvhNode>& nodes, std::vector<int>& leafPrims);
 int rs_quantize_occlusion_bvh(const std::vector<rs::BvhNode>& nodes, float base[3], float scale[3], std::vector<unsigned>& out);
-int rs_split_top_levels(const std::vector<rs::BvhNode>& nodes, const std::vector<unsigned>& packed, int levels, std::vector<unsigned>& top, std::vector<unsigned>& rest);
 int rs_build_ordered_bvh(int numPrims, const float* primBoxes, const int* seq, std::vector<rs::BvhNode>& forward, std::vector<rs::BvhNode>& mirrored);
 int rs_reference_chain_tables(int bvhSize, const int* order0, std::vector<int>& parent, std::vector<int>& leafOfPrim, int numPrims);

@@ -65,9 +65,7 @@ struct DevScene {
     const AliasRec* envAlias;     // envMapSampler (src/scene.h:364-376), envLen = width*height of the map, 0 = none
     int envTex, envLen;           // envMap = textures + envTex (src/scene.cpp:495-498), -1 = none
     float sumLightPowerInv;       // src/scene.cpp:489
-    const uint4*   occNodes;      // shadow tree below its top levels; a link with bit 0 set leads into occTop (occlusion_bvh.cpp rs_split_top_levels)
-    const uint4*   occTop;        // its kOccTopLevels top levels, occTopCount records: a kernel may stage them in LDS (stage_occ_top)
-    int occTopCount;
+    const uint4*   occNodes;
     const BvhNode* occChain;
     const TriRec*  occTris;
     f3 occBase, occScale;         // grid plane q on axis c = occBase.c + q * occScale.c
@@ -96,14 +94,6 @@ struct DevScene {
 constexpr int kSobolGuard = 4096;
 
 typedef float vf2 __attribute__((ext_vector_type(2)));     // operands of the packed FP32 instructions (v_pk_add / mul / fma_f32)
-#ifndef RS_OCC_TOP_LEVELS
-#define RS_OCC_TOP_LEVELS 10
-#endif
-#ifndef RS_OCC_LDS
-#define RS_OCC_LDS 1                                       // kernels stage the top table in LDS (0: they read it from memory)
-#endif
-constexpr int kOccTopLevels = RS_OCC_TOP_LEVELS;           // the shadow tree's levels kept as a table of their own: at most 2^levels - 1 nodes
-constexpr int kOccTopMax = (1 << kOccTopLevels) + (1 << (kOccTopLevels - 1));      // + 2^(levels-1) + 1 empty records (rs_split_top_levels): 24 KB for 10 levels
 
 struct Ray { f3 o, d; };
 
@@ -564,8 +554,7 @@ __device__ __forceinline__ bool occlusion_tree_usable(const DevScene& s, f3 o) {
            gabs(o.z - s.occBase.z) <= reach * s.occScale.z;
 }
 
-// ldsTop: the block's copy of s.occTop in LDS (stage_occ_top), or null -- the top records are then read from memory like the others
-__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active, const uint4* ldsTop = nullptr) {
+__device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray& ray, const RayBoxCtx& ctx, float limit, bool active) {
     const char* nodes = reinterpret_cast<const char*>(s.occNodes);
     const unsigned endOff = (unsigned)s.occCount * 16u;
     // slab distance of grid plane q: (base + q*scale - o) / d = q * A + B
@@ -579,7 +568,7 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
     const float tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - ctx.o.x) * ctx.dinv.x), gabs((s.occRootHi.x - ctx.o.x) * ctx.dinv.x)),
                                     fmaxf(gabs((s.occRootLo.y - ctx.o.y) * ctx.dinv.y), gabs((s.occRootHi.y - ctx.o.y) * ctx.dinv.y))),
                               fmaxf(gabs((s.occRootLo.z - ctx.o.z) * ctx.dinv.z), gabs((s.occRootHi.z - ctx.o.z) * ctx.dinv.z)));
-    unsigned cur = active ? 1u : endOff;                        // the root is record 0 of the top table (bit 0: "in top")
+    unsigned cur = active ? 0u : endOff;
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;                 // LIFO of queued leaf codes
     bool occluded = false;
     // Which of the two grid planes of an axis is the near one depends on the sign of A only (fma is monotone in q): a byte
@@ -610,9 +599,10 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #endif
 #endif
             {   // every lane, also one whose walk has ended: it reads the record past the end, an empty box linked to itself (scene.hip)
-                uint4 n;
-                if (cur & 1u) n = ldsTop ? ldsTop[cur >> 4] : s.occTop[cur >> 4];
-                else n = *reinterpret_cast<const uint4*>(nodes + cur);
+                const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+#if defined(RS_WALK_STATS) && !defined(RS_WALK_STATS_TIME)
+                if (s.walkStats && s.occDepth && cur != endOff) { const int dep = s.occDepth[cur >> 4]; atomicAdd(&s.walkStats[44 + (dep < 19 ? dep : 19)], 1ull); }
+#endif
                 const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
                 const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
                 const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
@@ -823,7 +813,7 @@ __device__ __forceinline__ WalkResult walk_ordered_tree(const DevScene& s, const
 
 // all 64 lanes of the wave must call this
 template <bool ANYHIT>
-__device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active, const uint4* ldsTop = nullptr) {
+__device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, const Ray& ray, float limit, bool active) {
     RayBoxCtx ctx = make_box_ctx(ray);
     ctx.cull = s.axisCull;
     const bool special = active && (ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x));
@@ -832,7 +822,7 @@ __device__ __forceinline__ WalkResult walk_dispatch_paired(const DevScene& s, co
         r.closest = limit; r.prim = kNullPrim; r.bx = 0.f; r.by = 0.f;
         if (s.occNodes) {
             const bool slow = active && (special || !occlusion_tree_usable(s, ray.o));
-            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !slow, ldsTop);
+            r.any = walk_occlusion_tree(s, ray, ctx, limit, active && !slow);
             if (__any(slow)) r.any = walk_anyhit_deferred<false>(s, ray, ctx, limit, slow) || r.any;
         }
         else
@@ -1185,22 +1175,13 @@ __device__ inline Hit trace_closest_wave(const DevScene& s, const Ray& ray, bool
 
 // testOcclusion for a whole wave of (incoherent) segments with the pair-cooperative fetch; every lane of
 // the wave must call it, `active` false where there is no segment
-// ldsTop: the block's LDS copy of the shadow tree's top levels (stage_occ_top) or null
-__device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool active, const uint4* ldsTop = nullptr) {
+__device__ inline bool trace_occluded_wave(const DevScene& s, f3 x, f3 y, bool active) {
     f3 dir = y - x;
     float dist = length(dir);
     dir = div3_exact_signed(dir, dist);
     Ray ray; ray.o = x + dir * 1e-5f; ray.d = dir;       // makeOffsetedRay (intersections.h:13-15)
     dist -= 1e-4f * 2.f;
-    return walk_dispatch_paired<true>(s, ray, dist, active, ldsTop).any;
-}
-// The shadow tree's top levels into the block's LDS (kOccTopMax records of 16 bytes): every thread of the block calls it once, before the
-// first trace_occluded_wave that is handed the copy; returns null (nothing staged) for a scene without the shadow tree.
-__device__ __forceinline__ const uint4* stage_occ_top(const DevScene& s, uint4* lds) {
-    if (!RS_OCC_LDS || !s.occNodes) return nullptr;
-    for (int i = threadIdx.x; i < s.occTopCount; i += blockDim.x) lds[i] = s.occTop[i];
-    __syncthreads();
-    return lds;
+    return walk_dispatch_paired<true>(s, ray, dist, active).any;
 }
 
 // DevScene::testOcclusion (src/scene.h:286-316): any hit between x and y

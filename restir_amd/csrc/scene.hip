@@ -82,15 +82,9 @@ int build_occlusion_side(rs_scene* s) {
     s->dev.occRootHi = ld3(&s->hBoxes[(size_t)root * 6 + 3]);
     // one record past the end: an empty box (lo = 65535 > hi = 0 on every axis fails the slab test for either sign of the direction)
     // whose link is its own offset -- a lane whose walk has ended stays there, so the walk loop needs no "has this lane ended" region
-    // (rs_split_top_levels appends it to the lower table; the top levels are a table of their own that kernels stage in LDS)
-    std::vector<unsigned> top, rest;
-    if (int e = rs_split_top_levels(nodes, packed, kOccTopLevels, top, rest)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
-    if (top.size() / 4 > (size_t)kOccTopMax) return rs_fail(RS_ERR_UNSUPPORTED, "shadow tree: top table larger than its bound");
-    const size_t restCount = rest.size() / 4 - 1;
-    RS_TRY(rs_dev_alloc(&s->dOccNodes, restCount + 1));
-    RS_HIP(hipMemcpy(s->dOccNodes, rest.data(), rest.size() * 4, hipMemcpyHostToDevice));
-    RS_TRY(rs_dev_alloc(&s->dOccTop, top.size() / 4));
-    RS_HIP(hipMemcpy(s->dOccTop, top.data(), top.size() * 4, hipMemcpyHostToDevice));
+    packed.push_back(0xffffffffu); packed.push_back(0x0000ffffu); packed.push_back(0u); packed.push_back((unsigned)(no * 16));
+    RS_TRY(rs_dev_alloc(&s->dOccNodes, no + 1));
+    RS_HIP(hipMemcpy(s->dOccNodes, packed.data(), (no + 1) * 16, hipMemcpyHostToDevice));
     RS_TRY(upload(&s->dOccChain, chain));
     RS_TRY(upload(&s->dOccTris, rec));
 #ifdef RS_WALK_STATS
@@ -114,11 +108,9 @@ int build_occlusion_side(rs_scene* s) {
     }
 #endif
     s->dev.occNodes = s->dOccNodes;
-    s->dev.occTop = s->dOccTop;
-    s->dev.occTopCount = (int)(top.size() / 4);
     s->dev.occChain = s->dOccChain;
     s->dev.occTris = s->dOccTris;
-    s->dev.occCount = (int)restCount;                 // the end record of the lower table sits at this index
+    s->dev.occCount = (int)no;
     s->dev.occBase = mk3(base[0], base[1], base[2]);
     s->dev.occScale = mk3(scale[0], scale[1], scale[2]);
     return 0;
@@ -216,7 +208,7 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
     (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
     (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
-    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccTop); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris); rs_dev_free(s->dOrdNodes); rs_dev_free(s->dOrdTris);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris); rs_dev_free(s->dOrdNodes); rs_dev_free(s->dOrdTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords); rs_dev_free(s->dSampleSeq);
@@ -426,7 +418,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
     s->dev.numPrims = s->numPrims;
     s->dev.numLights = s->numLights;
     s->dev.numMaterials = d->numMaterials;
-    s->dev.occNodes = nullptr; s->dev.occTop = nullptr; s->dev.occTopCount = 0; s->dev.occChain = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
+    s->dev.occNodes = nullptr; s->dev.occChain = nullptr; s->dev.occTris = nullptr; s->dev.occCount = 0;
     s->dev.occBase = splat(0.f); s->dev.occScale = splat(0.f);
     s->dev.walkStats = nullptr; s->dev.occDepth = nullptr;
     s->dev.occNested = false; s->dev.occRootLo = splat(0.f); s->dev.occRootHi = splat(0.f);
