@@ -215,7 +215,6 @@ int rs_context_destroy(rs_context* c) {
         (void)rs_synchronize();
         for (hipStream_t& st : c->aux) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
         if (c->ptRayCount) { (void)hipFree(c->ptRayCount); c->ptRayCount = nullptr; }
-        rs_gi_scratch_free(c);
     }
     if (t_current == c) t_current = nullptr;
     delete c;

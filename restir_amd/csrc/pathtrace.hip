@@ -153,7 +153,7 @@ int rs_path_trace_init(void) {
     if (!rs_ctx()->ptRayCount) RS_TRY(rs_dev_alloc(&rs_ctx()->ptRayCount, 1));
     return 0;
 }
-int rs_path_trace_free(void) { rs_ctx_scope scope(nullptr); rs_dev_free(rs_ctx()->ptRayCount); rs_gi_scratch_free(rs_ctx()); return 0; }
+int rs_path_trace_free(void) { rs_ctx_scope scope(nullptr); rs_dev_free(rs_ctx()->ptRayCount); return 0; }
 
 int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* devDirectIllum, int iter, int looper, unsigned long long* rays) {
     RS_SCOPE(scene);

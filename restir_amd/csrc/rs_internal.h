@@ -33,10 +33,8 @@ struct rs_context {
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
     int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
-    struct rs_gi_scratch* gi = nullptr;         // queues of the multi-bounce kernels' wavefront form (gi.hip), allocated on first use
     int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): from the environment (RS_TILE_SPLIT) or 768; 0 off; negative: |value|, also for launches that overlap others
 };
-void rs_gi_scratch_free(rs_context* c);                 // gi.hip
 rs_context* rs_ctx();                                   // the context this thread's library code runs under right now
 struct rs_ctx_scope {                                   // entry points: run under the context of the object they were handed
     rs_context* prev;

@@ -33,16 +33,7 @@ def all_kernels():
     run("ReSTIRIndirect", lambda f: restir.indirect(scene, cam, gbuf, i.data_ptr(), 0, f, 1, DEPTH))
 
 
-if "--form" in sys.argv:       # one form only (profiling)
-    capi.lib().rs_debug_set_path_form(int(sys.argv[sys.argv.index("--form") + 1]))
-    all_kernels()
-elif "--ab-form" in sys.argv:   # one kernel per path / the wavefront form, interleaved on one box
-    for rep in range(2):
-        for form in (0, 1):
-            capi.lib().rs_debug_set_path_form(form)
-            print("-- multi-bounce kernels:", "wavefront (one launch per stage and bounce)" if form else "one kernel per path")
-            all_kernels()
-elif "--ab" in sys.argv:       # bounce rays through the closest-hit trees in the reference's orders / through the reference's own tree, interleaved on one box
+if "--ab" in sys.argv:       # bounce rays through the closest-hit trees in the reference's orders / through the reference's own tree, interleaved on one box
     for rep in range(2):
         for on in (True, False):
             capi.set_ordered_tree(scene, on)
