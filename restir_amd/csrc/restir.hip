@@ -627,6 +627,7 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
     st3(directIllum + (size_t)index * 3, iter == 0 ? acc : acc / (float)(iter + 1));
 }
 
+constexpr int kBandTiles = 48;
 template <bool SOBOL>
 __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
                                                              float* __restrict__ directIllum, int iter, int looper, int reuse,
@@ -641,7 +642,18 @@ __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevSce
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
     }
 
-    const int ox = (tile % tilesX) * kBTileW, oy = y0 + (tile / tilesX) * kBTileH;
+    // ... and inside that run the tiles go band by band: a tile re-reads the five halo rows its upper neighbour staged one ROW OF TILES
+    // earlier, and a row of tiles is 30.6 KB x tilesX of staged records -- 1.8 MB at 1920 pixels, which the XCD's 4 MB L2 still holds, 3.7 MB
+    // at 3840, which it does not (counter traffic 1.46 x the algorithmic bytes against 1.21 x at 1080p).  Frames wider than kBandTiles tiles
+    // are therefore swept in vertical bands of at most that many tiles, each band top to bottom (the order changes nothing but cache hits).
+    int tcol = tile % tilesX, trow = tile / tilesX;
+    if (tilesX > kBandTiles) {
+        const int tilesY = numTiles / tilesX, bands = (tilesX + kBandTiles - 1) / kBandTiles, bw = (tilesX + bands - 1) / bands;
+        const int full = bw * tilesY, last = (bands - 1) * full;
+        const int b = tile >= last ? bands - 1 : tile / full, r = tile - b * full, w = tile >= last ? tilesX - (bands - 1) * bw : bw;
+        trow = r / w; tcol = b * bw + r % w;
+    }
+    const int ox = tcol * kBTileW, oy = y0 + trow * kBTileH;
     const int W = g.width, H = g.height;
     const bool spatial = (reuse & 2) != 0;
 
