@@ -627,7 +627,10 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
     st3(directIllum + (size_t)index * 3, iter == 0 ? acc : acc / (float)(iter + 1));
 }
 
-constexpr int kBandTiles = 48;
+#ifndef RS_K4_BAND_TILES
+#define RS_K4_BAND_TILES 48
+#endif
+constexpr int kBandTiles = RS_K4_BAND_TILES;
 template <bool SOBOL>
 __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
                                                              float* __restrict__ directIllum, int iter, int looper, int reuse,
