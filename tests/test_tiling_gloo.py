@@ -39,7 +39,7 @@ def _worker(rank, world, port, moving, outdir, balanced=False, calibrated=False,
     bounds = BALANCED[world] if balanced else None
     if calibrated:                                  # what bench.py does for N > 1: measure, all-gather, rebalance; then fresh buffers
         from restir_amd.tiling import calibrate_bounds
-        bounds = calibrate_bounds(backend, world, rank, H, dist, lambda: None, rounds=2, frames=1)
+        bounds = calibrate_bounds(backend, world, rank, H, dist, lambda: None, rounds=2, frames=1, denoise=denoise, min_rows=32 if denoise else 8)
         backend = OracleBackend(backend.scene, cam, W, H)
         np.save(os.path.join(outdir, f"bounds_{rank}.npy"), np.array(bounds))
     r = StripRenderer(backend, world, rank, H, dist=dist, share_history=moving, bounds=bounds)
@@ -120,6 +120,26 @@ def test_eaw_on_strips_equals_full_frame_filter(tmp_path):
     assert np.abs(ref - o.image).max() > 1e-3
 
 
+def test_calibrated_strips_with_the_filter(tmp_path):
+    """What `bench.py --config 5 --gpus N` does: strip heights calibrated on frames that include the filter, never below the 32 rows its
+    levels reach into the neighbours; the filtered strips equal the full-frame LeveledEAWFilter."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, False, str(tmp_path), False, True, True), nprocs=2, join=True)
+    b = [np.load(tmp_path / f"bounds_{r}.npy") for r in range(2)]
+    assert np.array_equal(b[0], b[1]) and min(y1 - y0 for y0, y1 in b[0]) >= 32
+    got = np.concatenate([np.load(tmp_path / f"filtered_{r}.npy") for r in range(2)])
+    from oracle import binding as ob
+    from tests.common import OracleRenderer, get_scene
+    o = OracleRenderer(get_scene("sponza:0.02"), W, H)
+    for frame in range(FRAMES):
+        o.gbuf.render(o.scene, o.cam)
+        o.restir.direct(o.scene, o.cam, o.gbuf, o.image, 0, o.looper, 3)
+        o.looper += 1
+        ref = ob.eaw_filter(o.gbuf, o.cam, o.image).copy()
+        o.gbuf.update(o.cam)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_rebalance_bounds():
     from restir_amd.tiling import HALO, StripRenderer, rebalance_bounds, strip_bounds
     for height, world in ((1080, 8), (1080, 2), (2160, 8), (64, 3)):
@@ -132,6 +152,11 @@ def test_rebalance_bounds():
             assert all(nb[i][1] == nb[i + 1][0] for i in range(world - 1))
             assert min(y1 - y0 for y0, y1 in nb) >= max(HALO, 8)
             b = nb
+    for t in ([5.0, 1.0, 1.0, 1.0], [1.0, 1.0, 1.0, 9.0]):           # the filter's floor: no strip below 32 rows however skewed the costs
+        nb = rebalance_bounds([strip_bounds(1080, 4, r) for r in range(4)], t, 1080, min_rows=32)
+        assert min(y1 - y0 for y0, y1 in nb) >= 32 and nb[0][0] == 0 and nb[-1][1] == 1080
+    nb = rebalance_bounds([(0, 32), (32, 64)], [9.0, 1.0], 64, min_rows=32)
+    assert nb == [(0, 32), (32, 64)]
     # a strip that costs more per row gets fewer rows; equal costs keep an even split (up to the 8-row quantum)
     nb = rebalance_bounds([(0, 540), (540, 1080)], [2.0, 1.0], 1080)
     assert nb[0][1] < 540
