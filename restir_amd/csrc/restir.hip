@@ -333,173 +333,10 @@ __global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_shado
     if (shaded && occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
 }
 
-// ---- the shadow rays of a large launch: a resident grid of waves that REPLACE finished rays ---------------------------------------------
-// Where the shadow walk stands (tools/micro/gather_rate.hip, profiles/r04_gather_rate_microbenchmark.log): 90 % of its 190 M per-lane
-// fetches hit the CU's L1, and a CU serves DEPENDENT L1-resident 16-byte gathers at 1.45 per clock with all 64 lanes of its waves chasing
-// but at 1.0 per clock with 32 -- and a wave of k_shadow walks until its slowest ray is done, 139 iterations for 74 steps per ray, 54 % of
-// its lanes active: the pass runs at 94 % of that half-lane rate.  (The multi-bounce walks miss L1 in 62 % of their fetches and are bound by
-// the L2 / fabric gather rates instead, where active lanes do not matter: the same replacement measured slower there, commit d0141a4.)
-// Here a wave owns a run of consecutive 8x8 pixel tiles and, whenever at least kShadowRefillAt lanes have nothing left to do, those lanes
-// publish their result and take the next pixels of the run.  Per ray the walk is walk_occlusion_tree's: the same nodes, leaf rounds and
-// verification, only interleaved differently with the other lanes' (a ray's result does not depend on its neighbours).  Rays that take one
-// of AABB::intersect's special cases or start beyond the grid's reach wait in their lane and walk the reference's tree when the wave has
-// finished its run (walk_anyhit_deferred, as in trace_occluded_wave).
-constexpr int kShadowRefillAt = 16;
-#ifndef RS_SHADOW_STREAM_WAVES
-#define RS_SHADOW_STREAM_WAVES 8          // resident waves per SIMD of the streaming form (0: always one tile per wave, k_shadow)
-#endif
-__global__ void __launch_bounds__(256, RS_SHADOW_STREAM_WAVES ? RS_SHADOW_STREAM_WAVES : 8) k_shadow_stream(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX8, int slotsPerWave, int totalSlots) {
-    const int lane = threadIdx.x & 63;
-    int next = (blockIdx.x * 4 + (threadIdx.x >> 6)) * slotsPerWave;      // wave-uniform: the next pixel slot (tile * 64 + position in the tile) of this wave's run
-    const int waveEnd = min(totalSlots, next + slotsPerWave);
-    if (next >= waveEnd) return;
-    const char* nodes = reinterpret_cast<const char*>(s.occNodes);
-    const unsigned endOff = (unsigned)s.occCount * 16u;
-    // per lane: the ray and its walk (nothing to do: cur == endOff, qn == 0; index < 0: no result to publish)
-    f3 o = splat(0.f), d = splat(0.f), dinv = splat(0.f);
-    vf2 Axy = { 0.f, 0.f }, Bxy = { -1.f, -1.f }, Azz = { 0.f, 0.f }, Bzz = { -1.f, -1.f };
-    float tRoot = 0.f, limit = 0.f;
-    unsigned selX = 0x07060100u, selY = 0x05040302u, selZ = 0x07060100u, cur = endOff;
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0, index = -1;
-    bool occluded = false, slowPending = false;
-    for (;;) {
-        {   // ---- refill point
-            const bool done = (cur == endOff) & (qn == 0);
-            const bool idle = done & !slowPending;
-            const unsigned long long idleMask = __ballot(idle);
-            const int nIdle = __popcll(idleMask), nDone = __popcll(__ballot(done));
-            if (nDone == 64 || (nIdle >= kShadowRefillAt && next < waveEnd)) {
-                if (idle && index >= 0) {
-                    if (occluded) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;      // `if (testOcclusion(...)) reservoir.weight = 0`
-                    index = -1; occluded = false;
-                    Axy = vf2{ 0.f, 0.f }; Bxy = vf2{ -1.f, -1.f }; Azz = Axy; Bzz = Bxy;       // rests on the end record, whose test then fails whatever it holds
-                }
-                if (nDone == 64 && (next >= waveEnd || nIdle == 0)) {
-                    if (__any(slowPending)) {                                                    // the rays that walk the reference's tree
-                        Ray ray; ray.o = o; ray.d = d;
-                        RayBoxCtx ctx = make_box_ctx(ray);
-                        ctx.cull = s.axisCull;
-                        const bool occ = walk_anyhit_deferred<false>(s, ray, ctx, limit, slowPending);
-                        if (slowPending && occ) reinterpret_cast<float*>(sp.candWi + index)[3] = 0.f;
-                        if (slowPending) { slowPending = false; index = -1; }
-                    }
-                    if (next >= waveEnd) break;
-                    continue;
-                }
-                const int slot = next + __popcll(idleMask & ((1ull << lane) - 1ull));
-                const bool take = idle && slot < waveEnd;
-                next = min(waveEnd, next + nIdle);
-                if (take) {
-                    const int tile = slot >> 6, l = slot & 63;
-                    const int x = (tile % tilesX8) * 8 + (l & 7), y = y0 + (tile / tilesX8) * 8 + (l >> 3);
-                    if (x < width && y < y1) {
-                        const int pix = y * width + x;
-                        const float4 pm = sp.posMat[pix];
-                        if (mk_kind(__float_as_int(pm.w)) == kKindShaded) {
-                            const float4 cl = sp.candLi[pix], cw = sp.candWi[pix];
-                            const f3 pos = mk3(pm.x, pm.y, pm.z), target = pos + mk3(cw.x, cw.y, cw.z) * cl.w;
-                            // testOcclusion's segment (scene.h:286-299), as trace_occluded_wave sets it up
-                            f3 dir = target - pos;
-                            float dist = length(dir);
-                            dir = div3_exact_signed(dir, dist);
-                            d = dir; o = pos + dir * 1e-5f;                                       // makeOffsetedRay
-                            limit = dist - 1e-4f * 2.f;
-                            index = pix;
-                            Ray ray; ray.o = o; ray.d = d;
-                            const RayBoxCtx ctx = make_box_ctx(ray);
-                            const bool special = ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(d.x == d.x);
-                            if (special || !occlusion_tree_usable(s, o)) slowPending = true;
-                            else {
-                                dinv = ctx.dinv;
-                                const f3 A = mk3(s.occScale.x * dinv.x, s.occScale.y * dinv.y, s.occScale.z * dinv.z);
-                                const f3 B = mk3((s.occBase.x - o.x) * dinv.x, (s.occBase.y - o.y) * dinv.y, (s.occBase.z - o.z) * dinv.z);
-                                tRoot = fmaxf(fmaxf(fmaxf(gabs((s.occRootLo.x - o.x) * dinv.x), gabs((s.occRootHi.x - o.x) * dinv.x)),
-                                                    fmaxf(gabs((s.occRootLo.y - o.y) * dinv.y), gabs((s.occRootHi.y - o.y) * dinv.y))),
-                                              fmaxf(gabs((s.occRootLo.z - o.z) * dinv.z), gabs((s.occRootHi.z - o.z) * dinv.z)));
-                                selX = A.x < 0.f ? 0x01000706u : 0x07060100u; selY = A.y < 0.f ? 0x03020504u : 0x05040302u; selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;
-                                Axy = vf2{ A.x, A.y }; Bxy = vf2{ B.x, B.y }; Azz = vf2{ A.z, A.z }; Bzz = vf2{ B.z, B.z };
-                                cur = 0u;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // ---- walk phase (walk_occlusion_tree's): until some lane's leaf queue is full, every walk has ended, or enough lanes can be refilled
-        for (;;) {
-            if (!__ballot(cur != endOff)) break;
-            if (next < waveEnd && __popcll(__ballot((cur == endOff) & (qn == 0) & !slowPending)) >= kShadowRefillAt) break;
-            // a lane whose walk has ended but whose queue still holds leaves can neither walk nor be refilled: enough of them start a leaf round
-            if (__popcll(__ballot((cur == endOff) & (qn > 0))) >= kShadowRefillAt) break;
-            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
-            const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
-            const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
-            const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
-            const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
-            const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
-            const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
-            const bool pass = (tMax >= fmaxf(tMin, 0.f)) && (tMin < limit);
-            const int meta = (int)n.w;
-            const bool leaf = meta < 0;
-            const bool push = pass && leaf;
-            q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn = push ? qn + 1 : qn;
-            cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
-            if (__any(qn == kLeafQueue)) break;
-        }
-        if (!__any(qn > 0)) continue;
-        // ---- leaf round (walk_occlusion_tree's): every lane takes its newest queued leaf; a hit becomes a candidate that is verified
-        // against the reference's path to its leaf
-        int tri = 0, cnt = 0, verify = -1;
-        if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
-        for (;;) {
-            while (__any((cnt > 0) & (verify < 0))) {
-                if ((cnt > 0) & (verify < 0)) {
-                    const float4* p = reinterpret_cast<const float4*>(s.occTris + tri);
-                    const float4 a = p[0], b = p[1], c = p[2];
-                    float bx, by, dist;
-                    tri++; cnt--;
-                    if (tri_hit(o, d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist) && dist < limit)
-                        verify = __float_as_int(a.w);
-                }
-            }
-            if (!__any(verify >= 0)) break;
-            while (__any(verify >= 0)) {
-                if (verify >= 0) {
-                    const float4* rec = reinterpret_cast<const float4*>(s.occChain + verify);
-                    float4 lo, hi;
-                    node_unpack(rec[0], rec[1], lo, hi);
-                    const float t1x = (lo.x - o.x) * dinv.x, t1y = (lo.y - o.y) * dinv.y, t1z = (lo.z - o.z) * dinv.z;
-                    const float t2x = (hi.x - o.x) * dinv.x, t2y = (hi.y - o.y) * dinv.y, t2z = (hi.z - o.z) * dinv.z;
-                    const float nx = fminf(t1x, t2x), ny = fminf(t1y, t2y), nz = fminf(t1z, t2z);
-                    const float fx = fmaxf(t1x, t2x), fy = fmaxf(t1y, t2y), fz = fmaxf(t1z, t2z);
-                    const float dx = fx - nx, dy = fy - ny, dz = fz - nz;
-                    const bool overlap = (dy + dz > fz - ny) & (dz + dx > fx - nz) & (dx + dy > fy - nx);
-                    const float tMin = fmaxf(fmaxf(nx, ny), nz), tMax = fminf(fminf(fx, fy), fz);
-                    const bool open = overlap & (tMax >= 0.f) & (tMax >= tMin) & (tMin < limit);
-                    const bool clear = fminf(fminf(fy - nz, fz - nx), fx - ny) > tRoot * 3.814697265625e-6f;
-                    const int parent = __float_as_int(lo.w);
-                    const bool hit = open & ((parent < 0) | (clear & s.occNested));
-                    if (hit) { occluded = true; cur = endOff; qn = 0; cnt = 0; }
-                    verify = (open & !hit) ? parent : -1;
-                }
-            }
-        }
-    }
-}
-
-// the shadow rays of rows [y0, y1) on stream st: the streaming form when every resident wave gets at least three tiles, else one tile per wave
-int launch_shadow(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y1, int tilesX, int tilesY, hipStream_t st) {
-    static const int cus = []{ int dev = 0, v = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
-    const int waves = cus * 4 * RS_SHADOW_STREAM_WAVES;
-    const long long tiles = (long long)tilesX * 4 * tilesY;                // 8x8 tiles (a block of k_shadow is four of them side by side)
-    if (RS_SHADOW_STREAM_WAVES && scene->dev.occNodes && tiles >= 3ll * waves) {
-        const int slotsPerWave = (int)((tiles + waves - 1) / waves) * 64;
-        hipLaunchKernelGGL(k_shadow_stream, dim3(waves / 4), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX * 4, slotsPerWave, (int)(tiles * 64));
-    }
-    else hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
-    return 0;
-}
-
+// (The shadow rays as a resident grid of waves that replace finished rays from a run of tiles -- 87 % of the lanes walking instead of 54 % --
+// were built and measured in round 4: bit-exact and THREE TIMES slower, 0.475 -> 1.38 ms.  The 64 rays of an 8x8 tile start next to each
+// other and walk in lockstep through the same cache lines; replacement desynchronises them, and what the wave then fetches per step is 64
+// different lines.  EXPERIMENTS.md, commit 5febf79, profiles/r04_ab_shadow_streaming_replacement.log.)
 template <bool SOBOL>
 __global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp, const uint32_t* sampleSeq, int looper,
                                                   int first, int reuse, int n0, int n1, unsigned long long* rayWork, unsigned long long* rayDone) {
@@ -1108,13 +945,13 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  RS_SHADOW_ON_MAIN=0 / 1: never / always.
     const int shadowOnMain = plan->shadowOnMain;
     const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
-    if (!shadowMain) RS_TRY(launch_shadow(scene, sp, W, y0, y1, tilesX, tilesY, st));
+    if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
     if (aux) {
         RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS / shadow rays)"));
         RS_HIP(hipEventRecord(r->auxDone, aux));
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
-    if (shadowMain) RS_TRY(launch_shadow(scene, sp, W, y0, y1, tilesX, tilesY, rs_stream()));
+    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), rs_stream(), sp, gbuf_view(g),
                r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
