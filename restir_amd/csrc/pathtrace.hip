@@ -60,7 +60,9 @@ __global__ void __launch_bounds__(256, RS_PT_BLOCKS) k_pt_direct(DevScene s, Cam
             }
         }
     }
-    const bool occluded = trace_occluded_wave(s, h.pos, c.point, nee);
+    // (a sample without a valid pdf -- a single-sided light that faces away, scene.h:448-452 -- gives InvalidPdf whether its segment is
+    // occluded or not: counted as the reference's testOcclusion call, not walked; as in gi.hip)
+    const bool occluded = trace_occluded_wave(s, h.pos, c.point, nee && c.pdf > 0.f);
     if (nee) {
         walks++;
         const float pdf = occluded ? kInvalidPdf : c.pdf;
