@@ -11,12 +11,7 @@
 #include "rs_internal.h"
 
 #ifndef RS_WALK_WAVES
-#define RS_WALK_WAVES 8        // waves per SIMD the walk kernels are held to (A/B: -DRS_WALK_WAVES=4 -DRS_WALK_CAP)
-#endif
-#ifdef RS_WALK_CAP            // hold the kernels to exactly RS_WALK_WAVES waves per SIMD (more registers each, room for other kernels' waves)
-#define RS_WALK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RS_WALK_WAVES, RS_WALK_WAVES)))
-#else
-#define RS_WALK_WAVES_ATTR
+#define RS_WALK_WAVES 8        // waves per SIMD the walk kernels are held to (launch bound; holding them to exactly that many was A/B'd in round 3: no gain)
 #endif
 using namespace rs;
 
@@ -41,11 +36,11 @@ __device__ __forceinline__ void render_gbuffer_body(const DevScene& s, const Cam
 }
 
 template <bool TEX>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX) {
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX) {
     render_gbuffer_body<TEX, false>(s, cam, lastCam, g, y0, y1, tilesX, TileSplit{ nullptr, 0, 0 });
 }
 template <bool TEX>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX, TileSplit ts) {
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX, TileSplit ts) {
     render_gbuffer_body<TEX, true>(s, cam, lastCam, g, y0, y1, tilesX, ts);
 }
 

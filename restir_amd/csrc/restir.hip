@@ -27,12 +27,7 @@
 #include "rs_internal.h"
 
 #ifndef RS_WALK_WAVES
-#define RS_WALK_WAVES 8        // waves per SIMD the walk kernels are held to (A/B: -DRS_WALK_WAVES=4 -DRS_WALK_CAP)
-#endif
-#ifdef RS_WALK_CAP            // hold the kernels to exactly RS_WALK_WAVES waves per SIMD (more registers each, room for other kernels' waves)
-#define RS_WALK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RS_WALK_WAVES, RS_WALK_WAVES)))
-#else
-#define RS_WALK_WAVES_ATTR
+#define RS_WALK_WAVES 8        // waves per SIMD the walk kernels are held to (launch bound; holding them to exactly that many was A/B'd in round 3: no gain)
 #endif
 using namespace rs;
 
@@ -132,12 +127,12 @@ __device__ __forceinline__ void primary_body(const DevScene& s, const CamParams&
 }
 
 template <bool TEX, bool SOBOL>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
     primary_body<TEX, SOBOL, false>(s, cam, sp, looper, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
 }
 template <bool TEX, bool SOBOL>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_primary_split(DevScene s, CamParams cam, SurfPlanes sp, int looper,
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary_split(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
     primary_body<TEX, SOBOL, true>(s, cam, sp, looper, y0, y1, tilesX, rayCount, ts);
 }
@@ -183,12 +178,12 @@ __device__ __forceinline__ void gbuffer_primary_body(const DevScene& s, const Ca
 }
 
 template <bool TEX, bool SOBOL>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
                                                                   int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
     gbuffer_primary_body<TEX, SOBOL, false>(s, cam, lastCam, g, sp, looper, gy0, gy1, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
 }
 template <bool TEX, bool SOBOL>
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
                                                                   int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, TileSplit ts) {
     gbuffer_primary_body<TEX, SOBOL, true>(s, cam, lastCam, g, sp, looper, gy0, gy1, y0, y1, tilesX, rayCount, ts);
 }
@@ -316,7 +311,7 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
 // 8 blocks per CU = 8 waves per SIMD.
 // (A hand-off of each wave's last rays to one wave per block was built and measured in round 3 -- same results, a quarter fewer wave
 // iterations, no gain: the pass is bound by per-lane L1 look-ups; EXPERIMENTS.md, commit 933552f.)
-__global__ void RS_WALK_WAVES_ATTR __launch_bounds__(256, RS_WALK_WAVES) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
+__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
     const bool inside = x < width && y < y1;
