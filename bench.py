@@ -27,6 +27,8 @@ restir_amd/rccl.py); torch.distributed (gloo) is the control plane only: the id 
                              uses the same card; RCCL refuses two ranks on one device)
   BENCH_FORCE_STRIPS=1       N = 1 through the strip driver and a one-rank ncclComm as well
   BENCH_WATCHDOG=seconds     every rank (and the launcher) ends itself after that long (default 900 with N > 1)
+  BENCH_COMM_STREAM=library|own|auto   where the strip driver enqueues its RCCL transfers (rs_strips_set_comm_stream); auto (default over
+                             RCCL) times both before the warm-up and keeps the faster
 
 One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its HIP-event duration (events
@@ -568,6 +570,36 @@ def main():
     for _ in range(2):
         frame()
     barrier()
+    # N > 1 over RCCL: where the strip driver enqueues its transfers -- on the library stream (one group per frame, nothing overlaps the
+    # wire) or on a stream of its own (the interior rows of phase B run while the border rows travel, at the price of a fifth stream) -- is
+    # a property of the machine that no one-GPU box can measure: both are timed here, before the warm-up, and the faster one (by the slowest
+    # rank) runs the warm-up and the timed frames.  Results do not depend on it (strips_loopback_ranks compares both with the full frame).
+    # BENCH_COMM_STREAM=library|own skips the measurement.
+    comm_choice = None
+    if driver == "c" and world > 1:
+        want = os.environ.get("BENCH_COMM_STREAM", "auto" if transport == "rccl" else "library")
+        if want == "auto":
+            trial = {}
+            for own in (False, True):
+                barrier()
+                drv.set_comm_stream(own)
+                for _ in range(4):
+                    frame()
+                barrier()
+                ts = time.perf_counter()
+                for _ in range(12):
+                    frame()
+                barrier()
+                tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=ctl_device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                trial[own] = float(tt[0]) / 12 * 1e3
+            own = trial[True] < trial[False]
+            comm_choice = "%s (measured: library stream %.3f ms/frame, own stream %.3f)" % ("own stream" if own else "library stream", trial[False], trial[True])
+        else:
+            own = want == "own"
+            comm_choice = ("own stream" if own else "library stream") + " (set)"
+        barrier()
+        drv.set_comm_stream(own)
     for _ in range(args.warmup):
         frame()
     barrier()
@@ -775,6 +807,7 @@ def main():
                                      if transport == "rccl" else "host callbacks over torch.distributed gloo (rehearsal, not RCCL)"),
                        "rccl_ranks": (world if (driver == "c" and transport == "rccl") else (world if (driver == "py" and backend_name == "nccl" and world > 1) else 0)),
                        "strip_rows_per_rank": [b - a for a, b in bounds],
+                       "strip_transfers_on": comm_choice,
                        "strip_driver_fallback": fallback,
                        "halo_wait_ms_rank0": (float(np.median(halo_wait)) if halo_wait else None),
                        "rays_per_frame": total_rays / args.steps},
