@@ -104,7 +104,13 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
             }
             ray.o = pos + sample.dir * 1e-5f; ray.d = sample.dir;               // makeOffsetedRay
         }
-        h = trace_closest_wave(s, ray, alive);
+        // The last bounce only asks whether its closest hit is an emissive triangle (a surface would need another bounce to contribute,
+        // and without an environment map neither does a miss): rays that cannot hit one the way the reference accepts triangles
+        // (may_hit_emissive_wave, a walk of the few emissive triangles' own tree) are counted as the reference's intersect call and not walked.
+        // (ReSTIRIndirect at depth 1 records the hit point whatever it is: restir.cu:345-360.)
+        bool walk = alive;
+        if (depth == maxDepth && !env && !(MODE == kModeReSTIR && depth == 1)) walk = may_hit_emissive_wave(s, ray, alive);
+        h = trace_closest_wave(s, ray, walk);
         if (alive) {
             st.walks++;
             wo = -ray.d;

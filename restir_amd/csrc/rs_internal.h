@@ -137,6 +137,8 @@ struct rs_scene {
     uint4* dOccNodes = nullptr;      // shadow-ray tree (occlusion_bvh.cpp)
     rs::BvhNode* dOccChain = nullptr;   // reference boxes + parent links by original node id
     rs::TriRec* dOccTris = nullptr;
+    uint4* dEmiNodes = nullptr;      // tree of the emissive triangles alone (scene.hip build_emissive_side)
+    rs::TriRec* dEmiTris = nullptr;
     uint4* dOrdNodes = nullptr;      // closest-hit trees in the reference's visiting orders (occlusion_bvh.cpp rs_build_ordered_bvh)
     rs::TriRec* dOrdTris = nullptr;
     unsigned long long* dWalkStats = nullptr;   // -DRS_WALK_STATS builds only

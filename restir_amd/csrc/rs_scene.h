@@ -74,6 +74,12 @@ struct DevScene {
     bool axisCull;                // boxes contain their children and triangles (enables skip_far_on_axis)
     bool linksNested;             // in every threaded order the miss links nest: c in (a, link(a)) => link(c) <= link(a)
     int occCount;
+    // the emissive triangles alone, as a tree of the shadow tree's kind (scene.hip build_emissive_side; may_hit_emissive_wave):
+    // emiState 0 = not built (every ray may hit one), 1 = built, emiCount nodes (0: the scene has no emissive triangle)
+    const uint4*   emiNodes;
+    const TriRec*  emiTris;
+    f3 emiBase, emiScale;
+    int emiCount, emiState;
     // closest hit of incoherent rays: six trees in the reference's six visiting orders (occlusion_bvh.cpp rs_build_ordered_bvh), 16-byte
     // records on the shadow tree's grid, order k at byte offset k * ordStride, its end record at (k + 1) * ordStride - 16;
     // ordTris: per axis numPrims triangles in the even order's sequence (pad0 = reference leaf node, pad1 = primitive id).  Null = off.
@@ -684,6 +690,63 @@ __device__ __forceinline__ bool walk_occlusion_tree(const DevScene& s, const Ray
 #endif
 #undef RS_STAT
     return occluded;
+}
+
+// May the reference's closest hit of this ray be an EMISSIVE triangle?  False only if the ray hits (intersectTriangle) no emissive
+// triangle whose reference leaf box it passes -- then DevScene::intersect, which accepts a triangle only on those two conditions, cannot
+// return one.  The walk is walk_occlusion_tree's on the tree of the emissive triangles (no range, no verification: any hit answers "maybe");
+// special-case and far-origin rays answer "maybe" without walking.  Every lane of the wave must call it.
+__device__ __forceinline__ bool may_hit_emissive_wave(const DevScene& s, const Ray& ray, bool active) {
+    if (!s.emiState) return active;
+    if (s.emiCount == 0) return false;
+    RayBoxCtx ctx = make_box_ctx(ray);
+    const bool special = ctx.mode != 0 || ctx.zx || ctx.zy || ctx.zz || !(ray.d.x == ray.d.x);
+    const float reach = 4.f * 65535.f;
+    const bool usable = gabs(ray.o.x - s.emiBase.x) <= reach * s.emiScale.x && gabs(ray.o.y - s.emiBase.y) <= reach * s.emiScale.y &&
+                        gabs(ray.o.z - s.emiBase.z) <= reach * s.emiScale.z;
+    const bool maybe = active && (special || !usable);          // answered without a walk
+    const bool walks = active && !maybe;
+    const char* nodes = reinterpret_cast<const char*>(s.emiNodes);
+    const unsigned endOff = (unsigned)s.emiCount * 16u;
+    const f3 A = walks ? mk3(s.emiScale.x * ctx.dinv.x, s.emiScale.y * ctx.dinv.y, s.emiScale.z * ctx.dinv.z) : splat(0.f);
+    const f3 B = walks ? mk3((s.emiBase.x - ctx.o.x) * ctx.dinv.x, (s.emiBase.y - ctx.o.y) * ctx.dinv.y, (s.emiBase.z - ctx.o.z) * ctx.dinv.z) : splat(-1.f);
+    unsigned cur = walks ? 0u : endOff;
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;
+    bool found = false;
+    const unsigned selX = A.x < 0.f ? 0x01000706u : 0x07060100u, selY = A.y < 0.f ? 0x03020504u : 0x05040302u, selZ = A.z < 0.f ? 0x01000706u : 0x07060100u;
+    const vf2 Axy = { A.x, A.y }, Bxy = { B.x, B.y }, Azz = { A.z, A.z }, Bzz = { B.z, B.z };
+    for (;;) {
+        for (;;) {
+            if (!__ballot(cur != endOff)) break;
+            const uint4 n = *reinterpret_cast<const uint4*>(nodes + cur);
+            const unsigned px = __builtin_amdgcn_perm(n.y, n.x, selX), py = __builtin_amdgcn_perm(n.z, n.x, selY), pz = __builtin_amdgcn_perm(n.z, n.y, selZ);
+            const vf2 nearXY = __builtin_elementwise_fma(vf2{ (float)(px & 0xffffu), (float)(py & 0xffffu) }, Axy, Bxy);
+            const vf2 farXY = __builtin_elementwise_fma(vf2{ (float)(px >> 16), (float)(py >> 16) }, Axy, Bxy);
+            const vf2 zNF = __builtin_elementwise_fma(vf2{ (float)(pz & 0xffffu), (float)(pz >> 16) }, Azz, Bzz);
+            const float tMin = fmaxf(fmaxf(nearXY.x, nearXY.y), zNF.x);
+            const float tMax = fminf(fminf(farXY.x, farXY.y), zNF.y);
+            const bool pass = tMax >= fmaxf(tMin, 0.f);
+            const int meta = (int)n.w;
+            const bool leaf = meta < 0;
+            const bool push = pass && leaf;
+            q3 = push ? q2 : q3; q2 = push ? q1 : q2; q1 = push ? q0 : q1; q0 = push ? ~meta : q0; qn = push ? qn + 1 : qn;
+            cur = (pass || leaf) ? cur + 16u : (unsigned)meta;
+            if (__any(qn == kLeafQueue)) break;
+        }
+        if (!__any(qn > 0)) break;
+        int tri = 0, cnt = 0;
+        if (qn > 0) { tri = q0 >> 3; cnt = q0 & 7; q0 = q1; q1 = q2; q2 = q3; qn--; }
+        while (__any(cnt > 0)) {
+            if (cnt > 0) {
+                const float4* p = reinterpret_cast<const float4*>(s.emiTris + tri);
+                const float4 a = p[0], b = p[1], c = p[2];
+                float bx, by, dist;
+                tri++; cnt--;
+                if (tri_hit(ray.o, ray.d, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bx, by, dist)) { found = true; cur = endOff; qn = 0; cnt = 0; }
+            }
+        }
+    }
+    return maybe || found;
 }
 
 // ---- closest hit of incoherent rays through the trees that keep the reference's order ---------------------------------------

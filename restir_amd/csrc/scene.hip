@@ -116,6 +116,44 @@ int build_occlusion_side(rs_scene* s) {
     return 0;
 }
 
+// The tree of the EMISSIVE triangles alone (rs_scene.h may_hit_emissive_wave).  The last bounce of a path (gi.hip) only asks whether its
+// closest hit is an emissive triangle; the reference accepts a triangle only if intersectTriangle hits it and its leaf box was entered, so a
+// ray that hits no emissive triangle whose reference leaf box it passes cannot have an emissive closest hit -- and that question is asked
+// of a tree over the reference leaf boxes of the few emissive triangles (the shadow tree's builder and grid: its relaxed box test cannot
+// miss a triangle whose reference leaf box the ray passes), which stays in L1, instead of the scene's.  Needs the shadow side's preconditions.
+int build_emissive_side(rs_scene* s) {
+    if (!s->dev.occNodes) return 0;
+    std::vector<int> prims;
+    for (int p = 0; p < s->numPrims; p++) {
+        const int m = s->hMaterialIds[(size_t)p];
+        if (m >= 0 && m < (int)s->hMaterials.size() && s->hMaterials[(size_t)m].type == 4) prims.push_back(p);
+    }
+    if (prims.empty()) { s->dev.emiState = 1; s->dev.emiCount = 0; return 0; }      // no emissive triangle: no closest hit is one
+    std::vector<float> boxes(prims.size() * 6);
+    for (size_t i = 0; i < prims.size(); i++) std::memcpy(&boxes[i * 6], &s->hBoxes[(size_t)s->hLeafOf[(size_t)prims[i]] * 6], 6 * sizeof(float));
+    std::vector<BvhNode> nodes;
+    std::vector<int> leafPrims;
+    if (int e = rs_build_occlusion_bvh((int)prims.size(), boxes.data(), nodes, leafPrims)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
+    float base[3], scale[3];
+    std::vector<unsigned> packed;
+    if (int e = rs_quantize_occlusion_bvh(nodes, base, scale, packed)) return e == RS_ERR_UNSUPPORTED ? 0 : e;
+    const size_t no = nodes.size();
+    packed.push_back(0xffffffffu); packed.push_back(0x0000ffffu); packed.push_back(0u); packed.push_back((unsigned)(no * 16));      // the end record
+    std::vector<TriRec> rec(prims.size());
+    for (size_t i = 0; i < prims.size(); i++) {
+        const float* t = &s->hVertices[(size_t)prims[(size_t)leafPrims[i]] * 9];
+        const f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6), e1 = v1 - v0, e2 = v2 - v0;
+        rec[i] = TriRec{ v0.x, v0.y, v0.z, 0.f, e1.x, e1.y, e1.z, 0.f, e2.x, e2.y, e2.z, 0.f };
+    }
+    RS_TRY(rs_dev_alloc(&s->dEmiNodes, no + 1));
+    RS_HIP(hipMemcpy(s->dEmiNodes, packed.data(), (no + 1) * 16, hipMemcpyHostToDevice));
+    RS_TRY(upload(&s->dEmiTris, rec));
+    s->dev.emiNodes = s->dEmiNodes; s->dev.emiTris = s->dEmiTris; s->dev.emiCount = (int)no;
+    s->dev.emiBase = mk3(base[0], base[1], base[2]); s->dev.emiScale = mk3(scale[0], scale[1], scale[2]);
+    s->dev.emiState = 1;
+    return 0;
+}
+
 // The closest-hit trees of the incoherent rays (occlusion_bvh.cpp rs_build_ordered_bvh, rs_scene.h walk_ordered_tree): per axis
 // one tree over the leaf sequence of the even threaded order, emitted in forward and mirrored pre-order -> six arrays of 16-byte
 // grid-box records like the shadow tree's, laid out at a common stride in ONE allocation so that a lane addresses its order by
@@ -208,7 +246,7 @@ extern "C" int rs_scene_destroy(rs_scene* s) {
     if (!s) return 0;
     (void)rs_gbuffer_release_scene(s);                  // asynchronous mode: a GBuffer::render of this scene that has only been recorded so far
     (void)rs_synchronize();                             // ... and kernels on the library / auxiliary streams may still read the scene
-    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris); rs_dev_free(s->dOrdNodes); rs_dev_free(s->dOrdTris);
+    rs_dev_free(s->dNodesAll); rs_dev_free(s->dWalkStats); rs_dev_free(s->dOccNodes); rs_dev_free(s->dEmiNodes); rs_dev_free(s->dEmiTris); rs_dev_free(s->dOccChain); rs_dev_free(s->dOccTris); rs_dev_free(s->dOrdNodes); rs_dev_free(s->dOrdTris);
     rs_dev_free(s->dTris); rs_dev_free(s->dVertices); rs_dev_free(s->dNormals);
     rs_dev_free(s->dMaterialIds); rs_dev_free(s->dMaterials); rs_dev_free(s->dLights); rs_dev_free(s->dAlias);
     rs_dev_free(s->dTextures); rs_dev_free(s->dEnvAlias); rs_dev_free(s->dTexcoords); rs_dev_free(s->dSampleSeq);
@@ -468,6 +506,7 @@ extern "C" int rs_scene_create(const rs_scene_desc* d, rs_scene** out) {
 #endif
     if (int e = build_occlusion_side(s)) { rs_scene_destroy(s); return e; }
     if (int e = build_ordered_side(s)) { rs_scene_destroy(s); return e; }
+    if (int e = build_emissive_side(s)) { rs_scene_destroy(s); return e; }
     *out = s;
     return 0;
 }

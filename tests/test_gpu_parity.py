@@ -424,6 +424,33 @@ def test_multi_bounce_kernels_bit_exact(hip, correctly_rounded_libm, name):
     assert o.restir.ind_last["numSamples"].max() > 2 and oi.max() > 0
 
 
+@pytest.mark.parametrize("name", ["cornell", "cornell_textured", "sponza:0.03"])
+def test_restir_indirect_shallow_depths(hip, correctly_rounded_libm, name):
+    """ReSTIRIndirect at trace depths 1 and 2.  The last bounce of a path only asks whether its closest hit is emissive and is answered
+    through the emissive triangles' own tree (rs_scene.h may_hit_emissive_wave) -- except at depth 1 of ReSTIRIndirect, whose sample records
+    the hit point whatever it is (src/restir.cu:345-360), and in scenes with an environment map, where a miss contributes: both exceptions
+    and the rule itself against the oracle, images, ray counts and reservoirs bit for bit."""
+    import torch
+    sd = _gi_scene(name)
+    W, H = 96, 64
+    for depth in (1, 2):
+        o = OracleRenderer(sd, W, H)
+        h = HipRenderer(hip, sd, W, H)
+        oi = np.zeros((W * H, 3), np.float32)
+        hi = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
+        for frame in range(2):
+            o.gbuf.render(o.scene, o.cam); h.gbuf.render(h.scene, h.cam)
+            ra = o.restir.indirect(o.scene, o.cam, o.gbuf, oi, 0, frame, 1, depth)
+            rb = h.restir.indirect(h.scene, h.cam, h.gbuf, hi.data_ptr(), 0, frame, 1, depth)
+            assert ra == rb, (depth, frame, ra, rb)
+            assert bits_equal(oi, hi.cpu().numpy()), (depth, frame, radiance_stats(oi, hi.cpu().numpy()))
+            a, b = o.restir.ind_last, h.restir.download_indirect(1)
+            assert np.array_equal(a["numSamples"], b["numSamples"])
+            for k in ("Lo", "xv", "nv", "xs", "ns", "weight"):
+                assert bits_equal(a[k], b[k]), (depth, frame, k)
+            o.gbuf.update(o.cam); h.gbuf.update(h.cam)
+
+
 def test_textured_scene_against_glibc_libm(hip):
     """The same scene against the oracle's default libm mode (glibc sinf / cosf / atan2f, what a host build of the
     reference computes): one-ulp differences of the four libm calls stay inside the stated tolerance."""
