@@ -68,16 +68,22 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
             if (nee) c = env ? sample_light_nv<true, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r)
                              : sample_light_nv<false, const AliasRec*, const LightRec*>(s, s.alias, s.lights, s.numLights, pos, r);
         }
-        // A sample without a valid pdf (the light faces away, scene.h:448-452) contributes nothing whether its segment is occluded or not --
-        // sampleDirectLight returns InvalidPdf either way: it is counted as the reference's testOcclusion call that it is, and not walked
-        // (42 % of the segments on the Sponza-class scene: pathTrace 8.83 -> 7.75 ms, profiles/r04_gi_ab_wavefront_final_sponza.log).
-        const bool occluded = trace_occluded_wave(s, pos, c.point, nee && c.pdf > 0.f);
+        // What the segment's visibility decides is whether `add` is added (pathtrace.cu:205-212).  It is not asked -- the segment is counted
+        // as the reference's testOcclusion call and not walked -- where the answer cannot matter: a sample without a valid pdf (the light faces
+        // away, scene.h:448-452: sampleDirectLight returns InvalidPdf either way; 42 % of the segments on the Sponza-class scene), and a
+        // contribution whose three components are all +0 (the light is below the surface's horizon, sat_dot = 0, or the BSDF is zero):
+        // x + (+0) = x for every x but -0, and the sums, which start at +0, never become -0.  A NaN or -0 component: the segment is walked.
+        f3 add = splat(0.f);
+        const bool valid = nee && c.pdf > 0.f;
+        if (valid) {
+            const float bsdfPdf = material_pdf(material, norm, wo, c.wi);
+            add = ((((throughput * material_bsdf(material, norm, wo, c.wi)) * c.Li) * sat_dot(norm, c.wi)) / c.pdf) * power_heuristic(c.pdf, bsdfPdf);
+        }
+        const bool matters = valid && (__float_as_uint(add.x) | __float_as_uint(add.y) | __float_as_uint(add.z)) != 0u;
+        const bool occluded = trace_occluded_wave(s, pos, c.point, matters);
         if (nee) {
             st.walks++;
-            const float lightPdf = occluded ? kInvalidPdf : c.pdf;
-            if (lightPdf > 0.f) {
-                const float bsdfPdf = material_pdf(material, norm, wo, c.wi);
-                const f3 add = ((((throughput * material_bsdf(material, norm, wo, c.wi)) * c.Li) * sat_dot(norm, c.wi)) / lightPdf) * power_heuristic(lightPdf, bsdfPdf);
+            if (matters && !occluded) {
                 if (MODE == kModePT && depth == 1) st.direct = st.direct + add; else st.indirect = st.indirect + add;
             }
         }

@@ -60,14 +60,18 @@ __global__ void __launch_bounds__(256, RS_PT_BLOCKS) k_pt_direct(DevScene s, Cam
             }
         }
     }
-    // (a sample without a valid pdf -- a single-sided light that faces away, scene.h:448-452 -- gives InvalidPdf whether its segment is
-    // occluded or not: counted as the reference's testOcclusion call, not walked; as in gi.hip)
-    const bool occluded = trace_occluded_wave(s, h.pos, c.point, nee && c.pdf > 0.f);
+    // The segment's visibility decides whether `value` becomes the pixel's radiance.  It is not asked (the segment is counted as the
+    // reference's testOcclusion call, not walked) where the answer cannot matter: a sample without a valid pdf (a single-sided light that
+    // faces away, scene.h:448-452: InvalidPdf either way) and a value whose three components are all +0 (the light is below the surface's
+    // horizon): `direct` is that very +0 already.  As in gi.hip.
+    f3 value = splat(0.f);
+    const bool valid = nee && c.pdf > 0.f;
+    if (valid) value = ((c.Li * eval_bsdf(m.type, m.baseColor, m.metallic, m.roughness, norm, wo, c.wi)) * sat_dot(norm, c.wi)) / c.pdf;
+    const bool matters = valid && (__float_as_uint(value.x) | __float_as_uint(value.y) | __float_as_uint(value.z)) != 0u;
+    const bool occluded = trace_occluded_wave(s, h.pos, c.point, matters);
     if (nee) {
         walks++;
-        const float pdf = occluded ? kInvalidPdf : c.pdf;
-        if (pdf > 0.f)
-            direct = ((c.Li * eval_bsdf(m.type, m.baseColor, m.metallic, m.roughness, norm, wo, c.wi)) * sat_dot(norm, c.wi)) / pdf;
+        if (matters && !occluded) direct = value;
     }
     if (inside) {
         float* o = directIllum + (size_t)index * 3;
