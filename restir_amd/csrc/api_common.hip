@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "rs_internal.h"
@@ -47,6 +48,23 @@ int rs_check_hip(hipError_t e, const char* what) {
 hipStream_t rs_stream() { return rs_ctx()->stream; }
 bool rs_sync_enabled() { return rs_ctx()->sync; }
 
+// The runtime spreads a process's streams over FOUR hardware queues PER PRIORITY LEVEL, whichever stream asks first, and the legacy
+// default stream holds one of the normal level's: a caller's ordinary stream (torch.cuda.Stream(), hipStreamCreate) next to three
+// normal-priority auxiliary streams is five streams on four queues, and when the pair that shares is the library stream and a chain,
+// a frame's temporal / spatial passes queue behind another frame's walks -- a 1/8 strip of 1080p 0.194 -> 0.289 ms per frame, exactly
+// the case of `bench.py --gpus N` and of any C++ caller over RCCL (profiles/r05_ab_stream_priority_pools.log).  The library's own
+// streams (the auxiliary ones, the strip driver's transfer stream) are therefore created at the OTHER level than the caller's:
+// high priority next to the default stream or an ordinary stream, normal next to a high-priority one.  What decides is the pool,
+// not the priority: every combination with the two kinds in different pools measures the same (same log; round 3's A/B of
+// priorities, all on the default stream, agrees).
+int rs_internal_stream_priority() {
+    rs_context* c = rs_ctx();
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int own = 0;
+    if (c->stream && hipStreamGetPriority(c->stream, &own) != hipSuccess) { (void)hipGetLastError(); own = 0; }
+    return (greatest < 0 && own > greatest) ? greatest : 0;       // the caller's stream is not in the high pool: ours are
+}
 // Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 + k the primary-ray + RIS + shadow-ray kernels of every
 // kChains-th frame (frames take the chains in turn, so that these chains of consecutive frames overlap each other
 // as well as the passes of the frames before); for small launches, whose render is part of the chain's first launch, stream 0 is
@@ -74,8 +92,12 @@ hipStream_t rs_aux_stream(int i) {
     }
     if (c->sync || !c->auxMode || i < 0 || i >= rs_context::kAux) return nullptr;
     if (!c->aux[i]) {
-        // (stream priorities were A/B'd in round 3 and changed nothing: EXPERIMENTS.md)
-        const hipError_t err = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+        c->auxPriority = rs_internal_stream_priority();
+        int prio = c->auxPriority;
+#ifdef RS_AUX_PRIORITY_ENV                              // measurement builds: RS_AUX_PRIORITIES=-1,-1,0,... per auxiliary stream
+        if (const char* e = std::getenv("RS_AUX_PRIORITIES")) { for (int k = 0; k < i && e; k++) { e = std::strchr(e, ','); if (e) e++; } if (e) prio = std::atoi(e); }
+#endif
+        const hipError_t err = hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio);
         if (err != hipSuccess) { c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
     }
     return c->aux[i];
@@ -230,6 +252,10 @@ int rs_set_stream(void* hipStream) {
     rs_context* c = rs_ctx();
     if ((hipStream_t)hipStream != c->stream) RS_TRY(rs_synchronize());   // events recorded on the old stream order the auxiliary ones
     c->stream = (hipStream_t)hipStream;
+    // auxiliary streams made for the old stream's priority level may share the new one's hardware queues (rs_internal_stream_priority):
+    // they are idle after the synchronisation above and are made again on first use
+    if (c->auxPriority != rs_internal_stream_priority())
+        for (hipStream_t& st : c->aux) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     return 0;
 }
 int rs_set_sync(int sync) { rs_ctx()->sync = sync != 0; return 0; }

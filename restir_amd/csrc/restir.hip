@@ -885,7 +885,8 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         r->tuneCounted = true;
         fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
     }
-    static const int kThreeStreams[rs_restir::kSmallChains] = { 1, 2, 0 };
+    int kThreeStreams[rs_restir::kSmallChains];                 // the chain streams first, the render's stream (idle after a fused launch) last
+    for (int i = 0; i < rs_restir::kSmallChains; i++) kThreeStreams[i] = i < 2 ? 1 + i : i == 2 ? 0 : i;
     const bool three = fuse && parityStreams && r->phaseACalls == 0;
     const hipStream_t aux = asyncMode ? rs_aux_stream(three ? kThreeStreams[r->smallChain] : parityStreams ? 1 + r->chain : 1) : nullptr;
     r->lastFused = fuse ? 1 : 0;

@@ -4,11 +4,14 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#ifndef RS_AUX_STREAMS
+#define RS_AUX_STREAMS 3
+#endif
 #ifndef RS_GBUF_SETS
-#define RS_GBUF_SETS 5
+#define RS_GBUF_SETS (RS_AUX_STREAMS + 2)
 #endif
 #ifndef RS_SURF_SETS
-#define RS_SURF_SETS 4
+#define RS_SURF_SETS (RS_AUX_STREAMS + 1)
 #endif
 #include <vector>
 
@@ -23,11 +26,12 @@
 // contexts -- two host threads, two devices, two streams, a synchronous and an asynchronous caller -- do not see each
 // other's settings.  A thread that never asks for one uses the default context (what rs_init / rs_set_* configure).
 struct rs_context {
-    static constexpr int kAux = 3;        // 0: GBuffer::render, 1 + k: the primary -> RIS -> shadow chain of every second frame (rs_restir::kChains)
+    static constexpr int kAux = RS_AUX_STREAMS;   // 0: GBuffer::render, 1 + k: the primary -> RIS -> shadow chain of every second frame (rs_restir::kChains); small launches: all of them chains in turn
     int device = 0;
     hipStream_t stream = nullptr;
     bool sync = true;
     hipStream_t aux[kAux] = {};
+    int auxPriority = 0;                  // what the auxiliary streams were created with (rs_internal_stream_priority at that time)
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory: -1 from the environment (RS_RIS_GLOBAL_BELOW) or 384 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
@@ -56,6 +60,7 @@ int rs_after_launch(const char* what);
 hipStream_t rs_aux_stream(int i);
 hipStream_t rs_aux_stream_any(int i);                  // the same stream whatever the launch mode (null only when the side streams are switched off)
 int rs_aux_synchronize();
+int rs_internal_stream_priority();                     // the priority level the library's own streams are created at: not the caller's stream's
 
 #define RS_TRY(expr)                                       \
     do {                                                   \
@@ -300,7 +305,7 @@ struct rs_restir {
     // four hardware queues (slower).  A small launch -- a strip, whose kernels last as long as their slowest wave -- therefore
     // takes the fused launch (render + primary rays, k_gbuffer_primary), after which nothing runs on the render's stream, and
     // gives that stream to a third chain (kSmallChains; restir.hip phase_a_impl): 8 strips of 1080p 5.96x -> 6.5x.
-    static constexpr int kChains = 2, kSmallChains = 3, kSurfSets = RS_SURF_SETS;
+    static constexpr int kChains = 2, kSmallChains = rs_context::kAux, kSurfSets = RS_SURF_SETS;
     int width = 0, height = 0;
     ResvPlanes cur;      // devDirectReservoir      (written this frame)
     ResvPlanes last;     // devLastDirectReservoir  (read by the temporal merge)
@@ -340,7 +345,7 @@ struct rs_restir {
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
-static_assert(rs_context::kAux == 1 + rs_restir::kChains, "one auxiliary stream for GBuffer::render and one per chain");
+static_assert(rs_context::kAux >= 1 + rs_restir::kChains, "one auxiliary stream for GBuffer::render and one per chain");
 
 struct rs_eaw {
     rs_context* ctx = nullptr;

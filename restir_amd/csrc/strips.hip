@@ -363,7 +363,7 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
     for (bool pending : s->gatherPending) if (pending) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_set_comm_stream: a gather is in flight");
     RS_TRY(rs_synchronize());
     if (s->commStream) RS_HIP(hipStreamSynchronize(s->commStream));
-    if (ownStream && !s->commStream && s->comm->world > 1) RS_HIP(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking));
+    if (ownStream && !s->commStream && s->comm->world > 1) RS_HIP(hipStreamCreateWithPriority(&s->commStream, hipStreamNonBlocking, rs_internal_stream_priority()));
     s->commOnMain = !(ownStream && s->commStream);
     return 0;
 }
