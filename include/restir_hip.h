@@ -170,8 +170,9 @@ int  rs_set_sync(int sync);
  *   4 = overlapped frames, measured choice (the default) */
 int  rs_set_side_stream(int enable);
 /* The RIS pass keeps the light table (up to 1 024 lights) in LDS, one copy per 1 024-thread block; a launch of fewer than `pixels`
- * pixels reads it from global memory in 256-thread blocks instead, which spread evenly over the CUs (default 384 Ki pixels, i.e.
- * about 1.5 of the large blocks per CU).  Same results either way; 0 = always LDS. */
+ * pixels reads it from global memory in 256-thread blocks instead, which spread evenly over the CUs (default 64 Ki pixels: a quarter
+ * of the CUs with a block; rounds 2-4 had 384 Ki, which cost every rank of an 8-way split of 1080p 1-13 % of its frame period once the
+ * library's streams no longer shared hardware queues).  Same results either way; 0 = always LDS. */
 int  rs_set_ris_table_pixels(int pixels);
 /* How the overlapped mode spreads a frame's kernels over the internal streams (a setting of the current context; every argument
  * -1 = keep).  chainStreams 1 / 2: the primary-ray -> RIS -> shadow-ray chains of all frames on one stream, or of alternating frames on

@@ -122,7 +122,7 @@ const rs_context* rs_stream_plan() {
 }
 int rs_ris_global_below() {
     rs_context* c = rs_ctx();
-    if (c->risGlobalBelow < 0) c->risGlobalBelow = 384 * 1024;
+    if (c->risGlobalBelow < 0) c->risGlobalBelow = 64 * 1024;
     return c->risGlobalBelow;
 }
 int rs_aux_synchronize() {
@@ -165,32 +165,68 @@ int rs_tile_split_threshold() {
 }
 void rs_tile_split_free(rs_tile_split* t) {
     rs_dev_free(t->base);
+    if (t->report) { (void)hipHostFree(t->report); t->report = nullptr; }
     t->bytes = 0; t->key = -1; t->rot = 0; t->numTiles = t->capacity = 0;
+    t->issued = t->wake = 0; t->sleep = 0;
 }
-int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, bool serial, hipStream_t st, rs::TileSplit* ts, int* helperBlocks) {
+constexpr int kTileSplitSleep = 29;
+int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, int mode, hipStream_t st, rs::TileSplit* ts, int* helperBlocks) {
     *ts = rs::TileSplit{ nullptr, 0, 0 };
     *helperBlocks = 0;
     int threshold = rs_tile_split_threshold();
-    if (threshold == 0 || numTiles <= 0 || (threshold > 0 && !serial)) return 0;
+    if (threshold == 0 || numTiles <= 0 || (threshold > 0 && mode == 0)) return 0;
+    const bool adaptive = threshold > 0 && mode == 2;
+    bool fresh = false;
+    unsigned found = 0;
+    if (adaptive) {
+        threshold += threshold / 3;
+        // The launch with sequence number q reports what launch q - 1 found, and the first launch after a (re)start reads a stale list:
+        // the first fresh report is that of launch wake + 2.  Never waited for -- the host may be a hundred frames ahead of the device
+        // (bench.py enqueues all its timed frames before it waits) -- so a site whose last fresh report said "none" goes back to the
+        // plain kernels after its two probing launches without waiting for their report, and a report that does name heavy tiles ends
+        // that sleep when it arrives.
+        if (t->report) {
+            const unsigned long long rep = *reinterpret_cast<volatile unsigned long long*>(t->report);
+            const unsigned seq = (unsigned)(rep >> 32);
+            fresh = rep != ~0ull && seq >= t->wake + 2 && seq <= t->issued;
+            found = (unsigned)rep;
+            if (fresh) t->lastNone = found == 0;
+        }
+        if (t->sleep > 0) {
+            if (fresh && found > 0) { t->sleep = 0; t->wake = t->issued; fresh = false; }
+            else {
+                if (--t->sleep == 0) t->wake = t->issued;
+                return 0;                               // a plain launch
+            }
+        }
+    }
     if (threshold < 0) threshold = -threshold;      // negative: for every launch, also next to other kernels (tests, measurements)
     const int capacity = std::min(rs_tile_split::kCapacity, std::max(64, regularBlocks / 2));
     key = key * 1048573 + threshold;
     const size_t hintInts = 2 + (size_t)capacity, flagOffset = (8 + 3 * hintInts) * sizeof(int), flagStride = ((size_t)numTiles + 15) & ~(size_t)15;
     const size_t bytes = flagOffset + 3 * flagStride;
     if (t->bytes < bytes) {                         // (hipFree waits for the device: nothing in flight reads the old arrays)
-        rs_tile_split_free(t);
+        rs_dev_free(t->base);
         unsigned char* p = nullptr;
         RS_TRY(rs_dev_alloc(&p, bytes));
-        t->base = reinterpret_cast<int*>(p); t->bytes = bytes;
+        t->base = reinterpret_cast<int*>(p); t->bytes = bytes; t->key = -1;
+    }
+    if (!t->report) {
+        RS_HIP(hipHostMalloc((void**)&t->report, sizeof(unsigned long long), hipHostMallocDefault));
+        *t->report = ~0ull;
     }
     if (t->key != key || t->numTiles != numTiles || t->capacity != capacity) {      // another geometry: no hints
         RS_HIP(hipMemsetAsync(t->base, 0, bytes, st));
-        hipLaunchKernelGGL(rs::k_tile_split_init, dim3(1), dim3(1), 0, st, t->base, capacity, threshold, numTiles, (int)flagOffset, (int)flagStride);
+        hipLaunchKernelGGL(rs::k_tile_split_init, dim3(1), dim3(1), 0, st, t->base, capacity, threshold, numTiles, (int)flagOffset, (int)flagStride, t->report);
         t->key = key; t->rot = 0; t->numTiles = numTiles; t->capacity = capacity;
+        t->wake = t->issued;                        // (the sequence numbers go on: reports of launches before this point stay behind `wake`)
     }
-    ts->base = t->base; ts->rot = t->rot; ts->helperBlocks = capacity;
+    t->issued = (t->issued + 1) & 0x0fffffffu;
+    if (t->issued == 0) t->wake = 0;
+    ts->base = t->base; ts->rot = t->rot + 3 * (int)t->issued; ts->helperBlocks = capacity;
     *helperBlocks = capacity;
     t->rot = (t->rot + 1) % 3;
+    if (adaptive && ((fresh && found == 0) || (!fresh && t->lastNone && t->issued - t->wake >= 2))) t->sleep = kTileSplitSleep;
     return 0;
 }
 

@@ -21,6 +21,7 @@ template <bool TEX, bool SPLIT>
 __device__ __forceinline__ void render_gbuffer_body(const DevScene& s, const CamParams& cam, const CamParams& lastCam, const GBufWrite& g,
                                                     int y0, int y1, int tilesX, const TileSplit& ts) {
     // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels (a tile that was heavy last time: four waves of 4x4, rs_tilesplit.h)
+    RS_SETPRIO(RS_PRIO_WALK);
     int x, py, tile;
     bool mine, helper;
     if (!tile_split_map<8, 8>(ts, tilesX, threadIdx.x & 63, x, py, mine, tile, helper)) return;
@@ -64,7 +65,8 @@ int launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* c
     GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
     TileSplit ts; int helpers = 0;
-    RS_TRY(rs_tile_split_prepare(&g->split[st == rs_stream() ? 0 : 1], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0)), st, &ts, &helpers));
+    RS_TRY(rs_tile_split_prepare(&g->split[st == rs_stream() ? 0 : 1], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY,
+                                 (st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0))) ? 1 : ((long long)tilesX * tilesY * 4 < kSmallLaunchWaves ? 2 : 0), st, &ts, &helpers));
     const CamParams cp = rs_make_cam_params(cam), lp = rs_make_cam_params(lastCam);
     if (ts.base) {
         if (scene->textured) hipLaunchKernelGGL(k_render_gbuffer_split<true>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX, ts);

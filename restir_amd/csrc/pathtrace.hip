@@ -107,6 +107,7 @@ __device__ __forceinline__ int gamma_byte(float c) {
 template <bool EXACT>
 __global__ void __launch_bounds__(256) k_send_image_to_pbo(uchar4* __restrict__ pbo, const float* __restrict__ image,
                                                            int n, int toneMapping, float scale) {
+    RS_SETPRIO(RS_PRIO_STREAM);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     f3 c = ld3(image + (size_t)i * 3) * scale;

@@ -104,6 +104,7 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
 template <bool TEX, bool SOBOL, bool SPLIT>
 __device__ __forceinline__ void primary_body(const DevScene& s, const CamParams& cam, const SurfPlanes& sp, int looper,
                                              int y0, int y1, int tilesX, unsigned long long* rayCount, const TileSplit& ts) {
+    RS_SETPRIO(RS_PRIO_WALK);
     int x, py, tile;
     bool mine, helper;
     if (!tile_split_map<8, 8>(ts, tilesX, threadIdx.x & 63, x, py, mine, tile, helper)) return;     // (a helper block without a tile)
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary_split(DevScene s
 // GBuffer::render and the primary rays of ReSTIRDirect in one launch (asynchronous mode, when the render of this frame is
 // still pending -- rs_gbuffer_render_rows defers it), each ray stored as k_render_gbuffer / k_primary store it.
 constexpr int kTuneA = 2, kTuneB = 8, kTuneC = 14;          // frames at which the measured launch choice takes its time stamps
-constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
+constexpr long long kFuseMinWaves = kSmallLaunchWaves;     // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
 
 // The two rays of a pixel sit in two LANES: a wave takes an 8x4 block of pixels, lanes 0-31 walk their pixel-centre rays and lanes
 // 32-63 their jittered rays -- 64 rays in the ordinary one-ray-per-lane packet walk.  The two rays of a pixel visit almost the same
@@ -151,6 +152,7 @@ constexpr long long kFuseMinWaves = 3 * 8192;              // three rounds of th
 template <bool TEX, bool SOBOL, bool SPLIT>
 __device__ __forceinline__ void gbuffer_primary_body(const DevScene& s, const CamParams& cam, const CamParams& lastCam, const GBufWrite& g, const SurfPlanes& sp, int looper,
                                                      int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, const TileSplit& ts) {
+    RS_SETPRIO(RS_PRIO_WALK);
     const int lane = threadIdx.x & 63;
     const bool shading = lane >= 32;                            // which of the pixel's two rays this lane carries
     int x, py, tile;
@@ -202,6 +204,7 @@ constexpr int kRisAliasLdsLights = 16384;        // alias records only: 128 KB o
 
 template <bool ENV, bool SOBOL, typename AliasPtr, typename LightPtr>
 __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& sp, AliasPtr alias, LightPtr lights, int index, int looper) {
+    RS_SETPRIO(RS_PRIO_RIS);
     const float4 pm = sp.posMat[index];
     const int mk = __float_as_int(pm.w);
     if (mk_kind(mk) != kKindShaded) return;
@@ -312,6 +315,7 @@ __device__ __forceinline__ void resv_store(const ResvPlanes& p, int i, const Res
 // (A hand-off of each wave's last rays to one wave per block was built and measured in round 3 -- same results, a quarter fewer wave
 // iterations, no gain: the pass is bound by per-lane L1 look-ups; EXPERIMENTS.md, commit 933552f.)
 __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_shadow(DevScene s, SurfPlanes sp, int width, int y0, int y1, int tilesX) {
+    RS_SETPRIO(RS_PRIO_WALK);
     int x, y;
     pixel_of_lane(tilesX, y0, x, y);
     const bool inside = x < width && y < y1;
@@ -335,6 +339,7 @@ __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_shadow(DevScene s, SurfP
 template <bool SOBOL>
 __global__ void __launch_bounds__(256) k_temporal(SurfPlanes sp, GBufView g, ResvPlanes last, ResvPlanes cur, TempPlanes temp, const uint32_t* sampleSeq, int looper,
                                                   int first, int reuse, int n0, int n1, unsigned long long* rayWork, unsigned long long* rayDone) {
+    RS_SETPRIO(RS_PRIO_STREAM);
     // this call's BVH-walk counters are complete (the launch is ordered after the chain that counted): publish them and leave the
     // working slot zero for its next user, so that the chain itself needs no clearing launch
     if (blockIdx.x == 0 && threadIdx.x < kRaySub) {
@@ -635,6 +640,7 @@ __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevSce
                                                              float* __restrict__ directIllum, int iter, int looper, int reuse,
                                                              int y0, int y1, int tilesX, int numTiles) {
     __shared__ Staged stage[kBStageN];
+    RS_SETPRIO(RS_PRIO_STREAM);
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
     // contiguous run of tiles so that neighbouring tiles' halos are served by the same L2.
@@ -815,13 +821,15 @@ namespace {
 // RIS over the light table for rows [y0, y1) on stream st; alone: nothing runs next to it (picks the alias-in-LDS form for large tables)
 int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y1, int looper, bool sobol, hipStream_t st, bool alone) {
     const int npx = (y1 - y0) * W;
-    // The LDS form runs one 1024-thread block per copy of the table: a launch of fewer than ~1.5 blocks per CU leaves CUs idle or
-    // gives a few of them two blocks, and lasts as long as those.  Below that size the table is read from global memory by
-    // 256-thread blocks, which spread evenly (a 1/8 strip of 1080p: 0.241 -> 0.231 ms per frame).
+    // The LDS form runs one 1024-thread block per copy of the table: a launch of a few dozen blocks leaves most CUs idle and lasts as
+    // long as one block.  Below 64 Ki pixels the table is read from global memory by 256-thread blocks, which spread evenly.  (Round 2
+    // drew the line at 384 Ki pixels -- a 1/8 strip of 1080p 0.241 -> 0.231 ms per frame with the global table; measured again in round 5
+    // through rs_strips_frame the LDS form wins on every rank of that split, 0.193 -> 0.191 ms on the heaviest strip and 0.149 -> 0.130 on
+    // the lightest, whose chain is mostly RIS: profiles/r05_ab_strip_knobs.log.)
     // Alone the alias-in-LDS form is a third faster (config 5: 645 -> 455 us); inside overlapped frames it is slower (1.88 -> 1.95 ms per
     // frame: one 1024-thread block with 82 KB of LDS per CU keeps the other streams' kernels off that CU), so it is taken when the
     // kernels run one after the other on the library stream only (`alone`; A/B in profiles/r03_ab_config5_ris_alias_lds.log).
-    const int risGlobalBelow = rs_ris_global_below();           // 384 Ki pixels unless rs_set_ris_table_pixels says otherwise
+    const int risGlobalBelow = rs_ris_global_below();           // 64 Ki pixels unless rs_set_ris_table_pixels says otherwise
     if (scene->numLights > 0 && scene->numLights <= kRisLdsLights && npx >= risGlobalBelow && scene->envMapTexId < 0)
         // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
         // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
@@ -918,7 +926,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         const int gTilesY = (d.y1 - d.y0 + 3) / 4;                // 8x4-pixel tiles: two rays per pixel fill the wave
         const CamParams lp = rs_make_cam_params(&d.lastCam);
         TileSplit ts; int helpers = 0;
-        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, !aux, st, &ts, &helpers));
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, !aux ? 1 : ((long long)tilesX * gTilesY * 4 < kSmallLaunchWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
         else RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
@@ -926,7 +934,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     }
     else {
         TileSplit ts; int helpers = 0;
-        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, !aux, st, &ts, &helpers));
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, !aux ? 1 : ((long long)tilesX * tilesY * 4 < kSmallLaunchWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
         else RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     }

@@ -33,7 +33,7 @@ struct rs_context {
     hipStream_t aux[kAux] = {};
     int auxPriority = 0;                  // what the auxiliary streams were created with (rs_internal_stream_priority at that time)
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
-    int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory: -1 from the environment (RS_RIS_GLOBAL_BELOW) or 384 Ki
+    int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory (rs_set_ris_table_pixels): -1 = the default, 64 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
     int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
@@ -106,12 +106,25 @@ struct rs_tile_split {
     int rot = 0;                                     // the hint the next launch reads
     long long key = -1;                              // the launch geometry (and threshold) the hints belong to
     int numTiles = 0, capacity = 0;                  // ... and what the device header says (a changed value re-initialises the hints whatever the key)
+    // small overlapped launches (mode 2): the device's report word and the host's view of it
+    unsigned long long* report = nullptr;            // pinned host memory (rs_tilesplit.h)
+    unsigned issued = 0, wake = 0;                   // split launches issued so far; the count when the site last (re)started splitting
+    int sleep = 0;                                   // plain launches left before the site looks again
+    bool lastNone = false;                           // the last fresh report named no heavy tile
 };
 // fills *ts for a launch of `regularBlocks` blocks of four tiles each on stream st (all zero when the feature is off) and
-// returns through *helperBlocks how many blocks the grid gets in front of them.  serial: the kernel runs with nothing next to it
-// (synchronous mode, per-pass timing) -- only then does a launch last as long as its longest chain; with the frames overlapped
-// the other frames' kernels fill in around a long tile, and splitting measured 2.5 % SLOWER (extra waves, extra blocks).
-int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, bool serial, hipStream_t st, rs::TileSplit* ts, int* helperBlocks);
+// returns through *helperBlocks how many blocks the grid gets in front of them.  mode:
+//   1  the kernel runs with nothing next to it (synchronous mode, per-pass timing): the launch lasts as long as its longest chain;
+//   0  a launch of several rounds of wave slots next to other frames' kernels: they fill in around a long tile, and splitting
+//      measured 2.5 % SLOWER (extra waves, extra blocks) -- no splitting;
+//   2  a launch of less than three rounds of wave slots next to other frames' kernels (a strip): a single round of waves ends with
+//      its slowest tile whatever runs next to it -- the 72- and 48-row strips of a cost-balanced 8-way split of the Bistro-class
+//      frame 0.42 / 0.46 -> 0.29 / 0.26 ms per frame (profiles/r05_ab_tile_split_on_strips.log).  Split at 4/3 of the threshold (768
+//      -> 1024: measured better than 768 on strips), and only while it finds heavy tiles: the kernels that count cost a scene
+//      without any (the Sponza-class strips) 1.3 %, so a site whose last fresh report says "none" runs the plain kernels for
+//      kTileSplitSleep launches before it looks again.
+int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, int mode, hipStream_t st, rs::TileSplit* ts, int* helperBlocks);
+constexpr long long kSmallLaunchWaves = 3 * 8192;   // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
 void rs_tile_split_free(rs_tile_split* t);
 int rs_tile_split_threshold();                      // of the current context
 
@@ -235,6 +248,23 @@ static inline GBufView gbuf_view(const rs_gbuffer* g) {
 }
 
 #if defined(__HIPCC__)
+// Wave priorities (s_setprio, 0-3: the SIMD's arbiter issues the ready wave of the highest priority first).  In the overlapped mode the
+// streaming kernels of the library stream (temporal merge, border-row copies, spatial pass, tone map) share every SIMD with the walks
+// and the RIS loop of other frames, and a GPU-paced kernel trace of a 1/8 strip shows them stretched seven-fold (k_temporal 13 -> 95 us:
+// the library stream busy 96 % of the frame period, tools/strip_trace_c.py).  Their waves are few and short, so they go first: full
+// frame 1.047 -> 1.027 ms, light strips -7 %, heavy strips -2 % (priority 1 and 3 measure the same).  The walks at ANY raised
+// priority cost a third of the frame (1.05 -> 1.42 ms: they take the issue slots of the RIS loop, which is what bounds the frame), and
+// the RIS loop raised gains nothing (profiles/r05_ab_wave_priorities.log).
+#ifndef RS_PRIO_WALK
+#define RS_PRIO_WALK 0
+#endif
+#ifndef RS_PRIO_STREAM
+#define RS_PRIO_STREAM 1
+#endif
+#ifndef RS_PRIO_RIS
+#define RS_PRIO_RIS 0
+#endif
+#define RS_SETPRIO(p) do { if ((p) > 0) __builtin_amdgcn_s_setprio(p); } while (0)
 // what renderGBuffer writes for one pixel (src/gbuffer.cu:21-72); shared by k_render_gbuffer and the kernel that walks the
 // G-buffer ray together with the shading ray (restir.hip)
 struct GBufWrite {

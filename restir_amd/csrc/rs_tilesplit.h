@@ -29,10 +29,14 @@ namespace rs {
 // kernels are held to 64 registers, and a struct of seven pointers kept live across the walk cost them 44 bytes of scratch per lane
 // and half their speed (k_primary 0.284 -> 0.437 ms) -- the fields are read where they are used instead.
 //   ints at base: [0] capacity  [1] configured threshold  [2] number of tiles  [3] ints per hint (2 + capacity)
-//                 [4] byte offset of the first flag array  [5] bytes per flag array;   hint h at int 8 + h * [3]
+//                 [4] byte offset of the first flag array  [5] bytes per flag array  [6..7] address of the host's report word (or 0);
+//                 hint h at int 8 + h * [3]
+// The report word (pinned host memory, written by the last block with one 8-byte store): sequence number of the reporting launch in the
+// high half, in the low half the number of heavy tiles the launch BEFORE it found.  The host never waits for it; it reads it when it
+// prepares a later launch and lets a launch site whose tiles are all light run the plain kernels for a while (rs_tile_split_prepare).
 struct TileSplit {                  // base == null: feature off (every wave is a regular wave)
     int* base;
-    int rot;                        // the hint this launch reads
+    int rot;                        // the hint this launch reads, + 3 * the launch's sequence number (every use is modulo 3)
     int helperBlocks;               // blocks at the front of the grid that take listed tiles (= capacity)
 };
 
@@ -83,6 +87,8 @@ __device__ __forceinline__ void tile_split_report(int* base, int rot, int tile, 
         tile_split_hint(base, rot + 2)[0] = 0;
         const int cap = base[0], found = in[0], thr = max(in[1], base[1]);
         tile_split_hint(base, rot + 1)[1] = found > cap ? min(thr * 2, 1 << 20) : (found < cap / 4 ? max(base[1], thr - thr / 4) : thr);
+        volatile unsigned long long* report = *reinterpret_cast<volatile unsigned long long**>(base + 6);
+        if (report) *report = ((unsigned long long)(unsigned)(rot / 3) << 32) | (unsigned)found;
     }
     if (helper) {
         __shared__ unsigned quadrant[4];
@@ -100,8 +106,9 @@ __device__ __forceinline__ void tile_split_report(int* base, int rot, int tile, 
 }
 
 // once per geometry: header and empty hints (the arrays behind them have been zeroed by a memset on the same stream)
-static __global__ void k_tile_split_init(int* base, int capacity, int threshold, int numTiles, int flagOffset, int flagStride) {
+static __global__ void k_tile_split_init(int* base, int capacity, int threshold, int numTiles, int flagOffset, int flagStride, unsigned long long* report) {
     base[0] = capacity; base[1] = threshold; base[2] = numTiles; base[3] = 2 + capacity; base[4] = flagOffset; base[5] = flagStride;
+    *reinterpret_cast<unsigned long long**>(base + 6) = report;
 }
 #endif
 

@@ -103,6 +103,7 @@ constexpr int kMaxSegs = 12;
 struct CopyTable { const char* src[kMaxSegs]; char* dst[kMaxSegs]; unsigned start[kMaxSegs + 1]; int n; };      // start: in units of `unit` bytes
 template <typename T>
 __global__ void __launch_bounds__(256) k_copy_segments(CopyTable t) {
+    RS_SETPRIO(RS_PRIO_STREAM);
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= t.start[t.n]) return;
     int k = 0;

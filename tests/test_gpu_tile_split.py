@@ -130,3 +130,48 @@ def test_split_tiles_on_row_ranges(hip):
     for x, y in zip(a, b):
         assert bits_equal(x, y)
     assert np.abs(a[-1]).sum() > 0
+
+
+@pytest.mark.parametrize("threshold", [6, 3000])
+def test_adaptive_split_of_small_overlapped_launches(hip, threshold):
+    """A POSITIVE threshold splits overlapped launches of less than three rounds of wave slots at 4/3 of it, and only while heavy tiles
+    are reported (rs_tile_split_prepare, mode 2): a site without any sleeps for 29 launches, probes twice, sleeps again.  100 overlapped
+    frames of an orbiting camera (threshold 6: practically every tile is heavy, the sites stay awake; 3000: none is, they sleep and
+    probe) equal the frames with the feature off -- images, reservoirs, G-buffer planes, ray counts."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.2")
+    W, H, frames = 640, 360, 100
+    scene = hip_scene(hip, sd)
+
+    def run(thr):
+        _set(hip, thr)
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        keep = {}
+        hip.set_sync(False)
+        try:
+            for frame in range(frames):
+                h.set_camera_position(orbit_position(sd.camera_args["position"], frame // 3, radius=0.5))
+                h.gbuf.render(h.scene, h.cam)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                h.looper += 1
+                if frame % 9 == 0 or frame == frames - 1:
+                    keep[frame] = h.image.clone()
+                h.gbuf.update(h.cam)
+                if frame % 25 == 24:
+                    hip.synchronize()              # lets the reports arrive: later launches see fresh verdicts
+            hip.synchronize()
+            torch.cuda.synchronize()
+            rays = h.restir.ray_count()
+        finally:
+            hip.set_sync(True)
+            _set(hip, 768)
+        return dict(images={k: t.cpu().numpy() for k, t in keep.items()}, resv=h.restir.download(1), gbuf=h.gbuf.download(), rays=rays)
+
+    a, b = run(threshold), run(0)
+    for f in a["images"]:
+        assert bits_equal(a["images"][f], b["images"][f]), f
+    assert a["rays"] == b["rays"]
+    for k in a["resv"].dtype.names:
+        assert bits_equal(a["resv"][k], b["resv"][k]), k
+    _same_gbuffer(a["gbuf"], b["gbuf"])

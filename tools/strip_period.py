@@ -28,7 +28,8 @@ from restir_amd.tiling import rebalance_bounds, strip_bounds
 CONFIG = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 W, H = (3840, 2160) if CONFIG == 4 else (1920, 1080)
 DENOISE = CONFIG == 5
-REUSE, TONEMAP = 3, 2
+REUSE, TONEMAP = int(os.environ.get("REUSE", "3")), 2
+NO_PBO = os.environ.get("NO_PBO", "0") == "1"            # sensitivity experiments: frames without the tone map and the display gather
 WORLDS = [int(x) for x in os.environ.get("WORLDS", "1,2,4,8").split(",")]
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 FRAMES = int(os.environ.get("FRAMES", "200"))
@@ -81,6 +82,8 @@ def period(world, rank, bounds, frames=FRAMES):
             shown = drv.eaw_filter(eaw, gbuf, cam, image.data_ptr())
         gbuf.update(cam)
         st["n"] += 1
+        if NO_PBO:
+            return
         drv.gather_end(k)
         capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * W * 4, shown + y0 * W * 12, W, y1 - y0, TONEMAP, 1.0)
         drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)

@@ -22,11 +22,25 @@ gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
 image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
 pbos = [torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
 y0, y1 = drv.y0, drv.y1
-for n in range(80):
+def frame(n):
     k = n % 2
     drv.frame(restir, scene, cam, gbuf, image.data_ptr(), 0, n, 3)
     gbuf.update(cam)
     drv.gather_end(k)
     capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * W * 4, image.data_ptr() + y0 * W * 12, W, y1 - y0, 2, 1.0)
     drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)
+
+
+for n in range(20):
+    frame(n)
+capi.synchronize(); torch.cuda.synchronize()
+# Under the profiler the HOST needs longer per frame than a 1/8 strip's GPU work (every dispatch is intercepted), and a host-bound
+# timeline says nothing about the GPU's own pace: SPIN_MS (default 60) of a spinning kernel on the library stream hold the frames'
+# temporal / spatial passes back while the host enqueues all 60 timed frames; what runs after the spin is paced by the GPU alone
+# (the first chains_in_flight + 1 chains do not wait for the library stream and run during the spin).
+spin_ms = float(os.environ.get("SPIN_MS", "60"))
+if spin_ms > 0:
+    torch.cuda._sleep(int(spin_ms * 1e-3 * 2.4e9))         # shader-clock cycles (2.5 ms per 6e6 measured)
+for n in range(20, 80):
+    frame(n)
 capi.synchronize(); torch.cuda.synchronize()
