@@ -116,6 +116,21 @@ def overlapped_kernel_us(config, kernel):
     return None, p
 
 
+def expected_compute_only(config, world):
+    """The committed compute-only frame period of an N-way split of `config` (tools/strip_period.py: every rank of the split alone on ONE
+    MI355X through rs_strips_frame over a transport that moves nothing, cost-balanced heights; profiles/r05_strip_period_c<config>.json):
+    what the first multi-GPU run is to be compared with -- ms_per_step minus this is the wire, RCCL's launches and the ranks' skew."""
+    p = os.path.join(ROOT, "profiles", "r05_strip_period_c%d.json" % config)
+    try:
+        with open(p) as fh:
+            t = json.load(fh)["worlds"]
+        w, one = t[str(world)], t["1"]
+        return {"ms": w["max_ms"], "per_rank_ms": w["ms"], "rows": w["rows"], "n1_ms_same_box": one["max_ms"],
+                "speedup_compute_only": one["max_ms"] / w["max_ms"], "source": "profiles/" + os.path.basename(p)}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_threads():
     """CPU share of this process: min(affinity, cgroup quota), capped at 64."""
     n = len(os.sched_getaffinity(0))
@@ -128,18 +143,83 @@ def host_threads():
     return max(1, min(n, 64))
 
 
+# ---- what a rank is doing, for the launcher's diagnosis of a failed run --------------------------------------------------------------------
+
+PHASES = ("start", "calibrate", "comm_init", "first_frames", "comm_stream_trial", "warmup", "timed", "post_timing", "parity", "done")
+
+
+def set_phase(name, **data):
+    """Every rank of an N > 1 run records the phase it has entered (and, once it has them, its own timings) in
+    $BENCH_STATUS_DIR/rank<r>.json -- written to a temporary name and renamed, so the launcher never reads half a file.  If the job dies
+    or hangs, the launcher's JSON line says which rank was where (launch_ranks).  No-op without the variable (N = 1, tests of other parts)."""
+    d = os.environ.get("BENCH_STATUS_DIR")
+    if not d:
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    rec = {"rank": rank, "phase": name, "time": time.time()}
+    rec.update(data)
+    tmp = os.path.join(d, "rank%d.json.tmp" % rank)
+    try:
+        with open(tmp, "w") as fh:
+            json.dump(rec, fh)
+        os.replace(tmp, os.path.join(d, "rank%d.json" % rank))
+    except OSError:
+        pass
+
+
+def read_status(d, n):
+    """{rank: record} of the status files the ranks left in d (ranks that never got to write one are absent)."""
+    out = {}
+    for r in range(n):
+        try:
+            with open(os.path.join(d, "rank%d.json" % r)) as fh:
+                out[r] = json.load(fh)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def diagnose(n, rc, status, stderr_tail):
+    """Which rank failed and where: the rank torch.distributed.run names as the first failure (its summary on stderr), else the rank that
+    got least far (a hang: every rank that is not done waits for that one); its phase from its status file."""
+    import re
+    text = "".join(stderr_tail)
+    failing = None
+    m = re.search(r"Root Cause.*?rank\s*:\s*(\d+)\s*\(local_rank", text, re.S) or re.search(r"rank\s*:\s*(\d+)\s*\(local_rank", text)
+    if m:
+        failing = int(m.group(1))
+    order = {p: i for i, p in enumerate(PHASES)}
+    seen = {r: order.get(rec.get("phase"), -1) for r, rec in status.items()}
+    for r in range(n):
+        seen.setdefault(r, -1)                                 # never wrote a status file: died before "start"
+    if failing is None:
+        unfinished = [r for r in sorted(seen) if seen[r] < order["done"]]
+        failing = min(unfinished, key=lambda r: seen[r]) if unfinished else None
+    phase = status.get(failing, {}).get("phase", "before start") if failing is not None else None
+    what = "the ranks were still running at the watchdog's limit" if rc == 124 else "the ranks ended with rc %d" % rc
+    return {"failed": True, "rc": rc, "error": "%s; rank %s was in phase %s" % (what, failing, phase), "failing_rank": failing, "phase": phase,
+            "phases": {str(r): status.get(r, {}).get("phase", "before start") for r in range(n)},
+            "per_rank": [status[r]["mine"] for r in sorted(status) if status[r].get("mine")] or None,
+            "stderr_tail": [l.rstrip() for l in list(stderr_tail)[-12:]]}
+
+
 # ---- the launcher: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE -------------------------------------------------------------
 
 def launch_ranks(n, argv, script=None, watchdog=960.0, out=None, err=None):
     """Start the n rank processes of one node as fresh children -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node n
     --master-addr 127.0.0.1 --master-port <free> script argv...`, the command the driver itself uses -- from a process that has made
-    no GPU call (nothing is re-exec'd).  Relays the ranks' stderr as it comes, keeps its tail, and prints the one JSON line rank 0
-    wrote on stdout.  Returns the exit code: the children's if they failed, 124 if they were still running after `watchdog` seconds
-    (their process group -- the one started here -- is killed), 1 if they ended cleanly without a JSON line."""
+    no GPU call (nothing is re-exec'd).  Relays the ranks' stderr as it comes, keeps its tail, and prints ONE JSON line on stdout: the
+    line rank 0 wrote, or -- when the job failed, hung or ended without one -- a line with "failed": true, "error", the failing rank, the
+    phase it was in and whatever per-rank data the ranks had recorded (set_phase); a line rank 0 printed before ANOTHER rank failed is
+    relayed with those fields added, so that a harness which parses stdout and ignores the exit code cannot take it for a result.
+    Returns the exit code: the children's if they failed, 124 if they were still running after `watchdog` seconds (their process group
+    -- the one started here -- is killed), 1 if they ended cleanly without a JSON line."""
     import collections
+    import shutil
     import signal
     import socket
     import subprocess
+    import tempfile
     import threading
     out = out or sys.stdout
     err = err or sys.stderr
@@ -151,6 +231,8 @@ def launch_ranks(n, argv, script=None, watchdog=960.0, out=None, err=None):
            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    status_dir = tempfile.mkdtemp(prefix="bench_status_")
+    env["BENCH_STATUS_DIR"] = status_dir
     print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=err, flush=True)
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, start_new_session=True)
     tail = collections.deque(maxlen=60)
@@ -197,8 +279,15 @@ def launch_ranks(n, argv, script=None, watchdog=960.0, out=None, err=None):
         rc = 1
     if rc != 0:
         print("bench.py: the ranks ended with rc %d; last lines of their stderr:\n%s" % (rc, "".join(list(tail)[-25:])), file=err, flush=True)
-    if result is not None:
-        out.write(result + "\n"); out.flush()
+        diag = diagnose(n, rc, read_status(status_dir, n), tail)
+        rec = json.loads(result) if result is not None else {"metric": "Mrays/s", "value": None, "unit": "Mrays/s", "n_gpus": n}
+        if result is not None and diag.get("per_rank") is None:
+            diag.pop("per_rank")                            # keep the line's own
+        rec.update(diag)
+        result = json.dumps(rec)
+        print("bench.py: " + diag["error"], file=err, flush=True)
+    shutil.rmtree(status_dir, ignore_errors=True)
+    out.write(result + "\n"); out.flush()
     return rc
 
 
@@ -369,6 +458,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(watchdog), exit=True)
 
+    set_phase("start")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -426,6 +516,7 @@ def main():
     # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
     # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights
     bounds = None
+    set_phase("calibrate")
     if world > 1 and os.environ.get("BENCH_EVEN_STRIPS", "0") != "1":
         bounds = calibrate_bounds(backend, world, rank, HEIGHT, dist, torch.cuda.synchronize, reuse=REUSE, denoise=DENOISE, min_rows=min_rows)
         torch.cuda.synchronize()
@@ -450,6 +541,7 @@ def main():
     if driver == "c":
         # ---- the product's strip driver: strips.hip through the C ABI ---------------------------------------------------------
         from restir_amd.rccl import GlooTransport, RcclComm
+        set_phase("comm_init")
         comm = None
         if transport == "rccl":
             def bcast(raw):
@@ -564,6 +656,7 @@ def main():
     # end after its last time stamp (frame 14) has been reached -- it never waits on the host -- hence the synchronisation and
     # the two frames after it.
     calibration_frames = 18
+    set_phase("first_frames")
     for _ in range(calibration_frames - 2):
         frame()
     barrier()
@@ -575,10 +668,14 @@ def main():
     # a property of the machine that no one-GPU box can measure: both are timed here, before the warm-up, and the faster one (by the slowest
     # rank) runs the warm-up and the timed frames.  Results do not depend on it (strips_loopback_ranks compares both with the full frame).
     # BENCH_COMM_STREAM=library|own skips the measurement.
-    comm_choice = None
+    comm_choice, comm_trial = None, None
+    set_phase("comm_stream_trial")
     if driver == "c" and world > 1:
         want = os.environ.get("BENCH_COMM_STREAM", "auto" if transport == "rccl" else "library")
         if want == "auto":
+            # The library stream stays unless the driver's own stream wins by more than 3 % over 40 frames each (a single short trial
+            # flips on noise, and the own-stream form has only ever carried data over the in-process loopback transport); both times go
+            # into the JSON line.  To pin the choice for a scaling curve: BENCH_COMM_STREAM=library|own.
             trial = {}
             for own in (False, True):
                 barrier()
@@ -587,27 +684,32 @@ def main():
                     frame()
                 barrier()
                 ts = time.perf_counter()
-                for _ in range(12):
+                for _ in range(40):
                     frame()
                 barrier()
                 tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=ctl_device)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                trial[own] = float(tt[0]) / 12 * 1e3
-            own = trial[True] < trial[False]
-            comm_choice = "%s (measured: library stream %.3f ms/frame, own stream %.3f)" % ("own stream" if own else "library stream", trial[False], trial[True])
+                trial[own] = float(tt[0]) / 40 * 1e3
+            own = trial[True] < 0.97 * trial[False]
+            comm_choice = "%s (measured over 40 frames each: library stream %.4f ms/frame, own stream %.4f; the own stream is taken when it wins by more than 3 %%)" % (
+                "own stream" if own else "library stream", trial[False], trial[True])
+            comm_trial = {"library_stream_ms": trial[False], "own_stream_ms": trial[True]}
         else:
             own = want == "own"
-            comm_choice = ("own stream" if own else "library stream") + " (set)"
+            comm_choice = ("own stream" if own else "library stream") + " (set by BENCH_COMM_STREAM)"
         barrier()
         drv.set_comm_stream(own)
+    set_phase("warmup")
     for _ in range(args.warmup):
         frame()
     barrier()
+    set_phase("timed")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
     barrier()
     elapsed = time.perf_counter() - t0
+    set_phase("post_timing", ms_per_step=elapsed / args.steps * 1e3)
     own_elapsed = elapsed
     timed_form = backend.restir.last_launch()             # (fused, chains) of the timed frames' launches: read before any other mode runs
     counted = min(args.steps, 1024)
@@ -625,6 +727,19 @@ def main():
         torch.cuda.synchronize()
         sync_ms.append((time.perf_counter() - ts) * 1e3)
     capi.set_sync(False)
+    barrier()
+
+    # one frame in flight, launches asynchronous: the latency an interactive loop sees when it does not pipeline frames ahead of its input
+    # (src/preview.cpp:337-361) but lets the library overlap what it can WITHIN the frame (the render next to -- or fused with -- the primary
+    # rays, RIS and shadow rays behind them); between the overlapped figure (three frames in flight) and the synchronous one
+    single_ms = []
+    for _ in range(14):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        frame()
+        finish_gathers()
+        capi.synchronize(); torch.cuda.synchronize()
+        single_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
 
     # how long this rank's library stream sat waiting for the neighbours' border rows (the part of the exchange the interior rows
@@ -710,6 +825,7 @@ def main():
     # frame's BIT FOR BIT; at the end the last two DISPLAY images (RGBA8, the asynchronous gathers) are compared with the full frame's
     # tone-mapped ones byte for byte.
     strips_parity = None
+    set_phase("parity", ms_per_step=own_elapsed / args.steps * 1e3)
     if driver == "c":
         chk = HipBackend(capi, scene, cam, WIDTH, HEIGHT)
         chk_state = {"looper": 0, "frame_no": 0}
@@ -751,12 +867,14 @@ def main():
     # what every rank saw, for the reader of a multi-GPU line: the slowest rank decides the frame time
     mine = {"rank": rank, "device": device, "rows": rows, "ms_per_step": own_elapsed / args.steps * 1e3,
             "ms_per_frame_synchronous": float(np.median(sync_ms[2:])),
+            "ms_per_frame_single_in_flight": float(np.median(single_ms[2:])),
             "halo_wait_ms": (float(np.median(halo_wait)) if halo_wait else None),
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]),
                         "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3]),
                         **({"eaw_positions": eaw_level_ms[0], "eaw_levels": eaw_level_ms[1:]} if eaw_level_ms else {})},
             "rays_per_frame": local_rays / args.steps}
     per_rank = [mine]
+    set_phase("parity", mine=mine)                          # (the launcher quotes it if a later step fails)
     if world > 1:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -799,6 +917,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_frame_synchronous": float(np.median(sync_ms[2:])),
+            "ms_per_frame_single_in_flight": float(np.median(single_ms[2:])),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -825,6 +944,7 @@ def main():
                        "rccl_ranks": (world if (driver == "c" and transport == "rccl") else (world if (driver == "py" and backend_name == "nccl" and world > 1) else 0)),
                        "strip_rows_per_rank": [b - a for a, b in bounds],
                        "strip_transfers_on": comm_choice,
+                       "strip_transfers_trial_ms": comm_trial,
                        "strip_driver_fallback": fallback,
                        "halo_wait_ms_rank0": (float(np.median(halo_wait)) if halo_wait else None),
                        "rays_per_frame": total_rays / args.steps},
@@ -856,6 +976,9 @@ def main():
                                    "note": "44 B per pixel and level (SURVEY.md 8d); `traffic` = mean HBM bytes of ONE level launch from the committed counters"}
         if world > 1:
             out["per_rank"] = per_rank
+            exp = expected_compute_only(args.config, world)
+            out["expected_compute_only_ms"] = exp["ms"] if exp else None
+            out["expected_compute_only"] = exp
         fused, chains = timed_form                            # what the timed frames launched, as the library reported it then
         form = "one fused launch" if fused == 1 else "two launches"
         how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
@@ -894,6 +1017,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    set_phase("done", mine=mine)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -14,7 +15,83 @@
 
 #define CHECK(x) do { int e_ = (x); if (e_) { std::fprintf(stderr, "%s failed: %d (%s)\n", #x, e_, rs_last_error()); return 1; } } while (0)
 
-int main() {
+// `strips_rccl_check latency`: what ONE RCCL group of a strip frame costs where one GPU can measure it -- the rank sends to itself, so
+// nothing crosses xGMI and the copy runs at HBM speed: a LOWER BOUND of the group's duration on a multi-GPU node (there the 653 KB per
+// edge travel over one 153 GB/s link: + >= 4.3 us per direction, and the ranks' skew is added), and the real figure for what does not
+// depend on the wire: RCCL's kernel launch, its host-side cost per group, and the gap it leaves on the stream.
+//   frame-shaped group      two sends + two receives of 1920 x 5 rows x 68 B = 652 800 B (a middle strip's two neighbours)
+//   + deferred gather       one more send + receive of 1920 x 135 rows x 4 B = 1 036 800 B (a rank's RGBA8 strip to rank 0)
+// each 200 times back to back between two HIP events on the stream that carries them (GPU time per group incl. the launch gap) and
+// against the host clock (host time per group: what rs_strips_frame's caller pays in ncclGroupEnd), on an ordinary stream as the
+// library stream and on a second stream ordered against it by events per group (rs_strips_set_comm_stream(s, 1)'s form).
+static int latency_mode() {
+    if (hipSetDevice(0) != hipSuccess) return 1;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+    ncclComm_t nccl = nullptr;
+    if (ncclCommInitRank(&nccl, 1, id, 0) != ncclSuccess) { std::fprintf(stderr, "ncclCommInitRank failed\n"); return 1; }
+    const size_t edge = 1920u * 5u * 68u, strip = 1920u * 135u * 4u;
+    char *sendBuf[3], *recvBuf[3];
+    const size_t bytes[3] = { edge, edge, strip };
+    for (int i = 0; i < 3; i++)
+        if (hipMalloc((void**)&sendBuf[i], bytes[i]) != hipSuccess || hipMalloc((void**)&recvBuf[i], bytes[i]) != hipSuccess) return 1;
+    hipStream_t lib = nullptr, own = nullptr;
+    if (hipStreamCreateWithFlags(&lib, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) return 1;
+    hipEvent_t e0, e1, packed, arrived;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventCreateWithFlags(&packed, hipEventDisableTiming); (void)hipEventCreateWithFlags(&arrived, hipEventDisableTiming);
+    const int reps = 200;
+    std::printf("# RCCL group to self on one MI355X (lower bound: no xGMI, no second rank); %d groups back to back per line\n", reps);
+    for (int ops = 2; ops <= 3; ops++) {
+        for (int ownStream = 0; ownStream <= 1; ownStream++) {
+            hipStream_t st = ownStream ? own : lib;
+            auto group = [&]() {
+                if (ownStream) { (void)hipEventRecord(packed, lib); (void)hipStreamWaitEvent(own, packed, 0); }
+                ncclGroupStart();
+                for (int i = 0; i < ops; i++) { ncclSend(sendBuf[i], bytes[i], ncclUint8, 0, nccl, st); ncclRecv(recvBuf[i], bytes[i], ncclUint8, 0, nccl, st); }
+                const ncclResult_t r = ncclGroupEnd();
+                if (ownStream) { (void)hipEventRecord(arrived, own); (void)hipStreamWaitEvent(lib, arrived, 0); }
+                return r;
+            };
+            for (int i = 0; i < 20; i++) if (group() != ncclSuccess) { std::fprintf(stderr, "ncclGroupEnd failed\n"); return 1; }
+            (void)hipStreamSynchronize(lib); (void)hipStreamSynchronize(own);
+            (void)hipEventRecord(e0, lib);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; i++) (void)group();
+            const auto t1 = std::chrono::steady_clock::now();
+            (void)hipEventRecord(e1, lib);
+            (void)hipStreamSynchronize(lib); (void)hipStreamSynchronize(own);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            // one group alone, the stream idle before it: its latency from enqueue to completion as the host sees it
+            double alone = 0;
+            for (int i = 0; i < 20; i++) {
+                (void)hipStreamSynchronize(lib); (void)hipStreamSynchronize(own);
+                const auto a0 = std::chrono::steady_clock::now();
+                (void)group();
+                (void)hipStreamSynchronize(lib); (void)hipStreamSynchronize(own);
+                alone += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a0).count();
+            }
+            std::printf("%s, transfers on %s: GPU %.1f us per group (events on the library stream), host %.1f us per group call, one group alone enqueue-to-done %.1f us\n",
+                        ops == 2 ? "frame-shaped group (2 x 652 800 B each way)  " : "frame-shaped group + deferred gather (1 036 800 B)",
+                        ownStream ? "a stream of their own (2 events per group)" : "the library stream                       ",
+                        ms * 1e3 / reps, std::chrono::duration<double, std::micro>(t1 - t0).count() / reps, alone / 20);
+        }
+    }
+    // for scale: the same bytes as plain device-to-device copies on the library stream
+    (void)hipEventRecord(e0, lib);
+    for (int i = 0; i < reps; i++) for (int k = 0; k < 3; k++) (void)hipMemcpyAsync(recvBuf[k], sendBuf[k], bytes[k], hipMemcpyDeviceToDevice, lib);
+    (void)hipEventRecord(e1, lib);
+    (void)hipStreamSynchronize(lib);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::printf("for scale: the three buffers as hipMemcpyAsync device-to-device on the library stream: %.1f us per set\n", ms * 1e3 / reps);
+    ncclCommDestroy(nccl);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::strcmp(argv[1], "latency") == 0) return latency_mode();
     CHECK(rs_init(0));
     ncclUniqueId id;
     if (ncclGetUniqueId(&id) != ncclSuccess) { std::fprintf(stderr, "ncclGetUniqueId failed\n"); return 1; }

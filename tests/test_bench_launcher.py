@@ -36,14 +36,45 @@ def test_launcher_relays_rank0_json(monkeypatch):
 
 def test_launcher_reports_a_failed_rank(monkeypatch):
     rc, out, err = _launch(monkeypatch, "fail")
-    assert rc != 0                                          # (rank 0 may have printed its line already: it is relayed, the rc decides)
+    assert rc != 0
     assert "giving up on purpose" in err and "ended with rc" in err
+    # rank 0 may have printed its line before the other rank failed: whatever reaches stdout is ONE line that says the run failed
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["failed"] is True and rec["rc"] == rc and rec["failing_rank"] == 1 and "error" in rec
+
+
+@pytest.mark.parametrize("phase", ["comm_init", "calibrate", "comm_stream_trial", "warmup", "timed", "parity"])
+def test_launcher_says_which_rank_died_in_which_phase(monkeypatch, phase):
+    """A rank that dies in any phase of bench.py's N > 1 run: the launcher still prints one JSON line -- "failed", the rank, the phase
+    it was in, the phases of the others, and the per-rank timings the ranks had already recorded -- and ends non-zero."""
+    rc, out, err = _launch(monkeypatch, "die:" + phase)
+    assert rc != 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["failed"] is True and rec["rc"] == rc
+    assert rec["failing_rank"] == 1 and rec["phase"] == phase, rec
+    assert set(rec["phases"]) == {"0", "1"} and rec["phases"]["1"] == phase
+    assert "dying in phase " + phase in "\n".join(rec["stderr_tail"]) or "dying in phase" in err
+    if phase == "parity":
+        assert rec["per_rank"] and rec["per_rank"][0]["ms_per_step"] == 0.5
+
+
+def test_launcher_names_the_rank_that_hangs(monkeypatch):
+    rc, out, err = _launch(monkeypatch, "hang:warmup", watchdog=25.0)
+    assert rc == 124
+    rec = json.loads([l for l in out.splitlines() if l.strip()][0])
+    assert rec["failed"] is True and rec["failing_rank"] == 1 and rec["phase"] == "warmup" and "watchdog" in rec["error"]
 
 
 def test_launcher_kills_hung_ranks(monkeypatch):
     rc, out, err = _launch(monkeypatch, "hang", watchdog=20.0)
     assert rc == 124
     assert "did not finish" in err
+    rec = json.loads([l for l in out.splitlines() if l.strip()][0])
+    assert rec["failed"] is True and rec["rc"] == 124
 
 
 def test_bench_main_takes_the_launcher_branch_before_any_gpu_call(tmp_path):
