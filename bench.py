@@ -79,7 +79,7 @@ CONFIGS = {
 
 def profile_file(config, suffix):
     """The committed rocprofv3 summary of this command for `config` (newest round first; None if there is none)."""
-    for name in ("r04_config%d_%s" % (config, suffix),) + (("r03_final2_%s" % suffix,) if config == 3 else ()):
+    for name in ("r05_config%d_%s" % (config, suffix), "r04_config%d_%s" % (config, suffix)) + (("r03_final2_%s" % suffix,) if config == 3 else ()):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             return p

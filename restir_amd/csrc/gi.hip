@@ -34,11 +34,35 @@ __device__ inline float primitive_area(const DevScene& s, int prim) {
     return length(cross(v1 - v0, v2 - v0)) * .5f;
 }
 
+// A three-vector kept in LDS, one column per thread (component k of thread t at p[k * 256 + t]: conflict-free).  The path loop's cold
+// state -- the radiance sums, touched once or twice per bounce, and ReSTIR-GI's four recorded points, written once per path -- lived in
+// registers the compiler had to spill around the walks (72 VGPRs at 7 blocks per CU; 172-268 bytes of scratch per lane, 310 scratch
+// instructions per bounce and wave, every one of them a trip to L2: a CU's 28 waves keep 360 KB of scratch behind a 32 KB L1).  21 floats
+// per lane of LDS the kernel did not use otherwise (18 KB per block, 7 blocks per CU = 126 of 160 KB).
+#ifndef RS_PATH_COLD_LDS
+#define RS_PATH_COLD_LDS 1
+#endif
+#if RS_PATH_COLD_LDS
+struct Cold3 {
+    float* p;
+    __device__ __forceinline__ f3 get() const { return mk3(p[0], p[256], p[512]); }
+    __device__ __forceinline__ void set(f3 v) const { p[0] = v.x; p[256] = v.y; p[512] = v.z; }
+    __device__ __forceinline__ void add(f3 v) const { set(get() + v); }
+};
+#else
+struct Cold3 {
+    f3 v;
+    __device__ __forceinline__ f3 get() const { return v; }
+    __device__ __forceinline__ void set(f3 x) { v = x; }
+    __device__ __forceinline__ void add(f3 x) { v = v + x; }
+};
+#endif
 struct PathState {
-    f3 direct, indirect;          // kModePT: direct / indirect; others: indirect only (ReSTIR: the sample's Lo)
+    Cold3 direct, indirect;       // kModePT: direct / indirect; others: indirect only (ReSTIR: the sample's Lo)
+    Cold3 throughput;
     // ReSTIR-GI bookkeeping (restir.cu:273-281,316-321)
     float primSamplePdf; bool primSampleDelta; f3 primWo; SurfMat primMaterial;
-    f3 xv, nv, xs, ns;
+    Cold3 xv, nv, xs, ns;
     int walks;
 };
 
@@ -49,7 +73,9 @@ struct PathState {
 // random draws and arithmetic is that of the reference.
 template <int MODE, bool TEX, typename Sampler>
 __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Sampler& rng, int maxDepth, bool alive, PathState& st) {
-    f3 throughput = splat(1.f);
+    Cold3& throughputC = st.throughput;
+    throughputC.set(splat(1.f));
+#define throughput throughputC.get()
     f3 norm = h.norm, pos = h.pos;
     f3 wo = -ray.d;
     const bool env = TEX && s.envTex >= 0;
@@ -84,7 +110,7 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
         if (nee) {
             st.walks++;
             if (matters && !occluded) {
-                if (MODE == kModePT && depth == 1) st.direct = st.direct + add; else st.indirect = st.indirect + add;
+                if (MODE == kModePT && depth == 1) st.direct.add(add); else st.indirect.add(add);
             }
         }
 
@@ -101,12 +127,12 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
         if (alive) {
             deltaSample = (sample.type & kBsSpecular) != 0;
             if (MODE != kModeReSTIR || depth > 1) {                             // restir.cu:315-325
-                throughput = throughput * ((sample.bsdf / sample.pdf) * (deltaSample ? 1.f : abs_dot(norm, sample.dir)));
+                throughputC.set(throughput * ((sample.bsdf / sample.pdf) * (deltaSample ? 1.f : abs_dot(norm, sample.dir))));
             }
             else {
                 st.primSamplePdf = sample.pdf;
                 st.primSampleDelta = deltaSample;
-                st.xv = pos; st.nv = norm;
+                st.xv.set(pos); st.nv.set(norm);
             }
             ray.o = pos + sample.dir * 1e-5f; ray.d = sample.dir;               // makeOffsetedRay
         }
@@ -124,7 +150,7 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
                 if (env) {
                     const f3 radiance = env_radiance(s, ray.d) * throughput;
                     const float weight = deltaSample ? 1.f : power_heuristic(sample.pdf, environment_map_pdf(s, ray.d));
-                    st.indirect = st.indirect + radiance * weight;
+                    st.indirect.add(radiance * weight);
                 }
                 alive = false;
             }
@@ -138,15 +164,16 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
                         const float weight = unweighted ? 1.f : power_heuristic(sample.pdf,
                             (luminance(radiance) * s.sumLightPowerInv * primitive_area(s, h.primId)) * dot(curPos - pos, curPos - pos) /
                                 abs_dot(norm, normalize(curPos - pos)));         // Math::pdfAreaToSolidAngle (mathUtil.h:182-185)
-                        st.indirect = st.indirect + (radiance * throughput) * weight;
-                        if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+                        st.indirect.add((radiance * throughput) * weight);
+                        if (MODE == kModeReSTIR && depth == 1) { st.xs.set(pos); st.ns.set(norm); }
                     }
                     alive = false;
                 }
-                else if (MODE == kModeReSTIR && depth == 1) { st.xs = pos; st.ns = norm; }
+                else if (MODE == kModeReSTIR && depth == 1) { st.xs.set(pos); st.ns.set(norm); }
             }
         }
     }
+#undef throughput
 }
 
 __device__ __forceinline__ void accumulate(float* image, int index, f3 v, int iter) {
@@ -191,9 +218,17 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     const Ray ray = camera_sample(cam, x, y, r.x, r.y);
     const Hit h = trace_closest_packet(s, ray, inside);                // all 64 lanes take part in the wave's walk
     PathState st;
-    st.direct = splat(0.f); st.indirect = splat(0.f); st.primSamplePdf = 0.f; st.primSampleDelta = false; st.primWo = -ray.d;
+#if RS_PATH_COLD_LDS
+    __shared__ float sCold[(MODE == kModeReSTIR ? 21 : MODE == kModePT ? 9 : 6) * 256];
+    st.indirect.p = sCold + threadIdx.x;
+    st.throughput.p = sCold + (MODE == kModeReSTIR ? 18 : MODE == kModePT ? 6 : 3) * 256 + threadIdx.x;
+    st.direct.p = MODE == kModePT ? sCold + 3 * 256 + threadIdx.x : st.indirect.p;                 // (only kModePT has a direct sum)
+    st.xv.p = st.nv.p = st.xs.p = st.ns.p = st.indirect.p;
+    if (MODE == kModeReSTIR) { st.xv.p = sCold + 6 * 256 + threadIdx.x; st.nv.p = st.xv.p + 3 * 256; st.xs.p = st.xv.p + 6 * 256; st.ns.p = st.xv.p + 9 * 256; }
+#endif
+    st.direct.set(splat(0.f)); st.indirect.set(splat(0.f)); st.primSamplePdf = 0.f; st.primSampleDelta = false; st.primWo = -ray.d;
     st.primMaterial = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
-    st.xv = st.nv = st.xs = st.ns = splat(0.f);
+    if (MODE == kModeReSTIR) { st.xv.set(splat(0.f)); st.nv.set(splat(0.f)); st.xs.set(splat(0.f)); st.ns.set(splat(0.f)); }
     st.walks = 0;
     // primary hit (pathtrace.cu:172-190 / 343-350, restir.cu:259-270); lanes that end here keep alive = false
     bool alive = false;
@@ -202,14 +237,14 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     if (inside) {
         st.walks = 1;
         if (h.primId == kNullPrim) {
-            if (MODE == kModePT) st.direct = splat(1.f);                               // pathtrace.cu:175-178
+            if (MODE == kModePT) st.direct.set(splat(1.f));                            // pathtrace.cu:175-178
         }
         else {
             f3 norm = h.norm;
             material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
             if (MODE == kModePT) material.baseColor = splat(1.f);                      // DENOISER_DEMODULATE (:181-185)
             if (material.type == 4) {
-                if (MODE == kModePT) st.direct = splat(1.f);                           // :187-190
+                if (MODE == kModePT) st.direct.set(splat(1.f));                        // :187-190
             }
             else {
                 hh.norm = norm;
@@ -221,18 +256,20 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     path_loop<MODE, TEX, SamplerT<SOBOL>>(s, hh, material, ray, rng, maxDepth, alive, st);                // every lane of the wave takes part
     if (inside) {
         if (MODE == kModePT) {
-            if (any_nan_or_inf(st.direct)) st.direct = splat(0.f);
-            if (any_nan_or_inf(st.indirect)) st.indirect = splat(0.f);
-            accumulate(directIllum, index, hdr_to_ldr(st.direct), iter);                // Math::HDRToLDR (:273-276)
-            accumulate(indirectIllum, index, hdr_to_ldr(st.indirect), iter);
+            f3 direct = st.direct.get(), indirect = st.indirect.get();
+            if (any_nan_or_inf(direct)) direct = splat(0.f);
+            if (any_nan_or_inf(indirect)) indirect = splat(0.f);
+            accumulate(directIllum, index, hdr_to_ldr(direct), iter);                   // Math::HDRToLDR (:273-276)
+            accumulate(indirectIllum, index, hdr_to_ldr(indirect), iter);
         }
         else if (MODE == kModePTIndirect) {
-            if (any_nan_or_inf(st.indirect)) st.indirect = splat(0.f);
-            accumulate(indirectIllum, index, st.indirect, iter);
+            f3 indirect = st.indirect.get();
+            if (any_nan_or_inf(indirect)) indirect = splat(0.f);
+            accumulate(indirectIllum, index, indirect, iter);
         }
         else {
             // WriteSample (restir.cu:372-416)
-            IndResv smp; smp.Lo = st.indirect; smp.xv = st.xv; smp.nv = st.nv; smp.xs = st.xs; smp.ns = st.ns; smp.M = 0; smp.W = 0.f;
+            IndResv smp; smp.Lo = st.indirect.get(); smp.xv = st.xv.get(); smp.nv = st.nv.get(); smp.xs = st.xs.get(); smp.ns = st.ns.get(); smp.M = 0; smp.W = 0.f;
             IndResv rv; rv.Lo = rv.xv = rv.nv = rv.xs = rv.ns = splat(0.f); rv.M = 0; rv.W = 0.f;
             float sampleWeight = 0.f;
             if (!(luminance(smp.Lo) < 1e-8f)) {                                         // !indirectSample.invalid()

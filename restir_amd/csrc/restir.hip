@@ -230,6 +230,17 @@ __device__ __forceinline__ void ris_pixel(const DevScene& s, const SurfPlanes& s
         f3 g = c.Li * eval_bsdf(m.type, baseColor, m.metallic, m.roughness, norm, wo, c.wi) * sat_dot(norm, c.wi);
         float weight = luminance(div3_exact(g, c.pdf, c.pdf <= 0.f));             // pdf <= 0: the weight is replaced by 0 below
         if (is_nan_or_inf(weight) || c.pdf <= 0.f) weight = 0.f;
+#ifdef RS_WALK_STATS        // measurement builds (tools/ris_stats.py): how many candidates end without a valid pdf / with a zero weight
+        {
+            const unsigned long long all = __ballot(true), inv = __ballot(c.pdf <= 0.f), zero = __ballot(c.pdf > 0.f && weight == 0.f);
+            if (s.walkStats && __lane_id() == (unsigned)__ffsll((long long)all) - 1u) {
+                atomicAdd(&s.walkStats[88], (unsigned long long)__popcll(all)); atomicAdd(&s.walkStats[89], (unsigned long long)__popcll(inv));
+                atomicAdd(&s.walkStats[90], (unsigned long long)__popcll(zero)); atomicAdd(&s.walkStats[91], 1ull);
+                if (inv == all) atomicAdd(&s.walkStats[92], 1ull);
+                if ((inv | zero) == all) atomicAdd(&s.walkStats[93], 1ull);
+            }
+        }
+#endif
         float u = rng.uniform();
         wsum += weight;                                    // Reservoir::update (restir.h:38-44)
         if (u * wsum < weight) {
@@ -878,7 +889,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     //  * A smaller launch -- a strip -- lasts as long as its slowest wave, and what bounds its frame rate is the length of the chain
     //    primary rays -> RIS -> shadow rays over the number of chains in flight.  With two chains the fused launch loses (its slowest
     //    wave: 0.25 ms against 0.18 on a 1/8 strip), but it leaves the render's stream idle, and with that stream as a THIRD chain
-    //    it wins: 8 strips of 1080p 5.96x -> 6.5x (RS_SMALL_CHAINS=0: two chains and a separate render).
+    //    it wins: 8 strips of 1080p 5.96x -> 6.5x (rs_set_stream_plan(-1, 0, -1): two chains and a separate render).
     // Whenever the launch is fused the frame's chain is one of three (a full frame gains another 0.9 % from the third).
     const bool smallChains = plan->smallChains != 0;
     const rs_gbuffer::Deferred& d = g->deferred;
@@ -946,7 +957,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // spatial pass: every stream then has slack against the frame period and three or four kernels are in flight at any time,
     // which is what a frame bound by VALU issue needs (1080p: 1.277 -> 1.245 ms).  A small launch -- a strip -- lasts as long as its
     // slowest wave, and there the library stream is the one chain that links consecutive frames: its shadow rays stay on the
-    // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  RS_SHADOW_ON_MAIN=0 / 1: never / always.
+    // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  rs_set_stream_plan(-1, -1, 0 / 1): never / always.
     const int shadowOnMain = plan->shadowOnMain;
     const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
     if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);

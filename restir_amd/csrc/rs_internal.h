@@ -34,10 +34,10 @@ struct rs_context {
     int auxPriority = 0;                  // what the auxiliary streams were created with (rs_internal_stream_priority at that time)
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory (rs_set_ris_table_pixels): -1 = the default, 64 Ki
-    int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 from the environment (RS_FUSE_GBUFFER)
+    int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 = not resolved yet (rs_set_side_stream; default: measured per rs_restir)
     int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
-    int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): from the environment (RS_TILE_SPLIT) or 768; 0 off; negative: |value|, also for launches that overlap others
+    int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): rs_set_tile_split, default 768; 0 off; negative: |value|, also for launches that overlap others
 };
 rs_context* rs_ctx();                                   // the context this thread's library code runs under right now
 struct rs_ctx_scope {                                   // entry points: run under the context of the object they were handed
@@ -383,7 +383,7 @@ struct rs_eaw {
     float sigLumin = 64.f, sigNormal = .2f, sigDepth = 1.f;     // src/denoiser.cu:455
     float* devTempImg = nullptr;
     float* devPos = nullptr;        // per-pixel cam.getPosition(x,y,depth), computed once per filter call
-    bool tiled = true;              // levels of step 1, 2, 4 from an LDS tile (k_wavelet_tiled); rs_eaw_set_tiled, RS_EAW_TILED=0
+    bool tiled = true;              // levels of step 1, 2, 4 from an LDS tile (k_wavelet_tiled); rs_eaw_set_tiled
     bool fused = true;              // taps in fused arithmetic (denoiser.hip kFusedTaps); rs_eaw_set_fused
 };
 

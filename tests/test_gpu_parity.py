@@ -235,6 +235,26 @@ def test_restir_spatial(hip, name, reuse, libm):
         ob.set_libm_mode(0)
 
 
+def test_spatial_pass_with_bands_of_unequal_width(hip):
+    """k_spatial_shade sweeps frames wider than 48 tiles in vertical bands (restir.hip, kBandTiles).  Every size of the other tests divides
+    into equal bands; 2016 pixels are 63 tiles = bands of 32 and 31, and 1570 pixels 50 tiles (the last one 2 pixels wide) = 25 + 25 --
+    the narrower last band and the partial tile must neither drop nor duplicate a tile: radiance and reservoirs against the oracle."""
+    ob.set_libm_mode(1)
+    try:
+        for W, H in ((2016, 40), (1570, 35)):
+            sd = get_scene("cornell")
+            o = OracleRenderer(sd, W, H)
+            h = HipRenderer(hip, sd, W, H)
+            for frame in range(3):
+                a = o.frame(3); b = h.frame(3)
+                st = radiance_stats(a, b)
+                assert st["bit_mismatch"] == 0, (W, H, frame, st)
+                _compare_reservoirs(o.restir.last, h.restir.download(1))
+            assert np.abs(a).sum() > 0
+    finally:
+        ob.set_libm_mode(0)
+
+
 def test_tap_estimate_error_is_inside_the_fallback_band(hip):
     """The spatial pass estimates tap positions with v_sqrt/v_sin/v_cos and re-evaluates exactly when
     an integer lies within kTapErr (4e-5) of the estimate (restir.hip disk_tap).  The band must cover

@@ -1,3 +1,4 @@
+#!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2; do
   for lib in "$@"; do
