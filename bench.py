@@ -512,6 +512,9 @@ def main():
         torch.cuda.set_stream(lib_stream)
     backend = HipBackend(capi, scene, cam, WIDTH, HEIGHT)          # (hands torch's current stream to the library: rs_set_stream)
     capi.set_sync(False)                   # launches are only enqueued; the timed region is bracketed by synchronize()
+    # a frame that runs the denoiser on the library stream does better with the library's own streams BELOW the caller's
+    # (rs_set_internal_stream_priority, before the first frame; profiles/r05_ab_stream_levels_by_workload.log)
+    capi.set_internal_stream_priority(int(os.environ.get("BENCH_STREAM_LEVEL", "1" if DENOISE else "2")))
     min_rows = 32 if DENOISE else 8        # the EAW levels on strips reach 32 rows (rs_strips_eaw_filter)
     # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
     # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights
@@ -984,6 +987,9 @@ def main():
         how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
         out["config"]["launch_choice"] = "%s (%s), chains on %d streams in turn" % (form, how, chains)
         out["config"]["calibration_frames_before_warmup"] = calibration_frames
+        lvl, chosen_us, fastest_us = capi.internal_streams_info()
+        out["config"]["internal_streams"] = {"priority_level": lvl, "calibration_us": chosen_us, "fastest_candidate_us": fastest_us,
+                                             "note": "the library's three own streams, chosen by measurement next to the caller's stream (rs_internal_streams_info)"}
         if strips_parity is not None:
             out["parity" if world > 1 else "strips_parity"] = strips_parity       # N = 1 through the strip driver keeps the oracle's `parity` below
         if world == 1 and args.cpu_frames > 0 and sobol_num is None:

@@ -150,6 +150,15 @@ int  rs_context_set_current(rs_context* ctx);       /* for the calling thread; N
 int  rs_init(int device);
 /* All work is enqueued on this hipStream_t (NULL = default stream). */
 int  rs_set_stream(void* hipStream);
+/* The streams the library makes for itself in overlapped mode (three: the chains of consecutive frames and the render) are CHOSEN BY
+ * MEASUREMENT when first needed, and again after rs_set_stream: whether four streams of a process run side by side depends on every
+ * stream the process has made before (torch's pool, an ncclComm's own), so candidates of every priority level are timed next to the
+ * caller's stream and the best three kept (about 25 ms, once, with the device idle; api_common.hip).  This call names the PREFERRED level
+ * among those that measure equal: 2 (default) = automatic, above the caller's stream first; -1 high / 0 normal / 1 low first.  A caller
+ * that runs a denoiser on the library stream every frame does 5 % better with 1 (config 5: 1.87 -> 1.78 ms).  Before the first frame. */
+int  rs_set_internal_stream_priority(int level);
+/* What the measurement chose: level, the chosen streams' calibration time and the fastest candidate's (us; 0 = plain streams in use). */
+int  rs_internal_streams_info(int* priority, double* chosenUs, double* fastestUs);
 /* 1 (default): every entry point synchronises and checks errors before returning, like
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);

@@ -108,7 +108,7 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_stream_plan", "rs_set_tile_split", "rs_synchronize",
+    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_internal_stream_priority", "rs_internal_streams_info", "rs_set_stream_plan", "rs_set_tile_split", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_closest_wave", "rs_scene_set_ordered_tree", "rs_ordered_bvh_host_check", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
@@ -316,6 +316,18 @@ def set_side_stream(enable):
     """Overlapped frames when launches are asynchronous (include/restir_hip.h): 0 off, 1 on with GBuffer::render as its own launch,
     2 / 3 on with the render deferred into ReSTIRDirect's primary-ray launch (3: at any size), 4 on with that choice measured."""
     check(lib().rs_set_side_stream(int(enable)))
+
+
+def set_internal_stream_priority(level):
+    """-1 high / 0 normal / 1 low / 2 automatic: the level of the library's own streams (before the first frame)."""
+    check(lib().rs_set_internal_stream_priority(int(level)))
+
+
+def internal_streams_info():
+    """(level, calibration us of the chosen streams, fastest candidate us) of the library's own streams; (level, 0, 0): plain streams."""
+    p, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+    check(lib().rs_internal_streams_info(C.byref(p), C.byref(a), C.byref(b)))
+    return p.value, a.value, b.value
 
 
 def set_ris_table_pixels(pixels):

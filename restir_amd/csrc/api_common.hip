@@ -48,22 +48,139 @@ int rs_check_hip(hipError_t e, const char* what) {
 hipStream_t rs_stream() { return rs_ctx()->stream; }
 bool rs_sync_enabled() { return rs_ctx()->sync; }
 
-// The runtime spreads a process's streams over FOUR hardware queues PER PRIORITY LEVEL, whichever stream asks first, and the legacy
-// default stream holds one of the normal level's: a caller's ordinary stream (torch.cuda.Stream(), hipStreamCreate) next to three
-// normal-priority auxiliary streams is five streams on four queues, and when the pair that shares is the library stream and a chain,
-// a frame's temporal / spatial passes queue behind another frame's walks -- a 1/8 strip of 1080p 0.194 -> 0.289 ms per frame, exactly
-// the case of `bench.py --gpus N` and of any C++ caller over RCCL (profiles/r05_ab_stream_priority_pools.log).  The library's own
-// streams (the auxiliary ones, the strip driver's transfer stream) are therefore created at the OTHER level than the caller's:
-// high priority next to the default stream or an ordinary stream, normal next to a high-priority one.  What decides is the pool,
-// not the priority: every combination with the two kinds in different pools measures the same (same log; round 3's A/B of
-// priorities, all on the default stream, agrees).
+// ---- which streams the library makes for itself ------------------------------------------------------------------------------------
+// In overlapped mode four streams carry work at any time: the caller's (temporal / spatial passes, tone map, the strip driver's
+// transfers) and three of the library's own (the chains of consecutive frames).  Whether four streams of a process really run side by
+// side is decided below the API: the runtime maps streams onto four hardware queues PER PRIORITY LEVEL in the order they are made, the
+// legacy default stream holds one of the normal level's, and how hardware queues share the command processor's pipes depends on every
+// queue the process has made before -- torch's stream pool, an ncclComm's own streams.  Measured on 1/8 strips of 1080p
+// (profiles/r05_ab_stream_priority_pools.log, r05_ab_stream_levels_with_rccl.log): three normal-priority streams next to an ordinary caller
+// stream 0.29 ms per frame instead of 0.19 (five streams on four queues); the same three at high priority 0.19 -- until a one-rank RCCL
+// communicator exists in the process, then 0.39, and only the normal level gives 0.17.  No fixed rule survives all of that, so the
+// streams are CHOSEN BY MEASUREMENT when they are first needed (and again after rs_set_stream): four candidates per level, and for
+// every triple of a level eight rounds of [a 20-us spin on each of the four streams, an event hand-over to the neighbour] are timed
+// (tools/micro/queue_quads.hip is the same test stand-alone: 280-320 us when the four run side by side, 450-860 when two of them take
+// turns).  The best triple within 8 % of the fastest is kept, levels in the order of rs_set_internal_stream_priority's preference
+// (default: above the caller's stream -- the chains are the frame's critical path, config 3 1.071 -> 1.045 ms; with a denoiser on the
+// library stream below it, config 5 1.87 -> 1.78 ms); the other nine streams are destroyed.  About 25 ms, once, with the device idle:
+// the one place where the overlapped mode waits on the host.
+namespace {
+__global__ void k_calibration_spin(long long ticks) {
+    const long long t0 = wall_clock64();                                // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+struct Calibration {
+    hipEvent_t begin = nullptr, end[4] = {}, hand[8][4] = {};
+    bool ok = true;
+    Calibration() {
+        ok = hipEventCreate(&begin) == hipSuccess;
+        for (auto& e : end) ok = ok && hipEventCreate(&e) == hipSuccess;
+        for (auto& r : hand) for (auto& e : r) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    }
+    ~Calibration() {
+        if (begin) (void)hipEventDestroy(begin);
+        for (auto& e : end) if (e) (void)hipEventDestroy(e);
+        for (auto& r : hand) for (auto& e : r) if (e) (void)hipEventDestroy(e);
+        (void)hipGetLastError();
+    }
+    // microseconds until all four streams have finished their eight rounds (best of three), or a negative value on error
+    double chained(const hipStream_t s[4]) {
+        double best = 1e30;
+        for (int rep = 0; rep < 3; rep++) {
+            if (hipDeviceSynchronize() != hipSuccess) return -1;
+            (void)hipEventRecord(begin, s[0]);
+            for (int r = 0; r < 8; r++) {
+                for (int k = 0; k < 4; k++) { hipLaunchKernelGGL(k_calibration_spin, dim3(1), dim3(64), 0, s[k], 2000); (void)hipEventRecord(hand[r][k], s[k]); }
+                for (int k = 0; k < 4; k++) (void)hipStreamWaitEvent(s[k], hand[r][(k + 1) % 4], 0);
+            }
+            for (int k = 0; k < 4; k++) (void)hipEventRecord(end[k], s[k]);
+            if (hipDeviceSynchronize() != hipSuccess) return -1;
+            float worst = 0.f;
+            for (int k = 0; k < 4; k++) { float t = 0.f; if (hipEventElapsedTime(&t, begin, end[k]) != hipSuccess) return -1; worst = t > worst ? t : worst; }
+            best = worst < best ? worst : best;
+        }
+        return best * 1e3;
+    }
+};
+}  // namespace
+
+// fills c->aux with the three streams chosen by measurement; false: nothing could be measured (the caller falls back to plain streams)
+static bool calibrate_internal_streams(rs_context* c) {
+    static_assert(rs_context::kAux >= 3, "three auxiliary streams");
+    if (rs_context::kAux != 3) return false;                           // (measurement builds with more streams: plain creation)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int levels[3] = { greatest, 0, least };
+    const int nLevels = (greatest < 0 ? 1 : 0) + 1 + (least > 0 ? 1 : 0);
+    int order[3], n = 0;                                               // preference: high, normal, low -- or low first when asked for
+    if (c->auxLevelSet && c->auxLevel > 0) { if (least > 0) order[n++] = 2; order[n++] = 1; if (greatest < 0) order[n++] = 0; }
+    else if (c->auxLevelSet && c->auxLevel == 0) { order[n++] = 1; if (greatest < 0) order[n++] = 0; if (least > 0) order[n++] = 2; }
+    else { if (greatest < 0) order[n++] = 0; order[n++] = 1; if (least > 0) order[n++] = 2; }
+    (void)nLevels;
+    // not the caller's own level: there the library's streams share the level's four hardware queues with the caller's stream and whatever
+    // else the process keeps at it, and the eight-round test does not always see it (RCCL in the process, ordinary caller stream, normal
+    // level: a calibration time as good as any and a config 5 frame of 2.14 ms instead of 1.79).  The default stream is no such caller: it
+    // holds one queue of the normal level, and next to it the normal level measures as well as any.
+    if (c->stream) {
+        int own = 0;
+        if (hipStreamGetPriority(c->stream, &own) != hipSuccess) { (void)hipGetLastError(); own = 0; }
+        int m = 0;
+        for (int q = 0; q < n; q++) if (levels[order[q]] != own) order[m++] = order[q];
+        if (m > 0) n = m;
+    }
+    Calibration cal;
+    if (!cal.ok) { (void)hipGetLastError(); return false; }
+    hipStream_t cand[3][4] = {};
+    bool made = true;
+    for (int q = 0; q < n && made; q++)
+        for (int i = 0; i < 4 && made; i++) made = hipStreamCreateWithPriority(&cand[order[q]][i], hipStreamNonBlocking, levels[order[q]]) == hipSuccess;
+    double t[3][4];
+    double fastest = 1e30;
+    for (int q = 0; q < n && made; q++)
+        for (int skip = 0; skip < 4; skip++) {
+            hipStream_t s[4] = { c->stream };
+            int k = 1;
+            for (int i = 0; i < 4; i++) if (i != skip) s[k++] = cand[order[q]][i];
+            t[order[q]][skip] = cal.chained(s);
+            if (t[order[q]][skip] < 0) { made = false; break; }
+            fastest = t[order[q]][skip] < fastest ? t[order[q]][skip] : fastest;
+        }
+    int level = -1, skip = -1;
+    for (int q = 0; q < n && made && level < 0; q++) {
+        int bestSkip = 0;
+        for (int i = 1; i < 4; i++) if (t[order[q]][i] < t[order[q]][bestSkip]) bestSkip = i;
+        if (t[order[q]][bestSkip] <= fastest * 1.08) { level = order[q]; skip = bestSkip; }
+    }
+    int k = 0;
+    for (int p = 0; p < 3; p++)
+        for (int i = 0; i < 4; i++) {
+            if (!cand[p][i]) continue;
+            if (p == level && i != skip) c->aux[k++] = cand[p][i];
+            else (void)hipStreamDestroy(cand[p][i]);
+        }
+    (void)hipGetLastError();
+    if (level < 0) { for (hipStream_t& st : c->aux) st = nullptr; return false; }
+    c->auxPriority = levels[level];
+    c->auxCalibratedUs = t[level][skip];
+    c->auxFastestUs = fastest;
+    return true;
+}
+
+// (kept for the streams the strip driver makes for itself, and as the fallback when nothing can be measured)
 int rs_internal_stream_priority() {
     rs_context* c = rs_ctx();
+    if (c->auxWant != -99) return c->auxWant;
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int own = 0;
     if (c->stream && hipStreamGetPriority(c->stream, &own) != hipSuccess) { (void)hipGetLastError(); own = 0; }
-    return (greatest < 0 && own > greatest) ? greatest : 0;       // the caller's stream is not in the high pool: ours are
+    int want = (greatest < 0 && own > greatest) ? greatest : 0;        // the caller's stream is not in the high pool: ours are
+    if (c->auxLevelSet) {                                               // the caller's choice, unless it is the caller's own level
+        const int asked = c->auxLevel < 0 ? greatest : c->auxLevel > 0 ? least : 0;
+        if (asked != own || !c->stream) want = asked;
+    }
+    c->auxWant = want;
+    return want;
 }
 // Auxiliary streams (asynchronous mode only): 0 carries GBuffer::render, 1 + k the primary-ray + RIS + shadow-ray kernels of every
 // kChains-th frame (frames take the chains in turn, so that these chains of consecutive frames overlap each other
@@ -91,14 +208,23 @@ hipStream_t rs_aux_stream(int i) {
         c->auxMode = (e && e[0] == '0') ? 0 : 1;
     }
     if (c->sync || !c->auxMode || i < 0 || i >= rs_context::kAux) return nullptr;
+    if (c->auxStale) {
+        // rs_set_stream handed the library another stream (or rs_set_internal_stream_priority another preference) after the streams were
+        // made: they are chosen again for the new stream.  The old ones are idle (rs_set_stream waited for them) and are destroyed.
+        for (hipStream_t& st : c->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+        c->auxStale = false;
+    }
     if (!c->aux[i]) {
+        bool any = false;
+        for (hipStream_t st : c->aux) any = any || st != nullptr;
+        if (!any && !c->auxPlain && calibrate_internal_streams(c)) return c->aux[i];
+        c->auxPlain = true;                                 // nothing could be measured: plain streams at the level the rule names
         c->auxPriority = rs_internal_stream_priority();
         int prio = c->auxPriority;
 #ifdef RS_AUX_PRIORITY_ENV                              // measurement builds: RS_AUX_PRIORITIES=-1,-1,0,... per auxiliary stream
         if (const char* e = std::getenv("RS_AUX_PRIORITIES")) { for (int k = 0; k < i && e; k++) { e = std::strchr(e, ','); if (e) e++; } if (e) prio = std::atoi(e); }
 #endif
-        const hipError_t err = hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio);
-        if (err != hipSuccess) { c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
+        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); c->aux[i] = nullptr; c->auxMode = 0; return nullptr; }
     }
     return c->aux[i];
 }
@@ -286,15 +412,33 @@ int rs_context_set_current(rs_context* c) {
 
 int rs_set_stream(void* hipStream) {
     rs_context* c = rs_ctx();
-    if ((hipStream_t)hipStream != c->stream) RS_TRY(rs_synchronize());   // events recorded on the old stream order the auxiliary ones
+    const bool changed = (hipStream_t)hipStream != c->stream;
+    if (changed) RS_TRY(rs_synchronize());              // events recorded on the old stream order the auxiliary ones
     c->stream = (hipStream_t)hipStream;
-    // auxiliary streams made for the old stream's priority level may share the new one's hardware queues (rs_internal_stream_priority):
-    // they are idle after the synchronisation above and are made again on first use
-    if (c->auxPriority != rs_internal_stream_priority())
-        for (hipStream_t& st : c->aux) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+    c->auxWant = -99;
+    if (changed) c->auxStale = true;                    // the library's own streams were chosen next to the old stream: chosen again on next use
     return 0;
 }
 int rs_set_sync(int sync) { rs_ctx()->sync = sync != 0; return 0; }
+// what the choice by measurement came to (for logs): the level of the three streams (-1 high / 0 normal / 1 low), the chosen triple's
+// calibration time and the fastest time any candidate triple reached, in microseconds (0 / 0: not chosen by measurement -- none made yet,
+// or the measurement failed and plain streams are in use)
+int rs_internal_streams_info(int* priority, double* chosenUs, double* fastestUs) {
+    rs_context* c = rs_ctx();
+    if (priority) *priority = c->auxPriority;
+    if (chosenUs) *chosenUs = c->auxPlain ? 0.0 : c->auxCalibratedUs;
+    if (fastestUs) *fastestUs = c->auxPlain ? 0.0 : c->auxFastestUs;
+    return 0;
+}
+int rs_set_internal_stream_priority(int level) {
+    rs_context* c = rs_ctx();
+    if (level < -1 || level > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_internal_stream_priority: -1 high, 0 normal, 1 low, 2 automatic");
+    const bool changed = c->auxLevelSet != (level != 2) || (level != 2 && c->auxLevel != level);
+    c->auxLevelSet = level != 2; c->auxLevel = level == 2 ? 0 : level;
+    c->auxWant = -99;
+    if (changed) { RS_TRY(rs_synchronize()); c->auxStale = true; }
+    return 0;
+}
 int rs_set_side_stream(int enable) {
     rs_context* c = rs_ctx();
     c->auxMode = enable ? 1 : 0;                        // work already enqueued on the auxiliary streams is still joined by its consumers

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(kTileThreads) k_wavelet_tiled(float* __restric
                                                                float* __restrict__ pos, const float* __restrict__ depth, CamParams cam, int W, int H,
                                                                float sigDepth, float sigNormal, float sigLumin, int y0, int y1) {
     constexpr int kHaloX = 2 * STEP, kRW = kTileW + 2 * kHaloX, kRH = kTileH + 4, kRN = kRW * kRH;
+    RS_SETPRIO(RS_PRIO_EAW);
     __shared__ float4 sColId[kRN];          // colour xyz, id bits
     __shared__ float4 sNormPx[kRN];         // normal xyz, position x
     __shared__ float2 sPyz[kRN];            // position y, z

@@ -31,7 +31,12 @@ struct rs_context {
     hipStream_t stream = nullptr;
     bool sync = true;
     hipStream_t aux[kAux] = {};
-    int auxPriority = 0;                  // what the auxiliary streams were created with (rs_internal_stream_priority at that time)
+    int auxPriority = 0;                  // the level the auxiliary streams were created at
+    int auxWant = -99;                    // cached rs_internal_stream_priority(); -99: recompute
+    bool auxLevelSet = false; int auxLevel = 0;   // rs_set_internal_stream_priority
+    bool auxStale = false;                // the auxiliary streams were chosen for another caller stream / preference: choose again on next use
+    bool auxPlain = false;                // the choice by measurement failed once: plain streams from then on
+    double auxCalibratedUs = 0, auxFastestUs = 0;   // the chosen triple's calibration time and the fastest of all candidates (rs_internal_streams_info)
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory (rs_set_ris_table_pixels): -1 = the default, 64 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 = not resolved yet (rs_set_side_stream; default: measured per rs_restir)
@@ -263,6 +268,9 @@ static inline GBufView gbuf_view(const rs_gbuffer* g) {
 #endif
 #ifndef RS_PRIO_RIS
 #define RS_PRIO_RIS 0
+#endif
+#ifndef RS_PRIO_EAW
+#define RS_PRIO_EAW 0
 #endif
 #define RS_SETPRIO(p) do { if ((p) > 0) __builtin_amdgcn_s_setprio(p); } while (0)
 // what renderGBuffer writes for one pixel (src/gbuffer.cu:21-72); shared by k_render_gbuffer and the kernel that walks the

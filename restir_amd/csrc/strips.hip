@@ -364,7 +364,15 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
     for (bool pending : s->gatherPending) if (pending) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_set_comm_stream: a gather is in flight");
     RS_TRY(rs_synchronize());
     if (s->commStream) RS_HIP(hipStreamSynchronize(s->commStream));
-    if (ownStream && !s->commStream && s->comm->world > 1) RS_HIP(hipStreamCreateWithPriority(&s->commStream, hipStreamNonBlocking, rs_internal_stream_priority()));
+    // (In the caller's priority pool.  Whichever pool it is in, this is a FIFTH stream with work in flight next to the library stream and
+    // three chains, and the device runs four queues at a time: a 1/8 strip 0.166 -> 0.48 ms per frame with a transport that moves
+    // nothing, exactly like a fourth chain -- profiles/r05_ab_four_chains.log.  The form exists for a machine where RCCL's kernel on
+    // the library stream costs more than that; bench.py times both and keeps this one only if it wins by 3 %.)
+    if (ownStream && !s->commStream && s->comm->world > 1) {
+        int prio = 0;
+        if (rs_stream() && hipStreamGetPriority(rs_stream(), &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+        RS_HIP(hipStreamCreateWithPriority(&s->commStream, hipStreamNonBlocking, prio));
+    }
     s->commOnMain = !(ownStream && s->commStream);
     return 0;
 }

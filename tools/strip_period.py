@@ -17,6 +17,8 @@ calibration does), N = 1 goes through the same driver (one-rank world).
     STREAM_PLAN=c,s,m        rs_set_stream_plan(chain_streams, small_chains, shadow_on_main)
     RIS_TABLE_PIXELS=n       rs_set_ris_table_pixels
     COMM_STREAM=1            transfers on the driver's own stream
+    RCCL=1                   create a one-rank ncclComm first (does RCCL's presence in the process move the period?)
+    STREAM_LEVEL=-1|0|1|2    rs_set_internal_stream_priority (default: 1 for config 5, else 2 = automatic)
     STREAM_KIND=torch|torch_high|hip|null   the library stream: of torch's pool (default), high priority, a plain HIP stream, the legacy default stream
 """
 import json, os, sys, time
@@ -52,7 +54,24 @@ elif KIND == "hip":                                 # a stream made by hipStream
     capi.set_stream(raw.value)
 else:
     assert KIND == "null"                           # the legacy default stream
+if os.environ.get("RCCL", "0") == "1":               # a one-rank ncclComm in the process, as bench.py --gpus N has one (RCCL makes streams of its own)
+    from restir_amd.rccl import RcclComm
+    _rccl = RcclComm(0, 1, lambda raw: raw)
+if os.environ.get("PRE_STREAMS"):                   # experiment: make (and with a trailing "d" destroy) n high-priority streams first
+    import ctypes
+    _hip = ctypes.CDLL("libamdhip64.so")
+    spec = os.environ["PRE_STREAMS"]
+    made = []
+    for _ in range(int(spec.rstrip("d"))):
+        h = ctypes.c_void_p()
+        assert _hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, -1) == 0
+        made.append(h)
+    if spec.endswith("d"):
+        for h in made:
+            assert _hip.hipStreamDestroy(h) == 0
 capi.set_sync(False)
+# what bench.py does: a frame with the denoiser on the library stream puts the library's own streams below it
+capi.set_internal_stream_priority(int(os.environ.get("STREAM_LEVEL", "1" if DENOISE else "2")))
 if os.environ.get("TILE_SPLIT"):
     capi.set_tile_split(int(os.environ["TILE_SPLIT"]))
 if os.environ.get("STREAM_PLAN"):
@@ -125,6 +144,8 @@ for n in WORLDS:
         print("config %d N=%d %s: rows %s  ms %s  max %.4f  host enqueue %.3f  launch (fused, chains) %s" % (
             CONFIG, n, "even" if it == 0 and not FIXED else "balanced %d" % it, " ".join(str(b - a) for a, b in bounds),
             " ".join("%.4f" % t for t in ms), max(ms), host, res[0][2]), flush=True)
+        if it == 0:
+            print("   internal streams (level, calibration us, fastest candidate us):", capi.internal_streams_info(), flush=True)
         if best is None or max(ms) < best["max_ms"]:
             best = {"rows": [b - a for a, b in bounds], "ms": ms, "max_ms": max(ms), "host_enqueue_ms": host}
         if it < rounds:
