@@ -570,6 +570,9 @@ def main():
                 transport, rccl, comm = "gloo", None, None
         if comm is None:
             comm = GlooTransport(capi, dist, torch).comm(rank, world)
+        # ncclCommInitRank made streams of its own after the library had chosen its streams (the calibration of the strip heights ran
+        # frames): which streams run side by side depends on every stream of the process, so the library chooses again
+        capi.choose_internal_streams_again()
         drv = capi.Strips(comm, WIDTH, HEIGHT, [b[0] for b in bounds] + [HEIGHT])
         y0, y1 = drv.y0, drv.y1
         assert (y0, y1) == tuple(bounds[rank])

@@ -159,6 +159,9 @@ int  rs_set_stream(void* hipStream);
 int  rs_set_internal_stream_priority(int level);
 /* What the measurement chose: level, the chosen streams' calibration time and the fastest candidate's (us; 0 = plain streams in use). */
 int  rs_internal_streams_info(int* priority, double* chosenUs, double* fastestUs);
+/* Chooses them again at the next overlapped launch (waits for the library's work): call after the process has made streams of its own
+ * since the library's first overlapped frame -- in particular after ncclCommInitRank, which makes several. */
+int  rs_choose_internal_streams_again(void);
 /* 1 (default): every entry point synchronises and checks errors before returning, like
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);

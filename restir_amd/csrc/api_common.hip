@@ -430,6 +430,14 @@ int rs_internal_streams_info(int* priority, double* chosenUs, double* fastestUs)
     if (fastestUs) *fastestUs = c->auxPlain ? 0.0 : c->auxFastestUs;
     return 0;
 }
+// Makes the choice again at the next overlapped launch: for a caller whose process has gained streams since the library chose (an
+// ncclComm created after the first frames, a torch stream pool touched for the first time).  Waits for the library's streams.
+int rs_choose_internal_streams_again(void) {
+    rs_context* c = rs_ctx();
+    RS_TRY(rs_synchronize());
+    c->auxStale = true; c->auxPlain = false; c->auxWant = -99;
+    return 0;
+}
 int rs_set_internal_stream_priority(int level) {
     rs_context* c = rs_ctx();
     if (level < -1 || level > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_internal_stream_priority: -1 high, 0 normal, 1 low, 2 automatic");
