@@ -923,6 +923,57 @@ def test_strip_tiling_equals_full_frame(hip):
         assert bits_equal(ref, got), (frame, radiance_stats(ref, got))
 
 
+def test_internal_streams_are_chosen_by_measurement_and_change_no_result(hip):
+    """The library chooses its three internal streams by measurement when an overlapped frame first needs them, again after
+    rs_choose_internal_streams_again / rs_set_internal_stream_priority / rs_set_stream with another stream (api_common.hip).  Which streams
+    carry the chains is scheduling only: overlapped frames under every preference, on the default stream and on an ordinary one, with the
+    choice repeated in the middle of the sequence, equal the synchronous frames bit for bit; rs_internal_streams_info reports a level and a
+    calibration time."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.1")
+    W, H, frames = 320, 180, 9
+    scene = hip_scene(hip, sd)
+
+    def run(overlapped, level=2, own_stream=False):
+        stream = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            hip.set_stream(stream.cuda_stream)                     # the library and torch's copies of the images on ONE stream
+            h = HipRenderer(hip, sd, W, H, scene=scene)
+            images = []
+            hip.set_sync(not overlapped)
+            hip.set_internal_stream_priority(level)
+            try:
+                for frame in range(frames):
+                    if overlapped and frame == 4:
+                        hip.choose_internal_streams_again()
+                    h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.5))
+                    h.gbuf.render(h.scene, h.cam)
+                    h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                    h.looper += 1
+                    images.append(h.image.clone())
+                    h.gbuf.update(h.cam)
+                hip.synchronize()
+                torch.cuda.synchronize()
+                info = hip.internal_streams_info()
+            finally:
+                hip.set_sync(True)
+                hip.set_internal_stream_priority(2)
+        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        return [t.cpu().numpy() for t in images], h.restir.download(1), info
+
+    ref_images, ref_resv, _ = run(False)
+    for level, own in ((2, False), (1, False), (0, True), (-1, True), (1, True)):
+        images, resv, info = run(True, level, own)
+        for f in range(frames):
+            assert bits_equal(images[f], ref_images[f]), (level, own, f)
+        for k in resv.dtype.names:
+            assert bits_equal(resv[k], ref_resv[k]), (level, own, k)
+        lvl, chosen_us, fastest_us = info
+        assert lvl in (-1, 0, 1)
+        assert chosen_us == 0.0 or (0.0 < fastest_us <= chosen_us <= fastest_us * 1.08 + 1e-6), info     # 0: plain streams (nothing could be measured)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_overlapped_frames_equal_synchronous_frames(hip, fused):
     """Asynchronous mode (rs_set_sync(0)) lets frames overlap: GBuffer::render and the primary-ray + RIS kernels of frame f + 1
