@@ -4,7 +4,8 @@
 //     GBuffer::render on the strip's rows
 //     ReSTIRDirect phase A on the strip's rows                      (restir.cu:127-194)
 //     5 border rows of published reservoirs + G-buffer id / normal / depth  ->  the strip above / below      <- the only exchange
-//     phase B on the interior rows while the border rows travel, then on the two 5-row bands (restir.cu:196-230)
+//     phase B (restir.cu:196-230): in one launch after the rows have arrived when the transfers share the library stream (default); with
+//     the transfers on a stream of the driver on the interior rows while the border rows travel, then on the two 5-row bands
 //
 // The exchange goes through a transport of two operations, send and recv of a device buffer, grouped:
 //   * RCCL: ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd on a stream of this driver that is ordered after the packing
@@ -416,6 +417,17 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
     if (timeMain) RS_HIP(hipEventRecord(s->waitFrom, rs_stream()));
     RS_TRY(post(s, ops, n));
     if (timeMain) { RS_HIP(hipEventRecord(s->waitTo, rs_stream())); s->waitValid = true; }
+    if (s->commOnMain && c->t.stream_ordered) {
+        // The transfers are in the library stream's own order: nothing runs next to them there, so splitting phase B into interior rows
+        // and two 5-row bands would only buy two more launches -- and the bands are 5 rows in 16-row tiles.  Unpack, then ONE launch over
+        // the strip (a 1/8 strip of 1080p: three launches of 14.6 + 8.5 + 8.8 us -> one of 15; results do not depend on the partition).
+        SegList l;
+        if (up) halo_segments(l, r, g, y0 - kHalo, kHalo, s->recvUp);
+        if (down) halo_segments(l, r, g, y1, kHalo, s->recvDown);
+        RS_TRY(copy_segments(l, false));
+        RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1));
+        return rs_restir_end_frame(r);
+    }
     // interior rows (their taps stay inside the strip) while the border rows travel
     const int topEnd = up ? (y0 + kHalo < y1 ? y0 + kHalo : y1) : y0;
     const int botStart = down ? (y1 - kHalo > topEnd ? y1 - kHalo : topEnd) : y1;
