@@ -186,13 +186,29 @@ int exchange_gbuffer_rows(rs_strips* s, rs_gbuffer* g, int reach) {
     const size_t gBytes = rs_gbuffer_rows_bytes(g, reach);
     for (int i = 0; i < 2; i++)
         if ((i == 0 ? up : down) && !s->eawSend[i]) { RS_TRY(rs_dev_alloc(&s->eawSend[i], gBytes)); RS_TRY(rs_dev_alloc(&s->eawRecv[i], gBytes)); }
+    // the packed layout of rs_gbuffer_rows_pack: id rows, normal rows, depth rows -- all six segments of a direction in ONE copy launch
+    // (as 12 hipMemcpyAsync calls they were a dozen launches of ~8 us on the library stream of every filtered frame)
+    RS_TRY(rs_gbuffer_join(g));
+    const int cur = g->cur();
+    const auto segments = [&](SegList& l, int y, char* packed) {
+        const size_t n = (size_t)s->width * reach, off = (size_t)y * s->width;
+        l.add(g->primId[cur] + off, packed, n * 4); l.add(g->normal[cur] + off * 3, packed + n * 4, n * 12); l.add(g->depth[cur] + off, packed + n * 16, n * 4);
+    };
     Xfer ops[4]; size_t n = 0;
-    if (up) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y0, reach, s->eawSend[0])); ops[n++] = { true, s->eawSend[0], gBytes, c->rank - 1 }; ops[n++] = { false, s->eawRecv[0], gBytes, c->rank - 1 }; }
-    if (down) { RS_TRY(rs_gbuffer_rows_pack(g, 0, y1 - reach, reach, s->eawSend[1])); ops[n++] = { true, s->eawSend[1], gBytes, c->rank + 1 }; ops[n++] = { false, s->eawRecv[1], gBytes, c->rank + 1 }; }
+    {
+        SegList l;
+        if (up) { segments(l, y0, s->eawSend[0]); ops[n++] = { true, s->eawSend[0], gBytes, c->rank - 1 }; ops[n++] = { false, s->eawRecv[0], gBytes, c->rank - 1 }; }
+        if (down) { segments(l, y1 - reach, s->eawSend[1]); ops[n++] = { true, s->eawSend[1], gBytes, c->rank + 1 }; ops[n++] = { false, s->eawRecv[1], gBytes, c->rank + 1 }; }
+        RS_TRY(copy_segments(l, true));
+    }
     RS_TRY(post(s, ops, n));
     RS_TRY(join(s, false));
-    if (up) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y0 - reach, reach, s->eawRecv[0]));
-    if (down) RS_TRY(rs_gbuffer_rows_unpack(g, 0, y1, reach, s->eawRecv[1]));
+    {
+        SegList l;
+        if (up) segments(l, y0 - reach, s->eawRecv[0]);
+        if (down) segments(l, y1, s->eawRecv[1]);
+        RS_TRY(copy_segments(l, false));
+    }
     return 0;
 }
 // the first / last `rows` rows of the strip's part of a row-major image (and of a second one) to the strips above / below, theirs
