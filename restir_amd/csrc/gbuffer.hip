@@ -66,7 +66,7 @@ int launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* c
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
     TileSplit ts; int helpers = 0;
     RS_TRY(rs_tile_split_prepare(&g->split[st == rs_stream() ? 0 : 1], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY,
-                                 (st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0))) ? 1 : ((long long)tilesX * tilesY * 4 < kSmallLaunchWaves ? 2 : 0), st, &ts, &helpers));
+                                 (st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0))) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
     const CamParams cp = rs_make_cam_params(cam), lp = rs_make_cam_params(lastCam);
     if (ts.base) {
         if (scene->textured) hipLaunchKernelGGL(k_render_gbuffer_split<true>, dim3(helpers + tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX, ts);

@@ -130,6 +130,10 @@ struct rs_tile_split {
 //      kTileSplitSleep launches before it looks again.
 int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, int mode, hipStream_t st, rs::TileSplit* ts, int* helperBlocks);
 constexpr long long kSmallLaunchWaves = 3 * 8192;   // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
+#ifndef RS_SPLIT_SMALL_ROUNDS
+#define RS_SPLIT_SMALL_ROUNDS 3
+#endif
+constexpr long long kSplitSmallWaves = (long long)RS_SPLIT_SMALL_ROUNDS * 8192;   // launches below this many waves split their heavy tiles also when other kernels run next to them
 void rs_tile_split_free(rs_tile_split* t);
 int rs_tile_split_threshold();                      // of the current context
 
