@@ -70,7 +70,8 @@ __global__ void k_calibration_spin(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 struct Calibration {
-    hipEvent_t begin = nullptr, end[4] = {}, hand[8][4] = {};
+    static constexpr int kMax = 8;
+    hipEvent_t begin = nullptr, end[kMax] = {}, hand[8][kMax] = {};
     bool ok = true;
     Calibration() {
         ok = hipEventCreate(&begin) == hipSuccess;
@@ -83,20 +84,20 @@ struct Calibration {
         for (auto& r : hand) for (auto& e : r) if (e) (void)hipEventDestroy(e);
         (void)hipGetLastError();
     }
-    // microseconds until all four streams have finished their eight rounds (best of three), or a negative value on error
-    double chained(const hipStream_t s[4]) {
+    // microseconds until all n streams have finished their eight rounds (best of three), or a negative value on error
+    double chained(const hipStream_t* s, int n = 4) {
         double best = 1e30;
         for (int rep = 0; rep < 3; rep++) {
             if (hipDeviceSynchronize() != hipSuccess) return -1;
             (void)hipEventRecord(begin, s[0]);
             for (int r = 0; r < 8; r++) {
-                for (int k = 0; k < 4; k++) { hipLaunchKernelGGL(k_calibration_spin, dim3(1), dim3(64), 0, s[k], 2000); (void)hipEventRecord(hand[r][k], s[k]); }
-                for (int k = 0; k < 4; k++) (void)hipStreamWaitEvent(s[k], hand[r][(k + 1) % 4], 0);
+                for (int k = 0; k < n; k++) { hipLaunchKernelGGL(k_calibration_spin, dim3(1), dim3(64), 0, s[k], 2000); (void)hipEventRecord(hand[r][k], s[k]); }
+                for (int k = 0; k < n; k++) (void)hipStreamWaitEvent(s[k], hand[r][(k + 1) % n], 0);
             }
-            for (int k = 0; k < 4; k++) (void)hipEventRecord(end[k], s[k]);
+            for (int k = 0; k < n; k++) (void)hipEventRecord(end[k], s[k]);
             if (hipDeviceSynchronize() != hipSuccess) return -1;
             float worst = 0.f;
-            for (int k = 0; k < 4; k++) { float t = 0.f; if (hipEventElapsedTime(&t, begin, end[k]) != hipSuccess) return -1; worst = t > worst ? t : worst; }
+            for (int k = 0; k < n; k++) { float t = 0.f; if (hipEventElapsedTime(&t, begin, end[k]) != hipSuccess) return -1; worst = t > worst ? t : worst; }
             best = worst < best ? worst : best;
         }
         return best * 1e3;
@@ -106,10 +107,35 @@ struct Calibration {
 
 // fills c->aux with the three streams chosen by measurement; false: nothing could be measured (the caller falls back to plain streams)
 static bool calibrate_internal_streams(rs_context* c) {
-    static_assert(rs_context::kAux >= 3, "three auxiliary streams");
-    if (rs_context::kAux != 3) return false;                           // (measurement builds with more streams: plain creation)
+    static_assert(rs_context::kAux >= 3 && rs_context::kAux < Calibration::kMax, "three auxiliary streams (measurement builds: up to seven)");
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (rs_context::kAux != 3) {
+        // measurement builds with more chains in flight (-DRS_AUX_STREAMS=4): twelve candidates, chosen greedily -- the stream that runs
+        // best next to the ones already chosen, one at a time
+        Calibration cal;
+        if (!cal.ok) { (void)hipGetLastError(); return false; }
+        std::vector<hipStream_t> cand;
+        for (int p : { greatest, 0, least }) for (int i = 0; i < 4; i++) { hipStream_t st = nullptr; if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, p) == hipSuccess) cand.push_back(st); }
+        (void)hipGetLastError();
+        hipStream_t chosen[Calibration::kMax] = { c->stream };
+        double last = 0;
+        for (int k = 1; k <= rs_context::kAux; k++) {
+            int best = -1; double bestT = 1e30;
+            for (size_t i = 0; i < cand.size(); i++) {
+                if (!cand[i]) continue;
+                chosen[k] = cand[i];
+                const double t = cal.chained(chosen, k + 1);
+                if (t >= 0 && t < bestT) { bestT = t; best = (int)i; }
+            }
+            if (best < 0) { for (hipStream_t st : cand) if (st) (void)hipStreamDestroy(st); return false; }
+            chosen[k] = cand[(size_t)best]; cand[(size_t)best] = nullptr; last = bestT;
+        }
+        for (hipStream_t st : cand) if (st) (void)hipStreamDestroy(st);
+        for (int k = 0; k < rs_context::kAux; k++) c->aux[k] = chosen[k + 1];
+        c->auxPriority = 0; c->auxCalibratedUs = last; c->auxFastestUs = last;
+        return true;
+    }
     const int levels[3] = { greatest, 0, least };
     const int nLevels = (greatest < 0 ? 1 : 0) + 1 + (least > 0 ? 1 : 0);
     int order[3], n = 0;                                               // preference: high, normal, low -- or low first when asked for
