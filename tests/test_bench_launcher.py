@@ -88,3 +88,34 @@ def test_bench_main_takes_the_launcher_branch_before_any_gpu_call(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert p.returncode != 0 and "needs an MI355X" in p.stderr
+
+
+def test_expected_compute_only_reads_the_committed_strip_periods():
+    """bench.py's N > 1 line quotes the compute-only frame period of the split from profiles/r05_strip_period_c<config>.json
+    (tools/strip_period.py): the figure the first multi-GPU run is to be compared with."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for config in (3, 4, 5):
+        one = bench.expected_compute_only(config, 1)
+        for world in (2, 4, 8):
+            e = bench.expected_compute_only(config, world)
+            assert e is not None and len(e["per_rank_ms"]) == world == len(e["rows"])
+            assert sum(e["rows"]) == (2160 if config == 4 else 1080)
+            assert e["ms"] == max(e["per_rank_ms"]) and 0 < e["ms"] < one["ms"]
+            assert abs(e["speedup_compute_only"] - one["ms"] / e["ms"]) < 1e-9 and 1.0 < e["speedup_compute_only"] <= world
+    assert bench.expected_compute_only(3, 3) is None and bench.expected_compute_only(7, 2) is None
+
+
+def test_diagnose_names_the_first_failure_of_the_elastic_summary():
+    """The failing rank comes from torch.distributed.run's own summary when it printed one, else from the ranks' status files."""
+    sys.path.insert(0, ROOT)
+    import bench
+    tail = ["noise\n", "Root Cause (first observed failure):\n", "[0]:\n", "  time      : 2026\n", "  rank      : 5 (local_rank: 5)\n", "  exitcode  : 3 (pid: 1)\n"]
+    status = {r: {"rank": r, "phase": "timed" if r != 5 else "warmup"} for r in range(8)}
+    d = bench.diagnose(8, 1, status, tail)
+    assert d["failed"] and d["failing_rank"] == 5 and d["phase"] == "warmup" and d["rc"] == 1
+    # no summary (a hang killed by the watchdog): the rank that got least far; ranks without a status file died before "start"
+    d = bench.diagnose(4, 124, {0: {"phase": "timed"}, 1: {"phase": "timed"}, 3: {"phase": "comm_init"}}, [])
+    assert d["failing_rank"] == 2 and d["phase"] == "before start" and "watchdog" in d["error"]
+    d = bench.diagnose(2, 124, {0: {"phase": "done"}, 1: {"phase": "first_frames", "mine": {"rank": 1}}}, [])
+    assert d["failing_rank"] == 1 and d["phase"] == "first_frames" and d["per_rank"] == [{"rank": 1}]
