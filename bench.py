@@ -878,7 +878,8 @@ def main():
             "pass_ms": {"gbuffer": float(np.median(gb_ms)), "to_rgba8": float(np.median(pbo_ms)), "primary": float(pass_ms[0]), "ris": float(pass_ms[1]),
                         "shadow_temporal": float(pass_ms[2]), "spatial_shade": float(pass_ms[3]),
                         **({"eaw_positions": eaw_level_ms[0], "eaw_levels": eaw_level_ms[1:]} if eaw_level_ms else {})},
-            "rays_per_frame": local_rays / args.steps}
+            "rays_per_frame": local_rays / args.steps,
+            "internal_streams": list(capi.internal_streams_info())}      # (priority level, calibration us of the chosen three, fastest candidate us) on this rank
     per_rank = [mine]
     set_phase("parity", mine=mine)                          # (the launcher quotes it if a later step fails)
     if world > 1:
