@@ -61,7 +61,8 @@ struct PathState {
     Cold3 direct, indirect;       // kModePT: direct / indirect; others: indirect only (ReSTIR: the sample's Lo)
     Cold3 throughput;
     // ReSTIR-GI bookkeeping (restir.cu:273-281,316-321)
-    float primSamplePdf; bool primSampleDelta; f3 primWo; SurfMat primMaterial;
+    float primSamplePdf; bool primSampleDelta; f3 primWo; SurfMat primMaterial;     // (primMaterial: textured scenes only; a plain material is read again from its id)
+    int primMatId;
     Cold3 xv, nv, xs, ns;
     int walks;
 };
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     if (MODE == kModeReSTIR) { st.xv.p = sCold + 6 * 256 + threadIdx.x; st.nv.p = st.xv.p + 3 * 256; st.xs.p = st.xv.p + 6 * 256; st.ns.p = st.xv.p + 9 * 256; }
 #endif
     st.direct.set(splat(0.f)); st.indirect.set(splat(0.f)); st.primSamplePdf = 0.f; st.primSampleDelta = false; st.primWo = -ray.d;
-    st.primMaterial = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f };
+    st.primMaterial = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f }; st.primMatId = -1;
     if (MODE == kModeReSTIR) { st.xv.set(splat(0.f)); st.nv.set(splat(0.f)); st.xs.set(splat(0.f)); st.ns.set(splat(0.f)); }
     st.walks = 0;
     // primary hit (pathtrace.cu:172-190 / 343-350, restir.cu:259-270); lanes that end here keep alive = false
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
             }
             else {
                 hh.norm = norm;
-                st.primMaterial = material;
+                if (TEX) st.primMaterial = material; else st.primMatId = h.matId;       // seven registers across the whole path loop, or one
                 alive = true;
             }
         }
@@ -306,7 +307,8 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
             if (!ind_invalid(rv.W)) {
                 const f3 primWi = normalize(rv.xs - rv.xv);
                 indirect = ((rv.Lo / luminance(rv.Lo)) * rv.W) / (float)rv.M;
-                indirect = indirect * (material_bsdf(st.primMaterial, rv.nv, st.primWo, primWi) * (st.primSampleDelta ? 1.f : sat_dot(rv.nv, primWi)));
+                const SurfMat primMaterial = TEX ? st.primMaterial : (st.primMatId >= 0 ? plain_material(s, st.primMatId) : SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f });
+                indirect = indirect * (material_bsdf(primMaterial, rv.nv, st.primWo, primWi) * (st.primSampleDelta ? 1.f : sat_dot(rv.nv, primWi)));
             }
             if (any_nan_or_inf(indirect)) indirect = splat(0.f);
             ind_store(resvOut + index, rv);
