@@ -418,9 +418,10 @@ typedef struct rs_transport {
 } rs_transport;
 /* ncclComm: an ncclComm_t of `world` ranks created by the caller (ncclCommInitRank); librccl.so is opened at run time, the
  * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on the library stream (rs_set_stream), between
- * the launch that packs the border rows and the interior rows of phase B; rs_strips_set_comm_stream(strips, 1) puts them on
- * a stream of the strip driver instead (measured slower with a transport that moves nothing: a fifth stream shares a hardware queue
- * with a chain) */
+ * the launch that packs the border rows and the launch that unpacks the neighbours'; rs_strips_set_comm_stream(strips, 1) puts them on
+ * a stream of the strip driver instead, with phase B's interior rows next to them (measured slower by a factor of three with a transport
+ * that moves nothing: it is a fifth stream that hands events to the others, and the device runs four of those side by side, DESIGN.md
+ * sections 4 and 5).  Create the communicator before the first overlapped frame or call rs_choose_internal_streams_again() after it. */
 int  rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** comm);
 /* The same, naming the copy of RCCL that created ncclComm (a process can hold two: PyTorch wheels bundle their own librccl.so).
  * librcclPath NULL or "" = rs_comm_create_rccl's search: symbols the process has linked or loaded globally, else a copy already
