@@ -28,14 +28,22 @@ restir_amd/rccl.py); torch.distributed (gloo) is the control plane only: the id 
   BENCH_FORCE_STRIPS=1       N = 1 through the strip driver and a one-rank ncclComm as well
   BENCH_WATCHDOG=seconds     every rank (and the launcher) ends itself after that long (default 900 with N > 1)
   BENCH_COMM_STREAM=library|own|auto   where the strip driver enqueues its RCCL transfers (rs_strips_set_comm_stream); auto (default over
-                             RCCL) times both before the warm-up and keeps the faster
+                             RCCL) times both over 40 frames before the warm-up and takes the own stream only if it wins by 3 %
+  BENCH_STREAM_LEVEL=-1|0|1|2          rs_set_internal_stream_priority: the preferred level of the library's own streams (default 2 =
+                             automatic; 1 with the denoiser of config 5).  The streams themselves are chosen by measurement
+                             (`config.internal_streams`, per rank in `per_rank`), again after ncclCommInitRank
 
 One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline      the spatial-reuse pass (k_spatial_shade): algorithmic 92 B/px over its average launch duration by HIP
                 events (20 back-to-back launches on the stream the kernel is launched on), against the 8 TB/s HBM3E peak; `traffic` is
                 filled from profiles/ PMC runs when known
   roofline_eaw  config 5: the five a-trous level kernels, 44 B/px and level
-  per_rank      N > 1: every rank's rows, ms per step, wait for the halo rows, per-pass times
+  per_rank      N > 1: every rank's rows, ms per step, wait for the halo rows, per-pass times, its choice of internal streams
+  expected_compute_only_ms   N > 1: the slowest rank's frame period of this split as measured on ONE GPU over a transport that moves nothing
+                (tools/strip_period.py, profiles/r05_strip_period_c<config>.json): ms_per_step minus this is the wire, RCCL's launches, the ranks' skew
+  ms_per_frame_single_in_flight   launches asynchronous, one frame at a time (between ms_per_step, three frames in flight, and
+                ms_per_frame_synchronous, a synchronisation after every call)
+  failed / error / failing_rank / phase   only when the run failed or hung: the launcher's diagnosis (which rank, in which phase)
   cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a bounded sample of the same workload
                 (rank 0, N = 1 only)
