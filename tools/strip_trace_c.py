@@ -8,16 +8,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from restir_amd import capi, scenes
 
-W, H = 1920, 1080
+CONFIG = int(os.environ.get("CONFIG", "3"))           # BASELINE config 3 (default), 4 (3840x2160) or 5 (Bistro-class + EAW filter)
+W, H = (3840, 2160) if CONFIG == 4 else (1920, 1080)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 capi.init(0)
-sd = scenes.sponza_class(seed=1, scale=1.0)
+sd = scenes.bistro_class(seed=2, scale=1.0) if CONFIG == 5 else scenes.sponza_class(seed=1, scale=1.0)
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
 cam = capi.camera_update(sd.camera(W, H))
 capi.set_sync(False)
+if CONFIG == 5:
+    capi.set_internal_stream_priority(1)
+eaw = capi.EAWFilter(W, H, 5) if CONFIG == 5 else None
 comm = capi.Comm(rank, world, lambda p, n, peer: None, lambda p, n, peer: None, None, None, stream_ordered=True)
-drv = capi.Strips(comm, W, H)
+bounds = None
+if os.environ.get("ROWS"):                                # strip heights of all ranks (default: equal heights)
+    ys = [0]
+    for r in os.environ["ROWS"].split(","):
+        ys.append(ys[-1] + int(r))
+    assert len(ys) == world + 1 and ys[-1] == H
+    bounds = ys
+drv = capi.Strips(comm, W, H, bounds)
 gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
 image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
 pbos = [torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -25,9 +36,10 @@ y0, y1 = drv.y0, drv.y1
 def frame(n):
     k = n % 2
     drv.frame(restir, scene, cam, gbuf, image.data_ptr(), 0, n, 3)
+    shown = drv.eaw_filter(eaw, gbuf, cam, image.data_ptr()) if eaw else image.data_ptr()
     gbuf.update(cam)
     drv.gather_end(k)
-    capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * W * 4, image.data_ptr() + y0 * W * 12, W, y1 - y0, 2, 1.0)
+    capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * W * 4, shown + y0 * W * 12, W, y1 - y0, 2, 1.0)
     drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)
 
 
