@@ -20,6 +20,9 @@ def _cited(text):
         if "*" in p or p.endswith("/"):
             continue
         out.update(_expand(p))
+    # profile files cited by their bare name (`r05_config3_hbm_counters.json`, `_kernel_stats.csv` continuations are not expanded)
+    for m in re.finditer(r"`(r0[1-9]_[A-Za-z0-9_{},-]+\.(?:log|json|csv|txt))`", text):
+        out.update("profiles/" + q for q in _expand(m.group(1)))
     return out
 
 
