@@ -17,6 +17,8 @@ calibration does), N = 1 goes through the same driver (one-rank world).
     STREAM_PLAN=c,s,m        rs_set_stream_plan(chain_streams, small_chains, shadow_on_main)
     RIS_TABLE_PIXELS=n       rs_set_ris_table_pixels
     COMM_STREAM=1            transfers on the driver's own stream
+    PRE_STREAMS=n[d]         make n idle high-priority streams first (d: and destroy them): the order in which a process makes its
+                             streams decides which of them run side by side (profiles/r05_ab_stream_levels_by_workload.log)
     RCCL=1                   create a one-rank ncclComm first (does RCCL's presence in the process move the period?)
     STREAM_LEVEL=-1|0|1|2    rs_set_internal_stream_priority (default: 1 for config 5, else 2 = automatic)
     STREAM_KIND=torch|torch_high|hip|null   the library stream: of torch's pool (default), high priority, a plain HIP stream, the legacy default stream
