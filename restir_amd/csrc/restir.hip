@@ -907,11 +907,14 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     int kThreeStreams[rs_restir::kSmallChains];                 // the chain streams first, the render's stream (idle after a fused launch) last
     for (int i = 0; i < rs_restir::kSmallChains; i++) kThreeStreams[i] = i < 2 ? 1 + i : i == 2 ? 0 : i;
     const bool three = fuse && parityStreams && r->phaseACalls == 0;
-    const hipStream_t aux = asyncMode ? rs_aux_stream(three ? kThreeStreams[r->smallChain] : parityStreams ? 1 + r->chain : 1) : nullptr;
+    // (a caller that keeps a stream of its own busy next to the frames -- the strip driver with its transfers on a stream of their own --
+    // leaves room for two chains: four streams that hand events to each other is what the device runs side by side, rs_context::chainsInFlight)
+    const int chainSlot = three ? kThreeStreams[plan->chainsInFlight >= rs_restir::kSmallChains ? r->smallChain : r->chain] : 0;
+    const hipStream_t aux = asyncMode ? rs_aux_stream(three ? chainSlot : parityStreams ? 1 + r->chain : 1) : nullptr;
     r->lastFused = fuse ? 1 : 0;
-    r->lastChains = !aux ? 0 : three ? rs_restir::kSmallChains : parityStreams ? rs_restir::kChains : 1;
+    r->lastChains = !aux ? 0 : three ? (plan->chainsInFlight >= rs_restir::kSmallChains ? rs_restir::kSmallChains : rs_restir::kChains) : parityStreams ? rs_restir::kChains : 1;
     const hipStream_t st = aux ? aux : rs_stream();
-    const int splitSlot = !aux ? 0 : 1 + (three ? kThreeStreams[r->smallChain] : parityStreams ? 1 + r->chain : 1);     // the hints of the stream this launch goes to (rs_tilesplit.h)
+    const int splitSlot = !aux ? 0 : 1 + (three ? chainSlot : parityStreams ? 1 + r->chain : 1);     // the hints of the stream this launch goes to (rs_tilesplit.h)
     const int splitCall = r->phaseACalls < 2 ? r->phaseACalls : 2;
     if (aux) {
         if (r->phaseACalls > 0) {

@@ -41,6 +41,7 @@ struct rs_context {
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory (rs_set_ris_table_pixels): -1 = the default, 64 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 = not resolved yet (rs_set_side_stream; default: measured per rs_restir)
     int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
+    int chainsInFlight = 3;               // fused launches rotate over this many streams (3; 2 while the strip driver keeps a transfer stream of its own busy)
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
     int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): rs_set_tile_split, default 768; 0 off; negative: |value|, also for launches that overlap others
 };

@@ -391,6 +391,9 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
         RS_HIP(hipStreamCreateWithPriority(&s->commStream, hipStreamNonBlocking, prio));
     }
     s->commOnMain = !(ownStream && s->commStream);
+    // the transfer stream is a stream with work in flight next to the library stream: with it the frames keep TWO chains in flight, not
+    // three (five streams that hand events to each other: 0.17 -> 0.48 ms per frame on a 1/8 strip)
+    rs_ctx()->chainsInFlight = s->commOnMain ? 3 : 2;
     return 0;
 }
 
