@@ -325,6 +325,7 @@ int rs_strips_destroy(rs_strips* s) {
     if (!s->deferred.empty()) (void)post(s, nullptr, 0);      // (every rank reaches this with the same deferred gathers)
     (void)rs_synchronize();
     if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
+    if (!s->commOnMain) rs_ctx()->chainsInFlight = 3;            // (the transfer stream is gone: three chains again)
     if (s->packed) (void)hipEventDestroy(s->packed);
     if (s->arrived) (void)hipEventDestroy(s->arrived);
     for (hipEvent_t& e : s->gathered) if (e) (void)hipEventDestroy(e);
