@@ -195,6 +195,19 @@ int  rs_set_ris_table_pixels(int pixels);
  * No entry point waits on the host in overlapped mode: the measurement of rs_set_side_stream's mode 4 polls its last time stamp
  * (hipEventQuery at the frame ends) and frames take two launches until it has arrived. */
 int  rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain);
+/* A denoiser in the loop (src/main.cpp:160-170: LeveledEAWFilter::filter between ReSTIRDirect and copyImageToPBO) makes the library
+ * stream both the one chain that links consecutive frames and the busiest stream (config 5: 98 % busy, the chain streams 51-57 %).
+ * 1: with rs_set_sync(0), rs_eaw_filter / rs_strips_eaw_filter -- and an rs_copy_image_to_pbo / rs_strips_gather_begin that reads their
+ * result -- are enqueued on a stream of the library, ordered after everything enqueued on the library stream so far, and run next to the
+ * NEXT frame's temporal and spatial passes; the chains of the frames then take turns on two internal streams instead of three (four
+ * streams with work in flight is what the device runs side by side).  Results are identical.  What changes is the ORDER CONTRACT of
+ * those calls' outputs (the filtered image, the display buffer, the gathered image): they are ordered for the library stream by events,
+ * which every library call that is handed one of those buffers waits for by itself, and which rs_join_denoise_stream() (enqueue-only)
+ * or rs_synchronize() hand to the caller's own work on that stream -- a caller that reads the display buffer with its own kernels or
+ * copies calls rs_join_denoise_stream() first (rs_pbo_unmap does).  0 (default): everything in library-stream order. */
+int  rs_set_denoise_stream(int enable);
+/* The library stream waits (on the device; the host does not) for everything enqueued on the denoise stream so far. */
+int  rs_join_denoise_stream(void);
 /* Closest-hit kernels (GBuffer::render, the primary rays of ReSTIRDirect): a tile whose packet walk visited at least `threshold`
  * nodes the last time the same launch ran is traced by four waves of 16 rays instead of one of 64 -- a launch that runs alone lasts
  * as long as its longest chain of node fetches; results do not depend on the grouping.  Applies where launches run one after the

@@ -108,7 +108,7 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_internal_stream_priority", "rs_internal_streams_info", "rs_choose_internal_streams_again", "rs_set_stream_plan", "rs_set_tile_split", "rs_synchronize",
+    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_internal_stream_priority", "rs_internal_streams_info", "rs_choose_internal_streams_again", "rs_set_stream_plan", "rs_set_denoise_stream", "rs_join_denoise_stream", "rs_set_tile_split", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_closest_wave", "rs_scene_set_ordered_tree", "rs_ordered_bvh_host_check", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
@@ -209,6 +209,8 @@ def lib():
     L.rs_debug_div_sigma_mismatches.argtypes = [C.c_float, C.POINTER(C.c_ulonglong)]
     L.rs_scene_set_sample_sequence.argtypes = [vp, vp, ci, ci]
     L.rs_set_stream_plan.argtypes = [ci, ci, ci]
+    L.rs_set_denoise_stream.argtypes = [ci]
+    L.rs_join_denoise_stream.argtypes = []
     L.rs_restir_rows_pack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_restir_rows_unpack.argtypes = [vp, ci, ci, ci, vp]
     L.rs_gbuffer_rows_bytes.argtypes = [vp, ci]
@@ -342,6 +344,17 @@ def set_ris_table_pixels(pixels):
 def set_stream_plan(chain_streams=-1, small_chains=-1, shadow_on_main=-1):
     """How the overlapped mode spreads a frame's kernels over the internal streams (rs_set_stream_plan); -1 keeps a value."""
     check(lib().rs_set_stream_plan(int(chain_streams), int(small_chains), int(shadow_on_main)))
+
+
+def set_denoise_stream(enable):
+    """LeveledEAWFilter and the tone map of its result on a stream of the library, next to the next frame's passes (rs_set_denoise_stream);
+    their outputs are then ordered by events: join_denoise_stream() or synchronize() before reading them outside the library."""
+    check(lib().rs_set_denoise_stream(int(enable)))
+
+
+def join_denoise_stream():
+    """The library stream waits (on the device) for everything enqueued on the denoise stream so far (rs_join_denoise_stream)."""
+    check(lib().rs_join_denoise_stream())
 
 
 def set_tile_split(threshold):

@@ -45,7 +45,7 @@ int rs_check_hip(hipError_t e, const char* what) {
     return rs_fail((int)e, m.c_str());
 }
 
-hipStream_t rs_stream() { return rs_ctx()->stream; }
+hipStream_t rs_stream() { rs_context* c = rs_ctx(); return c->streamOverride ? c->streamOverride : c->stream; }
 bool rs_sync_enabled() { return rs_ctx()->sync; }
 
 // ---- which streams the library makes for itself ------------------------------------------------------------------------------------
@@ -282,6 +282,99 @@ int rs_aux_synchronize() {
     return 0;
 }
 
+// ---- the denoise stream ---------------------------------------------------------------------------------------------------------------
+// With a filter in the loop the library stream is the one chain that links consecutive frames AND carries the most work (config 5 at
+// N = 1: shadow rays 794 us + temporal 208 + spatial 481 + five a-trous levels 243 + tone map, 98 % busy while the chain streams idle at
+// 51-57 %, profiles/r05_config5_strip_gpu_paced_traces.txt).  rs_set_denoise_stream(1) gives the filter -- and the tone map that reads
+// its result -- auxiliary stream 0: the levels of frame f wait for phase B of f by an event and run next to the temporal / spatial passes
+// of f + 1.  A fifth stream with work in flight halves the frame rate, so the chains then take turns on two streams.
+int rs_chains_in_flight() {
+    const rs_context* c = rs_ctx();
+    const int n = rs_context::kAux - (c->ownCommStreams > 0 ? 1 : 0) - (c->denoiseMode == 1 ? 1 : 0);
+    return n < 1 ? 1 : n;
+}
+hipStream_t rs_denoise_stream() {
+    rs_context* c = rs_ctx();
+    if (c->denoiseMode == 0 || c->sync) return nullptr;
+    const hipStream_t first = rs_aux_stream(0);         // (null: the auxiliary streams are switched off)
+    return (c->denoiseMode == 2 && first && c->lastChainAux) ? c->lastChainAux : first;
+}
+rs_denoise_scope::rs_denoise_scope(bool fork, bool enable) {
+    c = rs_ctx();
+    if (!enable || c->streamOverride) return;           // nested: already there
+    const hipStream_t d = rs_denoise_stream();
+    if (!d) return;
+    if (!c->denoiseFork) err = rs_check_hip(hipEventCreateWithFlags(&c->denoiseFork, hipEventDisableTiming), "hipEventCreate");
+    if (!err && !c->denoiseTail) err = rs_check_hip(hipEventCreateWithFlags(&c->denoiseTail, hipEventDisableTiming), "hipEventCreate");
+    // the frames' filters take the chain streams in turn (mode 2): this one after everything the last one enqueued on ITS stream
+    if (!err && c->denoiseLast && c->denoiseLast != d) err = rs_check_hip(hipStreamWaitEvent(d, c->denoiseTail, 0), "denoise stream: order");
+    if (!err && fork) {
+        err = rs_check_hip(hipEventRecord(c->denoiseFork, c->stream), "denoise stream: fork");
+        if (!err) err = rs_check_hip(hipStreamWaitEvent(d, c->denoiseFork, 0), "denoise stream: fork");
+    }
+    if (err) return;
+    c->streamOverride = d; active = true;
+}
+rs_denoise_scope::~rs_denoise_scope() {
+    if (!active) return;
+    if (c->denoiseMode == 2) (void)hipEventRecord(c->denoiseTail, c->streamOverride);
+    c->denoiseLast = c->streamOverride;
+    c->streamOverride = nullptr;
+}
+
+namespace {
+inline bool inside(const rs_context::DenoiseBuf& b, const void* p) { return (const char*)p >= b.base && (const char*)p < b.base + b.bytes; }
+}
+int rs_denoise_mark(const void* base, size_t bytes, bool readOnly) {
+    rs_context* c = rs_ctx();
+    if (!c->streamOverride || !base || bytes == 0) return 0;
+    rs_context::DenoiseBuf* e = nullptr;
+    for (auto& b : c->denoiseBufs) if (b.base == (const char*)base) { e = &b; break; }
+    if (!e) {
+        if (c->denoiseBufs.size() >= 32) {              // a caller that hands over ever new buffers: order the library stream after the oldest and reuse its entry
+            e = &c->denoiseBufs[0];
+            for (auto& b : c->denoiseBufs) if (!b.pending) { e = &b; break; }
+            if (e->pending) RS_HIP(hipStreamWaitEvent(c->stream, e->ev, 0));
+        }
+        else {
+            hipEvent_t ev = nullptr;
+            RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->denoiseBufs.push_back({ nullptr, 0, ev, true, false });
+            e = &c->denoiseBufs.back();
+        }
+        e->base = (const char*)base; e->bytes = 0; e->readOnly = true; e->pending = false;
+    }
+    e->bytes = bytes > e->bytes ? bytes : e->bytes;
+    e->readOnly = e->pending ? (e->readOnly && readOnly) : readOnly;
+    e->pending = true;
+    RS_HIP(hipEventRecord(e->ev, c->streamOverride));
+    return 0;
+}
+bool rs_denoise_owns(const void* p) {
+    const rs_context* c = rs_ctx();
+    for (const auto& b : c->denoiseBufs) if (b.pending && !b.readOnly && inside(b, p)) return true;
+    return false;
+}
+int rs_denoise_order(const void* p, bool write) {
+    rs_context* c = rs_ctx();
+    if (c->denoiseBufs.empty() || c->streamOverride || !p) return 0;      // (inside a scope: in that stream's order anyway)
+    for (auto& b : c->denoiseBufs) {
+        if (!b.pending || !inside(b, p) || (b.readOnly && !write)) continue;
+        RS_HIP(hipStreamWaitEvent(c->stream, b.ev, 0));
+        b.pending = false;
+    }
+    return 0;
+}
+int rs_denoise_join() {
+    rs_context* c = rs_ctx();
+    if (c->streamOverride || !c->denoiseLast) return 0;
+    if (!c->denoiseFork) RS_HIP(hipEventCreateWithFlags(&c->denoiseFork, hipEventDisableTiming));
+    RS_HIP(hipEventRecord(c->denoiseFork, c->denoiseLast));              // (everything earlier on another stream is ordered before this stream's part: the scopes wait for each other)
+    RS_HIP(hipStreamWaitEvent(c->stream, c->denoiseFork, 0));
+    for (auto& b : c->denoiseBufs) b.pending = false;
+    return 0;
+}
+
 int rs_after_launch(const char* what) {
     RS_TRY(rs_check_hip(hipGetLastError(), what));
     if (rs_ctx()->sync) RS_TRY(rs_check_hip(hipStreamSynchronize(rs_ctx()->stream), what));
@@ -425,6 +518,10 @@ int rs_context_destroy(rs_context* c) {
         (void)rs_synchronize();
         for (hipStream_t& st : c->aux) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
         if (c->ptRayCount) { (void)hipFree(c->ptRayCount); c->ptRayCount = nullptr; }
+        for (auto& b : c->denoiseBufs) if (b.ev) (void)hipEventDestroy(b.ev);
+        c->denoiseBufs.clear();
+        if (c->denoiseFork) { (void)hipEventDestroy(c->denoiseFork); c->denoiseFork = nullptr; }
+        if (c->denoiseTail) { (void)hipEventDestroy(c->denoiseTail); c->denoiseTail = nullptr; }
     }
     if (t_current == c) t_current = nullptr;
     delete c;
@@ -502,7 +599,25 @@ int rs_synchronize(void) {
     rs_ctx_scope scope(nullptr);
     RS_TRY(rs_aux_synchronize());
     RS_TRY(rs_check_hip(hipStreamSynchronize(rs_ctx()->stream), "rs_synchronize"));
-    return rs_aux_synchronize();                        // (an auxiliary launch may have been waiting for the library stream)
+    RS_TRY(rs_aux_synchronize());                       // (an auxiliary launch may have been waiting for the library stream)
+    for (auto& b : rs_ctx()->denoiseBufs) b.pending = false;      // everything the denoise stream was handed has finished
+    return 0;
+}
+// LeveledEAWFilter (rs_eaw_filter, rs_strips_eaw_filter) and an rs_copy_image_to_pbo that reads its result on a stream of the library
+// (asynchronous launches only): 1 on, 0 off (default).  Their results are then ordered for the caller's stream by events -- every library
+// call that is handed one of those buffers waits as needed, and rs_join_denoise_stream() / rs_synchronize() do for the caller's own work.
+int rs_set_denoise_stream(int enable) {
+    rs_ctx_scope scope(nullptr);
+    rs_context* c = rs_ctx();
+    if (enable < 0 || enable > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_denoise_stream: 0, 1 or 2");
+    if (c->denoiseMode == enable) return 0;
+    RS_TRY(rs_synchronize());
+    c->denoiseMode = enable;
+    return 0;
+}
+int rs_join_denoise_stream(void) {
+    rs_ctx_scope scope(nullptr);
+    return rs_denoise_join();
 }
 
 }  // extern "C"

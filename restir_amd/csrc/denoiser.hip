@@ -595,6 +595,15 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "EAW filter: size mismatch");
     const int n = f->width * f->height;
+    const size_t imageBytes = (size_t)n * 3 * sizeof(float);
+    // rs_set_denoise_stream(1), asynchronous launches: the levels go to the denoise stream, ordered after everything enqueued on the
+    // library stream so far (phase B of this frame, the render's join above); the library stream goes on with the next frame.  What
+    // the levels read and write there is noted with the events that cover it (rs_denoise_mark): the input image up to level 0 -- the
+    // next frame's phase B writes it --, the two buffers the levels alternate between and the G-buffer set up to the last level.
+    rs_denoise_scope onDenoiseStream(true);
+    RS_TRY(onDenoiseStream.err);
+    // (no denoise stream now, but there may have been one: the library stream after that stream's last use of these buffers; inside the scope these are no-ops)
+    RS_TRY(rs_denoise_order(devColorIn, false)); RS_TRY(rs_denoise_order(*devColorOut)); RS_TRY(rs_denoise_order(f->devTempImg));
     const bool fusedPositions = f->tiled;           // the tiled level 0 computes the positions while it stages its tile
     if (!fusedPositions) {
         hipLaunchKernelGGL(k_positions, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), rs_make_cam_params(cam),
@@ -604,9 +613,15 @@ int rs_eaw_filter(rs_eaw* f, float** devColorOut, const float* devColorIn, const
     // LeveledEAWFilter::filter (denoiser.cu:463-477): level 0 into out, then four ping-pongs with the
     // internal buffer; the caller's pointer and the internal one are swapped after each
     RS_TRY(wavelet_level(f, *devColorOut, devColorIn, g, 0, 0, f->height, fusedPositions ? cam : nullptr));
+    if (onDenoiseStream.active) RS_TRY(rs_denoise_mark(devColorIn, imageBytes, true));
     for (int level = 1; level <= 4; level++) {
         RS_TRY(wavelet_level(f, f->devTempImg, *devColorOut, g, level, 0, f->height));
         float* t = *devColorOut; *devColorOut = f->devTempImg; f->devTempImg = t;
+    }
+    if (onDenoiseStream.active) {
+        RS_TRY(rs_denoise_mark(*devColorOut, imageBytes, false));
+        RS_TRY(rs_denoise_mark(f->devTempImg, imageBytes, false));
+        RS_TRY(rs_gbuffer_denoise_mark(g));
     }
     return 0;
 }
@@ -637,6 +652,7 @@ int rs_eaw_level_rows(rs_eaw* f, float* devColorOut, const float* devColorIn, co
     if (y0 < 0) y0 = 0;
     if (y1 > f->height) y1 = f->height;
     if (y1 <= y0) return 0;
+    RS_TRY(rs_denoise_order(devColorIn, false)); RS_TRY(rs_denoise_order(devColorOut));
     return wavelet_level(f, devColorOut, devColorIn, g, level, y0, y1);
 }
 
@@ -801,6 +817,7 @@ int rs_svgf_filter(rs_svgf* f, float** devColorOut, const float* devColorIn, con
     if (!f || !devColorOut || !*devColorOut || !devColorIn || !g || !cam) return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: null argument");
     if (g->width != f->width || g->height != f->height || cam->resolution[0] != f->width || cam->resolution[1] != f->height)
         return rs_fail(RS_ERR_INVALID_ARGUMENT, "SVGF filter: size mismatch");
+    RS_TRY(rs_denoise_order(devColorIn, false)); RS_TRY(rs_denoise_order(*devColorOut));
     return rs_svgf_filter_rows(f, devColorOut, devColorIn, g, cam, 0, f->height, nullptr);
 }
 
@@ -809,6 +826,7 @@ int rs_modulate_albedo(float* devImage, const rs_gbuffer* g) {
     RS_TRY(rs_gbuffer_join(g));                         // the render may still be on the auxiliary stream
     if (!devImage || !g) return rs_fail(RS_ERR_INVALID_ARGUMENT, "modulateAlbedo: null argument");
     const int n = g->width * g->height;
+    RS_TRY(rs_denoise_order(devImage));
     hipLaunchKernelGGL(k_modulate, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devImage, g->albedo[g->latest()], n);
     return rs_after_launch("modulate");
 }
@@ -817,6 +835,7 @@ int rs_add_image(float* devImage, const float* devIn, int width, int height) {
     rs_ctx_scope scope(nullptr);
     if (!devImage || !devIn || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "addImage: bad argument");
     const int n = width * height * 3;
+    RS_TRY(rs_denoise_order(devImage)); RS_TRY(rs_denoise_order(devIn, false));
     hipLaunchKernelGGL(k_add, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devImage, devImage, devIn, n);
     return rs_after_launch("addImage");
 }
@@ -825,6 +844,7 @@ int rs_add_image3(float* devOut, const float* devIn1, const float* devIn2, int w
     rs_ctx_scope scope(nullptr);
     if (!devOut || !devIn1 || !devIn2 || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "addImage: bad argument");
     const int n = width * height * 3;
+    RS_TRY(rs_denoise_order(devOut)); RS_TRY(rs_denoise_order(devIn1, false)); RS_TRY(rs_denoise_order(devIn2, false));
     hipLaunchKernelGGL(k_add, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), devOut, devIn1, devIn2, n);
     return rs_after_launch("addImage");
 }

@@ -102,6 +102,18 @@ int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream) {
         RS_HIP(hipStreamWaitEvent(stream, g->forkEv, 0));
     }
     else if (g->useOf[g->cur()] >= 0) RS_HIP(hipStreamWaitEvent(stream, g->useEv[g->useOf[g->cur()]], 0));
+    if (g->denoiseValid[g->cur()]) {                    // (five frames old by now: a wait that has long been satisfied)
+        RS_HIP(hipStreamWaitEvent(stream, g->denoiseEv[g->cur()], 0));
+        g->denoiseValid[g->cur()] = false;
+    }
+    return 0;
+}
+
+int rs_gbuffer_denoise_mark(const rs_gbuffer* g) {
+    const int c = g->cur();
+    if (!g->denoiseEv[c]) RS_HIP(hipEventCreateWithFlags(&g->denoiseEv[c], hipEventDisableTiming));
+    RS_HIP(hipEventRecord(g->denoiseEv[c], rs_stream()));
+    g->denoiseValid[c] = true;
     return 0;
 }
 
@@ -144,6 +156,7 @@ int rs_gbuffer_destroy(rs_gbuffer* g) {
     for (int i = 0; i < rs_gbuffer::kSets; i++) {
         rs_dev_free(g->albedo[i]); rs_dev_free(g->motion[i]); rs_dev_free(g->normal[i]); rs_dev_free(g->primId[i]); rs_dev_free(g->depth[i]);
         if (g->useEv[i]) (void)hipEventDestroy(g->useEv[i]);
+        if (g->denoiseEv[i]) (void)hipEventDestroy(g->denoiseEv[i]);
     }
     if (g->forkEv) (void)hipEventDestroy(g->forkEv);
     if (g->doneEv) (void)hipEventDestroy(g->doneEv);

@@ -370,6 +370,7 @@ int rs_path_trace(const rs_scene* scene, const rs_camera* cam, float* devDirectI
     RS_SCOPE(scene);
     if (!scene || !cam || !devDirectIllum || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTrace: null argument");
     RS_TRY(gi_counters());
+    RS_TRY(rs_denoise_order(devDirectIllum)); RS_TRY(rs_denoise_order(devIndirectIllum));      // images a filter on the denoise stream may still be reading
     GBufView none{};
     RS_TRY(launch_path<kModePT>(scene, cam, devDirectIllum, devIndirectIllum, nullptr, nullptr, none, looper, iter, maxDepth, 0, 0));
     RS_TRY(rs_after_launch("pathTrace"));
@@ -381,6 +382,7 @@ int rs_path_trace_indirect(const rs_scene* scene, const rs_camera* cam, float* d
     RS_SCOPE(scene);
     if (!scene || !cam || !devIndirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceIndirect: null argument");
     RS_TRY(gi_counters());
+    RS_TRY(rs_denoise_order(devIndirectIllum));
     GBufView none{};
     RS_TRY(launch_path<kModePTIndirect>(scene, cam, nullptr, devIndirectIllum, nullptr, nullptr, none, looper, iter, maxDepth, 0, 0));
     RS_TRY(rs_after_launch("pathTrace"));
@@ -401,6 +403,7 @@ int rs_restir_indirect(rs_restir* r, const rs_scene* scene, const rs_camera* cam
             RS_HIP(hipMemsetAsync(r->indResv[i], 0, n * sizeof(rs_indirect_reservoir), rs_stream()));
         }
     RS_TRY(gi_counters());
+    RS_TRY(rs_denoise_order(devIndirectIllum));
     RS_TRY(launch_path<kModeReSTIR>(scene, cam, nullptr, devIndirectIllum, r->indResv[0], r->indResv[1], gbuf_view(g), looper, iter, maxDepth,
                                     r->firstFrame ? 1 : 0, reuse));
     { rs_indirect_reservoir* t = r->indResv[0]; r->indResv[0] = r->indResv[1]; r->indResv[1] = t; }      // std::swap (:463)

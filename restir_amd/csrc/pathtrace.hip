@@ -167,6 +167,7 @@ int rs_path_trace_direct(const rs_scene* scene, const rs_camera* cam, float* dev
     if (!scene || !cam || !devDirectIllum) return rs_fail(RS_ERR_INVALID_ARGUMENT, "pathTraceDirect: null argument");
     RS_TRY(rs_check_looper(scene, looper, "pathTraceDirect"));
     RS_TRY(rs_path_trace_init());
+    RS_TRY(rs_denoise_order(devDirectIllum));           // an image a filter on the denoise stream may still be reading
     RS_HIP(hipMemsetAsync(rs_ctx()->ptRayCount, 0, 8, rs_stream()));
     const int W = cam->resolution[0], H = cam->resolution[1];
     const int tilesX = (W + 31) / 32, tilesY = (H + 7) / 8;
@@ -184,10 +185,17 @@ int rs_copy_image_to_pbo(void* devPBO, const float* devImage, int width, int hei
     rs_ctx_scope scope(nullptr);                         // no object: the thread's current context
     if (!devPBO || !devImage || width <= 0 || height <= 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "copyImageToPBO: bad argument");
     const int n = width * height;
+    // An image that the denoise stream has written (rs_set_denoise_stream(1): the result of LeveledEAWFilter) is converted there, in that
+    // stream's order -- the library stream does not wait for the filter; the display buffer is then ordered by an event like the
+    // filter's own buffers (rs_join_denoise_stream, rs_synchronize, any library call that is handed it).
+    rs_denoise_scope onDenoiseStream(!rs_denoise_owns(devPBO), rs_denoise_owns(devImage));      // (fork for a display buffer that stream has never written: after its last use on the library stream)
+    RS_TRY(onDenoiseStream.err);
+    if (!onDenoiseStream.active) { RS_TRY(rs_denoise_order(devImage, false)); RS_TRY(rs_denoise_order(devPBO)); }
     if (std::getenv("RS_EXACT_GAMMA"))      // test switch: every pixel through the double-precision power
         hipLaunchKernelGGL(k_send_image_to_pbo<true>, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
     else
         hipLaunchKernelGGL(k_send_image_to_pbo<false>, dim3((n + 255) / 256), dim3(256), 0, rs_stream(), (uchar4*)devPBO, devImage, n, toneMapping, scale);
+    if (onDenoiseStream.active) RS_TRY(rs_denoise_mark(devPBO, (size_t)n * 4, false));
     return rs_after_launch("copyImageToPBO");
 }
 

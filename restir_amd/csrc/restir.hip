@@ -899,7 +899,9 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const bool large = fusable && (long long)tilesX * ((d.y1 - d.y0 + 7) / 8) * 4 >= kFuseMinWaves;
     const bool small = fusable && !large && smallChains && parityStreams && fuseMode == 3 && r->phaseACalls == 0;
     bool fuse = fusable && (small || large || fuseMode == 2);
-    if (fuse && large && fuseMode == 3) {                         // measured choice (end_frame advances the measurement)
+    // (with a denoise stream the render's own stream is that stream: a separate render would queue behind the previous frame's filter)
+    const bool denoiseStream = asyncMode && rs_ctx()->denoiseMode == 1;      // (mode 1: auxiliary stream 0)
+    if (fuse && large && fuseMode == 3 && !denoiseStream) {        // measured choice (end_frame advances the measurement)
         if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
         r->tuneCounted = true;
         fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
@@ -907,15 +909,30 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     int kThreeStreams[rs_restir::kSmallChains];                 // the chain streams first, the render's stream (idle after a fused launch) last
     for (int i = 0; i < rs_restir::kSmallChains; i++) kThreeStreams[i] = i < 2 ? 1 + i : i == 2 ? 0 : i;
     const bool three = fuse && parityStreams && r->phaseACalls == 0;
-    // (a caller that keeps a stream of its own busy next to the frames -- the strip driver with its transfers on a stream of their own --
-    // leaves room for two chains: four streams that hand events to each other is what the device runs side by side, rs_context::chainsInFlight)
-    const int chainSlot = three ? kThreeStreams[plan->chainsInFlight >= rs_restir::kSmallChains ? r->smallChain : r->chain] : 0;
-    const hipStream_t aux = asyncMode ? rs_aux_stream(three ? chainSlot : parityStreams ? 1 + r->chain : 1) : nullptr;
+    // (a context that keeps another stream busy next to the frames -- the strip driver with its transfers on a stream of their own, the
+    // denoise stream -- leaves room for two chains, or one: four streams that hand events to each other is what the device runs side by
+    // side, rs_chains_in_flight)
+    const int inFlight = rs_chains_in_flight();
+    const int chainSlot = three ? kThreeStreams[inFlight >= rs_restir::kSmallChains ? r->smallChain : inFlight == 2 ? r->chain : 0] : 0;
+    const hipStream_t aux = asyncMode ? rs_aux_stream(three ? chainSlot : (parityStreams && inFlight >= 2) ? 1 + r->chain : 1) : nullptr;
     r->lastFused = fuse ? 1 : 0;
-    r->lastChains = !aux ? 0 : three ? (plan->chainsInFlight >= rs_restir::kSmallChains ? rs_restir::kSmallChains : rs_restir::kChains) : parityStreams ? rs_restir::kChains : 1;
+    r->lastChains = !aux ? 0 : three ? (inFlight < rs_restir::kSmallChains ? inFlight : rs_restir::kSmallChains) : (parityStreams && inFlight >= 2) ? rs_restir::kChains : 1;
     const hipStream_t st = aux ? aux : rs_stream();
-    const int splitSlot = !aux ? 0 : 1 + (three ? chainSlot : parityStreams ? 1 + r->chain : 1);     // the hints of the stream this launch goes to (rs_tilesplit.h)
+    if (aux) rs_ctx()->lastChainAux = aux;                       // (rs_set_denoise_stream(2): this frame's filter goes behind its chain)
+    const int splitSlot = !aux ? 0 : 1 + (three ? chainSlot : (parityStreams && inFlight >= 2) ? 1 + r->chain : 1);     // the hints of the stream this launch goes to (rs_tilesplit.h)
     const int splitCall = r->phaseACalls < 2 ? r->phaseACalls : 2;
+    // One frame at a time -- a caller that waits for every frame before it enqueues the next (preview.cpp:337-361) -- has nothing running
+    // next to this frame's kernels, like the synchronous mode: a launch lasts as long as its longest tile and RIS has the CUs to itself, so
+    // it takes that mode's forms (heavy tiles split four ways, the alias table in LDS for large light sets).  Asked of the previous frame's
+    // end event, never waited for: config 5 one frame in flight 3.34 -> 2.6 ms (synchronous 2.84).
+    bool idle = false;
+    if (aux && r->phaseACalls == 0) {
+        const int prevSet = (r->surfSet + rs_restir::kSurfSets - 1) % rs_restir::kSurfSets;
+        const bool finished = !r->surfFreeValid[prevSet] || hipEventQuery(r->surfFree[prevSet]) == hipSuccess;
+        r->idleStreak = finished ? (r->idleStreak < 2 ? r->idleStreak + 1 : 2) : 0;      // (two frames in a row: a pipelined caller whose device catches up once keeps its forms)
+        r->idleFrame = idle = r->idleStreak >= 2;
+    }
+    else if (aux) idle = r->idleFrame;
     if (aux) {
         if (r->phaseACalls > 0) {
             RS_HIP(hipEventRecord(r->auxFork, rs_stream()));
@@ -940,7 +957,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         const int gTilesY = (d.y1 - d.y0 + 3) / 4;                // 8x4-pixel tiles: two rays per pixel fill the wave
         const CamParams lp = rs_make_cam_params(&d.lastCam);
         TileSplit ts; int helpers = 0;
-        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, !aux ? 1 : ((long long)tilesX * gTilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, (!aux || idle) ? 1 : ((long long)tilesX * gTilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
         else RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
@@ -948,13 +965,13 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     }
     else {
         TileSplit ts; int helpers = 0;
-        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, !aux ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, (!aux || idle) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
         else RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     }
     mark(r, 1);
     const int npx = (y1 - y0) * W;
-    RS_TRY(launch_ris(scene, sp, W, y0, y1, looper, sobol, st, !aux));
+    RS_TRY(launch_ris(scene, sp, W, y0, y1, looper, sobol, st, !aux || idle));
     mark(r, 2);
     // The shadow rays of a launch that fills the chip several times over go to the library stream, behind the previous frame's
     // spatial pass: every stream then has slack against the frame period and three or four kernels are in flight at any time,
@@ -987,6 +1004,7 @@ int phase_b_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const int tilesX = (r->width + kBTileW - 1) / kBTileW, tilesY = (y1 - y0 + kBTileH - 1) / kBTileH;
     const int numTiles = tilesX * tilesY;
     RS_TRY(rs_gbuffer_join(g));
+    RS_TRY(rs_denoise_order(devDirectIllum));                   // the previous frame's filter may still be reading the image on the denoise stream
     RS_LAUNCH1(k_spatial_shade, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
                r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
     mark(r, 4);

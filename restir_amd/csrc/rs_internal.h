@@ -41,7 +41,21 @@ struct rs_context {
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory (rs_set_ris_table_pixels): -1 = the default, 64 Ki
     int fuseMode = -1;                    // deferred G-buffer render walked with the primary rays: -1 = not resolved yet (rs_set_side_stream; default: measured per rs_restir)
     int chainStreams = -1, smallChains = -1, shadowOnMain = -1;   // rs_set_stream_plan; -1: not resolved yet (environment or default)
-    int chainsInFlight = 3;               // fused launches rotate over this many streams (3; 2 while the strip driver keeps a transfer stream of its own busy)
+    int ownCommStreams = 0;               // strip drivers of this context that keep a transfer stream of their own busy (rs_strips_set_comm_stream(s, 1))
+    // The denoise stream (rs_set_denoise_stream): LeveledEAWFilter of frame f -- and the tone map that reads its result -- on auxiliary
+    // stream 0, ordered after phase B of f by an event, next to the temporal / spatial passes of frame f + 1 on the library stream.  Four
+    // streams that hand events to each other is what the device runs side by side, so the chains then take turns on
+    // TWO streams (rs_chains_in_flight).  What that stream writes is ordered for the library stream by events, not by stream order:
+    // denoiseBufs lists those buffers with the event that covers their last use there, and every entry point that is handed a raw image
+    // pointer asks rs_denoise_order() first.
+    int denoiseMode = 0;                  // 0: filters run on the library stream; 1: on auxiliary stream 0, the chains on two streams; 2: behind the frame's own chain on its stream (asynchronous mode only)
+    hipStream_t streamOverride = nullptr; // inside an rs_denoise_scope: what rs_stream() returns
+    hipStream_t lastChainAux = nullptr;   // the auxiliary stream the last phase A put its chain on (mode 2: where that frame's filter goes)
+    struct DenoiseBuf { const char* base; size_t bytes; hipEvent_t ev; bool readOnly, pending; };
+    std::vector<DenoiseBuf> denoiseBufs;  // (an entry keeps its event for the buffer's next use)
+    hipStream_t denoiseLast = nullptr;    // the stream the last scope ran on, and an event at its end: a scope on ANOTHER stream waits for it first
+    hipEvent_t denoiseTail = nullptr;
+    hipEvent_t denoiseFork = nullptr;     // library stream -> denoise stream
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
     int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): rs_set_tile_split, default 768; 0 off; negative: |value|, also for launches that overlap others
 };
@@ -67,6 +81,24 @@ hipStream_t rs_aux_stream(int i);
 hipStream_t rs_aux_stream_any(int i);                  // the same stream whatever the launch mode (null only when the side streams are switched off)
 int rs_aux_synchronize();
 int rs_internal_stream_priority();                     // the priority level the library's own streams are created at: not the caller's stream's
+int rs_chains_in_flight();                             // how many auxiliary streams the frames' chains take in turn: 3, less one per other stream of the context with work in flight (a strip driver's transfer stream, the denoise stream)
+// ---- the denoise stream (api_common.hip) ----
+hipStream_t rs_denoise_stream();                       // auxiliary stream 0 when rs_set_denoise_stream(1) is in force and launches are asynchronous, else null
+// Work for the denoise stream: the constructor orders that stream after everything enqueued on the library stream so far (`fork`) and makes
+// rs_stream() return it; the destructor restores the library stream.  Inactive (everything stays on the library stream) when there is no
+// denoise stream.
+struct rs_denoise_scope {
+    rs_context* c = nullptr;
+    hipStream_t prev = nullptr;
+    bool active = false;
+    int err = 0;
+    explicit rs_denoise_scope(bool fork, bool enable = true);
+    ~rs_denoise_scope();
+};
+int rs_denoise_mark(const void* base, size_t bytes, bool readOnly);   // inside a scope: `base` is in use on the denoise stream up to here (readOnly: only read there)
+int rs_denoise_order(const void* p, bool write = true);               // the library stream waits for the denoise stream's last use of the buffer p points into (no-op for buffers it never touched; reads do not wait for reads)
+bool rs_denoise_owns(const void* p);                                  // p points into a buffer the denoise stream has written and the library stream has not been ordered after
+int rs_denoise_join();                                                // the library stream waits for everything enqueued on the denoise stream
 
 #define RS_TRY(expr)                                       \
     do {                                                   \
@@ -204,6 +236,10 @@ struct rs_gbuffer {
     hipEvent_t useEv[kSets] = {};   // recorded by update(): the frame that ended there has been enqueued
     int useOf[kSets];       // per set: which useEv covers its last readers (-1: none outstanding)
     rs_gbuffer() { for (int i = 0; i < kSets; i++) useOf[i] = -1; }
+    // a filter on the denoise stream reads (a strip's: also writes the rows just outside the strip of) the current set after the library
+    // stream has moved on: the next render into that set waits for this event as well (rs_gbuffer_order_before_render)
+    mutable hipEvent_t denoiseEv[kSets] = {};
+    mutable bool denoiseValid[kSets] = {};
     int updates = 0;
     bool renderedSinceUpdate = false;
     mutable bool pending = false;            // a render on the auxiliary stream has not been joined yet
@@ -232,6 +268,8 @@ void rs_gbuffer_deferred_taken(const rs_gbuffer* g);
 int rs_gbuffer_release_scene(const rs_scene* scene);
 // orders `stream` after the last readers of the set a (deferred) render is about to write
 int rs_gbuffer_order_before_render(const rs_gbuffer* g, hipStream_t stream);
+// inside an rs_denoise_scope: the current set is in use on the denoise stream up to here
+int rs_gbuffer_denoise_mark(const rs_gbuffer* g);
 bool rs_fuse_enabled();
 int rs_ris_global_below();
 const rs_context* rs_stream_plan();   // the current context with chainStreams / smallChains / shadowOnMain resolved
@@ -372,6 +410,8 @@ struct rs_restir {
     bool surfFreeValid[kSurfSets] = {};
     hipEvent_t auxFork = nullptr, auxDone = nullptr;
     int phaseACalls = 0;             // since the last end_frame
+    bool idleFrame = false;          // this frame's first phase-A call found the previous frames finished (restir.hip phase_a_impl)
+    int idleStreak = 0;
     // one traversal for the G-buffer ray and the shading ray of a pixel, or two?  Measured once per scene (rs_fuse_mode() == 3):
     // frames 2..7 with two launches, 8..13 with one, timed by events on the library stream at the frame ends
     unsigned long long tuneSceneId = 0;

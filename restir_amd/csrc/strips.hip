@@ -57,8 +57,13 @@ struct rs_strips {
     // rs_strips_set_comm_stream(s, 1): the transfers on a stream of their own, ordered by events (round 2's form).
     bool commOnMain = true;
     hipStream_t commStream = nullptr;              // carries the transfers when !commOnMain: ONE stream, so that every rank issues its groups in one order
-    std::vector<Xfer> deferred;             // rs_strips_gather_begin on the library stream: its transfers ride in the next group
-    int deferredSlots = 0;                         // bit per gather slot whose transfers are still in `deferred`
+    // rs_strips_gather_begin with the transfers in a stream's own order: they ride in the next group on that stream -- [0] the library
+    // stream (the next frame's border rows), [1] the denoise stream (rs_set_denoise_stream: the tone map of a filtered image runs there,
+    // and the next group there is the next frame's filter exchanging G-buffer rows)
+    std::vector<Xfer> deferred[2];
+    int deferredSlots[2] = { 0, 0 };               // bit per gather slot whose transfers are still in `deferred`
+    bool gatherOnDenoise[4] = {};                  // per slot: its rows were written, and its transfers are ordered, on the denoise stream
+    bool ownStreamCounted = false;                 // this driver is one of rs_context::ownCommStreams
     hipEvent_t packed = nullptr, arrived = nullptr;
     static constexpr int kGatherSlots = 4;
     hipEvent_t gathered[kGatherSlots] = {};        // rs_strips_gather_begin / _end: the gather of a slot has finished
@@ -146,13 +151,15 @@ void halo_segments(SegList& l, rs_restir* r, rs_gbuffer* g, int y, int rows, cha
 // transport (RCCL), from the host side of a finished library stream otherwise.  join() makes the library stream continue after it.
 int post(rs_strips* s, const Xfer* opsIn, size_t nIn) {
     const rs_comm* c = s->comm;
-    // transfers of a gather that was begun on the library stream travel in this group (one RCCL launch per frame instead of two)
+    // transfers of a gather that was begun in this stream's order travel in this group (one RCCL launch per frame instead of two)
+    const int which = rs_ctx()->streamOverride ? 1 : 0;          // posting from inside a denoise scope: that stream's list
     std::vector<Xfer> merged;
     const Xfer* ops = opsIn; size_t n = nIn;
-    if (!s->deferred.empty()) {
+    int carried = 0;
+    if (!s->deferred[which].empty()) {
         merged.assign(opsIn, opsIn + nIn);
-        merged.insert(merged.end(), s->deferred.begin(), s->deferred.end());
-        s->deferred.clear(); s->deferredSlots = 0;
+        merged.insert(merged.end(), s->deferred[which].begin(), s->deferred[which].end());
+        s->deferred[which].clear(); carried = s->deferredSlots[which]; s->deferredSlots[which] = 0;
         ops = merged.data(); n = merged.size();
     }
     if (n == 0) return 0;
@@ -171,9 +178,14 @@ int post(rs_strips* s, const Xfer* opsIn, size_t nIn) {
     if (c->t.group_end) {                                        // RCCL: the grouped transfers are enqueued here; a host-side transport completes here
         const int e2 = c->t.group_end(c->t.ctx);
         if (err) return rs_fail(err, firstError.c_str());
-        return e2;
+        if (e2) return e2;
     }
-    return err;
+    else if (err) return err;
+    // the gathers this group carried have travelled when the carrying stream gets here (rs_strips_gather_end)
+    if (c->t.stream_ordered)
+        for (int slot = 0; slot < rs_strips::kGatherSlots; slot++)
+            if (carried & (1 << slot)) RS_HIP(hipEventRecord(s->gathered[slot], ts));
+    return 0;
 }
 int join(rs_strips* s, bool timed);
 // the `reach` rows of the current G-buffer id / normal / depth planes beyond each edge of the strip, from the neighbouring strips
@@ -322,10 +334,11 @@ int rs_strips_destroy(rs_strips* s) {
     RS_SCOPE(s);
     if (!s) return 0;
     (void)rs_synchronize();
-    if (!s->deferred.empty()) (void)post(s, nullptr, 0);      // (every rank reaches this with the same deferred gathers)
+    if (!s->deferred[0].empty()) (void)post(s, nullptr, 0);   // (every rank reaches this with the same deferred gathers)
+    if (!s->deferred[1].empty()) { rs_denoise_scope onDenoiseStream(false); if (onDenoiseStream.active) (void)post(s, nullptr, 0); }
     (void)rs_synchronize();
     if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
-    if (!s->commOnMain) rs_ctx()->chainsInFlight = 3;            // (the transfer stream is gone: three chains again)
+    if (s->ownStreamCounted) { rs_ctx()->ownCommStreams--; s->ownStreamCounted = false; }      // (the transfer stream is gone: its chain is free again)
     if (s->packed) (void)hipEventDestroy(s->packed);
     if (s->arrived) (void)hipEventDestroy(s->arrived);
     for (hipEvent_t& e : s->gathered) if (e) (void)hipEventDestroy(e);
@@ -392,9 +405,11 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
         RS_HIP(hipStreamCreateWithPriority(&s->commStream, hipStreamNonBlocking, prio));
     }
     s->commOnMain = !(ownStream && s->commStream);
-    // the transfer stream is a stream with work in flight next to the library stream: with it the frames keep TWO chains in flight, not
-    // three (five streams that hand events to each other: 0.17 -> 0.48 ms per frame on a 1/8 strip)
-    rs_ctx()->chainsInFlight = s->commOnMain ? 3 : 2;
+    // the transfer stream is a stream with work in flight next to the library stream: with it the frames keep one chain less in flight
+    // (five streams that hand events to each other: 0.17 -> 0.48 ms per frame on a 1/8 strip).  Counted per driver, so that a second
+    // driver of the context (bench.py's parity check makes one) neither takes the chain back nor gives it away (rs_chains_in_flight).
+    if (!s->commOnMain && !s->ownStreamCounted) { rs_ctx()->ownCommStreams++; s->ownStreamCounted = true; }
+    if (s->commOnMain && s->ownStreamCounted) { rs_ctx()->ownCommStreams--; s->ownStreamCounted = false; }
     return 0;
 }
 
@@ -480,6 +495,13 @@ int rs_strips_eaw_filter(rs_strips* s, rs_eaw* f, rs_gbuffer* g, const rs_camera
         for (int r = 0; r < c->world; r++)
             if (s->bounds[(size_t)r + 1] - s->bounds[(size_t)r] < reach) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_eaw_filter: strips must be at least 32 rows tall");
     const size_t image = (size_t)W * s->height * 3 * sizeof(float);
+    // rs_set_denoise_stream(1): everything below -- the exchanges included -- goes to the denoise stream, ordered after this frame's phase B
+    // by an event; the library stream goes on with the next frame.  The transfers of that stream's groups are enqueued on it (or on the
+    // driver's transfer stream, ordered against it), and the display gather of a tone map that ran there rides in its next group.
+    RS_TRY(rs_gbuffer_join(g));                                  // (the library stream's own join, before the stream changes)
+    rs_denoise_scope onDenoiseStream(true);
+    RS_TRY(onDenoiseStream.err);
+    RS_TRY(rs_denoise_order(devColor)); RS_TRY(rs_denoise_order(s->eawBuf[0])); RS_TRY(rs_denoise_order(s->eawBuf[1]));      // (no-ops on the denoise stream)
     for (int i = 0; i < 2; i++)
         if (!s->eawBuf[i]) { RS_TRY(rs_dev_alloc(&s->eawBuf[i], image / sizeof(float))); RS_HIP(hipMemsetAsync(s->eawBuf[i], 0, image, rs_stream())); }
     RS_TRY(exchange_gbuffer_rows(s, g, reach));
@@ -497,6 +519,12 @@ int rs_strips_eaw_filter(rs_strips* s, rs_eaw* f, rs_gbuffer* g, const rs_camera
             RS_TRY(join(s, false));
         }
         RS_TRY(rs_eaw_level_rows(f, out, in, g, level, y0, y1));
+        // (the image: read by level 0, its rows just outside the strip written by that level's exchange; the next frame's phase B writes it)
+        if (level == 0 && onDenoiseStream.active) RS_TRY(rs_denoise_mark(devColor, image, false));
+    }
+    if (onDenoiseStream.active) {
+        RS_TRY(rs_denoise_mark(s->eawBuf[0], image, false)); RS_TRY(rs_denoise_mark(s->eawBuf[1], image, false));
+        RS_TRY(rs_gbuffer_denoise_mark(g));
     }
     *devResult = s->eawBuf[(kLevels - 1) % 2];
     return 0;
@@ -557,6 +585,7 @@ int rs_strips_exchange_history(rs_strips* s, rs_restir* r, rs_gbuffer* g) {
     if (g->width != s->width || g->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_exchange_history: G-buffer size differs from the strips' frame");
     const rs_comm* c = s->comm;
     if (c->world == 1) return 0;
+    RS_TRY(rs_denoise_join());                                   // a filter on the denoise stream writes rows of these planes just outside the strip
     auto resvBytes = [&](int rank) { return rs_restir_rows_bytes(r, 1, s->bounds[(size_t)rank + 1] - s->bounds[(size_t)rank]); };
     auto bytesOf = [&](int rank) { return resvBytes(rank) + rs_gbuffer_rows_bytes(g, s->bounds[(size_t)rank + 1] - s->bounds[(size_t)rank]); };
     size_t others = 0;
@@ -596,6 +625,7 @@ int rs_strips_gather(rs_strips* s, void* devImage, size_t bytesPerPixel, int roo
     if (c->world == 1) return 0;
     const size_t row = (size_t)s->width * bytesPerPixel;
     char* base = (char*)devImage;
+    RS_TRY(rs_denoise_order(base + (size_t)s->y0 * row));        // rows the denoise stream wrote: the library stream after it
     std::vector<Xfer> ops;
     for (int k = 0; k < c->world; k++) {
         if (k == c->rank) continue;
@@ -625,15 +655,24 @@ int rs_strips_gather_begin(rs_strips* s, void* devImage, size_t bytesPerPixel, i
         if (root < 0 || root == k) ops.push_back({ true, base + (size_t)s->y0 * row, (size_t)(s->y1 - s->y0) * row, k });
         if (root < 0 || root == c->rank) ops.push_back({ false, base + (size_t)s->bounds[(size_t)k] * row, (size_t)(s->bounds[(size_t)k + 1] - s->bounds[(size_t)k]) * row, k });
     }
+    // rows that the denoise stream wrote (the tone map of a filtered image, rs_set_denoise_stream): the gather is ordered on that stream
+    const bool there = rs_denoise_owns(base + (size_t)s->y0 * row) && rs_denoise_stream() != nullptr;
+    s->gatherOnDenoise[slot] = there;
     if (s->commOnMain && c->t.stream_ordered) {
-        // on the library stream a gather is in order with everything else anyway: its transfers wait for the next group (the next
-        // frame's border rows), or for rs_strips_gather_end if that comes first
-        s->deferred.insert(s->deferred.end(), ops.begin(), ops.end());
-        s->deferredSlots |= 1 << slot;
+        // in the stream's own order a gather is in order with everything else anyway: its transfers wait for the next group there (the next
+        // frame's border rows; on the denoise stream the next frame's filter), or for rs_strips_gather_end if that comes first
+        const int which = there ? 1 : 0;
+        s->deferred[which].insert(s->deferred[which].end(), ops.begin(), ops.end());
+        s->deferredSlots[which] |= 1 << slot;
         s->gatherPending[slot] = true;
         return 0;
     }
-    RS_TRY(post(s, ops.data(), ops.size()));
+    {
+        rs_denoise_scope onDenoiseStream(false, there);
+        RS_TRY(onDenoiseStream.err);
+        RS_TRY(post(s, ops.data(), ops.size()));
+        if (there && root == c->rank) RS_TRY(rs_denoise_mark(base, (size_t)s->height * row, false));      // (root: the other ranks' rows arrive in that stream's order)
+    }
     if (c->t.stream_ordered) RS_HIP(hipEventRecord(s->gathered[slot], s->commStream));
     s->gatherPending[slot] = true;
     return 0;
@@ -644,7 +683,18 @@ int rs_strips_gather_end(rs_strips* s, int slot) {
     if (!s->gatherPending[slot]) return 0;
     s->gatherPending[slot] = false;
     if (s->commOnMain && s->comm->t.stream_ordered) {
-        if (s->deferredSlots & (1 << slot)) RS_TRY(post(s, nullptr, 0));      // nothing has carried them yet: a group of their own
+        if (s->gatherOnDenoise[slot]) {
+            if (s->deferredSlots[1] & (1 << slot)) {                            // nothing has carried them yet: a group of their own, on that stream
+                rs_denoise_scope onDenoiseStream(false);
+                RS_TRY(onDenoiseStream.err);
+                RS_TRY(post(s, nullptr, 0));
+            }
+            // (the next tone map into the buffer runs on the denoise stream, in order; the library stream waits for the group that carried the
+            // rows -- the previous frame's, long finished in a running sequence)
+            RS_HIP(hipStreamWaitEvent(rs_stream(), s->gathered[slot], 0));
+            return 0;
+        }
+        if (s->deferredSlots[0] & (1 << slot)) RS_TRY(post(s, nullptr, 0));   // nothing has carried them yet: a group of their own
         return 0;                                                               // (in order on the library stream: nothing to wait for)
     }
     if (s->comm->t.stream_ordered) RS_HIP(hipStreamWaitEvent(rs_stream(), s->gathered[slot], 0));

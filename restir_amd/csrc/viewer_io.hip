@@ -99,6 +99,7 @@ static int save_image(const char* path, const float* devImage, int width, int he
     unsigned char* dev = nullptr;
     RS_TRY(rs_dev_alloc(&dev, n * 4));
     int e = rs_copy_image_to_pbo(dev, devImage, width, height, toneMapping, 1.f);
+    if (!e) e = rs_denoise_join();                      // (the conversion of an image the denoise stream wrote ran there)
     std::vector<unsigned char> rgba(n * 4);
     if (!e) e = rs_check_hip(hipStreamSynchronize(rs_stream()), "rs_save_image");
     if (!e) e = rs_check_hip(hipMemcpy(rgba.data(), dev, n * 4, hipMemcpyDeviceToHost), "rs_save_image");
@@ -153,6 +154,7 @@ int rs_pbo_unmap(rs_pbo* p) {
     if (!p) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_pbo_unmap: null");
     if (!p->mapped) return 0;
     p->mapped = false;
+    RS_TRY(rs_denoise_join());                          // (rs_set_denoise_stream(1): the tone map of a filtered image ran on that stream)
     RS_HIP(hipGraphicsUnmapResources(1, &p->res, rs_stream()));
     return rs_after_launch("rs_pbo_unmap");
 }

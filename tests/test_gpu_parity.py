@@ -1034,6 +1034,70 @@ def test_overlapped_frames_equal_synchronous_frames(hip, fused):
     assert not bits_equal(a["images"][0], a["images"][-1])
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("join_every_frame", [False, True])
+def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame, mode):
+    """rs_set_denoise_stream(1): LeveledEAWFilter of frame f and the tone map of its result run on a stream of the library next to the
+    passes of frame f + 1 (src/main.cpp:160-181's order of calls, unchanged for the caller).  Fourteen frames of an orbiting camera
+    enqueued without a host synchronisation -- and, in the first variant, without the library stream ever waiting for the denoise
+    stream, so that a phase B that overwrote the image an earlier filter still reads, or a render that overwrote its G-buffer set,
+    would show -- give the display image of EVERY frame, the last filtered image, the radiance and the reservoirs of the synchronous
+    run, bit for bit.  Second variant: the caller's own copy of every filtered image after rs_join_denoise_stream().  mode 1: a stream of
+    its own (the chains on two); mode 2: behind the frame's own chain on that chain's stream."""
+    import torch
+    from restir_amd.scenes import orbit_position
+    sd = get_scene("sponza:0.2")
+    W, H, frames = 640, 360, 14
+    scene = hip_scene(hip, sd)
+
+    def run(overlapped):
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        f = hip.EAWFilter(W, H, 5)
+        out = torch.zeros_like(h.image)
+        pbos = [torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        filtered = []
+        hip.set_sync(not overlapped)
+        hip.set_denoise_stream(mode if overlapped else 0)
+        try:
+            for frame in range(frames):
+                h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.5))
+                h.gbuf.render(h.scene, h.cam)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
+                h.looper += 1
+                p = f.filter(out.data_ptr(), h.image.data_ptr(), h.gbuf, h.cam)
+                hip.copy_image_to_pbo(pbos[frame].data_ptr(), p, W, H, 2, 1.0)
+                if join_every_frame:
+                    t = torch.empty_like(h.image)
+                    if overlapped:
+                        hip.join_denoise_stream()
+                    hip.hip_memcpy_d2d_async(t.data_ptr(), p, t.numel() * 4)          # on the library (= torch's current) stream
+                    filtered.append(t)
+                h.gbuf.update(h.cam)
+            hip.synchronize()
+            torch.cuda.synchronize()
+            last = torch.empty_like(h.image)
+            hip.hip_memcpy_d2d(last.data_ptr(), p, last.numel() * 4)
+            form = h.restir.last_launch()
+        finally:
+            hip.set_sync(True)
+            hip.set_denoise_stream(0)
+        res = dict(image=h.image.cpu().numpy(), last=last.cpu().numpy(), pbos=[t.cpu().numpy() for t in pbos],
+                   filtered=[t.cpu().numpy() for t in filtered], resv=h.restir.download(1), form=form)
+        f.destroy()
+        return res
+
+    a, b = run(False), run(True)
+    if mode == 1:
+        assert b["form"][1] <= 2, b["form"]                           # the chains of the frames take turns on two streams next to the denoise stream
+    assert bits_equal(a["image"], b["image"]) and bits_equal(a["last"], b["last"])
+    for frame in range(frames):
+        assert bits_equal(a["pbos"][frame], b["pbos"][frame]), frame
+    for frame in range(len(a["filtered"])):
+        assert bits_equal(a["filtered"][frame], b["filtered"][frame]), frame
+    assert a["resv"].tobytes() == b["resv"].tobytes()
+    assert not bits_equal(a["pbos"][0], a["pbos"][-1]) and a["pbos"][-1].any()
+
+
 def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     """Default asynchronous mode: ReSTIRDirect measures once per scene whether walking the G-buffer ray with the shading ray is
     faster (frames 8..13 run fused, 2..7 and all others until the decision separately).  Whatever it picks, a full-size run of
@@ -1263,14 +1327,18 @@ def test_strip_driver_stream_ordered_ranks_on_one_gpu():
     pair) that really moves the data -- the stream-ordered path of the strip driver, which RCCL itself can only run with one rank per
     device: border rows, the display gather DEFERRED into the next frame's group (transfers on the library stream) or on the driver's own
     stream, history exchange, EAW level rows.  bench.py's per-frame calls; every frame's gathered radiance / filtered image and every
-    frame's asynchronously gathered display image equal rank 0's own full frame, static and orbiting camera: 8 modes x 6 frames."""
+    frame's asynchronously gathered display image equal rank 0's own full frame, static and orbiting camera: 8 modes x 6 frames; then 4 modes with the filter, the tone map of its
+    result and the display gather on the library's denoise stream (rs_set_denoise_stream(1)), frames enqueued without the library stream ever
+    waiting for that stream."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "restir_amd", "host", "strips_loopback_ranks")
     assert os.path.exists(exe), "restir_amd/host/strips_loopback_ranks is built by restir_amd/csrc/Makefile"
     r = subprocess.run([exe, "3", "200"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "strips_loopback_ranks ok (3 ranks)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("== full frame over 6 frames: True") == 8, r.stdout[-3000:]
+    # 8 modes on the library stream + 2 x 4 with the EAW filter, the tone map and the display gather on the denoise stream (rs_set_denoise_stream 1 and 2)
+    assert r.stdout.count("== full frame over 6 frames: True") == 16, r.stdout[-3000:]
+    assert r.stdout.count("on the denoise stream") == 8, r.stdout[-3000:]
 
 
 def test_config4_4k_eight_strips_equal_full_frame(hip):
