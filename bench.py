@@ -43,6 +43,8 @@ One JSON line is printed by rank 0; besides the contract's fields it carries
                 (tools/strip_period.py, profiles/r05_strip_period_c<config>.json): ms_per_step minus this is the wire, RCCL's launches, the ranks' skew
   ms_per_frame_single_in_flight   launches asynchronous, one frame at a time (between ms_per_step, three frames in flight, and
                 ms_per_frame_synchronous, a synchronisation after every call)
+  ms_per_step_sustained / sustained   --sustained-frames (default 2 000) more overlapped frames AFTER the timed region, in ten windows: their mean and
+                the fastest / slowest window (the driver's --steps 20 is a 20-ms burst)
   failed / error / failing_rank / phase   only when the run failed or hung: the launcher's diagnosis (which rank, in which phase)
   cpu_reference_loop  closest-hit Mrays/s of a host loop over the reference's own compiled intersection code (primary rays only)
   cpu_baseline  the CPU oracle (oracle/restir_oracle.c, OpenMP) on this box's host cores, on a bounded sample of the same workload
@@ -87,7 +89,7 @@ CONFIGS = {
 
 def profile_file(config, suffix):
     """The committed rocprofv3 summary of this command for `config` (newest round first; None if there is none)."""
-    for name in ("r05_config%d_%s" % (config, suffix), "r04_config%d_%s" % (config, suffix)) + (("r03_final2_%s" % suffix,) if config == 3 else ()):
+    for name in ("r06_config%d_%s" % (config, suffix), "r05_config%d_%s" % (config, suffix), "r04_config%d_%s" % (config, suffix)) + (("r03_final2_%s" % suffix,) if config == 3 else ()):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             return p
@@ -108,9 +110,11 @@ def pmc_traffic(config, kernel):
         return None, None, p
 
 
-def overlapped_kernel_us(config, kernel):
-    """Average duration of a kernel in the committed rocprofv3 kernel trace of this command with the frames overlapped."""
-    p = profile_file(config, "kernel_stats_overlapped.csv")
+def trace_kernel_us(config, kernel, suffix):
+    """Average duration of a kernel in a committed rocprofv3 kernel trace of this command: suffix "kernel_stats.csv" = every kernel alone on
+    one stream (RS_SIDE_STREAM=0), "kernel_stats_overlapped.csv" = `bench.py --only-timed`, whose every frame is an overlapped one (since
+    round 6; the measurement's own launches of the spatial pass carry another name, k_spatial_shade_probe)."""
+    p = profile_file(config, suffix)
     try:
         import csv
         with open(p) as fh:
@@ -124,11 +128,17 @@ def overlapped_kernel_us(config, kernel):
     return None, p
 
 
+def overlapped_kernel_us(config, kernel):
+    return trace_kernel_us(config, kernel, "kernel_stats_overlapped.csv")
+
+
 def expected_compute_only(config, world):
     """The committed compute-only frame period of an N-way split of `config` (tools/strip_period.py: every rank of the split alone on ONE
     MI355X through rs_strips_frame over a transport that moves nothing, cost-balanced heights; profiles/r05_strip_period_c<config>.json):
     what the first multi-GPU run is to be compared with -- ms_per_step minus this is the wire, RCCL's launches and the ranks' skew."""
-    p = os.path.join(ROOT, "profiles", "r05_strip_period_c%d.json" % config)
+    p = os.path.join(ROOT, "profiles", "r06_strip_period_c%d.json" % config)
+    if not os.path.exists(p):
+        p = os.path.join(ROOT, "profiles", "r05_strip_period_c%d.json" % config)
     try:
         with open(p) as fh:
             t = json.load(fh)["worlds"]
@@ -449,6 +459,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json config (3 = the headline)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames timed for cpu_baseline (0 = skip; default depends on the config)")
     ap.add_argument("--orbit", action="store_true", help="orbit the camera (runCuda animateCamera) instead of the static default")
+    ap.add_argument("--sustained-frames", type=int, default=2000, help="overlapped frames run AFTER the timed region for ms_per_step_sustained (10 windows; 0 = skip)")
+    ap.add_argument("--only-timed", action="store_true", help="stop after the timed region and the sustained frames (profiling: every frame of the process is then an overlapped one)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     WIDTH, HEIGHT, DENOISE = cfg["width"], cfg["height"], cfg["denoise"]
@@ -523,6 +535,9 @@ def main():
     # a frame that runs the denoiser on the library stream does better with the library's own streams BELOW the caller's
     # (rs_set_internal_stream_priority, before the first frame; profiles/r05_ab_stream_levels_by_workload.log)
     capi.set_internal_stream_priority(int(os.environ.get("BENCH_STREAM_LEVEL", "1" if DENOISE else "2")))
+    # BENCH_DENOISE_STREAM=1: the filter, the tone map of its result and the display gather on the library's denoise stream
+    # (rs_set_denoise_stream; measured slower on config 5, profiles/r06_ab_denoise_stream_mode1.log: default 0)
+    capi.set_denoise_stream(int(os.environ.get("BENCH_DENOISE_STREAM", "0")) if DENOISE else 0)
     min_rows = 32 if DENOISE else 8        # the EAW levels on strips reach 32 rows (rs_strips_eaw_filter)
     # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
     # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights
@@ -730,6 +745,48 @@ def main():
     # G-buffer rays: only the strip's own rows count (the +-5 halo rows a strip re-renders are overhead, not throughput)
     local_rays = backend.restir.ray_total(counted) / counted * args.steps + rows * WIDTH * args.steps
 
+    # A sustained figure next to the timed region's (the driver's --steps 20 is a burst of ~20 ms): --sustained-frames more overlapped
+    # frames in ten windows, each bracketed like the timed region (the windows' ends drain the pipeline: ten drains in all).
+    sustained = None
+    if args.sustained_frames > 0:
+        per = max(1, args.sustained_frames // 10)
+        win = []
+        for _ in range(10):
+            ts = time.perf_counter()
+            for _ in range(per):
+                frame()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=ctl_device)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            win.append(float(tt[0]) / per * 1e3)
+        sustained = {"frames": per * 10, "windows": 10, "ms_per_step": sum(win) / len(win), "min_window_ms": min(win), "max_window_ms": max(win)}
+    # the spatial pass INSIDE overlapped frames, live: two events around the pass of each of 64 more frames, kept in a ring by the library
+    # and read after the last one (rs_restir_enable_timing(r, 2) / rs_restir_spatial_times: nothing waits inside the frames)
+    backend.restir.enable_timing(2)
+    for _ in range(64):
+        frame()
+    barrier()
+    spatial_in_frame_ms = backend.restir.spatial_times(64)
+    backend.restir.enable_timing(False)
+    if args.only_timed:
+        if rank == 0:
+            print(json.dumps({"metric": "Mrays/s", "only_timed": True, "n_gpus": world, "steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3,
+                              "sustained": sustained, "spatial_in_frame_us": float(np.mean(spatial_in_frame_ms)) * 1e3 if spatial_in_frame_ms else None}), flush=True)
+        finish_gathers()
+        capi.synchronize(); torch.cuda.synchronize()
+        if driver == "c":
+            drv.destroy(); comm.destroy()
+            if rccl is not None:
+                if world > 1:
+                    dist.barrier()
+                rccl.destroy()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        set_phase("done")
+        return
+
     # latency of one frame when nothing overlaps: the reference's own mode (every call synchronises, cudaUtil.h:15)
     capi.set_sync(True)
     sync_ms = []
@@ -789,12 +846,14 @@ def main():
     backend.phase_a(77, REUSE, y0, y1)                 # (any frame number: only the duration of the pass is read)
     backend.phase_b(0, REUSE, y0, y1)
     eb = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    backend.restir.set_probe(True)                     # these launches go out as k_spatial_shade_probe: a kernel trace tells them from the frames'
     torch.cuda.synchronize()
     eb[0].record()
     for _ in range(20):
         backend.phase_b(0, REUSE, y0, y1)
     eb[1].record()
     torch.cuda.synchronize()
+    backend.restir.set_probe(False)
     spatial_b2b_us = eb[0].elapsed_time(eb[1]) / 20 * 1e3
     backend.end_frame()
     # the passes outside ReSTIRDirect (the library enqueues on the stream it was handed, which is torch's current stream here)
@@ -920,6 +979,8 @@ def main():
         spatial_single_us = float(np.median(spatial_ms)) * 1e3
         spatial_us = spatial_b2b_us
         overlapped_us, overlapped_src = overlapped_kernel_us(args.config, "k_spatial_shade")
+        alone_trace_us, alone_trace_src = trace_kernel_us(args.config, "k_spatial_shade", "kernel_stats.csv")
+        in_frame_us = float(np.mean(spatial_in_frame_ms)) * 1e3 if spatial_in_frame_ms else None
         traffic, traffic_us, traffic_src = pmc_traffic(args.config, "k_spatial_shade")
         algo_bytes = ALGO_BYTES_PER_PIXEL * WIDTH * rows
         achieved = algo_bytes / (spatial_us * 1e-6) / 1e9
@@ -931,6 +992,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_sustained": sustained["ms_per_step"] if sustained else None,
+            "sustained": sustained,
             "ms_per_frame_synchronous": float(np.median(sync_ms[2:])),
             "ms_per_frame_single_in_flight": float(np.median(single_ms[2:])),
             "higher_is_better": True,
@@ -973,8 +1036,20 @@ def main():
                          # the same kernel inside the timed region's mode shares the CUs with the kernels of the other frames: its duration
                          # there comes from the committed kernel trace of this command with the frames overlapped (events would need the
                          # host to wait inside the frames, which drains the overlap they are meant to observe)
-                         "kernel_us_in_overlapped_frame": overlapped_us,
-                         "frac_in_overlapped_frame": (algo_bytes / (overlapped_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (overlapped_us and world == 1) else None,
+                         # three figures, each with its source.  (1) `frac` above: live, events around 20 warm back-to-back launches (the 190 MB
+                         # working set fits the 256 MB Infinity Cache).  (2) the kernel alone in the committed rocprofv3 trace of this command:
+                         "kernel_us_trace_alone": alone_trace_us if world == 1 else None,
+                         "frac_trace_alone": (algo_bytes / (alone_trace_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (alone_trace_us and world == 1) else None,
+                         "trace_alone_source": ("profiles/" + os.path.basename(alone_trace_src) + " (rocprofv3 --kernel-trace, RS_SIDE_STREAM=0: every kernel alone on one stream; the "
+                                                "measurement's own launches are k_spatial_shade_probe there)") if alone_trace_src else None,
+                         # (3) inside the overlapped frames -- the mode ms_per_step times -- live: two events around the pass of each of 64 frames
+                         # run after the timed region, read after the last of them (they include the events' own 2-4 us); and the same from the
+                         # committed kernel trace of `bench.py --only-timed`, whose every frame is an overlapped one
+                         "kernel_us_in_overlapped_frame": in_frame_us,
+                         "frac_in_overlapped_frame": (algo_bytes / (in_frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if in_frame_us else None,
+                         "in_overlapped_frame_how": "HIP events around the pass in each of 64 overlapped frames after the timed region (rs_restir_enable_timing 2), mean",
+                         "kernel_us_in_overlapped_frame_trace": overlapped_us if world == 1 else None,
+                         "frac_in_overlapped_frame_trace": (algo_bytes / (overlapped_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (overlapped_us and world == 1) else None,
                          "overlapped_source": ("profiles/" + os.path.basename(overlapped_src)) if overlapped_src else None,
                          "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                          "note": "rank 0's strip; the timed span includes the wait for the halo rows" if world > 1 else "full frame"},

@@ -386,6 +386,12 @@ int  rs_restir_pass_times(rs_restir* r, float ms[4]);
  * bracketed (ms[3]) and the launches stay where the overlapped mode puts them: the pass's duration while the kernels of other
  * frames share the CUs with it. */
 int  rs_restir_enable_timing(rs_restir* r, int enable);
+/* enable_timing(r, 2) keeps the two events of the last 256 frames: their spans (ms, oldest first; *count of them, at most `capacity`).
+ * Nothing waits inside the frames -- what the pass costs while other frames' kernels share the CUs.  Waits for the library stream. */
+int  rs_restir_spatial_times(rs_restir* r, float* ms, int capacity, int* count);
+/* 1: the spatial pass is launched under the name k_spatial_shade_probe (the same code) until 0 -- for the launches a measurement
+ * makes for itself, so that a kernel trace of the process tells them from the launches of the frames. */
+int  rs_restir_set_probe(rs_restir* r, int enable);
 /* Test hook: the spatial pass estimates tap positions with the hardware sqrt/sin/cos and falls back
  * to the exact evaluation inside an error band; this returns the largest estimate error over n
  * pseudo-random samples so a test can assert the band really covers it. */

@@ -115,7 +115,7 @@ EXPORTS = [
     "rs_gbuffer_get_view", "rs_gbuffer_rows_bytes", "rs_gbuffer_rows_pack", "rs_gbuffer_rows_unpack", "rs_restir_init", "rs_restir_free", "rs_restir_reset", "rs_restir_direct",
     "rs_restir_phase_a", "rs_restir_phase_b", "rs_restir_end_frame", "rs_restir_launch_choice", "rs_restir_halo_bytes", "rs_restir_halo_pack",
     "rs_restir_halo_unpack", "rs_restir_rows_bytes", "rs_restir_rows_pack", "rs_restir_rows_unpack", "rs_restir_download", "rs_restir_upload", "rs_restir_ray_count", "rs_restir_ray_total", "rs_restir_pass_times",
-    "rs_restir_enable_timing", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_save_image_jpg", "rs_write_png", "rs_write_jpg", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_debug_sqrt_of_unit_floats_mismatches", "rs_debug_exact_ops_mismatches", "rs_debug_div_sigma_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
+    "rs_restir_enable_timing", "rs_restir_spatial_times", "rs_restir_set_probe", "rs_restir_last_launch", "rs_pbo_register", "rs_pbo_map", "rs_pbo_unmap", "rs_pbo_unregister", "rs_save_image", "rs_save_image_jpg", "rs_write_png", "rs_write_jpg", "rs_debug_tap_estimate_error", "rs_debug_sqrt_of_uniform_mismatches", "rs_debug_sqrt_of_unit_floats_mismatches", "rs_debug_exact_ops_mismatches", "rs_debug_div_sigma_mismatches", "rs_path_trace_init", "rs_path_trace_free", "rs_path_trace_direct",
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_eaw_set_fused", "rs_svgf_set_params", "rs_svgf_get_params", "rs_svgf_set_tiled", "rs_svgf_set_fused", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
@@ -223,6 +223,8 @@ def lib():
     L.rs_restir_ray_total.argtypes = [vp, ci, C.POINTER(C.c_ulonglong)]
     L.rs_restir_pass_times.argtypes = [vp, C.POINTER(cf * 4)]
     L.rs_restir_enable_timing.argtypes = [vp, ci]
+    L.rs_restir_spatial_times.argtypes = [vp, C.POINTER(cf), ci, C.POINTER(ci)]
+    L.rs_restir_set_probe.argtypes = [vp, ci]
     L.rs_path_trace_direct.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, C.POINTER(C.c_ulonglong)]
     L.rs_path_trace.argtypes = [vp, C.POINTER(Camera), vp, vp, ci, ci, ci, C.POINTER(C.c_ulonglong)]
     L.rs_path_trace_indirect.argtypes = [vp, C.POINTER(Camera), vp, ci, ci, ci, C.POINTER(C.c_ulonglong)]
@@ -808,6 +810,17 @@ class ReSTIR:
         ms = (C.c_float * 4)()
         check(lib().rs_restir_pass_times(self.handle, C.byref(ms)))
         return [float(x) for x in ms]
+
+    def spatial_times(self, capacity=256):
+        """enable_timing(2): the spatial pass's duration (ms) in each of the last frames, oldest first (rs_restir_spatial_times)."""
+        ms = (C.c_float * capacity)()
+        n = C.c_int(0)
+        check(lib().rs_restir_spatial_times(self.handle, ms, capacity, C.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
+
+    def set_probe(self, on):
+        """The spatial pass under the name k_spatial_shade_probe (a measurement's own launches; rs_restir_set_probe)."""
+        check(lib().rs_restir_set_probe(self.handle, 1 if on else 0))
 
     def destroy(self):
         if self.handle:

@@ -647,10 +647,9 @@ __device__ __forceinline__ void spatial_pixel(const DevScene& s, const SurfPlane
 #endif
 constexpr int kBandTiles = RS_K4_BAND_TILES;
 template <bool SOBOL>
-__global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
-                                                             float* __restrict__ directIllum, int iter, int looper, int reuse,
-                                                             int y0, int y1, int tilesX, int numTiles) {
-    __shared__ Staged stage[kBStageN];
+__device__ __forceinline__ void spatial_shade_block(Staged* stage, const DevScene& s, const SurfPlanes& sp, const GBufView& g, const ResvPlanes& own, const TempPlanes& temp,
+                                                    float* __restrict__ directIllum, int iter, int looper, int reuse,
+                                                    int y0, int y1, int tilesX, int numTiles) {
     RS_SETPRIO(RS_PRIO_STREAM);
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
@@ -703,6 +702,22 @@ __global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevSce
     }
     if (!inside) return;
     spatial_pixel<true, SOBOL>(s, sp, g, own, temp, stage, ox - kHalo, oy - kHalo, directIllum, iter, looper, spatial, x, y, index, rm, albedo, prev);
+}
+template <bool SOBOL>
+__global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
+                                                             float* __restrict__ directIllum, int iter, int looper, int reuse,
+                                                             int y0, int y1, int tilesX, int numTiles) {
+    __shared__ Staged stage[kBStageN];
+    spatial_shade_block<SOBOL>(stage, s, sp, g, own, temp, directIllum, iter, looper, reuse, y0, y1, tilesX, numTiles);
+}
+// The same pass under another name: the launches a measurement makes for itself (bench.py's twenty back-to-back launches behind
+// `roofline.kernel_us`; rs_restir_set_probe), so that a kernel trace of the run tells them from the launches of the frames.
+template <bool SOBOL>
+__global__ void __launch_bounds__(kBThreads, RS_K4_WAVES) k_spatial_shade_probe(DevScene s, SurfPlanes sp, GBufView g, ResvPlanes own, TempPlanes temp,
+                                                                   float* __restrict__ directIllum, int iter, int looper, int reuse,
+                                                                   int y0, int y1, int tilesX, int numTiles) {
+    __shared__ Staged stage[kBStageN];
+    spatial_shade_block<SOBOL>(stage, s, sp, g, own, temp, directIllum, iter, looper, reuse, y0, y1, tilesX, numTiles);
 }
 
 // (A rolling-window form of this pass -- a block walks a column of tiles and keeps the shared halo rows in a ring, 1.45 staged records
@@ -763,6 +778,7 @@ int rs_restir_free(rs_restir* r) {
     for (auto& perStream : r->split) for (auto& t : perStream) rs_tile_split_free(&t);
     rs_dev_free(r->indResv[0]); rs_dev_free(r->indResv[1]);
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& pair : r->spatialEv) for (hipEvent_t& e : pair) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->surfFree) if (e) (void)hipEventDestroy(e);
     for (auto& e : r->tuneEv) if (e) (void)hipEventDestroy(e);
     if (r->auxFork) (void)hipEventDestroy(r->auxFork);
@@ -823,6 +839,36 @@ int rs_restir_enable_timing(rs_restir* r, int enable) {
     RS_SCOPE(r);
     if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_enable_timing: null");
     r->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+    if (r->timing == 2) {
+        for (auto& pair : r->spatialEv) for (hipEvent_t& e : pair) if (!e) RS_HIP(hipEventCreate(&e));
+        r->spatialNext = 0;
+    }
+    return 0;
+}
+
+// the launches of the spatial pass from now on go out as k_spatial_shade_probe (same code, another name in a kernel trace): 1 on, 0 off
+int rs_restir_set_probe(rs_restir* r, int enable) {
+    RS_SCOPE(r);
+    if (!r) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_set_probe: null");
+    r->probe = enable != 0;
+    return 0;
+}
+
+// rs_restir_enable_timing(r, 2): the durations (ms) of the spatial pass in the last frames, oldest first, at most `capacity` and at most the
+// ring's 256; *count = how many.  Waits for the library stream.
+int rs_restir_spatial_times(rs_restir* r, float* ms, int capacity, int* count) {
+    RS_SCOPE(r);
+    if (!r || !ms || !count || capacity < 0) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_spatial_times: bad argument");
+    *count = 0;
+    if (r->timing != 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_restir_spatial_times: rs_restir_enable_timing(r, 2) is not in force");
+    RS_HIP(hipStreamSynchronize(rs_stream()));
+    int n = r->spatialNext < rs_restir::kSpatialRing ? r->spatialNext : rs_restir::kSpatialRing;
+    if (n > capacity) n = capacity;
+    for (int i = 0; i < n; i++) {
+        const int slot = (r->spatialNext - n + i) % rs_restir::kSpatialRing;
+        RS_HIP(hipEventElapsedTime(&ms[i], r->spatialEv[slot][0], r->spatialEv[slot][1]));
+    }
+    *count = n;
     return 0;
 }
 
@@ -1005,8 +1051,16 @@ int phase_b_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const int numTiles = tilesX * tilesY;
     RS_TRY(rs_gbuffer_join(g));
     RS_TRY(rs_denoise_order(devDirectIllum));                   // the previous frame's filter may still be reading the image on the denoise stream
-    RS_LAUNCH1(k_spatial_shade, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
-               r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
+    // timing 2: the pass of every frame between two events of a ring, never waited for here (rs_restir_spatial_times reads them later)
+    const int slot = r->timing == 2 ? r->spatialNext % rs_restir::kSpatialRing : -1;
+    if (slot >= 0) RS_HIP(hipEventRecord(r->spatialEv[slot][0], rs_stream()));
+    if (r->probe)
+        RS_LAUNCH1(k_spatial_shade_probe, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
+                   r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
+    else
+        RS_LAUNCH1(k_spatial_shade, scene->dev.sampleSeq != nullptr, dim3(numTiles), dim3(kBThreads), rs_stream(), scene->dev, surf_of(r), gbuf_view(g),
+                   r->cur, r->temp, devDirectIllum, iter, r->looper, reuse, y0, y1, tilesX, numTiles);
+    if (slot >= 0) { RS_HIP(hipEventRecord(r->spatialEv[slot][1], rs_stream())); r->spatialNext++; }
     mark(r, 4);
     return last ? rs_after_launch("ReSTIR Direct (phase B)") : rs_check_hip(hipGetLastError(), "ReSTIR Direct (phase B)");
 }

@@ -426,6 +426,10 @@ struct rs_restir {
     // timing
     int timing = 0;                  // 0 off, 1 every pass on the library stream, 2 the spatial pass only, launches as in the overlapped mode
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    static constexpr int kSpatialRing = 256;
+    hipEvent_t spatialEv[kSpatialRing][2] = {};     // timing 2: the spatial pass of the last frames between two events each (rs_restir_spatial_times)
+    int spatialNext = 0;
+    bool probe = false;              // the spatial pass goes out as k_spatial_shade_probe (rs_restir_set_probe)
 };
 
 static_assert(rs_context::kAux >= 1 + rs_restir::kChains, "one auxiliary stream for GBuffer::render and one per chain");

@@ -14,7 +14,7 @@
 // for a static and an orbiting camera, with the transfers on the library stream (the default: deferred gathers ride in the next
 // frame's group) and on the driver's own stream (rs_strips_set_comm_stream), without and with the EAW filter.
 //
-//     strips_loopback_ranks [N [SECONDS]]     N ranks (default 3, at most 4); the process ends itself after SECONDS (default 240)
+//     strips_loopback_ranks [N [SECONDS]]     N ranks (default 3, at most 8: the split BASELINE's multi-GPU configs name); the process ends itself after SECONDS (default 240)
 #include <condition_variable>
 #include <deque>
 
@@ -23,7 +23,7 @@
 namespace {
 using namespace ranks;
 
-constexpr int kMaxRanks = 4, kSlots = 8;
+constexpr int kMaxRanks = 8, kSlots = 8;
 constexpr size_t kSlotBytes = 2u << 20;
 constexpr int kFrames = 6;
 
@@ -223,6 +223,7 @@ int main(int argc, char** argv) {
     if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) { std::fprintf(stderr, "no GPU\n"); return 1; }
     const int world = argc > 1 ? std::atoi(argv[1]) : 3;
     if (world < 1 || world > kMaxRanks) { std::fprintf(stderr, "1..%d ranks\n", kMaxRanks); return 2; }
+    if (world > 6) H = 36 * world;                                 // eight ranks: 288 rows, 36 per strip (the EAW levels reach 32 rows into the neighbours)
     if (H / world < 32) { std::fprintf(stderr, "strips of fewer than 32 rows (the EAW levels reach that far)\n"); return 2; }
     start_watchdog(argc > 2 ? std::atoi(argv[2]) : 240);
     static Mailbox box;

@@ -23,7 +23,8 @@
 
 namespace ranks {
 
-constexpr int W = 320, H = 200, FRAMES = 4;
+constexpr int W = 320, FRAMES = 4;
+inline int H = 200;                                   // (strips_loopback_ranks raises it for more than six ranks: 32 rows per strip at least with the filter)
 
 inline void (*g_abort_hook)() = nullptr;             // e.g. ncclCommAbort on every communicator created so far
 inline std::mutex g_fail_mutex;

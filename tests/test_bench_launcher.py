@@ -62,6 +62,21 @@ def test_launcher_says_which_rank_died_in_which_phase(monkeypatch, phase):
         assert rec["per_rank"] and rec["per_rank"][0]["ms_per_step"] == 0.5
 
 
+def test_launcher_with_eight_ranks(monkeypatch):
+    """The command the driver's scaling run ends with, `--gpus 8`: eight children, one JSON line relayed; and when one of the eight dies in
+    the timed region, one JSON line that says so, with all eight phases."""
+    rc, out, err = _launch(monkeypatch, "ok", n=8, watchdog=240.0)
+    assert rc == 0, err
+    rec = json.loads([l for l in out.splitlines() if l.strip()][0])
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == list(range(8))
+    rc, out, err = _launch(monkeypatch, "die:timed", n=8, watchdog=240.0)
+    assert rc != 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["failed"] is True and rec["failing_rank"] == 7 and rec["phase"] == "timed" and set(rec["phases"]) == {str(r) for r in range(8)}
+
+
 def test_launcher_names_the_rank_that_hangs(monkeypatch):
     rc, out, err = _launch(monkeypatch, "hang:warmup", watchdog=25.0)
     assert rc == 124

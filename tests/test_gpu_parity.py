@@ -1341,6 +1341,18 @@ def test_strip_driver_stream_ordered_ranks_on_one_gpu():
     assert r.stdout.count("on the denoise stream") == 8, r.stdout[-3000:]
 
 
+def test_strip_driver_eight_stream_ordered_ranks_on_one_gpu():
+    """The same check with EIGHT ranks -- the split BASELINE's configs 4 and 5 name, and more processes than a one-GPU box lets a job put on
+    its card, so here the ranks are threads of one process: 288 rows, 36 per strip, all 16 modes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "restir_amd", "host", "strips_loopback_ranks")
+    assert os.path.exists(exe), "restir_amd/host/strips_loopback_ranks is built by restir_amd/csrc/Makefile"
+    r = subprocess.run([exe, "8", "500"], capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0 and "strips_loopback_ranks ok (8 ranks)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("== full frame over 6 frames: True") == 16, r.stdout[-3000:]
+
+
 def test_config4_4k_eight_strips_equal_full_frame(hip):
     """BASELINE config 4: the bench scene at 3840x2160 cut into 8 row strips with the 5-row reservoir halo -- the
     eight ranks are run one after the other on this GPU -- against the full-frame result, bit for bit."""

@@ -98,6 +98,18 @@ def test_calibrated_strips_equal_full_frame(tmp_path):
     assert np.array_equal(got.view(np.uint32), _reference(True).view(np.uint32))
 
 
+def test_eight_calibrated_strips_equal_full_frame(tmp_path):
+    """World size 8, the split BASELINE's multi-GPU configs name: calibrate_bounds' eight-way all-gather and rebalancing (identical bounds on
+    every rank, no strip below 8 rows), two neighbours for six of the ranks, the history exchange of a moving camera among eight."""
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, True, str(tmp_path), False, True), nprocs=8, join=True)
+    b = [np.load(tmp_path / f"bounds_{r}.npy") for r in range(8)]
+    assert all(np.array_equal(b[0], x) for x in b) and b[0][0][0] == 0 and b[0][-1][1] == H and len(b[0]) == 8
+    assert min(y1 - y0 for y0, y1 in b[0]) >= 8
+    got = np.concatenate([np.load(tmp_path / f"strip_{r}.npy") for r in range(8)])
+    assert np.array_equal(got.view(np.uint32), _reference(True).view(np.uint32))
+
+
 def test_eaw_on_strips_equals_full_frame_filter(tmp_path):
     """BASELINE config 5's denoiser on a tiled framebuffer: five a-trous levels per strip with the 2 << level border rows of each
     level's input (and 32 G-buffer rows once) exchanged between neighbours reproduce the full-frame LeveledEAWFilter."""
