@@ -631,6 +631,10 @@ def main():
             return pbos[0].data_ptr() + y0 * WIDTH * 4
     else:
         # ---- restir_amd/tiling.py over torch.distributed (N = 1: the plain calls) -----------------------------------------------
+        # (init_process_group / ncclCommInitRank made streams after the library had chosen its own during the calibration of the strip
+        # heights: which streams run side by side depends on every stream of the process, so it chooses again -- as the C driver's branch does)
+        if world > 1:
+            capi.choose_internal_streams_again()
         strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit, bounds=bounds)
         y0, y1 = strips.y0, strips.y1
         rows = y1 - y0

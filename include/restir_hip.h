@@ -162,6 +162,11 @@ int  rs_internal_streams_info(int* priority, double* chosenUs, double* fastestUs
 /* Chooses them again at the next overlapped launch (waits for the library's work): call after the process has made streams of its own
  * since the library's first overlapped frame -- in particular after ncclCommInitRank, which makes several. */
 int  rs_choose_internal_streams_again(void);
+/* Makes the choice now instead of at the first overlapped launch (about 25 ms; waits for the caller's stream and the candidates, not for
+ * the device) -- for a caller that wants no pause inside its first frame.  A choice is kept per caller stream and preference: rs_set_stream
+ * back to a stream the library has measured next to takes that choice again.  While the caller's stream is being captured into a graph
+ * nothing is measured: plain streams. */
+int  rs_prepare_streams(void);
 /* 1 (default): every entry point synchronises and checks errors before returning, like
  * checkCUDAError after each launch in the reference.  0: launches are only enqueued. */
 int  rs_set_sync(int sync);
@@ -438,9 +443,9 @@ typedef struct rs_transport {
 /* ncclComm: an ncclComm_t of `world` ranks created by the caller (ncclCommInitRank); librccl.so is opened at run time, the
  * transfers are ncclSend / ncclRecv (ncclUint8) inside ncclGroupStart / ncclGroupEnd on the library stream (rs_set_stream), between
  * the launch that packs the border rows and the launch that unpacks the neighbours'; rs_strips_set_comm_stream(strips, 1) puts them on
- * a stream of the strip driver instead, with phase B's interior rows next to them (measured slower by a factor of three with a transport
- * that moves nothing: it is a fifth stream that hands events to the others, and the device runs four of those side by side, DESIGN.md
- * sections 4 and 5).  Create the communicator before the first overlapped frame or call rs_choose_internal_streams_again() after it. */
+ * a stream of the strip driver instead, with phase B's interior rows next to them (a fifth stream that hands events to the others, and the
+ * device runs four of those side by side: the frames then keep two chains in flight instead of three -- 0.17 -> 0.28 ms per frame on a 1/8
+ * strip of 1080p with a transport that moves nothing, DESIGN.md sections 4 and 5).  Create the communicator before the first overlapped frame or call rs_choose_internal_streams_again() after it. */
 int  rs_comm_create_rccl(void* ncclComm, int rank, int world, rs_comm** comm);
 /* The same, naming the copy of RCCL that created ncclComm (a process can hold two: PyTorch wheels bundle their own librccl.so).
  * librcclPath NULL or "" = rs_comm_create_rccl's search: symbols the process has linked or loaded globally, else a copy already

@@ -88,14 +88,14 @@ struct Calibration {
     double chained(const hipStream_t* s, int n = 4) {
         double best = 1e30;
         for (int rep = 0; rep < 3; rep++) {
-            if (hipDeviceSynchronize() != hipSuccess) return -1;
+            for (int k = 0; k < n; k++) if (hipStreamSynchronize(s[k]) != hipSuccess) return -1;      // (these streams only: other contexts' work goes on)
             (void)hipEventRecord(begin, s[0]);
             for (int r = 0; r < 8; r++) {
                 for (int k = 0; k < n; k++) { hipLaunchKernelGGL(k_calibration_spin, dim3(1), dim3(64), 0, s[k], 2000); (void)hipEventRecord(hand[r][k], s[k]); }
                 for (int k = 0; k < n; k++) (void)hipStreamWaitEvent(s[k], hand[r][(k + 1) % n], 0);
             }
             for (int k = 0; k < n; k++) (void)hipEventRecord(end[k], s[k]);
-            if (hipDeviceSynchronize() != hipSuccess) return -1;
+            for (int k = 0; k < n; k++) if (hipEventSynchronize(end[k]) != hipSuccess) return -1;
             float worst = 0.f;
             for (int k = 0; k < n; k++) { float t = 0.f; if (hipEventElapsedTime(&t, begin, end[k]) != hipSuccess) return -1; worst = t > worst ? t : worst; }
             best = worst < best ? worst : best;
@@ -234,16 +234,42 @@ hipStream_t rs_aux_stream(int i) {
         c->auxMode = (e && e[0] == '0') ? 0 : 1;
     }
     if (c->sync || !c->auxMode || i < 0 || i >= rs_context::kAux) return nullptr;
+    const int levelKey = c->auxLevelSet ? c->auxLevel : 2;
     if (c->auxStale) {
         // rs_set_stream handed the library another stream (or rs_set_internal_stream_priority another preference) after the streams were
-        // made: they are chosen again for the new stream.  The old ones are idle (rs_set_stream waited for them) and are destroyed.
-        for (hipStream_t& st : c->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
-        c->auxStale = false;
+        // made: they are chosen for the new stream.  The old ones are idle (rs_set_stream waited for them) and are KEPT under the stream and
+        // preference they were chosen for -- a caller that alternates between two streams measures each once, not at every switch (at most
+        // four choices are kept; rs_choose_internal_streams_again forgets them all).
+        bool any = false;
+        for (hipStream_t st : c->aux) any = any || st != nullptr;
+        if (any && !c->auxPlain && !c->auxForget) {
+            rs_context::AuxChoice keep{ c->auxForStream, c->auxForLevel, {}, c->auxPriority, c->auxCalibratedUs, c->auxFastestUs };
+            for (int k = 0; k < rs_context::kAux; k++) keep.aux[k] = c->aux[k];
+            if (c->auxKept.size() >= 4) { for (hipStream_t st : c->auxKept.front().aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } c->auxKept.erase(c->auxKept.begin()); }
+            c->auxKept.push_back(keep);
+        }
+        else {
+            for (hipStream_t& st : c->aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+            if (c->auxForget) { for (auto& k : c->auxKept) for (hipStream_t st : k.aux) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } c->auxKept.clear(); }
+        }
+        for (hipStream_t& st : c->aux) st = nullptr;
+        c->auxStale = false; c->auxForget = false; c->auxPlain = false;
+        for (size_t k = 0; k < c->auxKept.size(); k++)
+            if (c->auxKept[k].caller == c->stream && c->auxKept[k].level == levelKey) {
+                for (int j = 0; j < rs_context::kAux; j++) c->aux[j] = c->auxKept[k].aux[j];
+                c->auxPriority = c->auxKept[k].priority; c->auxCalibratedUs = c->auxKept[k].chosenUs; c->auxFastestUs = c->auxKept[k].fastestUs;
+                c->auxForStream = c->stream; c->auxForLevel = levelKey;
+                c->auxKept.erase(c->auxKept.begin() + (long)k);
+                break;
+            }
     }
     if (!c->aux[i]) {
         bool any = false;
         for (hipStream_t st : c->aux) any = any || st != nullptr;
-        if (!any && !c->auxPlain && calibrate_internal_streams(c)) return c->aux[i];
+        // a stream that is being captured into a graph cannot be timed (the spins and the waits would end the capture): plain streams
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (c->stream && hipStreamIsCapturing(c->stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+        if (!any && !c->auxPlain && capturing == hipStreamCaptureStatusNone && calibrate_internal_streams(c)) { c->auxForStream = c->stream; c->auxForLevel = levelKey; return c->aux[i]; }
         c->auxPlain = true;                                 // nothing could be measured: plain streams at the level the rule names
         c->auxPriority = rs_internal_stream_priority();
         int prio = c->auxPriority;
@@ -296,8 +322,7 @@ int rs_chains_in_flight() {
 hipStream_t rs_denoise_stream() {
     rs_context* c = rs_ctx();
     if (c->denoiseMode == 0 || c->sync) return nullptr;
-    const hipStream_t first = rs_aux_stream(0);         // (null: the auxiliary streams are switched off)
-    return (c->denoiseMode == 2 && first && c->lastChainAux) ? c->lastChainAux : first;
+    return rs_aux_stream(0);                            // (null: the auxiliary streams are switched off)
 }
 rs_denoise_scope::rs_denoise_scope(bool fork, bool enable) {
     c = rs_ctx();
@@ -305,9 +330,6 @@ rs_denoise_scope::rs_denoise_scope(bool fork, bool enable) {
     const hipStream_t d = rs_denoise_stream();
     if (!d) return;
     if (!c->denoiseFork) err = rs_check_hip(hipEventCreateWithFlags(&c->denoiseFork, hipEventDisableTiming), "hipEventCreate");
-    if (!err && !c->denoiseTail) err = rs_check_hip(hipEventCreateWithFlags(&c->denoiseTail, hipEventDisableTiming), "hipEventCreate");
-    // the frames' filters take the chain streams in turn (mode 2): this one after everything the last one enqueued on ITS stream
-    if (!err && c->denoiseLast && c->denoiseLast != d) err = rs_check_hip(hipStreamWaitEvent(d, c->denoiseTail, 0), "denoise stream: order");
     if (!err && fork) {
         err = rs_check_hip(hipEventRecord(c->denoiseFork, c->stream), "denoise stream: fork");
         if (!err) err = rs_check_hip(hipStreamWaitEvent(d, c->denoiseFork, 0), "denoise stream: fork");
@@ -317,8 +339,7 @@ rs_denoise_scope::rs_denoise_scope(bool fork, bool enable) {
 }
 rs_denoise_scope::~rs_denoise_scope() {
     if (!active) return;
-    if (c->denoiseMode == 2) (void)hipEventRecord(c->denoiseTail, c->streamOverride);
-    c->denoiseLast = c->streamOverride;
+    c->denoiseUsed = true;
     c->streamOverride = nullptr;
 }
 
@@ -367,9 +388,9 @@ int rs_denoise_order(const void* p, bool write) {
 }
 int rs_denoise_join() {
     rs_context* c = rs_ctx();
-    if (c->streamOverride || !c->denoiseLast) return 0;
+    if (c->streamOverride || !c->denoiseUsed || !c->aux[0]) return 0;    // (the streams are only ever replaced behind an rs_synchronize, which clears denoiseUsed)
     if (!c->denoiseFork) RS_HIP(hipEventCreateWithFlags(&c->denoiseFork, hipEventDisableTiming));
-    RS_HIP(hipEventRecord(c->denoiseFork, c->denoiseLast));              // (everything earlier on another stream is ordered before this stream's part: the scopes wait for each other)
+    RS_HIP(hipEventRecord(c->denoiseFork, c->aux[0]));
     RS_HIP(hipStreamWaitEvent(c->stream, c->denoiseFork, 0));
     for (auto& b : c->denoiseBufs) b.pending = false;
     return 0;
@@ -412,7 +433,7 @@ void rs_tile_split_free(rs_tile_split* t) {
     rs_dev_free(t->base);
     if (t->report) { (void)hipHostFree(t->report); t->report = nullptr; }
     t->bytes = 0; t->key = -1; t->rot = 0; t->numTiles = t->capacity = 0;
-    t->issued = t->wake = 0; t->sleep = 0;
+    t->issued = t->wake = 0; t->sleep = 0; t->lastNone = false;
 }
 constexpr int kTileSplitSleep = 29;
 int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int regularBlocks, int mode, hipStream_t st, rs::TileSplit* ts, int* helperBlocks) {
@@ -452,6 +473,7 @@ int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int reg
     const size_t bytes = flagOffset + 3 * flagStride;
     if (t->bytes < bytes) {                         // (hipFree waits for the device: nothing in flight reads the old arrays)
         rs_dev_free(t->base);
+        t->bytes = 0; t->key = -1;                  // (if the allocation below fails, the next launch tries again instead of clearing a null array)
         unsigned char* p = nullptr;
         RS_TRY(rs_dev_alloc(&p, bytes));
         t->base = reinterpret_cast<int*>(p); t->bytes = bytes; t->key = -1;
@@ -517,11 +539,12 @@ int rs_context_destroy(rs_context* c) {
         rs_ctx_scope scope(c);
         (void)rs_synchronize();
         for (hipStream_t& st : c->aux) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+        for (auto& k : c->auxKept) for (hipStream_t st : k.aux) if (st) (void)hipStreamDestroy(st);
+        c->auxKept.clear();
         if (c->ptRayCount) { (void)hipFree(c->ptRayCount); c->ptRayCount = nullptr; }
         for (auto& b : c->denoiseBufs) if (b.ev) (void)hipEventDestroy(b.ev);
         c->denoiseBufs.clear();
         if (c->denoiseFork) { (void)hipEventDestroy(c->denoiseFork); c->denoiseFork = nullptr; }
-        if (c->denoiseTail) { (void)hipEventDestroy(c->denoiseTail); c->denoiseTail = nullptr; }
     }
     if (t_current == c) t_current = nullptr;
     delete c;
@@ -558,7 +581,15 @@ int rs_internal_streams_info(int* priority, double* chosenUs, double* fastestUs)
 int rs_choose_internal_streams_again(void) {
     rs_context* c = rs_ctx();
     RS_TRY(rs_synchronize());
-    c->auxStale = true; c->auxPlain = false; c->auxWant = -99;
+    c->auxStale = true; c->auxForget = true; c->auxPlain = false; c->auxWant = -99;
+    return 0;
+}
+// Makes the choice NOW (about 25 ms: spins on the caller's stream and on twelve candidate streams, waits for those streams only) instead of
+// at the first overlapped launch -- for a caller that wants no such pause inside its first frame.  No-op when launches are synchronous,
+// the side streams are off, or a choice for the current stream and preference is in force.
+int rs_prepare_streams(void) {
+    rs_ctx_scope scope(nullptr);
+    (void)rs_aux_stream(0);
     return 0;
 }
 int rs_set_internal_stream_priority(int level) {
@@ -601,6 +632,7 @@ int rs_synchronize(void) {
     RS_TRY(rs_check_hip(hipStreamSynchronize(rs_ctx()->stream), "rs_synchronize"));
     RS_TRY(rs_aux_synchronize());                       // (an auxiliary launch may have been waiting for the library stream)
     for (auto& b : rs_ctx()->denoiseBufs) b.pending = false;      // everything the denoise stream was handed has finished
+    rs_ctx()->denoiseUsed = false;
     return 0;
 }
 // LeveledEAWFilter (rs_eaw_filter, rs_strips_eaw_filter) and an rs_copy_image_to_pbo that reads its result on a stream of the library
@@ -609,7 +641,7 @@ int rs_synchronize(void) {
 int rs_set_denoise_stream(int enable) {
     rs_ctx_scope scope(nullptr);
     rs_context* c = rs_ctx();
-    if (enable < 0 || enable > 2) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_denoise_stream: 0, 1 or 2");
+    if (enable != 0 && enable != 1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_denoise_stream: 0 or 1");
     if (c->denoiseMode == enable) return 0;
     RS_TRY(rs_synchronize());
     c->denoiseMode = enable;

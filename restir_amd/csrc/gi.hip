@@ -37,8 +37,9 @@ __device__ inline float primitive_area(const DevScene& s, int prim) {
 // A three-vector kept in LDS, one column per thread (component k of thread t at p[k * 256 + t]: conflict-free).  The path loop's cold
 // state -- the radiance sums, touched once or twice per bounce, and ReSTIR-GI's four recorded points, written once per path -- lived in
 // registers the compiler had to spill around the walks (72 VGPRs at 7 blocks per CU; 172-268 bytes of scratch per lane, 310 scratch
-// instructions per bounce and wave, every one of them a trip to L2: a CU's 28 waves keep 360 KB of scratch behind a 32 KB L1).  21 floats
-// per lane of LDS the kernel did not use otherwise (18 KB per block, 7 blocks per CU = 126 of 160 KB).
+// instructions per bounce and wave, every one of them a trip to L2: a CU's 28 waves keep 360 KB of scratch behind a 32 KB L1).  Round 5: 6 / 9
+// / 21 columns (pathTraceIndirect / pathTrace / ReSTIR-GI: 21.5 KB per block, 150 of 160 KB at 7 blocks per CU); round 6: with the surface
+// state below 19 / 22 / 22 columns = 19.5 / 22.5 / 22.5 KB per block, 136 / 158 / 158 KB per CU -- the kernel uses no other LDS.
 #ifndef RS_PATH_COLD_LDS
 #define RS_PATH_COLD_LDS 1
 #endif
@@ -57,13 +58,54 @@ struct Cold3 {
     __device__ __forceinline__ void add(f3 x) { v = v + x; }
 };
 #endif
+// The surface state a bounce carries across its shadow-ray walk -- the material (7 words), the shading normal and wo -- is dead weight
+// inside the walk and was the bulk of what the compiler parked in scratch around it.  Path tracing keeps it in LDS as well (13 more
+// columns: 22 floats per lane for pathTrace, 19 for pathTraceIndirect and ReSTIR-GI, which is what 7 blocks per CU leave of the 160 KB;
+// ReSTIR-GI's recorded points, which took 12 columns in round 5, wait in the output array instead: Glob3 below).
+template <bool IN_LDS> struct ColdSurf;
+template <> struct ColdSurf<true> {
+    float* p;
+    __device__ __forceinline__ SurfMat mat() const { SurfMat m; m.type = __float_as_int(p[0]); m.baseColor = mk3(p[256], p[512], p[768]); m.metallic = p[1024]; m.roughness = p[1280]; m.ior = p[1536]; return m; }
+    __device__ __forceinline__ int type() const { return __float_as_int(p[0]); }
+    __device__ __forceinline__ void set_mat(const SurfMat& m) { p[0] = __int_as_float(m.type); p[256] = m.baseColor.x; p[512] = m.baseColor.y; p[768] = m.baseColor.z; p[1024] = m.metallic; p[1280] = m.roughness; p[1536] = m.ior; }
+    __device__ __forceinline__ f3 norm() const { return mk3(p[1792], p[2048], p[2304]); }
+    __device__ __forceinline__ void set_norm(f3 n) { p[1792] = n.x; p[2048] = n.y; p[2304] = n.z; }
+    __device__ __forceinline__ f3 wo() const { return mk3(p[2560], p[2816], p[3072]); }
+    __device__ __forceinline__ void set_wo(f3 w) { p[2560] = w.x; p[2816] = w.y; p[3072] = w.z; }
+};
+template <> struct ColdSurf<false> {
+    SurfMat m; f3 n, w;
+    __device__ __forceinline__ SurfMat mat() const { return m; }
+    __device__ __forceinline__ int type() const { return m.type; }
+    __device__ __forceinline__ void set_mat(const SurfMat& x) { m = x; }
+    __device__ __forceinline__ f3 norm() const { return n; }
+    __device__ __forceinline__ void set_norm(f3 x) { n = x; }
+    __device__ __forceinline__ f3 wo() const { return w; }
+    __device__ __forceinline__ void set_wo(f3 x) { w = x; }
+};
+#ifndef RS_PATH_SURF_LDS
+#define RS_PATH_SURF_LDS 1
+#endif
+// ReSTIR-GI's four recorded points (xv, nv at the first hit, xs, ns at the second: restir.cu:316-321,345-360) are written once per path and read
+// once after it: they wait in the pixel's slot of the OUTPUT reservoir array (which the kernel overwrites at its end anyway, and which is not
+// the array the temporal neighbour is read from), so that the LDS columns they took hold the surface state instead.
+struct Glob3 {
+    float* p;
+    __device__ __forceinline__ f3 get() const { return ld3(p); }
+    __device__ __forceinline__ void set(f3 v) const { st3(p, v); }
+};
 struct PathState {
     Cold3 direct, indirect;       // kModePT: direct / indirect; others: indirect only (ReSTIR: the sample's Lo)
     Cold3 throughput;
     // ReSTIR-GI bookkeeping (restir.cu:273-281,316-321)
-    float primSamplePdf; bool primSampleDelta; f3 primWo; SurfMat primMaterial;     // (primMaterial: textured scenes only; a plain material is read again from its id)
+    float primSamplePdf; bool primSampleDelta; SurfMat primMaterial;     // (primMaterial: textured scenes only; a plain material is read again from its id)
+    Cold3 primWo;                 // (ReSTIR-GI: live from the primary hit to the end of the path)
     int primMatId;
+#if RS_PATH_COLD_LDS && RS_PATH_SURF_LDS
+    Glob3 xv, nv, xs, ns;
+#else
     Cold3 xv, nv, xs, ns;
+#endif
     int walks;
 };
 
@@ -72,18 +114,21 @@ struct PathState {
 // wave-level shadow-tree walk (trace_occluded_wave) and the continuation rays the pair-cooperative walk
 // (trace_closest_wave) instead of per-lane walks inside a divergent loop.  Per lane the sequence of
 // random draws and arithmetic is that of the reference.
-template <int MODE, bool TEX, typename Sampler>
-__device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray ray, Sampler& rng, int maxDepth, bool alive, PathState& st) {
+template <int MODE, bool TEX, typename Sampler, typename Surf>
+__device__ inline void path_loop(const DevScene& s, Hit h, Surf& surf, Ray ray, Sampler& rng, int maxDepth, bool alive, PathState& st) {
     Cold3& throughputC = st.throughput;
     throughputC.set(splat(1.f));
 #define throughput throughputC.get()
-    f3 norm = h.norm, pos = h.pos;
-    f3 wo = -ray.d;
+    f3 pos = h.pos;
+    surf.set_norm(h.norm); surf.set_wo(-ray.d);
     const bool env = TEX && s.envTex >= 0;
     for (int depth = 1; depth <= maxDepth; depth++) {
         if (!__any(alive)) break;
-        const bool deltaBSDF = material.type == 2;
-        if (alive && material.type != 2 && dot(norm, wo) < 0.f) norm = -norm;
+        const bool deltaBSDF = surf.type() == 2;
+        {
+            const f3 n0 = surf.norm();
+            if (alive && !deltaBSDF && dot(n0, surf.wo()) < 0.f) surf.set_norm(-n0);
+        }
 
         // next-event estimation (pathtrace.cu:203-213 / 365-376, restir.cu:291-302): sampleDirectLight = light sample,
         // occlusion test towards it, then the single-sided / pdf part
@@ -103,6 +148,8 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
         f3 add = splat(0.f);
         const bool valid = nee && c.pdf > 0.f;
         if (valid) {
+            const SurfMat material = surf.mat();
+            const f3 norm = surf.norm(), wo = surf.wo();
             const float bsdfPdf = material_pdf(material, norm, wo, c.wi);
             add = ((((throughput * material_bsdf(material, norm, wo, c.wi)) * c.Li) * sat_dot(norm, c.wi)) / c.pdf) * power_heuristic(c.pdf, bsdfPdf);
         }
@@ -118,9 +165,11 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
         BsdfSample sample;
         sample.dir = splat(0.f); sample.bsdf = splat(0.f); sample.pdf = 0.f; sample.type = kBsInvalid;
         bool deltaSample = false;
+        f3 norm = splat(0.f);
         if (alive) {
             const f3 r3 = mk3(rng.uniform(), rng.uniform(), rng.uniform());    // sample3D
-            sample = material_sample(material, norm, wo, r3);
+            norm = surf.norm();
+            sample = material_sample(surf.mat(), norm, surf.wo(), r3);
             if (sample.type == kBsInvalid) alive = false;
             else if (sample.pdf < 1e-8f) alive = false;
         }
@@ -146,7 +195,7 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
         h = trace_closest_wave(s, ray, walk);
         if (alive) {
             st.walks++;
-            wo = -ray.d;
+            surf.set_wo(-ray.d);
             if (h.primId == kNullPrim) {
                 if (env) {
                     const f3 radiance = env_radiance(s, ray.d) * throughput;
@@ -157,7 +206,8 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
             }
             else {
                 pos = h.pos; norm = h.norm;
-                material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+                const SurfMat material = TEX ? textured_material(s, h, norm) : plain_material(s, h.matId);
+                surf.set_mat(material); surf.set_norm(norm);
                 if (material.type == 4) {
                     if (!(dot(norm, ray.d) < 0.f)) {                            // SCENE_LIGHT_SINGLE_SIDED: the back side ends the path silently
                         const f3 radiance = material.baseColor;
@@ -175,6 +225,7 @@ __device__ inline void path_loop(const DevScene& s, Hit h, SurfMat material, Ray
         }
     }
 #undef throughput
+
 }
 
 __device__ __forceinline__ void accumulate(float* image, int index, f3 v, int iter) {
@@ -220,16 +271,30 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
     const Hit h = trace_closest_packet(s, ray, inside);                // all 64 lanes take part in the wave's walk
     PathState st;
 #if RS_PATH_COLD_LDS
-    __shared__ float sCold[(MODE == kModeReSTIR ? 21 : MODE == kModePT ? 9 : 6) * 256];
+    constexpr bool kSurfLds = RS_PATH_SURF_LDS != 0;
+    constexpr int kColdCols = MODE == kModePT ? 9 : (MODE == kModeReSTIR && !kSurfLds) ? 21 : 6;
+    constexpr int kPrimWoCols = (MODE == kModeReSTIR && kSurfLds) ? 3 : 0;
+    __shared__ float sCold[(kColdCols + (kSurfLds ? 13 : 0) + kPrimWoCols) * 256];
     st.indirect.p = sCold + threadIdx.x;
-    st.throughput.p = sCold + (MODE == kModeReSTIR ? 18 : MODE == kModePT ? 6 : 3) * 256 + threadIdx.x;
+    st.throughput.p = sCold + (kColdCols - 3) * 256 + threadIdx.x;
     st.direct.p = MODE == kModePT ? sCold + 3 * 256 + threadIdx.x : st.indirect.p;                 // (only kModePT has a direct sum)
+#if RS_PATH_SURF_LDS
+    {
+        float* slot = reinterpret_cast<float*>(resvOut + (MODE == kModeReSTIR && inside ? index : 0));      // (other modes: never touched)
+        st.xv.p = slot + 3; st.nv.p = slot + 6; st.xs.p = slot + 9; st.ns.p = slot + 12;
+    }
+#else
     st.xv.p = st.nv.p = st.xs.p = st.ns.p = st.indirect.p;
     if (MODE == kModeReSTIR) { st.xv.p = sCold + 6 * 256 + threadIdx.x; st.nv.p = st.xv.p + 3 * 256; st.xs.p = st.xv.p + 6 * 256; st.ns.p = st.xv.p + 9 * 256; }
 #endif
-    st.direct.set(splat(0.f)); st.indirect.set(splat(0.f)); st.primSamplePdf = 0.f; st.primSampleDelta = false; st.primWo = -ray.d;
+#endif
+#if RS_PATH_COLD_LDS
+    st.primWo.p = kPrimWoCols ? sCold + (kColdCols + 13) * 256 + threadIdx.x : st.indirect.p;
+#endif
+    st.direct.set(splat(0.f)); st.indirect.set(splat(0.f)); st.primSamplePdf = 0.f; st.primSampleDelta = false;
+    if (MODE == kModeReSTIR) st.primWo.set(-ray.d);
     st.primMaterial = SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f }; st.primMatId = -1;
-    if (MODE == kModeReSTIR) { st.xv.set(splat(0.f)); st.nv.set(splat(0.f)); st.xs.set(splat(0.f)); st.ns.set(splat(0.f)); }
+    if (MODE == kModeReSTIR && (inside || !(RS_PATH_COLD_LDS && RS_PATH_SURF_LDS))) { st.xv.set(splat(0.f)); st.nv.set(splat(0.f)); st.xs.set(splat(0.f)); st.ns.set(splat(0.f)); }
     st.walks = 0;
     // primary hit (pathtrace.cu:172-190 / 343-350, restir.cu:259-270); lanes that end here keep alive = false
     bool alive = false;
@@ -254,7 +319,14 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
             }
         }
     }
-    path_loop<MODE, TEX, SamplerT<SOBOL>>(s, hh, material, ray, rng, maxDepth, alive, st);                // every lane of the wave takes part
+#if RS_PATH_COLD_LDS
+    ColdSurf<kSurfLds> surf;
+    if constexpr (kSurfLds) surf.p = sCold + kColdCols * 256 + threadIdx.x;
+#else
+    ColdSurf<false> surf;
+#endif
+    surf.set_mat(material);
+    path_loop<MODE, TEX, SamplerT<SOBOL>>(s, hh, surf, ray, rng, maxDepth, alive, st);                // every lane of the wave takes part
     if (inside) {
         if (MODE == kModePT) {
             f3 direct = st.direct.get(), indirect = st.indirect.get();
@@ -308,7 +380,7 @@ __global__ void __launch_bounds__(256, RS_PATH_BLOCKS) k_path(DevScene s, CamPar
                 const f3 primWi = normalize(rv.xs - rv.xv);
                 indirect = ((rv.Lo / luminance(rv.Lo)) * rv.W) / (float)rv.M;
                 const SurfMat primMaterial = TEX ? st.primMaterial : (st.primMatId >= 0 ? plain_material(s, st.primMatId) : SurfMat{ 0, splat(0.f), 0.f, 0.f, 0.f });
-                indirect = indirect * (material_bsdf(primMaterial, rv.nv, st.primWo, primWi) * (st.primSampleDelta ? 1.f : sat_dot(rv.nv, primWi)));
+                indirect = indirect * (material_bsdf(primMaterial, rv.nv, st.primWo.get(), primWi) * (st.primSampleDelta ? 1.f : sat_dot(rv.nv, primWi)));
             }
             if (any_nan_or_inf(indirect)) indirect = splat(0.f);
             ind_store(resvOut + index, rv);

@@ -946,7 +946,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     const bool small = fusable && !large && smallChains && parityStreams && fuseMode == 3 && r->phaseACalls == 0;
     bool fuse = fusable && (small || large || fuseMode == 2);
     // (with a denoise stream the render's own stream is that stream: a separate render would queue behind the previous frame's filter)
-    const bool denoiseStream = asyncMode && rs_ctx()->denoiseMode == 1;      // (mode 1: auxiliary stream 0)
+    const bool denoiseStream = asyncMode && rs_ctx()->denoiseMode == 1;
     if (fuse && large && fuseMode == 3 && !denoiseStream) {        // measured choice (end_frame advances the measurement)
         if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
         r->tuneCounted = true;
@@ -964,7 +964,6 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     r->lastFused = fuse ? 1 : 0;
     r->lastChains = !aux ? 0 : three ? (inFlight < rs_restir::kSmallChains ? inFlight : rs_restir::kSmallChains) : (parityStreams && inFlight >= 2) ? rs_restir::kChains : 1;
     const hipStream_t st = aux ? aux : rs_stream();
-    if (aux) rs_ctx()->lastChainAux = aux;                       // (rs_set_denoise_stream(2): this frame's filter goes behind its chain)
     const int splitSlot = !aux ? 0 : 1 + (three ? chainSlot : (parityStreams && inFlight >= 2) ? 1 + r->chain : 1);     // the hints of the stream this launch goes to (rs_tilesplit.h)
     const int splitCall = r->phaseACalls < 2 ? r->phaseACalls : 2;
     // One frame at a time -- a caller that waits for every frame before it enqueues the next (preview.cpp:337-361) -- has nothing running

@@ -36,6 +36,10 @@ struct rs_context {
     bool auxLevelSet = false; int auxLevel = 0;   // rs_set_internal_stream_priority
     bool auxStale = false;                // the auxiliary streams were chosen for another caller stream / preference: choose again on next use
     bool auxPlain = false;                // the choice by measurement failed once: plain streams from then on
+    bool auxForget = false;               // rs_choose_internal_streams_again: the kept choices are dropped as well
+    hipStream_t auxForStream = nullptr; int auxForLevel = 2;     // the caller stream and the preference the current three were chosen for
+    struct AuxChoice { hipStream_t caller; int level; hipStream_t aux[RS_AUX_STREAMS]; int priority; double chosenUs, fastestUs; };
+    std::vector<AuxChoice> auxKept;       // choices made for other caller streams / preferences (rs_set_stream back to one of them takes its three again)
     double auxCalibratedUs = 0, auxFastestUs = 0;   // the chosen triple's calibration time and the fastest of all candidates (rs_internal_streams_info)
     int auxMode = -1;                     // -1: not decided yet (RS_SIDE_STREAM); 0 off; 1 on
     int risGlobalBelow = -1;              // launches of fewer pixels read the RIS light table from global memory (rs_set_ris_table_pixels): -1 = the default, 64 Ki
@@ -48,13 +52,11 @@ struct rs_context {
     // TWO streams (rs_chains_in_flight).  What that stream writes is ordered for the library stream by events, not by stream order:
     // denoiseBufs lists those buffers with the event that covers their last use there, and every entry point that is handed a raw image
     // pointer asks rs_denoise_order() first.
-    int denoiseMode = 0;                  // 0: filters run on the library stream; 1: on auxiliary stream 0, the chains on two streams; 2: behind the frame's own chain on its stream (asynchronous mode only)
+    int denoiseMode = 0;                  // 0: filters run on the library stream; 1: on auxiliary stream 0, the chains on two streams (asynchronous mode only)
     hipStream_t streamOverride = nullptr; // inside an rs_denoise_scope: what rs_stream() returns
-    hipStream_t lastChainAux = nullptr;   // the auxiliary stream the last phase A put its chain on (mode 2: where that frame's filter goes)
     struct DenoiseBuf { const char* base; size_t bytes; hipEvent_t ev; bool readOnly, pending; };
     std::vector<DenoiseBuf> denoiseBufs;  // (an entry keeps its event for the buffer's next use)
-    hipStream_t denoiseLast = nullptr;    // the stream the last scope ran on, and an event at its end: a scope on ANOTHER stream waits for it first
-    hipEvent_t denoiseTail = nullptr;
+    bool denoiseUsed = false;             // the denoise stream has carried work since the last rs_synchronize
     hipEvent_t denoiseFork = nullptr;     // library stream -> denoise stream
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
     int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): rs_set_tile_split, default 768; 0 off; negative: |value|, also for launches that overlap others

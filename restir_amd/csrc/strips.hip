@@ -396,9 +396,10 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
     RS_TRY(rs_synchronize());
     if (s->commStream) RS_HIP(hipStreamSynchronize(s->commStream));
     // (In the caller's priority pool.  Whichever pool it is in, this is a FIFTH stream with work in flight next to the library stream and
-    // three chains, and the device runs four queues at a time: a 1/8 strip 0.166 -> 0.48 ms per frame with a transport that moves
-    // nothing, exactly like a fourth chain -- profiles/r05_ab_four_chains.log.  The form exists for a machine where RCCL's kernel on
-    // the library stream costs more than that; bench.py times both and keeps this one only if it wins by 3 %.)
+    // three chains, and the device runs four queues at a time (a 1/8 strip 0.166 -> 0.48 ms per frame with a transport that moves
+    // nothing, exactly like a fourth chain -- profiles/r05_ab_four_chains.log), so with it the frames keep two chains in flight: 0.28 ms.
+    // The form exists for a machine where RCCL's kernel on the library stream costs more than that difference; bench.py times both and
+    // keeps this one only if it wins by 3 %.)
     if (ownStream && !s->commStream && s->comm->world > 1) {
         int prio = 0;
         if (rs_stream() && hipStreamGetPriority(rs_stream(), &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
@@ -406,7 +407,7 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
     }
     s->commOnMain = !(ownStream && s->commStream);
     // the transfer stream is a stream with work in flight next to the library stream: with it the frames keep one chain less in flight
-    // (five streams that hand events to each other: 0.17 -> 0.48 ms per frame on a 1/8 strip).  Counted per driver, so that a second
+    // (five streams that hand events to each other: 0.17 -> 0.48 ms per frame on a 1/8 strip; with two chains 0.28).  Counted per driver, so that a second
     // driver of the context (bench.py's parity check makes one) neither takes the chain back nor gives it away (rs_chains_in_flight).
     if (!s->commOnMain && !s->ownStreamCounted) { rs_ctx()->ownCommStreams++; s->ownStreamCounted = true; }
     if (s->commOnMain && s->ownStreamCounted) { rs_ctx()->ownCommStreams--; s->ownStreamCounted = false; }

@@ -1034,16 +1034,14 @@ def test_overlapped_frames_equal_synchronous_frames(hip, fused):
     assert not bits_equal(a["images"][0], a["images"][-1])
 
 
-@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("join_every_frame", [False, True])
-def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame, mode):
+def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame):
     """rs_set_denoise_stream(1): LeveledEAWFilter of frame f and the tone map of its result run on a stream of the library next to the
     passes of frame f + 1 (src/main.cpp:160-181's order of calls, unchanged for the caller).  Fourteen frames of an orbiting camera
     enqueued without a host synchronisation -- and, in the first variant, without the library stream ever waiting for the denoise
     stream, so that a phase B that overwrote the image an earlier filter still reads, or a render that overwrote its G-buffer set,
     would show -- give the display image of EVERY frame, the last filtered image, the radiance and the reservoirs of the synchronous
-    run, bit for bit.  Second variant: the caller's own copy of every filtered image after rs_join_denoise_stream().  mode 1: a stream of
-    its own (the chains on two); mode 2: behind the frame's own chain on that chain's stream."""
+    run, bit for bit.  Second variant: the caller's own copy of every filtered image after rs_join_denoise_stream()."""
     import torch
     from restir_amd.scenes import orbit_position
     sd = get_scene("sponza:0.2")
@@ -1057,7 +1055,7 @@ def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame, mode):
         pbos = [torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(frames)]
         filtered = []
         hip.set_sync(not overlapped)
-        hip.set_denoise_stream(mode if overlapped else 0)
+        hip.set_denoise_stream(1 if overlapped else 0)
         try:
             for frame in range(frames):
                 h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.5))
@@ -1087,8 +1085,7 @@ def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame, mode):
         return res
 
     a, b = run(False), run(True)
-    if mode == 1:
-        assert b["form"][1] <= 2, b["form"]                           # the chains of the frames take turns on two streams next to the denoise stream
+    assert b["form"][1] <= 2, b["form"]                               # the chains of the frames take turns on two streams next to the denoise stream
     assert bits_equal(a["image"], b["image"]) and bits_equal(a["last"], b["last"])
     for frame in range(frames):
         assert bits_equal(a["pbos"][frame], b["pbos"][frame]), frame
@@ -1336,21 +1333,21 @@ def test_strip_driver_stream_ordered_ranks_on_one_gpu():
     assert os.path.exists(exe), "restir_amd/host/strips_loopback_ranks is built by restir_amd/csrc/Makefile"
     r = subprocess.run([exe, "3", "200"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "strips_loopback_ranks ok (3 ranks)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    # 8 modes on the library stream + 2 x 4 with the EAW filter, the tone map and the display gather on the denoise stream (rs_set_denoise_stream 1 and 2)
-    assert r.stdout.count("== full frame over 6 frames: True") == 16, r.stdout[-3000:]
-    assert r.stdout.count("on the denoise stream") == 8, r.stdout[-3000:]
+    # 8 modes on the library stream + 4 with the EAW filter, the tone map and the display gather on the denoise stream (rs_set_denoise_stream)
+    assert r.stdout.count("== full frame over 6 frames: True") == 12, r.stdout[-3000:]
+    assert r.stdout.count("on the denoise stream") == 4, r.stdout[-3000:]
 
 
 def test_strip_driver_eight_stream_ordered_ranks_on_one_gpu():
     """The same check with EIGHT ranks -- the split BASELINE's configs 4 and 5 name, and more processes than a one-GPU box lets a job put on
-    its card, so here the ranks are threads of one process: 288 rows, 36 per strip, all 16 modes."""
+    its card, so here the ranks are threads of one process: 288 rows, 36 per strip, all 12 modes."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "restir_amd", "host", "strips_loopback_ranks")
     assert os.path.exists(exe), "restir_amd/host/strips_loopback_ranks is built by restir_amd/csrc/Makefile"
     r = subprocess.run([exe, "8", "500"], capture_output=True, text=True, timeout=560)
     assert r.returncode == 0 and "strips_loopback_ranks ok (8 ranks)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("== full frame over 6 frames: True") == 16, r.stdout[-3000:]
+    assert r.stdout.count("== full frame over 6 frames: True") == 12, r.stdout[-3000:]
 
 
 def test_config4_4k_eight_strips_equal_full_frame(hip):

@@ -5,7 +5,7 @@ OUT=${1:-gpurun_out/r06/ab_denoise_stream.log}
 ROWS8=${ROWS8:-160,144,128,104,96,136,144,168}
 : > "$OUT"
 for rep in 1 2; do
-  for ds in ${MODES:-0 2}; do
+  for ds in ${MODES:-0 1}; do
     for lvl in ${LEVELS:-1}; do
       echo "== rep $rep DENOISE_STREAM=$ds STREAM_LEVEL=$lvl N=1" >> "$OUT"
       DENOISE_STREAM=$ds STREAM_LEVEL=$lvl WORLDS=1 python tools/strip_period.py 5 2>&1 | grep -E "^config|internal" >> "$OUT" || exit 1

@@ -12,7 +12,7 @@ from restir_amd.tiling import HipBackend
 
 W, H = 1920, 1080
 capi.init(0)
-sd = scenes.sponza_class(seed=1, scale=1.0)
+sd = scenes.bistro_class(seed=2, scale=1.0) if "--bistro" in sys.argv else scenes.sponza_class(seed=1, scale=1.0)      # --bistro: config 5's scene
 scene = capi.Scene(sd.vertices, sd.normals, sd.texcoords, sd.material_ids, sd.materials)
 cam = capi.camera_update(sd.camera(W, H))
 b = HipBackend(capi, scene, cam, W, H)

@@ -22,8 +22,8 @@ calibration does), N = 1 goes through the same driver (one-rank world).
     RCCL=1                   create a one-rank ncclComm first (does RCCL's presence in the process move the period?)
     STREAM_LEVEL=-1|0|1|2    rs_set_internal_stream_priority (default: 1 for config 5, else 2 = automatic)
     STREAM_KIND=torch|torch_high|hip|null   the library stream: of torch's pool (default), high priority, a plain HIP stream, the legacy default stream
-    DENOISE_STREAM=0|1|2     rs_set_denoise_stream: config 5's filter, tone map and display gather on the library stream / a stream of their own
-                             (two chains) / behind the frame's chain on its stream (default 2)
+    DENOISE_STREAM=0|1       rs_set_denoise_stream: config 5's filter, tone map and display gather on the library stream (default) / on a stream of
+                             their own, the chains on two streams
 """
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -76,7 +76,7 @@ if os.environ.get("PRE_STREAMS"):                   # experiment: make (and with
 capi.set_sync(False)
 # what bench.py does: a frame with the denoiser on the library stream puts the library's own streams below it
 capi.set_internal_stream_priority(int(os.environ.get("STREAM_LEVEL", "1" if DENOISE else "2")))
-capi.set_denoise_stream(int(os.environ.get("DENOISE_STREAM", "2")) if DENOISE else 0)
+capi.set_denoise_stream(int(os.environ.get("DENOISE_STREAM", "0")) if DENOISE else 0)
 if os.environ.get("TILE_SPLIT"):
     capi.set_tile_split(int(os.environ["TILE_SPLIT"]))
 if os.environ.get("STREAM_PLAN"):
