@@ -875,6 +875,17 @@ int rs_restir_spatial_times(rs_restir* r, float* ms, int capacity, int* count) {
 }  // extern "C"
 
 namespace {
+// Measurement builds (-DRS_WALK_PAD_ENV): RS_WALK_LDS_PAD=<bytes> of dynamic LDS on every overlapped launch of the walk kernels and of the
+// global-table RIS kernel -- none of them uses LDS, so the pad only caps how many of their blocks a CU holds (22 KB: 7 of 8, 4 wave slots per
+// CU left to whatever else is launched) -- to see what the streaming kernels of the library stream do with slots of their own.
+static inline unsigned walk_lds_pad(bool overlapped) {
+#ifdef RS_WALK_PAD_ENV
+    static const unsigned pad = [] { const char* e = std::getenv("RS_WALK_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();
+    return overlapped ? pad : 0u;
+#else
+    (void)overlapped; return 0u;
+#endif
+}
 // RIS over the light table for rows [y0, y1) on stream st; alone: nothing runs next to it (picks the alias-in-LDS form for large tables)
 int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y1, int looper, bool sobol, hipStream_t st, bool alone) {
     const int npx = (y1 - y0) * W;
@@ -903,7 +914,7 @@ int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y
         else hipLaunchKernelGGL(k_ris_alias_lds<false>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
     }
     else                               // the environment map is one more light (scene.h:400-403)
-        RS_LAUNCH2(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), st, scene->dev, sp, W, y0, y1, looper);
+        RS_LAUNCH2L(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), walk_lds_pad(!alone), st, scene->dev, sp, W, y0, y1, looper);
     return 0;
 }
 
@@ -1004,7 +1015,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         TileSplit ts; int helpers = 0;
         RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, (!aux || idle) ? 1 : ((long long)tilesX * gTilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
-        else RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
+        else RS_LAUNCH2L(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), walk_lds_pad(aux != nullptr), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
         g->pending = true;
     }
@@ -1012,7 +1023,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         TileSplit ts; int helpers = 0;
         RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, (!aux || idle) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
-        else RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+        else RS_LAUNCH2L(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), walk_lds_pad(aux != nullptr), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     }
     mark(r, 1);
     const int npx = (y1 - y0) * W;
@@ -1025,13 +1036,13 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  rs_set_stream_plan(-1, -1, 0 / 1): never / always.
     const int shadowOnMain = plan->shadowOnMain;
     const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
-    if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
+    if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), walk_lds_pad(aux != nullptr), st, scene->dev, sp, W, y0, y1, tilesX);
     if (aux) {
         RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS / shadow rays)"));
         RS_HIP(hipEventRecord(r->auxDone, aux));
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
-    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
+    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), walk_lds_pad(true), rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), rs_stream(), sp, gbuf_view(g),
                r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);

@@ -128,6 +128,14 @@ static inline void rs_dev_free(T*& p) {
         else   { if (b) hipLaunchKernelGGL((kernel<false, true>), grid, block, 0, stream, __VA_ARGS__);             \
                  else   hipLaunchKernelGGL((kernel<false, false>), grid, block, 0, stream, __VA_ARGS__); }          \
     } while (0)
+// (the same with a dynamic LDS size: measurement builds pad the walk kernels' blocks to cap their occupancy, RS_WALK_PAD_ENV)
+#define RS_LAUNCH2L(kernel, a, b, grid, block, lds, stream, ...)                                                    \
+    do {                                                                                                            \
+        if (a) { if (b) hipLaunchKernelGGL((kernel<true, true>), grid, block, lds, stream, __VA_ARGS__);            \
+                 else   hipLaunchKernelGGL((kernel<true, false>), grid, block, lds, stream, __VA_ARGS__); }         \
+        else   { if (b) hipLaunchKernelGGL((kernel<false, true>), grid, block, lds, stream, __VA_ARGS__);           \
+                 else   hipLaunchKernelGGL((kernel<false, false>), grid, block, lds, stream, __VA_ARGS__); }        \
+    } while (0)
 #define RS_LAUNCH1(kernel, a, grid, block, stream, ...)                                                             \
     do {                                                                                                            \
         if (a) hipLaunchKernelGGL((kernel<true>), grid, block, 0, stream, __VA_ARGS__);                             \
