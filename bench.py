@@ -683,12 +683,12 @@ def main():
         torch.cuda.synchronize()
 
     # Before the warm-up: the library measures once per scene whether GBuffer::render is walked together with the primary rays
-    # (frames 2-13 of a new rs_restir, restir.hip); those frames run here, so that warm-up and timed frames all use the form it
+    # (frames 2-33 of a new rs_restir, restir.hip); those frames run here, so that warm-up and timed frames all use the form it
     # chose.  Strips too small for the fused launch have nothing to choose (-2).
     # The count is the same on every rank (a frame exchanges halo rows with the neighbours).  The library decides at the first frame
-    # end after its last time stamp (frame 14) has been reached -- it never waits on the host -- hence the synchronisation and
+    # end after its last time stamp (frame 34) has been reached -- it never waits on the host -- hence the synchronisation and
     # the two frames after it.
-    calibration_frames = 18
+    calibration_frames = 38
     set_phase("first_frames")
     for _ in range(calibration_frames - 2):
         frame()

@@ -179,7 +179,7 @@ int  rs_set_sync(int sync);
  * passes.  Results are identical; output buffers are valid in library-stream order as before.  GBuffer::render can in addition
  * be deferred until ReSTIRDirect, which then walks the pixel-centre ray and the jittered ray of every pixel in one traversal:
  * faster or slower by a few percent depending on the scene and the launch size, so by default
- * every rs_restir measures the frame period both ways once per scene (frames 2..13) and keeps the faster.
+ * every rs_restir measures the frame period both ways once per scene (frames 6..17 against 22..33) and keeps the faster.
  *   0 = everything on the library stream (RS_SIDE_STREAM=0 in the environment pre-sets this: the profiling scripts use it)
  *   1 = overlapped frames, the render always its own launch
  *   2 = overlapped frames, the render always deferred for launches of at least three rounds of the chip's wave slots

@@ -140,7 +140,12 @@ __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary_split(DevScene s
 
 // GBuffer::render and the primary rays of ReSTIRDirect in one launch (asynchronous mode, when the render of this frame is
 // still pending -- rs_gbuffer_render_rows defers it), each ray stored as k_render_gbuffer / k_primary store it.
-constexpr int kTuneA = 2, kTuneB = 8, kTuneC = 14;          // frames at which the measured launch choice takes its time stamps
+// Frames at which the measured launch choice takes its time stamps: two launches until kTuneB, one fused launch from there to kTuneD; the
+// first span is frames kTuneA..kTuneB, the second kTuneC..kTuneD -- twelve frames each, and the four frames after every switch are not
+// timed: chains run up to four frames ahead of the library stream, so the frames around a switch carry the other form's kernels next to
+// them.  (Rounds 1-5 timed 2..8 against 8..14: on the Bistro-class scene, where the forms differ by 18 %, one run in four took the
+// slower one -- 2.10 instead of 1.78 ms per frame, profiles/r06_fuse_tuner_flips.log.)
+constexpr int kTuneA = 6, kTuneB = 18, kTuneC = 22, kTuneD = 34;
 constexpr long long kFuseMinWaves = kSmallLaunchWaves;     // three rounds of the chip's 8 192 wave slots (256 CUs x 4 SIMDs x 8 waves)
 
 // The two rays of a pixel sit in two LANES: a wave takes an 8x4 block of pixels, lanes 0-31 walk their pixel-centre rays and lanes
@@ -875,17 +880,9 @@ int rs_restir_spatial_times(rs_restir* r, float* ms, int capacity, int* count) {
 }  // extern "C"
 
 namespace {
-// Measurement builds (-DRS_WALK_PAD_ENV): RS_WALK_LDS_PAD=<bytes> of dynamic LDS on every overlapped launch of the walk kernels and of the
-// global-table RIS kernel -- none of them uses LDS, so the pad only caps how many of their blocks a CU holds (22 KB: 7 of 8, 4 wave slots per
-// CU left to whatever else is launched) -- to see what the streaming kernels of the library stream do with slots of their own.
-static inline unsigned walk_lds_pad(bool overlapped) {
-#ifdef RS_WALK_PAD_ENV
-    static const unsigned pad = [] { const char* e = std::getenv("RS_WALK_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();
-    return overlapped ? pad : 0u;
-#else
-    (void)overlapped; return 0u;
+#ifndef RS_RIS_ALIAS_OVERLAPPED
+#define RS_RIS_ALIAS_OVERLAPPED 0      // (measurement builds: 1 = the alias-in-LDS form also next to other frames' kernels)
 #endif
-}
 // RIS over the light table for rows [y0, y1) on stream st; alone: nothing runs next to it (picks the alias-in-LDS form for large tables)
 int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y1, int looper, bool sobol, hipStream_t st, bool alone) {
     const int npx = (y1 - y0) * W;
@@ -902,7 +899,7 @@ int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y
         // (one block per CU instead of two -- half of the wave slots left to the latency-bound kernels of the other streams -- measured
         // slower: frame 1.088 -> 1.142 ms, profiles/r03_ab_ris_blocks_per_cu.log)
         RS_LAUNCH1(k_ris_lds, sobol, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), st, scene->dev, sp, W, y0, y1, looper);
-    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && alone) {
+    else if (scene->envMapTexId < 0 && scene->numLights > kRisLdsLights && scene->numLights <= kRisAliasLdsLights && npx >= risGlobalBelow && (alone || RS_RIS_ALIAS_OVERLAPPED)) {
         const size_t lds = (size_t)scene->numLights * sizeof(AliasRec);
         static const bool ldsAllowed = []{      // more than 64 KB of dynamic LDS is opt-in
             const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ris_alias_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRisAliasLdsLights * (int)sizeof(AliasRec)) == hipSuccess;
@@ -914,7 +911,7 @@ int launch_ris(const rs_scene* scene, const SurfPlanes& sp, int W, int y0, int y
         else hipLaunchKernelGGL(k_ris_alias_lds<false>, dim3((npx + kRisThreads - 1) / kRisThreads), dim3(kRisThreads), lds, st, scene->dev, sp, W, y0, y1, looper);
     }
     else                               // the environment map is one more light (scene.h:400-403)
-        RS_LAUNCH2L(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), walk_lds_pad(!alone), st, scene->dev, sp, W, y0, y1, looper);
+        RS_LAUNCH2(k_ris, scene->envMapTexId >= 0, sobol, dim3((npx + 255) / 256), dim3(256), st, scene->dev, sp, W, y0, y1, looper);
     return 0;
 }
 
@@ -961,7 +958,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     if (fuse && large && fuseMode == 3 && !denoiseStream) {        // measured choice (end_frame advances the measurement)
         if (r->tuneSceneId != scene->id) { r->tuneSceneId = scene->id; r->tuneFrame = 0; r->tuneChoice = -1; }
         r->tuneCounted = true;
-        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneC);
+        fuse = r->tuneChoice >= 0 ? r->tuneChoice == 1 : (r->tuneFrame >= kTuneB && r->tuneFrame < kTuneD);
     }
     int kThreeStreams[rs_restir::kSmallChains];                 // the chain streams first, the render's stream (idle after a fused launch) last
     for (int i = 0; i < rs_restir::kSmallChains; i++) kThreeStreams[i] = i < 2 ? 1 + i : i == 2 ? 0 : i;
@@ -1015,7 +1012,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         TileSplit ts; int helpers = 0;
         RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, (!aux || idle) ? 1 : ((long long)tilesX * gTilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
-        else RS_LAUNCH2L(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), walk_lds_pad(aux != nullptr), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
+        else RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
         g->pending = true;
     }
@@ -1023,7 +1020,7 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         TileSplit ts; int helpers = 0;
         RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, (!aux || idle) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
         if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
-        else RS_LAUNCH2L(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), walk_lds_pad(aux != nullptr), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
+        else RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     }
     mark(r, 1);
     const int npx = (y1 - y0) * W;
@@ -1036,13 +1033,13 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  rs_set_stream_plan(-1, -1, 0 / 1): never / always.
     const int shadowOnMain = plan->shadowOnMain;
     const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
-    if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), walk_lds_pad(aux != nullptr), st, scene->dev, sp, W, y0, y1, tilesX);
+    if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
     if (aux) {
         RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS / shadow rays)"));
         RS_HIP(hipEventRecord(r->auxDone, aux));
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
-    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), walk_lds_pad(true), rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
+    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), rs_stream(), sp, gbuf_view(g),
                r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
@@ -1120,18 +1117,19 @@ int rs_restir_end_frame(rs_restir* r) {
     r->chain = (r->chain + 1) % rs_restir::kChains;
     r->smallChain = (r->smallChain + 1) % rs_restir::kSmallChains;
     r->phaseACalls = 0;
-    // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA, kTuneB and kTuneC begin (two
-    // launches in the first span, one fused launch in the second); from frame kTuneC on every frame end asks (hipEventQuery, no
-    // wait) whether the last stamp has been reached, and the shorter span decides; until then frames take two launches.  A caller that
-    // times frames runs kTuneC + 2 frames and a synchronisation first (bench.py does, before its warm-up) and then sees one launch form only.
+    // the measurement of rs_fuse_mode() == 3: time stamps on the library stream where frames kTuneA .. kTuneD end (two launches up to
+    // kTuneB, one fused launch from there to kTuneD; the spans kTuneA-kTuneB and kTuneC-kTuneD are compared); from frame kTuneD on every
+    // frame end asks (hipEventQuery, no wait) whether the last stamp has been reached, and the shorter span decides; until then frames take
+    // two launches.  A caller that times frames runs kTuneD + 2 frames and a synchronisation first (bench.py does, before its warm-up) and
+    // then sees one launch form only.
     if (r->tuneCounted && r->tuneChoice < 0) {
         const int f = ++r->tuneFrame;
-        if (f == kTuneA || f == kTuneB || f == kTuneC) RS_HIP(hipEventRecord(r->tuneEv[f == kTuneA ? 0 : f == kTuneB ? 1 : 2], rs_stream()));
-        if (f >= kTuneC) {                                          // never a host wait: the stamp is asked for at every frame end until it is there
+        if (f == kTuneA || f == kTuneB || f == kTuneC || f == kTuneD) RS_HIP(hipEventRecord(r->tuneEv[f == kTuneA ? 0 : f == kTuneB ? 1 : f == kTuneC ? 2 : 3], rs_stream()));
+        if (f >= kTuneD) {                                          // never a host wait: the stamp is asked for at every frame end until it is there
             float separate = 0.f, fused = 0.f;
-            const hipError_t q = hipEventQuery(r->tuneEv[2]);
+            const hipError_t q = hipEventQuery(r->tuneEv[3]);
             if (q == hipSuccess) {
-                if (hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess && hipEventElapsedTime(&fused, r->tuneEv[1], r->tuneEv[2]) == hipSuccess)
+                if (hipEventElapsedTime(&separate, r->tuneEv[0], r->tuneEv[1]) == hipSuccess && hipEventElapsedTime(&fused, r->tuneEv[2], r->tuneEv[3]) == hipSuccess)
                     r->tuneChoice = fused < separate ? 1 : 0;
                 else { (void)hipGetLastError(); r->tuneChoice = 0; }
             }

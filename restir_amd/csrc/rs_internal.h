@@ -128,14 +128,6 @@ static inline void rs_dev_free(T*& p) {
         else   { if (b) hipLaunchKernelGGL((kernel<false, true>), grid, block, 0, stream, __VA_ARGS__);             \
                  else   hipLaunchKernelGGL((kernel<false, false>), grid, block, 0, stream, __VA_ARGS__); }          \
     } while (0)
-// (the same with a dynamic LDS size: measurement builds pad the walk kernels' blocks to cap their occupancy, RS_WALK_PAD_ENV)
-#define RS_LAUNCH2L(kernel, a, b, grid, block, lds, stream, ...)                                                    \
-    do {                                                                                                            \
-        if (a) { if (b) hipLaunchKernelGGL((kernel<true, true>), grid, block, lds, stream, __VA_ARGS__);            \
-                 else   hipLaunchKernelGGL((kernel<true, false>), grid, block, lds, stream, __VA_ARGS__); }         \
-        else   { if (b) hipLaunchKernelGGL((kernel<false, true>), grid, block, lds, stream, __VA_ARGS__);           \
-                 else   hipLaunchKernelGGL((kernel<false, false>), grid, block, lds, stream, __VA_ARGS__); }        \
-    } while (0)
 #define RS_LAUNCH1(kernel, a, grid, block, stream, ...)                                                             \
     do {                                                                                                            \
         if (a) hipLaunchKernelGGL((kernel<true>), grid, block, 0, stream, __VA_ARGS__);                             \
@@ -423,13 +415,13 @@ struct rs_restir {
     bool idleFrame = false;          // this frame's first phase-A call found the previous frames finished (restir.hip phase_a_impl)
     int idleStreak = 0;
     // one traversal for the G-buffer ray and the shading ray of a pixel, or two?  Measured once per scene (rs_fuse_mode() == 3):
-    // frames 2..7 with two launches, 8..13 with one, timed by events on the library stream at the frame ends
+    // frames 6..17 with two launches against 22..33 with one (the four frames after each switch are not timed), by events on the library stream at the frame ends
     unsigned long long tuneSceneId = 0;
     int tuneFrame = 0;               // frames with a fusable launch since tuning began
     int tuneChoice = -1;             // -1 measuring, 0 separate, 1 fused
     int lastFused = -1, lastChains = 0;   // form of the last phase-A launch: render fused with the primary rays? how many chain streams in turn? (rs_restir_launch_choice)
     bool tuneCounted = false;        // this frame had a launch the choice applies to
-    hipEvent_t tuneEv[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t tuneEv[4] = { nullptr, nullptr, nullptr, nullptr };
     unsigned long long* dRayCount = nullptr;   // ring of per-frame counters (1024 slots)
     rs_tile_split split[1 + rs_context::kAux][3];   // primary-ray launches: per stream (library, auxiliary 0..2) and per call within a frame (strips: interior rows, border rows)
     int raySlot = 0;

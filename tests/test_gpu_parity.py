@@ -1097,12 +1097,12 @@ def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame):
 
 def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     """Default asynchronous mode: ReSTIRDirect measures once per scene whether walking the G-buffer ray with the shading ray is
-    faster (frames 8..13 run fused, 2..7 and all others until the decision separately).  Whatever it picks, a full-size run of
-    30 frames equals the synchronous run bit for bit."""
+    faster (frames 18..33 run fused, all others until the decision separately).  Whatever it picks, a full-size run of
+    40 frames equals the synchronous run bit for bit."""
     import torch
     from restir_amd.scenes import orbit_position
     sd = get_scene("sponza:0.1")
-    W, H, frames = 1920, 1080, 30
+    W, H, frames = 1920, 1080, 40
     scene = hip_scene(hip, sd)
 
     def run(overlapped):
@@ -1116,13 +1116,13 @@ def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
                 h.gbuf.render(h.scene, h.cam)
                 h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
                 h.looper += 1
-                if frame in (3, 11, 13, 19, 27, 29):
+                if frame in (3, 11, 17, 19, 27, 33, 35, 39):
                     keep.append(h.image.clone())
                 h.gbuf.update(h.cam)
             hip.synchronize(); torch.cuda.synchronize()
             out = [t.cpu().numpy() for t in keep] + [h.restir.download(1).view(np.uint8), h.gbuf.download()["depth"][0]]
             # the library never waits on the host for its measurement: it asks at every frame end whether the last time stamp has
-            # been reached, so the decision falls at the first frame end after the GPU has caught up with frame 14
+            # been reached, so the decision falls at the first frame end after the GPU has caught up with frame 34
             h.gbuf.render(h.scene, h.cam)
             h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
             h.gbuf.update(h.cam)
@@ -1135,7 +1135,7 @@ def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     choices = []
     for a, b in zip(run(False), run(True)):
         assert bits_equal(a, b)
-    assert choices[0] == -2 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided once the stamp of frame 14 is there
+    assert choices[0] == -2 and choices[1] in (0, 1)          # synchronous launches: nothing to choose; overlapped: decided once the stamp of frame 34 is there
 
 
 def test_scene_destroyed_while_a_render_is_only_recorded(hip):

@@ -112,7 +112,10 @@ def period(world, rank, bounds, frames=FRAMES):
         capi.copy_image_to_pbo(pbos[k].data_ptr() + y0 * W * 4, shown + y0 * W * 12, W, y1 - y0, TONEMAP, 1.0)
         drv.gather_begin(pbos[k].data_ptr(), 4, 0, k)
 
-    for _ in range(20):                       # (N = 1: past the library's measured launch choice, frames 2-14)
+    for _ in range(36):                       # (N = 1: past the library's measured launch choice, frames 2-34 ...
+        frame()
+    capi.synchronize(); torch.cuda.synchronize()
+    for _ in range(2):                        # ... which is read at the first frame end after the last stamp has been reached)
         frame()
     capi.synchronize(); torch.cuda.synchronize()
     t0 = time.perf_counter()
