@@ -1030,18 +1030,13 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     // frame's own chain (8 strips of 1080p: 0.235 ms against 0.270).  rs_set_stream_plan(-1, -1, 0 / 1): never / always.
     const int shadowOnMain = plan->shadowOnMain;
     const bool shadowMain = aux && (shadowOnMain == 1 || (shadowOnMain == 2 && (long long)tilesX * tilesY * 4 >= kFuseMinWaves));
-    // (measurement: RS_SHADOW_CHAIN_SHARE=<percent> of a large launch's shadow-ray rows stay on the chain, the rest goes to the library stream)
-    static const int chainShare = [] { const char* e = std::getenv("RS_SHADOW_CHAIN_SHARE"); return e ? std::atoi(e) : 0; }();
-    int ySplit = y0;                                            // rows [y0, ySplit) on the chain, [ySplit, y1) on the library stream
-    if (shadowMain && chainShare > 0) { ySplit = y0 + ((y1 - y0) * chainShare / 100 + 7) / 8 * 8; if (ySplit > y1) ySplit = y1; }
     if (!shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, sp, W, y0, y1, tilesX);
-    else if (ySplit > y0) hipLaunchKernelGGL(k_shadow, dim3(tilesX * ((ySplit - y0 + 7) / 8)), dim3(256), 0, st, scene->dev, sp, W, y0, ySplit, tilesX);
     if (aux) {
         RS_TRY(rs_check_hip(hipGetLastError(), "ReSTIR Direct (primary / RIS / shadow rays)"));
         RS_HIP(hipEventRecord(r->auxDone, aux));
         RS_HIP(hipStreamWaitEvent(rs_stream(), r->auxDone, 0));
     }
-    if (shadowMain && y1 > ySplit) hipLaunchKernelGGL(k_shadow, dim3(tilesX * ((y1 - ySplit + 7) / 8)), dim3(256), 0, rs_stream(), scene->dev, sp, W, ySplit, y1, tilesX);
+    if (shadowMain) hipLaunchKernelGGL(k_shadow, dim3(tilesX * tilesY), dim3(256), 0, rs_stream(), scene->dev, sp, W, y0, y1, tilesX);
     RS_TRY(rs_gbuffer_join(g));                                 // first consumer of the G-buffer planes
     RS_LAUNCH1(k_temporal, sobol, dim3((npx + 255) / 256), dim3(256), rs_stream(), sp, gbuf_view(g),
                r->last, r->cur, r->temp, scene->dev.sampleSeq, looper, r->firstFrame ? 1 : 0, reuse, y0 * W, y1 * W, rayCounter, rayDone);
