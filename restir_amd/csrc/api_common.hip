@@ -469,7 +469,7 @@ int rs_tile_split_prepare(rs_tile_split* t, long long key, int numTiles, int reg
     if (threshold < 0) threshold = -threshold;      // negative: for every launch, also next to other kernels (tests, measurements)
     const int capacity = std::min(rs_tile_split::kCapacity, std::max(64, regularBlocks / 2));
     key = key * 1048573 + threshold;
-    const size_t hintInts = 2 + 4 * (size_t)capacity, flagOffset = (8 + 3 * hintInts) * sizeof(int), flagStride = ((size_t)numTiles + 15) & ~(size_t)15;
+    const size_t hintInts = 2 + (size_t)capacity, flagOffset = (8 + 3 * hintInts) * sizeof(int), flagStride = ((size_t)numTiles + 15) & ~(size_t)15;
     const size_t bytes = flagOffset + 3 * flagStride;
     if (t->bytes < bytes) {                         // (hipFree waits for the device: nothing in flight reads the old arrays)
         rs_dev_free(t->base);

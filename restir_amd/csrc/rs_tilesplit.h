@@ -1,4 +1,4 @@
-// rs_tilesplit.h -- heavy tiles of the closest-hit kernels as four waves instead of one, the heaviest as sixteen.
+// rs_tilesplit.h -- heavy tiles of the closest-hit kernels as four waves instead of one.
 //
 // A packet walk (rs_scene.h trace_closest_packet) is a chain of dependent node fetches as long as the UNION of the nodes its 64
 // rays visit, and a launch lasts at least as long as its longest chain: on the Bistro-class scene the mean tile has 270 union
@@ -16,15 +16,6 @@
 //     flagged tile does nothing.  The helper block keeps the tile listed while the sum of its quadrant counts stays at the threshold.
 // A tile is flagged iff it is in the first `capacity` list entries, both are written by the same kernel and read by a later launch
 // on the same stream, so every tile is traced exactly once whatever the hints say; a camera that moves only makes them stale.
-//
-// Two levels (round 6).  A helper block's launch still lasts as long as its longest QUADRANT: on the Bistro-class scene the heaviest tile's
-// quadrants keep 1 500-1 800 union nodes, which is the 0.55-0.7 ms of every closest-hit launch that contains that tile -- a full frame
-// launched alone and the 88-row strip of an 8-way split alike (profiles/r06_config5_n8_strip_traces.txt).  A helper block one of whose
-// quadrants reaches the threshold again therefore lists its tile FOUR times, marked fine: four helper blocks, one per quadrant, whose
-// waves take a 2x2 sixteenth (4 lanes) each.  The four add their counts into the slot of the first (sum, largest, arrivals); the last to
-// arrive decides for the next launch: fine again while the largest of the four sums reaches the threshold, else once (four quadrants)
-// while the total does, else not at all.  The group of four is appended by ONE thread with one atomic, kept only if all four fit, so a
-// tile's flag still says exactly whether helper blocks trace it.
 #pragma once
 
 namespace rs {
@@ -37,11 +28,9 @@ namespace rs {
 // Everything but three dwords lives in device memory behind `base` (written once per geometry by k_tile_split_init): the walk
 // kernels are held to 64 registers, and a struct of seven pointers kept live across the walk cost them 44 bytes of scratch per lane
 // and half their speed (k_primary 0.284 -> 0.437 ms) -- the fields are read where they are used instead.
-//   ints at base: [0] capacity  [1] configured threshold  [2] number of tiles  [3] ints per hint (2 + 4 x capacity: the list, then per
-//                 list slot the fine blocks' sum, largest sum and arrivals -- zero between launches)
+//   ints at base: [0] capacity  [1] configured threshold  [2] number of tiles  [3] ints per hint (2 + capacity)
 //                 [4] byte offset of the first flag array  [5] bytes per flag array  [6..7] address of the host's report word (or 0);
 //                 hint h at int 8 + h * [3]
-// A list entry: bits 0-25 the tile, bit 28 fine (a quadrant of the tile, bits 26-27 which); -1: a slot of a group that did not fit.
 // The report word (pinned host memory, written by the last block with one 8-byte store): sequence number of the reporting launch in the
 // high half, in the low half the number of heavy tiles the launch BEFORE it found.  The host never waits for it; it reads it when it
 // prepares a later launch and lets a launch site whose tiles are all light run the plain kernels for a while (rs_tile_split_prepare).
@@ -60,7 +49,6 @@ __device__ __forceinline__ unsigned char* tile_split_flags(int* base, int h) { r
 // Returns false when the whole BLOCK has nothing to do (a helper block without a tile) -- block-uniform, so the caller may return
 // before any barrier.  Outputs: px, py relative to the launch's first row; active = this lane has a pixel; tile = the tile it
 // belongs to (wave-uniform); helper = this block is a helper block.
-constexpr int kTileSplitTileMask = 0x3ffffff, kTileSplitFineBit = 1 << 28;
 template <int TW, int TH>
 __device__ __forceinline__ bool tile_split_map(const TileSplit& ts, int tilesX, int l, int& px, int& py, bool& active, int& tile, bool& helper) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -69,19 +57,9 @@ __device__ __forceinline__ bool tile_split_map(const TileSplit& ts, int tilesX, 
     if (helper) {
         const int* in = tile_split_hint(ts.base, ts.rot);
         const int n = min(in[0], ts.helperBlocks);
-        const int entry = (int)blockIdx.x < n ? in[2 + blockIdx.x] : -1;
-        tile = entry & kTileSplitTileMask;
-        if (entry < 0 || tile >= ts.base[2]) return false;
+        tile = (int)blockIdx.x < n ? in[2 + blockIdx.x] : -1;
+        if (tile < 0 || tile >= ts.base[2]) return false;
         const int tx = tile % perRow, ty = tile / perRow;
-        if (entry & kTileSplitFineBit) {                // one quadrant of the tile: every wave a sixteenth (2x2 pixels; 2x1 of the 8x4 tile)
-            constexpr int SW = TW / 4, SH = TH / 4;
-            const int sub = (entry >> 26) & 3;
-            const int qx = (sub & 1) * 2 + (wave & 1), qy = (sub >> 1) * 2 + (wave >> 1);
-            px = tx * TW + qx * SW + (l % SW);
-            py = ty * TH + qy * SH + (l / SW) % SH;
-            active = l < SW * SH;
-            return true;
-        }
         constexpr int QW = TW / 2, QH = TH / 2;
         px = tx * TW + (wave & 1) * QW + (l % QW);
         py = ty * TH + (wave >> 1) * QH + (l / QW) % QH;
@@ -93,7 +71,7 @@ __device__ __forceinline__ bool tile_split_map(const TileSplit& ts, int tilesX, 
     tile = by * perRow + bx * 4 + wave;
     px = bx * (TW * 4) + wave * TW + (l % TW);
     py = by * TH + l / TW;
-    active = !(ts.base && tile_split_flags(ts.base, ts.rot)[tile]);            // a flagged tile is traced by its helper block(s)
+    active = !(ts.base && tile_split_flags(ts.base, ts.rot)[tile]);            // a flagged tile is traced by its helper block
     return true;
 }
 
@@ -112,43 +90,24 @@ __device__ __forceinline__ void tile_split_report(int* base, int rot, int tile, 
         volatile unsigned long long* report = *reinterpret_cast<volatile unsigned long long**>(base + 6);
         if (report) *report = ((unsigned long long)(unsigned)(rot / 3) << 32) | (unsigned)found;
     }
-    const int cap = base[0];
-    unsigned total = unionNodes, largest = 0;           // regular wave: its own count; never split further than into quadrants from here
     if (helper) {
-        __shared__ unsigned part[4];
-        if (lane == 0) part[threadIdx.x >> 6] = unionNodes;
+        __shared__ unsigned quadrant[4];
+        if (lane == 0) quadrant[threadIdx.x >> 6] = unionNodes;
         __syncthreads();
         if (threadIdx.x != 0) return;
-        total = part[0] + part[1] + part[2] + part[3];                               // >= the undivided count of what the block traced
-        largest = max(max(part[0], part[1]), max(part[2], part[3]));
-        int* in = tile_split_hint(base, rot);
-        const int entry = in[2 + blockIdx.x];
-        if (entry & kTileSplitFineBit) {
-            // one of the tile's four fine blocks: the counts meet in the slot of the first; the last to arrive decides
-            int* acc = in + 2 + cap + ((int)blockIdx.x - ((entry >> 26) & 3));
-            atomicAdd(acc, (int)total);
-            atomicMax(acc + cap, (int)total);                                        // (a fine block's sum bounds its quadrant's count from above)
-            __threadfence();
-            if (atomicAdd(acc + 2 * cap, 1) != 3) return;
-            total = (unsigned)atomicExch(acc, 0); largest = (unsigned)atomicExch(acc + cap, 0); atomicExch(acc + 2 * cap, 0);
-        }
+        unionNodes = quadrant[0] + quadrant[1] + quadrant[2] + quadrant[3];       // >= the undivided tile's count
     }
     else if (lane != 0 || skipped) return;
     int* out = tile_split_hint(base, rot + 1);
     const unsigned threshold = (unsigned)max(tile_split_hint(base, rot)[1], base[1]);        // the effective threshold of this launch
     bool keep = false;
-    if (largest >= threshold) {                          // a quadrant as long as a heavy tile: four fine blocks next time, all or none
-        const int slot = atomicAdd(out, 4);
-        keep = slot + 3 < cap;
-        for (int k = 0; k < 4; k++) if (slot + k < cap) out[2 + slot + k] = keep ? (tile | (k << 26) | kTileSplitFineBit) : -1;
-    }
-    if (!keep && total >= threshold) { const int slot = atomicAdd(out, 1); keep = slot < cap; if (keep) out[2 + slot] = tile; }
+    if (unionNodes >= threshold) { const int slot = atomicAdd(out, 1); keep = slot < base[0]; if (keep) out[2 + slot] = tile; }
     tile_split_flags(base, rot + 1)[tile] = keep ? 1 : 0;
 }
 
 // once per geometry: header and empty hints (the arrays behind them have been zeroed by a memset on the same stream)
 static __global__ void k_tile_split_init(int* base, int capacity, int threshold, int numTiles, int flagOffset, int flagStride, unsigned long long* report) {
-    base[0] = capacity; base[1] = threshold; base[2] = numTiles; base[3] = 2 + 4 * capacity; base[4] = flagOffset; base[5] = flagStride;
+    base[0] = capacity; base[1] = threshold; base[2] = numTiles; base[3] = 2 + capacity; base[4] = flagOffset; base[5] = flagStride;
     *reinterpret_cast<unsigned long long**>(base + 6) = report;
 }
 #endif
