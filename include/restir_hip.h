@@ -191,12 +191,6 @@ int  rs_set_side_stream(int enable);
  * of the CUs with a block; rounds 2-4 had 384 Ki, which cost every rank of an 8-way split of 1080p 1-13 % of its frame period once the
  * library's streams no longer shared hardware queues).  Same results either way; 0 = always LDS. */
 int  rs_set_ris_table_pixels(int pixels);
-/* How GBuffer::render and the primary rays of ReSTIRDirect (DevScene::intersect, src/scene.h:245-284, on the camera rays) find their closest
- * hits: 0 = the wave-cooperative packet walk of the reference's tree (a wave visits the union of its 64 rays' nodes once); 1 = every lane walks
- * its own ray through the closest-hit trees that keep the reference's visiting order (the service of the multi-bounce kernels' bounce rays).
- * Same hits.  The packet walk wins where the rays of an 8x8 tile stay together (Sponza-class: 0.27 against 0.39 ms for the 2 M camera rays),
- * the per-lane walk where they do not (Bistro-class: a tile's union is 270 nodes on average and 3 669 at worst).  Default 0. */
-int  rs_set_primary_walk(int perLane);
 /* How the overlapped mode spreads a frame's kernels over the internal streams (a setting of the current context; every argument
  * -1 = keep).  chainStreams 1 / 2: the primary-ray -> RIS -> shadow-ray chains of all frames on one stream, or of alternating frames on
  * two (default 2).  smallChains 0 / 1: a launch below three rounds of the chip's wave slots (a strip) takes the fused render and rotates

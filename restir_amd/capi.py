@@ -108,7 +108,7 @@ class GBufferView(C.Structure):
 
 # every symbol include/restir_hip.h declares; tests check that the library exports all of them
 EXPORTS = [
-    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_primary_walk", "rs_set_internal_stream_priority", "rs_internal_streams_info", "rs_choose_internal_streams_again", "rs_prepare_streams", "rs_set_stream_plan", "rs_set_denoise_stream", "rs_join_denoise_stream", "rs_set_tile_split", "rs_synchronize",
+    "rs_last_error", "rs_context_create", "rs_context_destroy", "rs_context_set_current", "rs_init", "rs_set_stream", "rs_set_sync", "rs_set_side_stream", "rs_set_ris_table_pixels", "rs_set_internal_stream_priority", "rs_internal_streams_info", "rs_choose_internal_streams_again", "rs_prepare_streams", "rs_set_stream_plan", "rs_set_denoise_stream", "rs_join_denoise_stream", "rs_set_tile_split", "rs_synchronize",
     "rs_build_bvh", "rs_build_light_table", "rs_build_alias_table", "rs_build_envmap_pdf", "rs_scene_build", "rs_scene_build_textured", "rs_scene_create",
     "rs_scene_host_desc", "rs_scene_set_sample_sequence", "rs_scene_destroy", "rs_camera_update", "rs_trace_closest", "rs_trace_closest_wave", "rs_scene_set_ordered_tree", "rs_ordered_bvh_host_check", "rs_trace_occlusion",
     "rs_gbuffer_create", "rs_gbuffer_destroy", "rs_gbuffer_render", "rs_gbuffer_render_rows", "rs_gbuffer_update",
@@ -209,7 +209,6 @@ def lib():
     L.rs_debug_div_sigma_mismatches.argtypes = [C.c_float, C.POINTER(C.c_ulonglong)]
     L.rs_scene_set_sample_sequence.argtypes = [vp, vp, ci, ci]
     L.rs_set_stream_plan.argtypes = [ci, ci, ci]
-    L.rs_set_primary_walk.argtypes = [ci]
     L.rs_set_denoise_stream.argtypes = [ci]
     L.rs_join_denoise_stream.argtypes = []
     L.rs_restir_rows_pack.argtypes = [vp, ci, ci, ci, vp]
@@ -347,11 +346,6 @@ def set_ris_table_pixels(pixels):
 def prepare_streams():
     """Choose the library's own streams now rather than inside the first overlapped frame (rs_prepare_streams)."""
     check(lib().rs_prepare_streams())
-
-
-def set_primary_walk(per_lane):
-    """GBuffer::render and the primary rays through per-lane walks of the closest-hit trees (1) instead of the packet walk (0); rs_set_primary_walk."""
-    check(lib().rs_set_primary_walk(1 if per_lane else 0))
 
 
 def set_stream_plan(chain_streams=-1, small_chains=-1, shadow_on_main=-1):

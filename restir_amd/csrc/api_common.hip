@@ -298,9 +298,6 @@ const rs_context* rs_stream_plan() {
     if (c->shadowOnMain < 0) c->shadowOnMain = 2;
     return c;
 }
-bool rs_primary_walk_per_lane(const rs_scene* scene) {
-    return rs_ctx()->primaryWalk == 1 && scene && scene->dev.ordNodes != nullptr;
-}
 int rs_ris_global_below() {
     rs_context* c = rs_ctx();
     if (c->risGlobalBelow < 0) c->risGlobalBelow = 64 * 1024;
@@ -622,14 +619,6 @@ int rs_set_stream_plan(int chainStreams, int smallChains, int shadowOnMain) {
     if (chainStreams >= 1) c->chainStreams = chainStreams;
     if (smallChains >= 0) c->smallChains = smallChains;
     if (shadowOnMain >= 0) c->shadowOnMain = shadowOnMain;
-    return 0;
-}
-// How GBuffer::render and the primary rays of ReSTIRDirect find their closest hits: 0 (default) the wave-cooperative packet walk of the
-// reference's tree, 1 per-lane walks of the closest-hit trees that keep the reference's visiting order (what the bounce rays of the multi-bounce
-// kernels use; scenes built without those trees keep the packet walk).  Same hits either way.
-int rs_set_primary_walk(int perLane) {
-    if (perLane != 0 && perLane != 1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_set_primary_walk: 0 or 1");
-    rs_ctx()->primaryWalk = perLane;
     return 0;
 }
 int rs_set_ris_table_pixels(int pixels) {

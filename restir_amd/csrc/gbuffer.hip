@@ -17,11 +17,7 @@ using namespace rs;
 
 // TEX: the scene has texture maps or an environment map (getTexturedMaterialAndSurface, gbuffer.cu:38,59-62)
 // 8 blocks per CU: without the bound the kernel takes 100+ SGPRs and runs at 7 waves per SIMD (0.392 -> 0.370 ms at 1080p)
-// LANE: every lane walks its own ray through the closest-hit trees that keep the reference's visiting order (trace_closest_wave, the service of
-// the bounce rays) instead of the wave walking the union of its rays' nodes through the reference tree: same hit, and on a scene whose tiles
-// diverge -- the Bistro-class one: 270 union nodes per tile on average, 3 669 at worst, against 100 steps for a ray of its own -- the shorter
-// walk (rs_set_primary_walk; restir.hip has the two other closest-hit kernels)
-template <bool TEX, bool SPLIT, bool LANE = false>
+template <bool TEX, bool SPLIT>
 __device__ __forceinline__ void render_gbuffer_body(const DevScene& s, const CamParams& cam, const CamParams& lastCam, const GBufWrite& g,
                                                     int y0, int y1, int tilesX, const TileSplit& ts) {
     // block = 4 waves, each an 8x8 tile; the block covers 32x8 pixels (a tile that was heavy last time: four waves of 4x4, rs_tilesplit.h)
@@ -35,7 +31,7 @@ __device__ __forceinline__ void render_gbuffer_body(const DevScene& s, const Cam
 
     Ray ray = camera_center_ray(cam, x, y);
     unsigned unionNodes = 0;
-    Hit h = LANE ? trace_closest_wave(s, ray, inside) : trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
+    Hit h = trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
     if (inside) gbuffer_store<TEX>(s, cam, lastCam, g, idx, ray, h);
     if (SPLIT) tile_split_report(ts.base, ts.rot, tile, helper, !helper && !mine, unionNodes);
 }
@@ -47,11 +43,6 @@ __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer(DevScene 
 template <bool TEX>
 __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX, TileSplit ts) {
     render_gbuffer_body<TEX, true>(s, cam, lastCam, g, y0, y1, tilesX, ts);
-}
-
-template <bool TEX>
-__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_render_gbuffer_lane(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, int y0, int y1, int tilesX) {
-    render_gbuffer_body<TEX, false, true>(s, cam, lastCam, g, y0, y1, tilesX, TileSplit{ nullptr, 0, 0 });
 }
 
 namespace {
@@ -73,12 +64,6 @@ int launch_render(const rs_gbuffer* g, const rs_scene* scene, const rs_camera* c
     const int c = g->cur();
     GBufWrite w{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
     const int tilesX = (g->width + 31) / 32, tilesY = (y1 - y0 + 7) / 8;
-    if (rs_primary_walk_per_lane(scene)) {                 // (no union of nodes to be long: no tile split either)
-        const CamParams cp = rs_make_cam_params(cam), lp = rs_make_cam_params(lastCam);
-        if (scene->textured) hipLaunchKernelGGL(k_render_gbuffer_lane<true>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX);
-        else hipLaunchKernelGGL(k_render_gbuffer_lane<false>, dim3(tilesX * tilesY), dim3(256), 0, st, scene->dev, cp, lp, w, y0, y1, tilesX);
-        return 0;
-    }
     TileSplit ts; int helpers = 0;
     RS_TRY(rs_tile_split_prepare(&g->split[st == rs_stream() ? 0 : 1], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY,
                                  (st == rs_stream() && (rs_sync_enabled() || !rs_aux_stream(0))) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));

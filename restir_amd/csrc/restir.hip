@@ -101,8 +101,7 @@ __device__ __forceinline__ int primary_store(const DevScene& s, const SurfPlanes
 }
 
 // SPLIT: the launch splits its heavy tiles (rs_tilesplit.h) and counts the nodes of every walk for it; the plain kernel carries none of that
-// LANE: per-lane walks of the closest-hit trees instead of the packet walk (gbuffer.hip render_gbuffer_body; rs_set_primary_walk)
-template <bool TEX, bool SOBOL, bool SPLIT, bool LANE = false>
+template <bool TEX, bool SOBOL, bool SPLIT>
 __device__ __forceinline__ void primary_body(const DevScene& s, const CamParams& cam, const SurfPlanes& sp, int looper,
                                              int y0, int y1, int tilesX, unsigned long long* rayCount, const TileSplit& ts) {
     RS_SETPRIO(RS_PRIO_WALK);
@@ -117,7 +116,7 @@ __device__ __forceinline__ void primary_body(const DevScene& s, const CamParams&
     f4 r = rng.uniform4();                              // sample4D: all four are drawn, two are used
     Ray ray = camera_sample(cam, x, y, r.x, r.y);
     unsigned unionNodes = 0;
-    Hit h = LANE ? trace_closest_wave(s, ray, inside) : trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
+    Hit h = trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);       // all 64 lanes take part in the wave's walk
     if (inside) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
     // BVH walks for the Mrays/s metric: one per pixel here, one more per shaded pixel (shadow ray)
     const unsigned long long ballotIn = __ballot(inside), ballotSh = __ballot(shaded);
@@ -132,11 +131,6 @@ template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary(DevScene s, CamParams cam, SurfPlanes sp, int looper,
                                                  int y0, int y1, int tilesX, unsigned long long* rayCount) {
     primary_body<TEX, SOBOL, false>(s, cam, sp, looper, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
-}
-template <bool TEX, bool SOBOL>
-__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary_lane(DevScene s, CamParams cam, SurfPlanes sp, int looper,
-                                                 int y0, int y1, int tilesX, unsigned long long* rayCount) {
-    primary_body<TEX, SOBOL, false, true>(s, cam, sp, looper, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
 }
 template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_primary_split(DevScene s, CamParams cam, SurfPlanes sp, int looper,
@@ -160,7 +154,7 @@ constexpr long long kFuseMinWaves = kSmallLaunchWaves;     // three rounds of th
 // the single walk's cost per visit.  (Round 1's form walked both rays in one lane, one after the other at every node of an 8x8 tile's
 // union: it paid both slab tests per visit and, after the round-2 walk, measured 1.29 ms per frame against 1.20 for two launches and
 // 1.193 for this form.)  Tiles are 8x4 from the G-buffer rows [gy0, gy1), blocks 32x4 pixels; the shading ray is active on rows [y0, y1).
-template <bool TEX, bool SOBOL, bool SPLIT, bool LANE = false>
+template <bool TEX, bool SOBOL, bool SPLIT>
 __device__ __forceinline__ void gbuffer_primary_body(const DevScene& s, const CamParams& cam, const CamParams& lastCam, const GBufWrite& g, const SurfPlanes& sp, int looper,
                                                      int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount, const TileSplit& ts) {
     RS_SETPRIO(RS_PRIO_WALK);
@@ -176,7 +170,7 @@ __device__ __forceinline__ void gbuffer_primary_body(const DevScene& s, const Ca
     const f4 r = rng.uniform4();
     const Ray ray = shading ? camera_sample(cam, x, y, r.x, r.y) : camera_center_ray(cam, x, y);
     unsigned unionNodes = 0;
-    const Hit h = LANE ? trace_closest_wave(s, ray, inside) : trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);
+    const Hit h = trace_closest_packet<SPLIT>(s, ray, inside, &unionNodes);
     int shaded = 0;
     if (inside) {
         if (shading) shaded = primary_store<TEX>(s, sp, index, ray, h, rng.word());
@@ -194,11 +188,6 @@ template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
                                                                   int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
     gbuffer_primary_body<TEX, SOBOL, false>(s, cam, lastCam, g, sp, looper, gy0, gy1, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
-}
-template <bool TEX, bool SOBOL>
-__global__ void __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary_lane(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
-                                                                       int gy0, int gy1, int y0, int y1, int tilesX, unsigned long long* rayCount) {
-    gbuffer_primary_body<TEX, SOBOL, false, true>(s, cam, lastCam, g, sp, looper, gy0, gy1, y0, y1, tilesX, rayCount, TileSplit{ nullptr, 0, 0 });
 }
 template <bool TEX, bool SOBOL>
 __global__ void __launch_bounds__(256, RS_WALK_WAVES) k_gbuffer_primary_split(DevScene s, CamParams cam, CamParams lastCam, GBufWrite g, SurfPlanes sp, int looper,
@@ -1009,7 +998,6 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
     }
     const SurfPlanes sp = surf_of(r);
     const CamParams cp = rs_make_cam_params(cam);
-    const bool perLane = rs_primary_walk_per_lane(scene);       // (rs_set_primary_walk: per-lane walks of the closest-hit trees instead of the packet walk)
     mark(r, 0);
     if (fuse) {
         RS_TRY(rs_gbuffer_order_before_render(g, aux));
@@ -1018,21 +1006,17 @@ int phase_a_impl(rs_restir* r, const rs_scene* scene, const rs_camera* cam, cons
         const GBufWrite gw{ g->albedo[c], g->motion[c], g->normal[c], g->primId[c], g->depth[c] };
         const int gTilesY = (d.y1 - d.y0 + 3) / 4;                // 8x4-pixel tiles: two rays per pixel fill the wave
         const CamParams lp = rs_make_cam_params(&d.lastCam);
-        TileSplit ts{ nullptr, 0, 0 }; int helpers = 0;
-        if (perLane) RS_LAUNCH2(k_gbuffer_primary_lane, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
-        else RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, (!aux || idle) ? 1 : ((long long)tilesX * gTilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
-        if (perLane) {}
-        else if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
+        TileSplit ts; int helpers = 0;
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], ((((long long)1 << 20 | d.y0) << 20 | d.y1) << 12 | tilesX) ^ ((long long)(y0 * 4099 + y1) << 44), tilesX * 4 * gTilesY, tilesX * gTilesY, (!aux || idle) ? 1 : ((long long)tilesX * gTilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
+        if (ts.base) RS_LAUNCH2(k_gbuffer_primary_split, scene->textured, sobol, dim3(helpers + tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter, ts);
         else RS_LAUNCH2(k_gbuffer_primary, scene->textured, sobol, dim3(tilesX * gTilesY), dim3(256), st, scene->dev, cp, lp, gw, sp, looper, d.y0, d.y1, y0, y1, tilesX, rayCounter);
         RS_HIP(hipEventRecord(g->doneEv, aux));              // the planes are ready when this kernel is
         g->pending = true;
     }
     else {
-        TileSplit ts{ nullptr, 0, 0 }; int helpers = 0;
-        if (perLane) RS_LAUNCH2(k_primary_lane, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
-        else RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, (!aux || idle) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
-        if (perLane) {}
-        else if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
+        TileSplit ts; int helpers = 0;
+        RS_TRY(rs_tile_split_prepare(&r->split[splitSlot][splitCall], (((long long)y0 << 20 | y1) << 12 | tilesX), tilesX * 4 * tilesY, tilesX * tilesY, (!aux || idle) ? 1 : ((long long)tilesX * tilesY * 4 < kSplitSmallWaves ? 2 : 0), st, &ts, &helpers));
+        if (ts.base) RS_LAUNCH2(k_primary_split, scene->textured, sobol, dim3(helpers + tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter, ts);
         else RS_LAUNCH2(k_primary, scene->textured, sobol, dim3(tilesX * tilesY), dim3(256), st, scene->dev, cp, sp, looper, y0, y1, tilesX, rayCounter);
     }
     mark(r, 1);

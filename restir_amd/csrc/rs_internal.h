@@ -59,7 +59,6 @@ struct rs_context {
     bool denoiseUsed = false;             // the denoise stream has carried work since the last rs_synchronize
     hipEvent_t denoiseFork = nullptr;     // library stream -> denoise stream
     unsigned long long* ptRayCount = nullptr;   // pathTraceDirect's walk counter (pathtrace.hip)
-    int primaryWalk = 0;                  // rs_set_primary_walk: 0 the packet walk of the reference tree, 1 per-lane walks of the closest-hit trees (scenes that have them)
     int tileSplit = 0; bool tileSplitSet = false;   // union nodes from which a tile of a closest-hit kernel is traced by four waves (rs_tilesplit.h): rs_set_tile_split, default 768; 0 off; negative: |value|, also for launches that overlap others
 };
 rs_context* rs_ctx();                                   // the context this thread's library code runs under right now
@@ -277,7 +276,6 @@ bool rs_fuse_enabled();
 int rs_ris_global_below();
 const rs_context* rs_stream_plan();   // the current context with chainStreams / smallChains / shadowOnMain resolved
 int rs_fuse_mode();     // 0 never, 1 always (large launches), 2 always, 3 measured per rs_restir
-bool rs_primary_walk_per_lane(const rs_scene* scene);   // the closest-hit kernels of the DI frame walk per lane (rs_set_primary_walk(1) and the scene has its closest-hit trees)
 
 // device view of the planes the kernels read
 struct GBufView {

@@ -1095,51 +1095,6 @@ def test_denoise_stream_equals_synchronous_frames(hip, join_every_frame):
     assert not bits_equal(a["pbos"][0], a["pbos"][-1]) and a["pbos"][-1].any()
 
 
-@pytest.mark.parametrize("overlapped", [False, True])
-def test_primary_rays_per_lane_through_the_closest_hit_trees(hip, overlapped):
-    """rs_set_primary_walk(1): GBuffer::render and the primary rays of ReSTIRDirect walk per lane through the closest-hit trees that keep the
-    reference's visiting order instead of the packet walk of the reference tree.  The hits are the same, so eight frames of an orbiting
-    camera -- radiance, every G-buffer plane, the reservoirs, the ray counts -- equal the packet walk's bit for bit, synchronous (two launches)
-    and with the frames overlapped (the fused launch); and the packet walk's equal the oracle's elsewhere in this file."""
-    import torch
-    from restir_amd.scenes import orbit_position
-    sd = get_scene("sponza:0.2")
-    W, H, frames = 640, 360, 8
-    scene = hip_scene(hip, sd)
-
-    def run(per_lane):
-        h = HipRenderer(hip, sd, W, H, scene=scene)
-        hip.set_primary_walk(per_lane)
-        hip.set_sync(not overlapped)
-        images, rays = [], []
-        try:
-            for frame in range(frames):
-                h.set_camera_position(orbit_position(sd.camera_args["position"], frame, radius=0.5))
-                h.gbuf.render(h.scene, h.cam)
-                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, h.looper, 3)
-                h.looper += 1
-                images.append(h.image.clone())
-                h.gbuf.update(h.cam)
-                if not overlapped:
-                    rays.append(h.restir.ray_count())
-            hip.synchronize(); torch.cuda.synchronize()
-        finally:
-            hip.set_sync(True)
-            hip.set_primary_walk(0)
-        return dict(images=[t.cpu().numpy() for t in images], resv=h.restir.download(1), gbuf=h.gbuf.download(), rays=rays)
-
-    a, b = run(0), run(1)
-    for frame in range(frames):
-        assert bits_equal(a["images"][frame], b["images"][frame]), frame
-    assert a["resv"].tobytes() == b["resv"].tobytes() and a["rays"] == b["rays"]
-    for k in ("albedo", "motion"):
-        assert bits_equal(a["gbuf"][k], b["gbuf"][k]), k
-    for k in ("normal", "prim_id", "depth"):
-        for i in range(2):
-            assert bits_equal(a["gbuf"][k][i], b["gbuf"][k][i]), (k, i)
-    assert a["images"][-1].any()
-
-
 def test_measured_choice_of_the_fused_walk_keeps_the_images(hip):
     """Default asynchronous mode: ReSTIRDirect measures once per scene whether walking the G-buffer ray with the shading ray is
     faster (frames 18..33 run fused, all others until the decision separately).  Whatever it picks, a full-size run of

@@ -77,8 +77,6 @@ capi.set_sync(False)
 # what bench.py does: a frame with the denoiser on the library stream puts the library's own streams below it
 capi.set_internal_stream_priority(int(os.environ.get("STREAM_LEVEL", "1" if DENOISE else "2")))
 capi.set_denoise_stream(int(os.environ.get("DENOISE_STREAM", "0")) if DENOISE else 0)
-if os.environ.get("PRIMARY_WALK"):                   # 1: GBuffer::render and the primary rays per lane through the closest-hit trees (rs_set_primary_walk)
-    capi.set_primary_walk(int(os.environ["PRIMARY_WALK"]))
 if os.environ.get("TILE_SPLIT"):
     capi.set_tile_split(int(os.environ["TILE_SPLIT"]))
 if os.environ.get("STREAM_PLAN"):
