@@ -538,6 +538,7 @@ def main():
     # BENCH_DENOISE_STREAM=1: the filter, the tone map of its result and the display gather on the library's denoise stream
     # (rs_set_denoise_stream; measured slower on config 5, profiles/r06_ab_denoise_stream_mode1.log: default 0)
     capi.set_denoise_stream(int(os.environ.get("BENCH_DENOISE_STREAM", "0")) if DENOISE else 0)
+    capi.prepare_streams()                 # the library chooses its own streams NOW (about 25 ms), not inside the first frame
     min_rows = 32 if DENOISE else 8        # the EAW levels on strips reach 32 rows (rs_strips_eaw_filter)
     # N > 1: strip heights balanced by measured cost before the warm-up (rows near the horizon cost several times a sky row and
     # the slowest strip sets the frame time); BENCH_EVEN_STRIPS=1 keeps equal heights
@@ -596,6 +597,7 @@ def main():
         # ncclCommInitRank made streams of its own after the library had chosen its streams (the calibration of the strip heights ran
         # frames): which streams run side by side depends on every stream of the process, so the library chooses again
         capi.choose_internal_streams_again()
+        capi.prepare_streams()
         drv = capi.Strips(comm, WIDTH, HEIGHT, [b[0] for b in bounds] + [HEIGHT])
         y0, y1 = drv.y0, drv.y1
         assert (y0, y1) == tuple(bounds[rank])
@@ -635,6 +637,7 @@ def main():
         # heights: which streams run side by side depends on every stream of the process, so it chooses again -- as the C driver's branch does)
         if world > 1:
             capi.choose_internal_streams_again()
+            capi.prepare_streams()
         strips = StripRenderer(backend, world, rank, HEIGHT, dist=dist if world > 1 else None, share_history=args.orbit, bounds=bounds)
         y0, y1 = strips.y0, strips.y1
         rows = y1 - y0

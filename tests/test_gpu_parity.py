@@ -974,6 +974,30 @@ def test_internal_streams_are_chosen_by_measurement_and_change_no_result(hip):
         assert chosen_us == 0.0 or (0.0 < fastest_us <= chosen_us <= fastest_us * 1.08 + 1e-6), info     # 0: plain streams (nothing could be measured)
 
 
+def test_stream_choice_is_kept_per_caller_stream(hip):
+    """rs_prepare_streams makes the choice at once; rs_set_stream back to a stream the library has measured next to takes that choice again
+    instead of measuring (about 25 ms) once more -- a caller that alternates between two streams pays twice, not at every switch."""
+    import time
+    import torch
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    hip.set_sync(False)
+    try:
+        took = []
+        for st in (a, b, a, b, a):
+            hip.set_stream(st.cuda_stream)
+            t0 = time.perf_counter()
+            hip.prepare_streams()
+            took.append((time.perf_counter() - t0) * 1e3)
+            lvl, chosen_us, fastest_us = hip.internal_streams_info()
+            assert lvl in (-1, 0, 1)
+        measured = took[:2]
+        if min(measured) > 5.0:                                    # (the measurement ran: a box where it fails uses plain streams and has nothing to keep)
+            assert max(took[2:]) < 0.5 * min(measured), took
+    finally:
+        hip.set_sync(True)
+        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_overlapped_frames_equal_synchronous_frames(hip, fused):
     """Asynchronous mode (rs_set_sync(0)) lets frames overlap: GBuffer::render and the primary-ray + RIS kernels of frame f + 1
