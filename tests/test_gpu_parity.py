@@ -974,6 +974,39 @@ def test_internal_streams_are_chosen_by_measurement_and_change_no_result(hip):
         assert chosen_us == 0.0 or (0.0 < fastest_us <= chosen_us <= fastest_us * 1.08 + 1e-6), info     # 0: plain streams (nothing could be measured)
 
 
+def test_spatial_pass_event_ring_and_probe_name(hip):
+    """Measurement hooks of bench.py: rs_restir_enable_timing(r, 2) keeps the two events around the spatial pass of every frame in a ring that
+    is read afterwards (nothing waits inside the frames), and rs_restir_set_probe(r, 1) launches the pass under another kernel name -- the same
+    code: frames rendered either way are bit-identical."""
+    import torch
+    sd = get_scene("sponza:0.1")
+    W, H = 320, 180
+    scene = hip_scene(hip, sd)
+
+    def run(probe, timing):
+        h = HipRenderer(hip, sd, W, H, scene=scene)
+        hip.set_sync(False)
+        try:
+            h.restir.set_probe(probe)
+            if timing:
+                h.restir.enable_timing(2)
+            for frame in range(7):
+                h.gbuf.render(h.scene, h.cam)
+                h.restir.direct(h.scene, h.cam, h.gbuf, h.image.data_ptr(), 0, frame, 3)
+                h.gbuf.update(h.cam)
+            times = h.restir.spatial_times(64) if timing else []
+            hip.synchronize(); torch.cuda.synchronize()
+        finally:
+            h.restir.set_probe(False); h.restir.enable_timing(False)
+            hip.set_sync(True)
+        return h.image.cpu().numpy(), h.restir.download(1), times
+
+    a = run(False, False)
+    b = run(True, True)
+    assert bits_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
+    assert len(b[2]) == 7 and all(0.0 < t < 50.0 for t in b[2]), b[2]
+
+
 def test_stream_choice_is_kept_per_caller_stream(hip):
     """rs_prepare_streams makes the choice at once; rs_set_stream back to a stream the library has measured next to takes that choice again
     instead of measuring (about 25 ms) once more -- a caller that alternates between two streams pays twice, not at every switch."""
