@@ -916,7 +916,9 @@ def main():
         differing, l1_sum, frames_checked = 0, 0.0, 6
         for f in range(frames_checked):
             frame(chk, chk_state, chk_pbos)
-            # the strip's rows of what was shown, copied into a buffer of our own (the driver's filter result buffer is the driver's)
+            # the strip's rows of what was shown, copied into a buffer of our own (the driver's filter result buffer is the driver's); a
+            # copy of the caller's own: with BENCH_DENOISE_STREAM=1 it needs the join first
+            capi.join_denoise_stream(); capi.synchronize()
             capi.hip_memcpy_d2d(gathered.data_ptr() + y0 * WIDTH * 12, chk_state["shown"] + y0 * WIDTH * 12, rows * WIDTH * 12)
             drv.gather(gathered.data_ptr(), 12, 0)
             if ref is not None:

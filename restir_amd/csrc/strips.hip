@@ -149,10 +149,10 @@ void halo_segments(SegList& l, rs_restir* r, rs_gbuffer* g, int y, int rows, cha
 
 // One grouped exchange, ordered after everything enqueued on the library stream so far: on the driver's stream for a stream-ordered
 // transport (RCCL), from the host side of a finished library stream otherwise.  join() makes the library stream continue after it.
-int post(rs_strips* s, const Xfer* opsIn, size_t nIn) {
+int post(rs_strips* s, const Xfer* opsIn, size_t nIn, int list = -1) {
     const rs_comm* c = s->comm;
     // transfers of a gather that was begun in this stream's order travel in this group (one RCCL launch per frame instead of two)
-    const int which = rs_ctx()->streamOverride ? 1 : 0;          // posting from inside a denoise scope: that stream's list
+    const int which = list >= 0 ? list : (rs_ctx()->streamOverride ? 1 : 0);      // posting from inside a denoise scope: that stream's list (or the list the caller names)
     std::vector<Xfer> merged;
     const Xfer* ops = opsIn; size_t n = nIn;
     int carried = 0;
@@ -335,7 +335,7 @@ int rs_strips_destroy(rs_strips* s) {
     if (!s) return 0;
     (void)rs_synchronize();
     if (!s->deferred[0].empty()) (void)post(s, nullptr, 0);   // (every rank reaches this with the same deferred gathers)
-    if (!s->deferred[1].empty()) { rs_denoise_scope onDenoiseStream(false); if (onDenoiseStream.active) (void)post(s, nullptr, 0); }
+    if (!s->deferred[1].empty()) { rs_denoise_scope onDenoiseStream(false); (void)post(s, nullptr, 0, 1); }      // (on that stream if it still exists, else on the library stream: everything has finished)
     (void)rs_synchronize();
     if (s->commStream) { (void)hipStreamSynchronize(s->commStream); (void)hipStreamDestroy(s->commStream); }
     if (s->ownStreamCounted) { rs_ctx()->ownCommStreams--; s->ownStreamCounted = false; }      // (the transfer stream is gone: its chain is free again)
@@ -686,9 +686,9 @@ int rs_strips_gather_end(rs_strips* s, int slot) {
     if (s->commOnMain && s->comm->t.stream_ordered) {
         if (s->gatherOnDenoise[slot]) {
             if (s->deferredSlots[1] & (1 << slot)) {                            // nothing has carried them yet: a group of their own, on that stream
-                rs_denoise_scope onDenoiseStream(false);
+                rs_denoise_scope onDenoiseStream(false);         // (inactive if the mode was switched off since: rs_set_denoise_stream waited for everything, the library stream will do)
                 RS_TRY(onDenoiseStream.err);
-                RS_TRY(post(s, nullptr, 0));
+                RS_TRY(post(s, nullptr, 0, 1));
             }
             // (the next tone map into the buffer runs on the denoise stream, in order; the library stream waits for the group that carried the
             // rows -- the previous frame's, long finished in a running sequence)
