@@ -1080,7 +1080,7 @@ def main():
             out["expected_compute_only"] = exp
         fused, chains = timed_form                            # what the timed frames launched, as the library reported it then
         form = "one fused launch" if fused == 1 else "two launches"
-        how = {-2: "not measured: a launch below three rounds of wave slots", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
+        how = {-2: "not measured: a launch below three rounds of wave slots, or a form that is forced", -1: "measurement not finished within this run", 0: "measured", 1: "measured"}[backend.restir.launch_choice()]
         out["config"]["launch_choice"] = "%s (%s), chains on %d streams in turn" % (form, how, chains)
         out["config"]["calibration_frames_before_warmup"] = calibration_frames
         lvl, chosen_us, fastest_us = capi.internal_streams_info()
