@@ -599,6 +599,8 @@ def main():
         capi.choose_internal_streams_again()
         capi.prepare_streams()
         drv = capi.Strips(comm, WIDTH, HEIGHT, [b[0] for b in bounds] + [HEIGHT])
+        if DENOISE and world > 1 and os.environ.get("BENCH_GBUFFER_HALO", "32") != "5":
+            drv.set_gbuffer_halo(32)           # the 32 G-buffer rows the filter's taps reach travel with the reservoir rows: one exchange per frame less
         y0, y1 = drv.y0, drv.y1
         assert (y0, y1) == tuple(bounds[rank])
         rows = y1 - y0

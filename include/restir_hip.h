@@ -463,6 +463,10 @@ int  rs_strips_rows(const rs_strips* strips, int* y0, int* y1);
  * unpacking copies; 1 = on a stream of the driver, ordered by events, so that the interior rows of phase B run while the border rows
  * travel.  Same results.  Call between frames with no gather in flight. */
 int  rs_strips_set_comm_stream(rs_strips* strips, int ownStream);
+/* Rows of the G-buffer id / normal / depth planes that travel with the 5 reservoir rows of an edge: 5 (default) for the spatial taps; 32 when a
+ * denoiser follows (src/main.cpp:160-170), whose own exchange of those rows -- a packing launch, a group and an unpacking launch per frame -- is
+ * then skipped.  The same value on every rank; strips of at least that many rows; between frames. */
+int  rs_strips_set_gbuffer_halo(rs_strips* strips, int rows);
 /* GBuffer::render + ReSTIRDirect of this rank's rows; GBuffer::update stays with the caller, as in runCuda.  Afterwards rows
  * [y0, y1) of devDirectIllum hold the frame's radiance. */
 int  rs_strips_frame(rs_strips* strips, rs_restir* r, const rs_scene* scene, const rs_camera* cam, rs_gbuffer* g,

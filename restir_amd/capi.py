@@ -119,7 +119,7 @@ EXPORTS = [
     "rs_path_trace", "rs_path_trace_indirect", "rs_restir_indirect", "rs_restir_download_indirect",
     "rs_svgf_create", "rs_svgf_destroy", "rs_svgf_filter", "rs_svgf_next_frame", "rs_svgf_get_view",
     "rs_copy_image_to_pbo", "rs_copy_image2_to_pbo", "rs_copy_imagef_to_pbo", "rs_copy_imagei_to_pbo", "rs_eaw_create", "rs_eaw_destroy", "rs_eaw_set_params", "rs_eaw_get_params", "rs_eaw_set_tiled", "rs_eaw_set_fused", "rs_svgf_set_params", "rs_svgf_get_params", "rs_svgf_set_tiled", "rs_svgf_set_fused", "rs_eaw_filter", "rs_eaw_positions_rows", "rs_eaw_level_rows", "rs_modulate_albedo",
-    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create_rccl_lib", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_set_comm_stream", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_svgf_filter", "rs_strips_exchange_svgf_history", "rs_strips_exchange_history", "rs_strips_gather", "rs_strips_gather_begin", "rs_strips_gather_end", "rs_strips_enable_timing", "rs_strips_halo_wait_ms",
+    "rs_add_image", "rs_add_image3", "rs_comm_create_rccl", "rs_comm_create_rccl_lib", "rs_comm_create", "rs_comm_destroy", "rs_comm_self_exchange", "rs_strips_create", "rs_strips_destroy", "rs_strips_rows", "rs_strips_set_comm_stream", "rs_strips_set_gbuffer_halo", "rs_strips_frame", "rs_strips_eaw_filter", "rs_strips_svgf_filter", "rs_strips_exchange_svgf_history", "rs_strips_exchange_history", "rs_strips_gather", "rs_strips_gather_begin", "rs_strips_gather_end", "rs_strips_enable_timing", "rs_strips_halo_wait_ms",
     "rs_scene_file_load", "rs_scene_file_get", "rs_scene_file_free", "rs_build_transformation_matrix", "rs_bake_instance",
 ]
 
@@ -245,6 +245,7 @@ def lib():
     L.rs_strips_destroy.argtypes = [vp]
     L.rs_strips_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.rs_strips_set_comm_stream.argtypes = [vp, ci]
+    L.rs_strips_set_gbuffer_halo.argtypes = [vp, ci]
     L.rs_strips_frame.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, vp, ci, ci, ci]
     L.rs_strips_eaw_filter.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, C.POINTER(vp)]
     L.rs_strips_exchange_history.argtypes = [vp, vp, vp]
@@ -891,6 +892,10 @@ class Strips:
     def set_comm_stream(self, own_stream):
         """Stream-ordered transports: transfers on the library stream (False, default) or on a stream of the driver (True)."""
         check(lib().rs_strips_set_comm_stream(self.handle, 1 if own_stream else 0))
+
+    def set_gbuffer_halo(self, rows):
+        """G-buffer rows that travel with the reservoir rows of a frame: 5 (default), or 32 when a denoiser follows (rs_strips_set_gbuffer_halo)."""
+        check(lib().rs_strips_set_gbuffer_halo(self.handle, int(rows)))
 
     def frame(self, restir, scene, cam, gbuf, dev_direct_illum_ptr, iter_, looper, reuse):
         check(lib().rs_strips_frame(self.handle, restir.handle, scene.handle, C.byref(cam), gbuf.handle, dev_direct_illum_ptr, iter_, looper, reuse))

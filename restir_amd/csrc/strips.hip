@@ -47,6 +47,11 @@ struct rs_strips {
     std::vector<int> bounds;                       // world + 1 row offsets
     int y0 = 0, y1 = 0;
     size_t haloBytes = 0;                          // one edge: reservoirs + G-buffer rows
+    // How many rows of the G-buffer id / normal / depth planes travel with the 5 reservoir rows of an edge (rs_strips_set_gbuffer_halo): 5 is
+    // what the spatial taps need; a caller whose frame goes on with a denoiser sets 32, and the filter finds its G-buffer rows already there
+    // (one packing launch, one group and one unpacking launch less per frame than exchanging them again: gbufFresh)
+    int gReach = RS_SPATIAL_HALO_ROWS;
+    bool gbufFresh = false;                        // the current G-buffer set holds the neighbours' gReach rows (set by rs_strips_frame, consumed by the filters)
     char* sendUp = nullptr; char* recvUp = nullptr; char* sendDown = nullptr; char* recvDown = nullptr;
     // Where the transfers are enqueued.  commOnMain (default): on the library stream itself, in order with the packing copies before
     // and the unpacking copies after them -- no extra stream, no events.  The overlapped mode already keeps four streams busy (the
@@ -139,12 +144,14 @@ int copy_segments(const SegList& l, bool pack) {
     return rs_check_hip(hipGetLastError(), "strip border rows");
 }
 // the border rows of one edge in the packed layout of rs_restir_halo_pack followed by rs_gbuffer_rows_pack: li, wi, tap, id, normal, depth
-void halo_segments(SegList& l, rs_restir* r, rs_gbuffer* g, int y, int rows, char* packed) {
-    const size_t n = (size_t)r->width * rows, off = (size_t)y * r->width;
+// (yResv: first of the kHalo reservoir rows; yG: first of the gRows G-buffer rows -- the same edge of the strip, so the two ranges end or begin together)
+void halo_segments(SegList& l, rs_restir* r, rs_gbuffer* g, int yResv, int yG, int gRows, char* packed) {
+    const size_t n = (size_t)r->width * kHalo, off = (size_t)yResv * r->width;
     const int c = g->cur();
     l.add(r->temp.li + off, packed, n * 16); l.add(r->temp.wi + off, packed + n * 16, n * 16); l.add(r->temp.tap + off, packed + n * 32, n * 16);
     char* gb = packed + n * 48;
-    l.add(g->primId[c] + off, gb, n * 4); l.add(g->normal[c] + off * 3, gb + n * 4, n * 12); l.add(g->depth[c] + off, gb + n * 16, n * 4);
+    const size_t m = (size_t)r->width * gRows, offG = (size_t)yG * r->width;
+    l.add(g->primId[c] + offG, gb, m * 4); l.add(g->normal[c] + offG * 3, gb + m * 4, m * 12); l.add(g->depth[c] + offG, gb + m * 16, m * 4);
 }
 
 // One grouped exchange, ordered after everything enqueued on the library stream so far: on the driver's stream for a stream-ordered
@@ -414,6 +421,27 @@ int rs_strips_set_comm_stream(rs_strips* s, int ownStream) {
     return 0;
 }
 
+// How many rows of the G-buffer id / normal / depth planes travel to the neighbours with the reservoir rows of rs_strips_frame: 5 (default) is what
+// the spatial taps compare against; 32 makes the rows a denoiser's taps reach arrive in the same group, and rs_strips_eaw_filter /
+// rs_strips_svgf_filter then skip their own exchange of them.  Every rank must set the same value (it is the size of the messages); strips of at
+// least `rows` rows; between frames.
+int rs_strips_set_gbuffer_halo(rs_strips* s, int rows) {
+    RS_SCOPE(s);
+    if (!s || rows < kHalo || rows > 64) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_set_gbuffer_halo: 5 to 64 rows");
+    const rs_comm* c = s->comm;
+    if (c->world > 1)
+        for (int r = 0; r < c->world; r++)
+            if (s->bounds[(size_t)r + 1] - s->bounds[(size_t)r] < rows) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_set_gbuffer_halo: a strip is shorter than the rows asked for");
+    if (rows == s->gReach) return 0;
+    RS_TRY(rs_synchronize());
+    s->gReach = rows; s->gbufFresh = false;
+    s->haloBytes = (size_t)s->width * ((size_t)kHalo * 48u + (size_t)rows * 20u);
+    rs_dev_free(s->sendUp); rs_dev_free(s->recvUp); rs_dev_free(s->sendDown); rs_dev_free(s->recvDown);
+    if (c->rank > 0) { RS_TRY(rs_dev_alloc(&s->sendUp, s->haloBytes)); RS_TRY(rs_dev_alloc(&s->recvUp, s->haloBytes)); }
+    if (c->rank + 1 < c->world) { RS_TRY(rs_dev_alloc(&s->sendDown, s->haloBytes)); RS_TRY(rs_dev_alloc(&s->recvDown, s->haloBytes)); }
+    return 0;
+}
+
 int rs_strips_rows(const rs_strips* s, int* y0, int* y1) {
     RS_SCOPE(s);
     if (!s || !y0 || !y1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_rows: null argument");
@@ -430,6 +458,7 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
     if (g->width != s->width || g->height != s->height) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_frame: G-buffer size differs from the strips' frame");
     const int y0 = s->y0, y1 = s->y1;
     const rs_comm* c = s->comm;
+    s->gbufFresh = false;
     RS_TRY(rs_gbuffer_render_rows(g, scene, cam, y0, y1));
     RS_TRY(rs_restir_phase_a(r, scene, cam, g, looper, reuse, y0, y1));
     const bool up = c->rank > 0, down = c->rank + 1 < c->world;
@@ -441,8 +470,8 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
     RS_TRY(rs_gbuffer_join(g));
     {
         SegList l;
-        if (up) halo_segments(l, r, g, y0, kHalo, s->sendUp);
-        if (down) halo_segments(l, r, g, y1 - kHalo, kHalo, s->sendDown);
+        if (up) halo_segments(l, r, g, y0, y0, s->gReach, s->sendUp);
+        if (down) halo_segments(l, r, g, y1 - kHalo, y1 - s->gReach, s->gReach, s->sendDown);
         RS_TRY(copy_segments(l, true));
     }
     // the transfers: after the packing copies
@@ -458,8 +487,9 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
         // and two 5-row bands would only buy two more launches -- and the bands are 5 rows in 16-row tiles.  Unpack, then ONE launch over
         // the strip (a 1/8 strip of 1080p: three launches of 14.6 + 8.5 + 8.8 us -> one of 15; results do not depend on the partition).
         SegList l;
-        if (up) halo_segments(l, r, g, y0 - kHalo, kHalo, s->recvUp);
-        if (down) halo_segments(l, r, g, y1, kHalo, s->recvDown);
+        if (up) halo_segments(l, r, g, y0 - kHalo, y0 - s->gReach, s->gReach, s->recvUp);
+        if (down) halo_segments(l, r, g, y1, y1, s->gReach, s->recvDown);
+        s->gbufFresh = true;
         RS_TRY(copy_segments(l, false));
         RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, y1));
         return rs_restir_end_frame(r);
@@ -471,8 +501,9 @@ int rs_strips_frame(rs_strips* s, rs_restir* r, const rs_scene* scene, const rs_
     RS_TRY(join(s, true));
     {
         SegList l;
-        if (up) halo_segments(l, r, g, y0 - kHalo, kHalo, s->recvUp);
-        if (down) halo_segments(l, r, g, y1, kHalo, s->recvDown);
+        if (up) halo_segments(l, r, g, y0 - kHalo, y0 - s->gReach, s->gReach, s->recvUp);
+        if (down) halo_segments(l, r, g, y1, y1, s->gReach, s->recvDown);
+        s->gbufFresh = true;
         RS_TRY(copy_segments(l, false));
     }
     if (topEnd > y0) RS_TRY(rs_restir_phase_b(r, scene, cam, g, devDirectIllum, iter, reuse, y0, topEnd));
@@ -505,7 +536,8 @@ int rs_strips_eaw_filter(rs_strips* s, rs_eaw* f, rs_gbuffer* g, const rs_camera
     RS_TRY(rs_denoise_order(devColor)); RS_TRY(rs_denoise_order(s->eawBuf[0])); RS_TRY(rs_denoise_order(s->eawBuf[1]));      // (no-ops on the denoise stream)
     for (int i = 0; i < 2; i++)
         if (!s->eawBuf[i]) { RS_TRY(rs_dev_alloc(&s->eawBuf[i], image / sizeof(float))); RS_HIP(hipMemsetAsync(s->eawBuf[i], 0, image, rs_stream())); }
-    RS_TRY(exchange_gbuffer_rows(s, g, reach));
+    if (!(s->gbufFresh && s->gReach >= reach)) RS_TRY(exchange_gbuffer_rows(s, g, reach));      // (rs_strips_set_gbuffer_halo(s, 32): they came with the reservoir rows)
+    s->gbufFresh = false;
     RS_TRY(rs_eaw_positions_rows(f, g, cam, y0 - reach > 0 ? y0 - reach : 0, y1 + reach < s->height ? y1 + reach : s->height));
     for (int level = 0; level < kLevels; level++) {
         float* in = level == 0 ? devColor : s->eawBuf[(level - 1) % 2];
@@ -548,7 +580,8 @@ int rs_strips_svgf_filter(rs_strips* s, rs_svgf* f, rs_gbuffer* g, const rs_came
     const int reach = 2 << 4;
     for (int r = 0; r < c->world; r++)
         if (s->bounds[(size_t)r + 1] - s->bounds[(size_t)r] < reach + 1) return rs_fail(RS_ERR_INVALID_ARGUMENT, "rs_strips_svgf_filter: strips must be at least 33 rows tall");
-    RS_TRY(exchange_gbuffer_rows(s, g, reach));
+    if (!(s->gbufFresh && s->gReach >= reach)) RS_TRY(exchange_gbuffer_rows(s, g, reach));
+    s->gbufFresh = false;
     const rs_svgf_row_hooks hooks{ s, svgf_exchange_hook };
     return rs_svgf_filter_rows(f, devColorOut, devColorIn, g, cam, s->y0, s->y1, &hooks);
 }

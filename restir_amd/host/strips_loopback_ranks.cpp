@@ -116,6 +116,7 @@ void run_rank(int rank, int world, Mailbox* box) {
         rs_strips* strips = nullptr;
         CHECK(rs_strips_create(comm, W, H, nullptr, &strips));
         CHECK(rs_strips_set_comm_stream(strips, ownStream ? 1 : 0));
+        if (denoise && orbit) CHECK(rs_strips_set_gbuffer_halo(strips, 32));      // (half of the filter modes: its 32 G-buffer rows travel with the reservoir rows)
         int y0 = 0, y1 = 0;
         CHECK(rs_strips_rows(strips, &y0, &y1));
         const int sets = rank == 0 ? 2 : 1;                        // rank 0: the strips' objects and a full-frame renderer of its own

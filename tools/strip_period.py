@@ -22,6 +22,7 @@ calibration does), N = 1 goes through the same driver (one-rank world).
     RCCL=1                   create a one-rank ncclComm first (does RCCL's presence in the process move the period?)
     STREAM_LEVEL=-1|0|1|2    rs_set_internal_stream_priority (default: 1 for config 5, else 2 = automatic)
     STREAM_KIND=torch|torch_high|hip|null   the library stream: of torch's pool (default), high priority, a plain HIP stream, the legacy default stream
+    GBUFFER_HALO=5|32        rs_strips_set_gbuffer_halo with the filter (default 32, as bench.py)
     DENOISE_STREAM=0|1       rs_set_denoise_stream: config 5's filter, tone map and display gather on the library stream (default) / on a stream of
                              their own, the chains on two streams
 """
@@ -94,6 +95,8 @@ def period(world, rank, bounds, frames=FRAMES):
     drv = capi.Strips(comm, W, H, [b[0] for b in bounds] + [H])
     if os.environ.get("COMM_STREAM", "0") == "1":
         drv.set_comm_stream(True)
+    if DENOISE and world > 1 and os.environ.get("GBUFFER_HALO", "32") != "5":       # what bench.py does: the filter's G-buffer rows travel with the reservoir rows
+        drv.set_gbuffer_halo(32)
     gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
     y0, y1 = drv.y0, drv.y1
     st = {"n": 0}

@@ -29,6 +29,8 @@ if os.environ.get("ROWS"):                                # strip heights of all
     assert len(ys) == world + 1 and ys[-1] == H
     bounds = ys
 drv = capi.Strips(comm, W, H, bounds)
+if eaw and world > 1 and os.environ.get("GBUFFER_HALO", "32") != "5":
+    drv.set_gbuffer_halo(32)
 gbuf, restir = capi.GBuffer(W, H), capi.ReSTIR(W, H)
 image = torch.zeros((W * H, 3), dtype=torch.float32, device="cuda")
 pbos = [torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
