@@ -1395,6 +1395,23 @@ def test_strip_driver_stream_ordered_ranks_on_one_gpu():
     assert r.stdout.count("on the denoise stream") == 4, r.stdout[-3000:]
 
 
+def test_gbuffer_halo_setting_of_the_strip_driver(hip):
+    """rs_strips_set_gbuffer_halo: 5 to 64 rows, never more than the shortest strip has; the value is the size of the messages, so a bad one
+    is refused instead of sent (what it changes in a frame is compared with the full frame by strips_loopback_ranks)."""
+    noop = lambda p, n, peer: None
+    comm = hip.Comm(0, 2, noop, noop, None, None, stream_ordered=True)
+    drv = hip.Strips(comm, 320, 100, [0, 40, 100])                    # strips of 40 and 60 rows
+    try:
+        for bad in (4, 65, 41):
+            with pytest.raises(hip.RestirHipError):
+                drv.set_gbuffer_halo(bad)
+        drv.set_gbuffer_halo(32)
+        drv.set_gbuffer_halo(40)
+        drv.set_gbuffer_halo(5)
+    finally:
+        drv.destroy(); comm.destroy()
+
+
 def test_strip_driver_eight_stream_ordered_ranks_on_one_gpu():
     """The same check with EIGHT ranks -- the split BASELINE's configs 4 and 5 name, and more processes than a one-GPU box lets a job put on
     its card, so here the ranks are threads of one process: 288 rows, 36 per strip, all 12 modes."""
