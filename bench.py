@@ -40,7 +40,7 @@ One JSON line is printed by rank 0; besides the contract's fields it carries
   roofline_eaw  config 5: the five a-trous level kernels, 44 B/px and level
   per_rank      N > 1: every rank's rows, ms per step, wait for the halo rows, per-pass times, its choice of internal streams
   expected_compute_only_ms   N > 1: the slowest rank's frame period of this split as measured on ONE GPU over a transport that moves nothing
-                (tools/strip_period.py, profiles/r05_strip_period_c<config>.json): ms_per_step minus this is the wire, RCCL's launches, the ranks' skew
+                (tools/strip_period.py, profiles/r06_strip_period_c<config>.json): ms_per_step minus this is the wire, RCCL's launches, the ranks' skew
   ms_per_frame_single_in_flight   launches asynchronous, one frame at a time (between ms_per_step, three frames in flight, and
                 ms_per_frame_synchronous, a synchronisation after every call)
   ms_per_step_sustained / sustained   --sustained-frames (default 2 000) more overlapped frames AFTER the timed region, in ten windows: their mean and
@@ -134,7 +134,7 @@ def overlapped_kernel_us(config, kernel):
 
 def expected_compute_only(config, world):
     """The committed compute-only frame period of an N-way split of `config` (tools/strip_period.py: every rank of the split alone on ONE
-    MI355X through rs_strips_frame over a transport that moves nothing, cost-balanced heights; profiles/r05_strip_period_c<config>.json):
+    MI355X through rs_strips_frame over a transport that moves nothing, cost-balanced heights; profiles/r06_strip_period_c<config>.json, round 5's if that is absent):
     what the first multi-GPU run is to be compared with -- ms_per_step minus this is the wire, RCCL's launches and the ranks' skew."""
     p = os.path.join(ROOT, "profiles", "r06_strip_period_c%d.json" % config)
     if not os.path.exists(p):

@@ -106,7 +106,7 @@ def test_bench_main_takes_the_launcher_branch_before_any_gpu_call(tmp_path):
 
 
 def test_expected_compute_only_reads_the_committed_strip_periods():
-    """bench.py's N > 1 line quotes the compute-only frame period of the split from profiles/r05_strip_period_c<config>.json
+    """bench.py's N > 1 line quotes the compute-only frame period of the split from profiles/r06_strip_period_c<config>.json
     (tools/strip_period.py): the figure the first multi-GPU run is to be compared with."""
     sys.path.insert(0, ROOT)
     import bench
